@@ -1,0 +1,172 @@
+/*
+ * include/r8bsrc.h -- C ABI of libr8bsrc_hip.so, the MI355X-native batched sample-rate converter.
+ *
+ * Part 1 re-declares, symbol for symbol, what the reference's DLL exports
+ * (reference DLL/r8bsrc.h:31-132, implemented there by DLL/r8bsrc.cpp:67-107), so that a program
+ * linked against the reference's r8bsrc library links against this one unchanged.
+ * Part 2 is additive: an N-channel batch object whose process() takes DEVICE (HBM) pointers --
+ * this is the entry point the throughput numbers are quoted on.  Every signature uses plain
+ * pointers and sizes only (no torch types, no C++ types).
+ *
+ * All functions are thread-compatible the same way the reference is (DLL/r8bsrc.h, README
+ * "one object per stream"): distinct objects may be used from distinct threads, one object must
+ * not be used concurrently.
+ */
+#ifndef R8BSRC_HIP_INCLUDED
+#define R8BSRC_HIP_INCLUDED
+
+#ifndef R8BSRC_DECL
+	#define R8BSRC_DECL __attribute__((visibility("default")))
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * Part 1: drop-in symbols (reference DLL/r8bsrc.h)
+ * ------------------------------------------------------------------------------------------- */
+
+/* reference DLL/r8bsrc.h:31 */
+typedef void* CR8BResampler;
+
+/* reference DLL/r8bsrc.h:37-43; ReqAtten 136.45 / 109.56 / 180.15 dB
+ * (reference CDSPResampler.h:746,777,807 via DLL/r8bsrc.cpp:67-85). */
+enum ER8BResamplerRes
+{
+	r8brr16 = 0,
+	r8brr16IR = 1,
+	r8brr24 = 2
+};
+
+/* replaces reference DLL/r8bsrc.h:68-70 (r8b_create).  Returns NULL (after printing the reason to
+ * stderr) when no MI355X/HIP device is usable: there is no CPU fallback. */
+R8BSRC_DECL CR8BResampler r8b_create(double SrcSampleRate, double DstSampleRate, int MaxInLen,
+	double ReqTransBand, enum ER8BResamplerRes Res);
+
+/* replaces reference DLL/r8bsrc.h:79 */
+R8BSRC_DECL void r8b_delete(CR8BResampler rs);
+
+/* replaces reference DLL/r8bsrc.h:92 (CDSPResampler::getInputRequiredForOutput,
+ * CDSPResampler.h:476-484) */
+R8BSRC_DECL int r8b_inlen(CR8BResampler rs, int ReqOutSamples);
+
+/* replaces reference DLL/r8bsrc.h:102 */
+R8BSRC_DECL void r8b_clear(CR8BResampler rs);
+
+/* replaces reference DLL/r8bsrc.h:131-132.  The reference declares `double*& op0`; at ABI level
+ * that is a `double**` (DLL/r8bsrc.pas:31-32 binds it as `var op0: PR8BDouble`).  `ip0` and `*op0`
+ * are HOST pointers, exactly like the reference: `*op0` points into a buffer owned by the object,
+ * valid until the next call on it (CDSPResampler.h:546-552); if Src == Dst, `*op0 = ip0`. */
+#ifdef __cplusplus
+R8BSRC_DECL int r8b_process(CR8BResampler rs, double* ip0, int l, double*& op0);
+#else
+R8BSRC_DECL int r8b_process(CR8BResampler rs, double* ip0, int l, double** op0);
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * Part 2: N-channel batch object (additive; no counterpart in the reference, whose callers loop
+ * "for each channel: process(same length)" -- example.cpp:63-67, bench/r8bfreesrc.cpp:120-124)
+ * ------------------------------------------------------------------------------------------- */
+
+typedef void* CR8BBatch;
+
+/* Creates `nch` independent linear-phase resamplers that share one schedule, on HIP device
+ * `device` (-1 = current).  ReqAtten is the reference constructor's ReqAtten in dB
+ * (CDSPResampler.h:117-120).  NULL + message in r8b_last_error() on failure. */
+R8BSRC_DECL CR8BBatch r8b_batch_create(double SrcSampleRate, double DstSampleRate, int MaxInLen,
+	double ReqTransBand, double ReqAtten, int nch, int device);
+
+R8BSRC_DECL void r8b_batch_delete(CR8BBatch b);
+R8BSRC_DECL void r8b_batch_clear(CR8BBatch b);
+R8BSRC_DECL int r8b_batch_channels(CR8BBatch b);
+
+/* CDSPResampler::getMaxOutLen(0) for the MaxInLen given at creation (CDSPResampler.h:502-519):
+ * the minimum per-channel capacity of the output buffer. */
+R8BSRC_DECL int r8b_batch_max_out_len(CR8BBatch b);
+/* CDSPResampler::getInputRequiredForOutput / getInLenBeforeOutPos (CDSPResampler.h:476-484,406) */
+R8BSRC_DECL int r8b_batch_inlen(CR8BBatch b, int ReqOutSamples);
+R8BSRC_DECL int r8b_batch_inlen_before_outpos(CR8BBatch b, int OutPos);
+
+/* One process() step for all channels.  d_in / d_out are DEVICE pointers, channel-major:
+ * channel c's samples start at d_in + c*in_stride (doubles), l <= MaxInLen samples each;
+ * channel c's output is written at d_out + c*out_stride (out_stride >= r8b_batch_max_out_len).
+ * `stream` is a hipStream_t (NULL = default stream); the call only enqueues work on it.
+ * Returns the number of output samples produced per channel (identical for all channels and equal
+ * to what the reference's process() returns for the same call sequence), or -1 on error. */
+R8BSRC_DECL int r8b_batch_process(CR8BBatch b, const double* d_in, long long in_stride, int l,
+	double* d_out, long long out_stride, void* stream);
+
+/* Convenience: same with HOST buffers (copies through the device, synchronous). */
+R8BSRC_DECL int r8b_batch_process_host(CR8BBatch b, const double* in, long long in_stride, int l,
+	double* out, long long out_stride);
+
+/* Single DSP stage as a batch object (the reference's CDSPProcessor boundary,
+ * CDSPProcessor.h:64-127), used by the stage-level parity tests:
+ *   kind 0: CDSPBlockConvolver(getLPFilter(a=ReqNormFreq, b=ReqTransBand, c=ReqAtten, linear,
+ *           d=ReqGain), i0=UpFactor, i1=DownFactor)           (CDSPBlockConvolver.h:62)
+ *   kind 1: CDSPFracInterpolator(a=SrcRate, b=DstRate, c=ReqAtten, i0=IsThird)
+ *                                                              (CDSPFracInterpolator.h:713)
+ *   kind 2: CDSPHBUpsampler(a=ReqAtten, i0=SteepIndex, i1=IsThird)   (CDSPHBUpsampler.h:572)
+ *   kind 3: CDSPHBDownsampler(a=ReqAtten, i0=SteepIndex, i1=IsThird) (CDSPHBDownsampler.h:47) */
+R8BSRC_DECL CR8BBatch r8b_batch_create_stage(int kind, double a, double b, double c, double d,
+	int i0, int i1, int MaxInLen, int nch, int device);
+
+/* Number of stages and a printable description of the chain (what the reference prints through
+ * R8BCONSOLE, r8bconf.h:31-42).  Returns the full length; writes at most cap-1 chars. */
+R8BSRC_DECL int r8b_batch_describe(CR8BBatch b, char* buf, int cap);
+
+/* Kernel tuning/instrumentation knob: name/value pairs understood by the engine
+ * ("fuse", "conv_threads", ...).  Returns 0 if the knob exists. */
+R8BSRC_DECL int r8b_batch_set_option(CR8BBatch b, const char* name, int value);
+
+/* Last error message of the calling thread ("" if none). */
+R8BSRC_DECL const char* r8b_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Part 3: host-side designer/plan queries (no device needed).  These expose the read-only
+ * coefficient sets the kernels consume so that they can be compared with the reference's
+ * (CDSPFIRFilter.h:220-537, CDSPFracInterpolator.h:61-189, CDSPHBUpsampler.h:47-552).
+ * ------------------------------------------------------------------------------------------- */
+
+/* Low-pass taps h[0..KernelLen) (zero-phase filter, centre at KernelLen/2, DC gain ReqGain).
+ * Returns KernelLen; fills at most cap taps; *BlockLenBits and *Latency like
+ * CDSPFIRFilter::getBlockLenBits/getLatency (CDSPFIRFilter.h:139-164). */
+R8BSRC_DECL int r8b_design_lpfilter(double ReqNormFreq, double ReqTransBand, double ReqAtten,
+	double ReqGain, int* BlockLenBits, int* Latency, double* taps, int cap);
+
+/* Fractional-delay bank (CDSPFracDelayFilterBank): rows 0..FilterFracs, FilterLen*ElementSize
+ * doubles each, natural (unshuffled) element order.  FilterFracs = -1 selects the default
+ * (CDSPFracInterpolator.h:79-84).  Returns the total number of doubles. */
+R8BSRC_DECL int r8b_design_fracbank(int FilterFracs, int ElementSize, int InterpPoints,
+	double ReqAtten, int IsThird, int* FilterLen, int* Fracs, double* table, int cap);
+
+/* Half-band taps (CDSPHBUpsampler::getHBFilter / getHBFilterThird).  Returns the tap count. */
+R8BSRC_DECL int r8b_design_hbfilter(double ReqAtten, int SteepIndex, int IsThird, double* taps,
+	double* att);
+
+/* getWholeStepping (CDSPFracInterpolator.h:644-673). */
+R8BSRC_DECL int r8b_design_whole_stepping(double SSampleRate, double DSampleRate, int* InStep,
+	int* OutStep);
+
+/* Host-only schedule object: the integer bookkeeping of a resampler without any device work.
+ * r8b_plan_step feeds l input samples and returns how many output samples the reference's
+ * process() returns for that call. */
+typedef void* CR8BPlan;
+R8BSRC_DECL CR8BPlan r8b_plan_create(double SrcSampleRate, double DstSampleRate, int MaxInLen,
+	double ReqTransBand, double ReqAtten);
+R8BSRC_DECL void r8b_plan_delete(CR8BPlan p);
+R8BSRC_DECL void r8b_plan_clear(CR8BPlan p);
+R8BSRC_DECL int r8b_plan_step(CR8BPlan p, int l);
+R8BSRC_DECL int r8b_plan_max_out_len(CR8BPlan p);
+R8BSRC_DECL int r8b_plan_inlen(CR8BPlan p, int ReqOutSamples);
+R8BSRC_DECL int r8b_plan_inlen_before_outpos(CR8BPlan p, int OutPos);
+R8BSRC_DECL int r8b_plan_describe(CR8BPlan p, char* buf, int cap);
+
+R8BSRC_DECL const char* r8b_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* R8BSRC_HIP_INCLUDED */

@@ -1,0 +1,74 @@
+// r8b_design.h -- host-side designer of the read-only coefficient sets and of the stage chain.
+//
+// Everything here runs once per parameter set, on the host, in fp64; its outputs (low-pass
+// spectrum, fractional-delay bank, half-band taps, chain topology) are uploaded to HBM and are
+// the only inputs the kernels take besides samples.  The numbers must equal the reference's to
+// rounding level or the resampled stream differs, so every routine cites what it reproduces:
+//   low-pass designer        reference CDSPFIRFilter.h:220-537, CDSPSincFilterGen.h:114-123,
+//                            230-241, 312-338, 586-605
+//   fractional-delay bank    reference CDSPFracInterpolator.h:61-189, 279-341,
+//                            CDSPSincFilterGen.h:168-177, 452-552
+//   half-band tap selection  reference CDSPHBUpsampler.h:47-316, 331-552
+//   chain topology           reference CDSPResampler.h:135-394
+#ifndef R8B_DESIGN_H
+#define R8B_DESIGN_H
+
+#include <string>
+#include <vector>
+
+namespace r8bhip {
+
+struct LpFilter
+{
+	std::vector<double> taps; // h[-fl2..fl2] stored at [0..2*fl2], DC gain == gain
+	int fl2 = 0;              // one-sided length == latency in samples
+	int kernel_len = 0;       // 2*fl2+1
+	int block_len_bits = 0;   // CDSPFIRFilter::getBlockLenBits()
+};
+
+// Kaiser-power-windowed sinc low-pass (zero phase).
+const LpFilter& design_lp(double norm_freq, double trans_band, double atten, double gain);
+
+struct FracBank
+{
+	int filter_len = 0;
+	int fracs = 0;        // FilterFracs
+	int element_size = 0; // 1 (plain taps) or 3 (c0,c1,c2 per tap)
+	double atten = 0.0;   // rounded attenuation of the chosen row
+	std::vector<double> table; // (fracs+1) rows x filter_len*element_size
+};
+
+const FracBank& design_frac_bank(int fracs, int element_size, int interp_points, double atten,
+	bool third);
+
+// Tap selection over the generated half-band tables.  Returns tap count, *taps points to
+// static storage.
+int select_hb_filter(double atten, int steep, bool third, const double** taps, double* att);
+
+bool whole_stepping(double ssr, double dsr, int* in_step, int* out_step);
+
+inline int bit_occupancy(long long v)
+{
+	int b = 0;
+	while (v > 0) { b++; v >>= 1; }
+	return b < 1 ? 1 : b;
+}
+
+enum StageKind { kConv = 0, kFrac = 1, kHBUp = 2, kHBDown = 3 };
+
+struct StageDesc
+{
+	StageKind kind;
+	// conv: a=norm_freq b=trans_band c=atten d=gain i0=up i1=down
+	// frac: a=src b=dst c=atten i0=third
+	// hbup/hbdown: a=atten i0=steep i1=third
+	double a = 0, b = 0, c = 0, d = 0;
+	int i0 = 0, i1 = 0;
+};
+
+// Stage chain a CDSPResampler(src, dst, ., tb, atten, linear phase) is made of.
+std::vector<StageDesc> build_topology(double src, double dst, double tb, double atten);
+
+} // namespace r8bhip
+
+#endif

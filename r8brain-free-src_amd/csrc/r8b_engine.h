@@ -1,0 +1,71 @@
+// r8b_engine.h -- N-channel batch resampler: host schedule (r8b_plan.h) + device state + launches.
+//
+// One Engine = `nch` independent streams that share one ChainPlan.  process() mirrors
+// r8b::CDSPResampler::process (reference CDSPResampler.h:559-575): it walks the stage chain, but
+// instead of ping-ponging host buffers it enqueues one position-addressed kernel per stage on a
+// HIP stream.  Stage-to-stage streams live in per-channel rings in HBM; the first stage reads the
+// caller's device buffer directly (plus a short history ring), the last stage writes the caller's
+// device buffer directly.
+#ifndef R8B_ENGINE_H
+#define R8B_ENGINE_H
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "r8b_launch.h"
+#include "r8b_plan.h"
+
+namespace r8bhip {
+
+class Engine
+{
+public:
+	Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int device);
+	~Engine();
+	Engine(const Engine&) = delete;
+	Engine& operator=(const Engine&) = delete;
+
+	// returns output samples per channel produced by this call
+	int process(const double* d_in, long long in_stride, int l, double* d_out,
+		long long out_stride, void* stream);
+	void clear();
+	bool set_option(const std::string& name, int value);
+
+	const ChainPlan& plan() const { return plan_; }
+	int channels() const { return nch_; }
+	int device() const { return device_; }
+
+private:
+	struct StageDev
+	{
+		double* ring = nullptr; // input ring of this stage, nch x ring_size
+		long long ring_size = 0;
+		double* H = nullptr;
+		cd* tw = nullptr;
+		int tw_len = 0;
+		double* table = nullptr;
+		std::vector<int> fwd_radix, inv_radix;
+	};
+
+	void plan_transforms();
+	void launch_stage(size_t s, long long m_prev, long long a, long long b, const PolyState& ps,
+		const SrcView& src, const DstView& dst, void* stream);
+
+	ChainPlan plan_;
+	int nch_;
+	int device_;
+	std::vector<StageDev> dev_;
+	std::map<std::string, int> opt_;
+};
+
+// complex twiddle table exp(-2 pi i e / len), exact on the axes; interleaved (re, im)
+std::vector<double> make_twiddles(int len);
+// zero-phase kernel spectrum H[m] = sum_t h[t] cos(2 pi m t / bl2), m = 0..bl2/2, times `scale`
+std::vector<double> kernel_spectrum(const LpFilter& f, int bl2, double scale);
+// radices (each in {2,4,8,16}, <= max_radix) whose product is N, largest first
+std::vector<int> plan_radices(int N, int max_radix);
+
+} // namespace r8bhip
+
+#endif

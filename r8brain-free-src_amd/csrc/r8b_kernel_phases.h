@@ -1,0 +1,521 @@
+// r8b_kernel_phases.h -- the arithmetic of every kernel, written as per-thread "phase" functions.
+//
+// A kernel in r8b_kernels.hip is a sequence of phases separated by __syncthreads(); each phase is
+// a function of (thread id, thread count, LDS pointers, launch parameters) defined here.  The
+// includer defines R8B_HD (`__device__ __forceinline__` in r8b_kernels.hip).  tests/emul/ includes
+// the same header with R8B_HD empty and runs the phases thread by thread on the host, so the
+// index arithmetic can be unit-tested in a container without a GPU; the product library never
+// contains that build.
+//
+// Stream semantics each kernel reproduces (reference file:line):
+//   overlap-save block convolver   CDSPBlockConvolver.h:252-354, 512-593, 606-629,
+//                                  CDSPRealFFT.h:98-170, 289-385 (K1..K7 of SURVEY.md 2.1)
+//   whole-step polyphase FIR       CDSPFracInterpolator.h:991-1060
+//   polynomial-interpolated bank   CDSPFracInterpolator.h:1069-1179
+//   half-band 2x up / down         CDSPHBUpsampler.h:773-786, CDSPHBDownsampler.h:282-295
+#ifndef R8B_KERNEL_PHASES_H
+#define R8B_KERNEL_PHASES_H
+
+#ifndef R8B_HD
+	#error "define R8B_HD before including r8b_kernel_phases.h"
+#endif
+
+#include "r8b_launch.h"
+
+namespace r8bhip {
+
+struct alignas(16) cd
+{
+	double re, im;
+};
+
+// ------------------------------------------------------------------------------------ views
+
+R8B_HD double src_load(const SrcView& s, int ch, long long pos)
+{
+	if (pos < 0) return 0.0;
+	if (pos >= s.cur_base) return s.cur[(long long) ch * s.cur_stride + (pos - s.cur_base)];
+	return s.ring[(long long) ch * s.ring_stride + (pos & s.ring_mask)];
+}
+
+R8B_HD void dst_store(const DstView& d, int ch, long long q, double v)
+{
+	d.p[(long long) ch * d.stride + ((q + d.off) & d.mask)] = v;
+}
+
+// ------------------------------------------------------------------------------------ small DFTs
+
+// (r,i) *= w16^E with w16 = exp(-2 pi i / 16); CONJ selects exp(+...)
+template<int E, bool CONJ>
+R8B_HD void mul_w16(double& r, double& i)
+{
+	constexpr double C1 = 0.92387953251128674; // cos(pi/8)
+	constexpr double S1 = 0.38268343236508977; // sin(pi/8)
+	constexpr double C2 = 0.70710678118654752; // cos(pi/4)
+	if constexpr (E == 0)
+	{
+	}
+	else if constexpr (E == 4)
+	{
+		const double t = r;
+		if constexpr (CONJ) { r = -i; i = t; }
+		else { r = i; i = -t; }
+	}
+	else
+	{
+		constexpr double c = E == 1 ? C1 : (E == 2 ? C2 : (E == 3 ? S1 : (E == 5 ? -S1 :
+			(E == 6 ? -C2 : -C1))));
+		constexpr double s0 = E == 1 ? S1 : (E == 2 ? C2 : (E == 3 ? C1 : (E == 5 ? C1 :
+			(E == 6 ? C2 : S1))));
+		constexpr double s = CONJ ? -s0 : s0; // w = c - i*s
+		const double tr = r * c + i * s;
+		const double ti = i * c - r * s;
+		r = tr;
+		i = ti;
+	}
+}
+
+template<int R, int H, int IDX>
+struct DifBf
+{
+	static R8B_HD void run(double* vr, double* vi)
+	{
+		constexpr int g = (IDX / H) * 2 * H, u = IDX % H, E = u * (8 / H);
+		constexpr int i0 = g + u, i1 = g + u + H;
+		const double ar = vr[i0], ai = vi[i0], br = vr[i1], bi = vi[i1];
+		vr[i0] = ar + br;
+		vi[i0] = ai + bi;
+		double dr = ar - br, di = ai - bi;
+		mul_w16<E, false>(dr, di);
+		vr[i1] = dr;
+		vi[i1] = di;
+		if constexpr (IDX + 1 < R / 2) DifBf<R, H, IDX + 1>::run(vr, vi);
+	}
+};
+
+template<int R, int H>
+struct DifSt
+{
+	static R8B_HD void run(double* vr, double* vi)
+	{
+		DifBf<R, H, 0>::run(vr, vi);
+		if constexpr (H > 1) DifSt<R, H / 2>::run(vr, vi);
+	}
+};
+
+template<int R, int H, int IDX>
+struct DitBf
+{
+	static R8B_HD void run(double* vr, double* vi)
+	{
+		constexpr int g = (IDX / H) * 2 * H, u = IDX % H, E = u * (8 / H);
+		constexpr int i0 = g + u, i1 = g + u + H;
+		const double ar = vr[i0], ai = vi[i0];
+		double br = vr[i1], bi = vi[i1];
+		mul_w16<E, true>(br, bi);
+		vr[i0] = ar + br;
+		vi[i0] = ai + bi;
+		vr[i1] = ar - br;
+		vi[i1] = ai - bi;
+		if constexpr (IDX + 1 < R / 2) DitBf<R, H, IDX + 1>::run(vr, vi);
+	}
+};
+
+template<int R, int H>
+struct DitSt
+{
+	static R8B_HD void run(double* vr, double* vi)
+	{
+		DitBf<R, H, 0>::run(vr, vi);
+		if constexpr (2 * H < R) DitSt<R, 2 * H>::run(vr, vi);
+	}
+};
+
+// R-point forward DFT in registers, natural order in, bit-reversed order out
+template<int R> R8B_HD void dif_regs(double* vr, double* vi) { DifSt<R, R / 2>::run(vr, vi); }
+// R-point backward (conjugate, unnormalised) DFT, bit-reversed order in, natural order out
+template<int R> R8B_HD void dit_regs(double* vr, double* vi) { DitSt<R, 1>::run(vr, vi); }
+
+template<int R> constexpr int bitrev_c(int p)
+{
+	int r = 0;
+	for (int b = 1; b < R; b <<= 1)
+	{
+		r = (r << 1) | (p & 1);
+		p >>= 1;
+	}
+	return r;
+}
+
+R8B_HD int ilog2(int v)
+{
+	int b = 0;
+	while ((1 << b) < v) b++;
+	return b;
+}
+
+R8B_HD unsigned bitrev32(unsigned v)
+{
+	v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+	v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+	v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+	v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+	return (v >> 16) | (v << 16);
+}
+
+R8B_HD int bitrev_n(int v, int bits) { return bits == 0 ? 0 : (int) (bitrev32((unsigned) v) >> (32 - bits)); }
+
+// ------------------------------------------------------------------------------------ FFT passes
+//
+// In-place decimation-in-frequency forward transform: a pass with sub-transform length n and
+// radix R performs log2(R) radix-2 DIF stages of every length-n sub-block, so after all passes the
+// spectrum sits in plain bit-reversed order (bin k at position bitrev(k)).  The backward transform
+// is the transposed flow graph (decimation in time, conjugate twiddles): bit-reversed in, natural
+// out, unnormalised.  No reordering pass exists anywhere: the spectral stage in between addresses
+// bins through bitrev().  `tw` holds exp(-2 pi i e / tw_len), e < tw_len.
+
+template<int R>
+R8B_HD void dif_pass_one(cd* buf, int n, int bidx, const cd* tw, int tw_len)
+{
+	const int q = n / R;
+	const int blk = bidx / q, j = bidx - blk * q;
+	cd* p0 = buf + (long) blk * n + j;
+	double vr[R], vi[R];
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		const cd v = p0[p * q];
+		vr[p] = v.re;
+		vi[p] = v.im;
+	}
+	dif_regs<R>(vr, vi);
+	if (q > 1)
+	{
+		const int ts = tw_len / n * j;
+#pragma unroll
+		for (int p = 1; p < R; p++)
+		{
+			const cd w = tw[ts * bitrev_c<R>(p)];
+			const double tr = vr[p] * w.re - vi[p] * w.im;
+			const double ti = vr[p] * w.im + vi[p] * w.re;
+			vr[p] = tr;
+			vi[p] = ti;
+		}
+	}
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		cd v;
+		v.re = vr[p];
+		v.im = vi[p];
+		p0[p * q] = v;
+	}
+}
+
+template<int R>
+R8B_HD void dit_pass_one(cd* buf, int n, int bidx, const cd* tw, int tw_len)
+{
+	const int q = n / R;
+	const int blk = bidx / q, j = bidx - blk * q;
+	cd* p0 = buf + (long) blk * n + j;
+	double vr[R], vi[R];
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		const cd v = p0[p * q];
+		vr[p] = v.re;
+		vi[p] = v.im;
+	}
+	if (q > 1)
+	{
+		const int ts = tw_len / n * j;
+#pragma unroll
+		for (int p = 1; p < R; p++)
+		{
+			const cd w = tw[ts * bitrev_c<R>(p)]; // multiply by conj(w)
+			const double tr = vr[p] * w.re + vi[p] * w.im;
+			const double ti = vi[p] * w.re - vr[p] * w.im;
+			vr[p] = tr;
+			vi[p] = ti;
+		}
+	}
+	dit_regs<R>(vr, vi);
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		cd v;
+		v.re = vr[p];
+		v.im = vi[p];
+		p0[p * q] = v;
+	}
+}
+
+// one whole pass over a length-N complex buffer (all sub-blocks), strided over the threads
+R8B_HD void fft_pass(cd* buf, int N, int n, int radix, bool inverse, const cd* tw, int tw_len,
+	int tid, int nthr)
+{
+	const int nb = N / radix;
+	for (int b = tid; b < nb; b += nthr)
+	{
+		if (!inverse)
+		{
+			if (radix == 16) dif_pass_one<16>(buf, n, b, tw, tw_len);
+			else if (radix == 8) dif_pass_one<8>(buf, n, b, tw, tw_len);
+			else if (radix == 4) dif_pass_one<4>(buf, n, b, tw, tw_len);
+			else dif_pass_one<2>(buf, n, b, tw, tw_len);
+		}
+		else
+		{
+			if (radix == 16) dit_pass_one<16>(buf, n, b, tw, tw_len);
+			else if (radix == 8) dit_pass_one<8>(buf, n, b, tw, tw_len);
+			else if (radix == 4) dit_pass_one<4>(buf, n, b, tw, tw_len);
+			else dit_pass_one<2>(buf, n, b, tw, tw_len);
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------ convolver
+
+// K1: assemble the circular input block k of channel ch as n_in reals in LDS.
+// (reference CDSPBlockConvolver.h:283-305 and, for non-2^k up-sampling, copyUpsample :414-496)
+R8B_HD void conv_load(const ConvLaunch& L, double* a, long long k, int ch, int tid, int nthr)
+{
+	if (L.up_pow2)
+	{
+		const int iln = L.in_len / L.up; // new input samples per block
+		const long long base = k * iln;
+		for (int i = tid; i < L.n_in; i += nthr)
+		{
+			const long long pos = i < iln ? base + i : base + i - L.n_in;
+			a[i] = src_load(L.src, ch, pos);
+		}
+	}
+	else
+	{
+		const long long base = k * (long long) L.in_len;
+		for (int i = tid; i < L.n_in; i += nthr)
+		{
+			const long long t = i < L.in_len ? base + i : base + i - L.bl2;
+			double v = 0.0;
+			if (t >= 0 && t % L.up == 0) v = src_load(L.src, ch, t / L.up);
+			a[i] = v;
+		}
+	}
+}
+
+// spectrum bin k (0 <= k <= N) of the 2N-point real sequence whose packed N-point complex DFT
+// sits bit-reversed in `za`
+R8B_HD cd real_bin(const cd* za, int k, int N, int logN, const cd* tw, int tw_len)
+{
+	const int k1 = k & (N - 1), k2 = (N - k) & (N - 1);
+	const cd z1 = za[bitrev_n(k1, logN)], z2 = za[bitrev_n(k2, logN)];
+	const double er = 0.5 * (z1.re + z2.re), ei = 0.5 * (z1.im - z2.im);
+	// O = (Z1 - conj Z2) / (2i)
+	const double dr = z1.re - z2.re, di = z1.im + z2.im;
+	const double orr = 0.5 * di, oi = -0.5 * dr;
+	const cd w = tw[(long) k * (tw_len / (2 * N))];
+	cd r;
+	r.re = er + (w.re * orr - w.im * oi);
+	r.im = ei + (w.re * oi + w.im * orr);
+	return r;
+}
+
+// bin m (0 <= m <= bl2/2) of the spectrum of the zero-stuffed block: the 2N-point spectrum
+// repeated with period 2N (K3, reference CDSPBlockConvolver.h:606-629)
+R8B_HD cd stuffed_bin(const cd* za, int m, int N, int logN, const cd* tw, int tw_len)
+{
+	const int mm = m & (2 * N - 1);
+	if (mm <= N) return real_bin(za, mm, N, logN, tw, tw_len);
+	cd r = real_bin(za, 2 * N - mm, N, logN, tw, tw_len);
+	r.im = -r.im;
+	return r;
+}
+
+// bin m (0 <= m <= N2) of the product spectrum handed to the inverse transform (K4, K5):
+// multiply by the real zero-phase kernel (reference CDSPRealFFT.h:289-385); when decimating by
+// 2^k the Nyquist bin of the shortened transform is the reference's fix-up
+// (reference CDSPBlockConvolver.h:329-342).
+R8B_HD cd product_bin(const ConvLaunch& L, const cd* za, int m, int N, int logN, int N2)
+{
+	cd r = stuffed_bin(za, m, N, logN, L.tw, L.tw_len);
+	const double h = L.H[m];
+	if (m == N2 && L.down_pow2 && L.down > 1)
+	{
+		r.re = h * (r.re + r.im);
+		r.im = 0.0;
+		return r;
+	}
+	r.re *= h;
+	r.im *= h;
+	return r;
+}
+
+// K3+K4+K5 and the packing for the half-length complex backward transform: reads the forward
+// result (bit-reversed, buffer za, N complex), writes N2 complex values bit-reversed into zb.
+R8B_HD void conv_spectral(const ConvLaunch& L, const cd* za, cd* zb, int tid, int nthr)
+{
+	const int N = L.n_in / 2, N2 = L.n_out / 2;
+	const int logN = ilog2(N), logN2 = ilog2(N2);
+	const int tsh = L.tw_len / (2 * N2);
+	for (int kp = tid; kp <= N2 / 2; kp += nthr)
+	{
+		const cd sa = product_bin(L, za, kp, N, logN, N2);
+		const cd sb = product_bin(L, za, N2 - kp, N, logN, N2);
+		// Z'[k] = (Sa + conj Sb) + i * conj(w^k) * (Sa - conj Sb),  w = exp(-2 pi i / (2 N2))
+		{
+			const cd w = L.tw[(long) kp * tsh];
+			const double er = sa.re + sb.re, ei = sa.im - sb.im;
+			const double dr = sa.re - sb.re, di = sa.im + sb.im;
+			// conj(w) * D
+			const double pr = w.re * dr + w.im * di, pi = w.re * di - w.im * dr;
+			cd z;
+			z.re = er - pi;
+			z.im = ei + pr;
+			zb[bitrev_n(kp, logN2)] = z;
+		}
+		const int k2 = N2 - kp;
+		if (kp != 0 && k2 != kp)
+		{
+			const cd w = L.tw[(long) k2 * tsh];
+			const double er = sb.re + sa.re, ei = sb.im - sa.im;
+			const double dr = sb.re - sa.re, di = sb.im + sa.im;
+			const double pr = w.re * dr + w.im * di, pi = w.re * di - w.im * dr;
+			cd z;
+			z.re = er - pi;
+			z.im = ei + pr;
+			zb[bitrev_n(k2, logN2)] = z;
+		}
+	}
+}
+
+// K7: emit the valid part of block k that falls into the call's output range [L.a, L.b)
+// (reference CDSPBlockConvolver.h:512-593)
+R8B_HD void conv_store(const ConvLaunch& L, const double* y, long long k, int ch, int tid, int nthr)
+{
+	const long long t0 = k * (long long) L.in_len - L.fl2; // first time (virtual rate) of the block
+	const long long t1 = t0 + L.in_len;
+	long long q0 = t0 <= 0 ? 0 : (t0 + L.down - 1) / L.down;
+	long long q1 = t1 <= 0 ? 0 : (t1 + L.down - 1) / L.down;
+	if (q0 < L.a) q0 = L.a;
+	if (q1 > L.b) q1 = L.b;
+	const long long kb = k * (long long) L.in_len;
+	for (long long q = q0 + tid; q < q1; q += nthr)
+	{
+		long long c = q * L.down - kb;
+		if (c < 0) c += L.bl2;
+		const int idx = L.down_pow2 ? (int) (c / L.down) : (int) c;
+		dst_store(L.dst, ch, q, y[idx]);
+	}
+}
+
+// ------------------------------------------------------------------------------------ interpolators
+
+// whole-step polyphase FIR: tile of outputs [j0, j1) of channel ch; x tile staged in `xs`
+R8B_HD void whole_tile_span(const WholeLaunch& L, long long j0, long long j1, long long* lo,
+	int* len)
+{
+	const long long r0 = j0 * L.in_step / L.out_step - L.fll;
+	const long long r1 = (j1 - 1) * L.in_step / L.out_step + L.fl2;
+	*lo = r0;
+	*len = (int) (r1 - r0 + 1);
+}
+
+R8B_HD void whole_load(const WholeLaunch& L, double* xs, long long lo, int len, int ch, int tid,
+	int nthr)
+{
+	for (int i = tid; i < len; i += nthr) xs[i] = src_load(L.src, ch, lo + i);
+}
+
+R8B_HD void whole_compute(const WholeLaunch& L, const double* xs, long long lo, long long j0,
+	long long j1, int ch, int tid, int nthr)
+{
+	for (long long j = j0 + tid; j < j1; j += nthr)
+	{
+		const long long p = j * L.in_step;
+		const long long r = p / L.out_step;
+		const int ph = (int) (p - r * L.out_step);
+		const double* row = L.table + (long) ph * L.flen;
+		const double* x = xs + (r - L.fll - lo);
+		double s = 0.0;
+		for (int i = 0; i < L.flen; i++) s += row[i] * x[i];
+		dst_store(L.dst, ch, j, s);
+	}
+}
+
+// polynomial-interpolated bank: output number i of this call (absolute index L.a + i)
+R8B_HD void poly_position(const PolyLaunch& L, long long i, long long* rpos, double* fpos)
+{
+	// bit-identical to the host plan's counter (r8b_plan.cpp): no fused multiply-add here
+#pragma clang fp contract(off)
+	if (i == 0)
+	{
+		*rpos = L.rpos0;
+		*fpos = L.fpos0;
+		return;
+	}
+	const double nxt = ((double) (L.counter0 + i) + L.shift) * L.ssr / L.dsr;
+	const long long ni = (long long) nxt;
+	*rpos = L.rpos0 + (ni - L.pos_int0);
+	*fpos = nxt - (double) ni;
+}
+
+R8B_HD double poly_one(const PolyLaunch& L, int ch, long long i)
+{
+	long long rpos;
+	double fpos;
+	poly_position(L, i, &rpos, &fpos);
+	double x, x2;
+	int fti;
+	{
+#pragma clang fp contract(off)
+		x = fpos * L.fracs;
+		fti = (int) x;
+		x -= fti;
+		x2 = x * x;
+	}
+	const double* c = L.table + (long) fti * L.flen * 3;
+	double s = 0.0;
+	for (int t = 0; t < L.flen; t++)
+	{
+		const double coef = c[0] + c[1] * x + c[2] * x2;
+		s += coef * src_load(L.src, ch, rpos - L.fll + t);
+		c += 3;
+	}
+	return s;
+}
+
+// ------------------------------------------------------------------------------------ half-band
+
+// 2x up: tile of input indices [n0, n1); xs holds x[n0 - T + 1 .. n1 + T - 1 + 1)
+R8B_HD void hbup_compute(const HBLaunch& L, const double* xs, long long n0, long long n1, int ch,
+	int tid, int nthr)
+{
+	const int T = L.ntaps;
+	for (long long n = n0 + tid; n < n1; n += nthr)
+	{
+		const double* x = xs + (n - n0) + (T - 1); // x[0] == stream x[n]
+		double s = 0.0;
+		for (int k = 0; k < T; k++) s += L.taps[k] * (x[1 + k] + x[-k]);
+		const long long q = 2 * n;
+		if (q >= L.a && q < L.b) dst_store(L.dst, ch, q, x[0]);
+		if (q + 1 >= L.a && q + 1 < L.b) dst_store(L.dst, ch, q + 1, s);
+	}
+}
+
+// 2x down: tile of output indices [n0, n1); xs holds x[2 n0 - 2T + 1 .. 2 (n1-1) + 2T - 1]
+R8B_HD void hbdown_compute(const HBLaunch& L, const double* xs, long long n0, long long n1, int ch,
+	int tid, int nthr)
+{
+	const int T = L.ntaps;
+	for (long long n = n0 + tid; n < n1; n += nthr)
+	{
+		const double* x = xs + 2 * (n - n0) + (2 * T - 1); // x[0] == stream x[2n]
+		double s = x[0];
+		for (int k = 0; k < T; k++) s += L.taps[k] * (x[1 + 2 * k] + x[-1 - 2 * k]);
+		dst_store(L.dst, ch, n, s);
+	}
+}
+
+} // namespace r8bhip
+
+#endif

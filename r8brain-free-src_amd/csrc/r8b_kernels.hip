@@ -1,0 +1,264 @@
+// r8b_kernels.hip -- gfx950 kernels and launchers of the batched resampler (generic, unfused
+// stage kernels: one launch per stage per process() call).  The arithmetic of each phase lives in
+// r8b_kernel_phases.h; this file only arranges phases, barriers, LDS and grids.
+//
+// Grid convention: blockIdx.y = channel, blockIdx.x = tile (FFT block / output tile) of that
+// channel's stream.  All global accesses of a workgroup are contiguous runs of one channel's
+// stream (coalesced 8-byte lanes); tables (kernel spectrum, twiddles, polyphase bank) are small
+// and stay L2 resident.
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+
+#define R8B_HD __device__ __forceinline__
+#include "r8b_kernel_phases.h"
+
+namespace r8bhip {
+
+namespace {
+
+void check(hipError_t e, const char* what)
+{
+	if (e != hipSuccess)
+		throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// ------------------------------------------------------------------ overlap-save block convolver
+// one workgroup = one FFT block of one channel, everything between the global load of the input
+// samples and the global store of the valid outputs stays in LDS
+__global__ void k_conv(const ConvLaunch L)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	double* const ra = reinterpret_cast<double*>(smem);
+	cd* const za = reinterpret_cast<cd*>(smem);
+	double* const rb = ra + L.n_in;
+	cd* const zb = reinterpret_cast<cd*>(rb);
+	const int tid = threadIdx.x, nthr = blockDim.x;
+	const long long k = L.k0 + blockIdx.x;
+	const int ch = blockIdx.y;
+
+	conv_load(L, ra, k, ch, tid, nthr);
+	__syncthreads();
+	const int N = L.n_in / 2;
+	int n = N;
+	for (int p = 0; p < L.n_fwd; p++)
+	{
+		fft_pass(za, N, n, L.fwd_radix[p], false, L.tw, L.tw_len, tid, nthr);
+		n /= L.fwd_radix[p];
+		__syncthreads();
+	}
+	conv_spectral(L, za, zb, tid, nthr);
+	__syncthreads();
+	const int N2 = L.n_out / 2;
+	n = 1;
+	for (int p = 0; p < L.n_inv; p++)
+	{
+		n *= L.inv_radix[p];
+		fft_pass(zb, N2, n, L.inv_radix[p], true, L.tw, L.tw_len, tid, nthr);
+		__syncthreads();
+	}
+	conv_store(L, rb, k, ch, tid, nthr);
+}
+
+// ------------------------------------------------------------------ whole-step polyphase FIR
+__global__ void k_whole(const WholeLaunch L)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	double* const xs = reinterpret_cast<double*>(smem);
+	const int tid = threadIdx.x, nthr = blockDim.x;
+	const int ch = blockIdx.y;
+	const long long j0 = L.a + (long long) blockIdx.x * L.tile;
+	long long j1 = j0 + L.tile;
+	if (j1 > L.b) j1 = L.b;
+	long long lo;
+	int len;
+	whole_tile_span(L, j0, j1, &lo, &len);
+	whole_load(L, xs, lo, len, ch, tid, nthr);
+	__syncthreads();
+	whole_compute(L, xs, lo, j0, j1, ch, tid, nthr);
+}
+
+// ------------------------------------------------------------------ polynomial-interpolated bank
+__global__ void k_poly(const PolyLaunch L)
+{
+	const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+	const int ch = blockIdx.y;
+	if (L.a + i < L.b) dst_store(L.dst, ch, L.a + i, poly_one(L, ch, i));
+}
+
+// ------------------------------------------------------------------ half-band stages
+__global__ void k_hbup(const HBLaunch L)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	double* const xs = reinterpret_cast<double*>(smem);
+	const int tid = threadIdx.x, nthr = blockDim.x;
+	const int ch = blockIdx.y;
+	const int T = L.ntaps;
+	const long long nb = L.a / 2, ne = (L.b + 1) / 2;
+	const long long n0 = nb + (long long) blockIdx.x * L.tile;
+	long long n1 = n0 + L.tile;
+	if (n1 > ne) n1 = ne;
+	const long long lo = n0 - (T - 1);
+	const int len = (int) (n1 - n0) + 2 * T - 1;
+	for (int i = tid; i < len; i += nthr) xs[i] = src_load(L.src, ch, lo + i);
+	__syncthreads();
+	hbup_compute(L, xs, n0, n1, ch, tid, nthr);
+}
+
+__global__ void k_hbdown(const HBLaunch L)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	double* const xs = reinterpret_cast<double*>(smem);
+	const int tid = threadIdx.x, nthr = blockDim.x;
+	const int ch = blockIdx.y;
+	const int T = L.ntaps;
+	const long long n0 = L.a + (long long) blockIdx.x * L.tile;
+	long long n1 = n0 + L.tile;
+	if (n1 > L.b) n1 = L.b;
+	const long long lo = 2 * n0 - (2 * T - 1);
+	const int len = (int) (2 * (n1 - n0 - 1) + 1) + 2 * (2 * T - 1);
+	for (int i = tid; i < len; i += nthr) xs[i] = src_load(L.src, ch, lo + i);
+	__syncthreads();
+	hbdown_compute(L, xs, n0, n1, ch, tid, nthr);
+}
+
+// ------------------------------------------------------------------ history tail of the caller's buffer
+__global__ void k_tail(const TailLaunch L)
+{
+	const long long i = L.p0 + (long long) blockIdx.x * blockDim.x + threadIdx.x;
+	const int ch = blockIdx.y;
+	if (i < L.p1)
+		L.ring[(long long) ch * L.ring_stride + (i & L.ring_mask)] =
+			L.cur[(long long) ch * L.cur_stride + (i - L.cur_base)];
+}
+
+bool g_attr_done = false;
+
+void set_lds_attrs()
+{
+	if (g_attr_done) return;
+	const int big = 160 * 1024;
+	check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv),
+		hipFuncAttributeMaxDynamicSharedMemorySize, big), "hipFuncSetAttribute(k_conv)");
+	check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_whole),
+		hipFuncAttributeMaxDynamicSharedMemorySize, big), "hipFuncSetAttribute(k_whole)");
+	g_attr_done = true;
+}
+
+} // namespace
+
+void launch_conv(const ConvLaunch& L, void* stream)
+{
+	set_lds_attrs();
+	const size_t lds = (size_t) (L.n_in + L.n_out) * sizeof(double);
+	hipLaunchKernelGGL(k_conv, dim3((unsigned) L.nblk, (unsigned) L.nch), dim3((unsigned) L.threads),
+		lds, (hipStream_t) stream, L);
+	check(hipGetLastError(), "launch k_conv");
+}
+
+void launch_whole(const WholeLaunch& L, void* stream)
+{
+	set_lds_attrs();
+	const long long n = L.b - L.a;
+	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
+	hipLaunchKernelGGL(k_whole, dim3(tiles, (unsigned) L.nch), dim3(256),
+		(size_t) L.span_max * sizeof(double), (hipStream_t) stream, L);
+	check(hipGetLastError(), "launch k_whole");
+}
+
+void launch_poly(const PolyLaunch& L, void* stream)
+{
+	const long long n = L.b - L.a;
+	hipLaunchKernelGGL(k_poly, dim3((unsigned) ((n + 255) / 256), (unsigned) L.nch), dim3(256), 0,
+		(hipStream_t) stream, L);
+	check(hipGetLastError(), "launch k_poly");
+}
+
+void launch_hbup(const HBLaunch& L, void* stream)
+{
+	const long long n = (L.b + 1) / 2 - L.a / 2;
+	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
+	hipLaunchKernelGGL(k_hbup, dim3(tiles, (unsigned) L.nch), dim3(256),
+		(size_t) (L.tile + 2 * L.ntaps) * sizeof(double), (hipStream_t) stream, L);
+	check(hipGetLastError(), "launch k_hbup");
+}
+
+void launch_hbdown(const HBLaunch& L, void* stream)
+{
+	const long long n = L.b - L.a;
+	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
+	hipLaunchKernelGGL(k_hbdown, dim3(tiles, (unsigned) L.nch), dim3(256),
+		(size_t) (2 * L.tile + 4 * L.ntaps) * sizeof(double), (hipStream_t) stream, L);
+	check(hipGetLastError(), "launch k_hbdown");
+}
+
+void launch_tail(const TailLaunch& L, void* stream)
+{
+	const long long n = L.p1 - L.p0;
+	if (n <= 0) return;
+	hipLaunchKernelGGL(k_tail, dim3((unsigned) ((n + 255) / 256), (unsigned) L.nch), dim3(256), 0,
+		(hipStream_t) stream, L);
+	check(hipGetLastError(), "launch k_tail");
+}
+
+// ------------------------------------------------------------------ memory helpers
+
+void dev_select(int device)
+{
+	if (device >= 0) check(hipSetDevice(device), "hipSetDevice");
+	else
+	{
+		int cur = 0;
+		check(hipGetDevice(&cur), "hipGetDevice (is a HIP device visible? there is no CPU fallback)");
+	}
+}
+
+void* dev_alloc(size_t bytes)
+{
+	void* p = nullptr;
+	if (bytes == 0) bytes = 8;
+	check(hipMalloc(&p, bytes), "hipMalloc");
+	check(hipMemset(p, 0, bytes), "hipMemset");
+	return p;
+}
+
+void dev_free(void* p)
+{
+	if (p) (void) hipFree(p);
+}
+
+void dev_zero(void* p, size_t bytes, void* stream)
+{
+	check(hipMemsetAsync(p, 0, bytes, (hipStream_t) stream), "hipMemsetAsync");
+}
+
+void dev_upload(void* dst, const void* src, size_t bytes)
+{
+	check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), "hipMemcpy H2D");
+}
+
+void dev_upload_async(void* dst, const void* src, size_t bytes, void* stream)
+{
+	check(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t) stream),
+		"hipMemcpyAsync H2D");
+}
+
+void dev_download(void* dst, const void* src, size_t bytes, void* stream)
+{
+	check(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t) stream),
+		"hipMemcpyAsync D2H");
+	check(hipStreamSynchronize((hipStream_t) stream), "hipStreamSynchronize");
+}
+
+void dev_sync(void* stream)
+{
+	check(hipStreamSynchronize((hipStream_t) stream), "hipStreamSynchronize");
+}
+
+void dev_check_last(const char* what)
+{
+	check(hipGetLastError(), what);
+}
+
+} // namespace r8bhip

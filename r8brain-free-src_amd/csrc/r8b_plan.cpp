@@ -1,0 +1,261 @@
+// r8b_plan.cpp -- see r8b_plan.h.
+#include "r8b_plan.h"
+
+#include <cmath>
+#include <cstdio>
+
+namespace r8bhip {
+
+StagePlan make_stage_plan(const StageDesc& d)
+{
+	StagePlan s;
+	s.desc = d;
+	if (d.kind == kConv)
+	{
+		// geometry, reference CDSPBlockConvolver.h:62-185 (linear phase, PrevLatency 0,
+		// DoConsumeLatency)
+		const LpFilter& f = design_lp(d.a, d.b, d.c, d.d);
+		s.lp = &f;
+		ConvGeom& g = s.cg;
+		g.up = d.i0;
+		g.down = d.i1;
+		g.fl2 = f.fl2;
+		g.bl2 = 2 << f.block_len_bits;
+		const int ups = bit_occupancy(g.up) - 1;
+		g.up_pow2 = (1 << ups) == g.up;
+		if (g.up_pow2)
+		{
+			g.prev_len = (f.kernel_len - 1 + g.up - 1) / g.up;
+			g.in_len = g.bl2 - g.prev_len * g.up;
+			g.n_in = g.bl2 / g.up;
+		}
+		else
+		{
+			g.prev_len = f.kernel_len - 1;
+			g.in_len = g.bl2 - g.prev_len;
+			g.n_in = g.bl2;
+		}
+		g.latency = g.in_len + g.fl2;
+		const int dsh = bit_occupancy(g.down) - 1;
+		g.down_pow2 = ((1 << dsh) == g.down) && g.down > 1;
+		g.n_out = g.bl2;
+		if (g.down_pow2)
+		{
+			const int ilc = g.in_len & (g.down - 1);
+			g.prev_len += ilc;
+			g.in_len -= ilc;
+			g.latency -= ilc;
+			g.n_out = g.bl2 / g.down;
+		}
+	}
+	else if (d.kind == kFrac)
+	{
+		s.ssr = d.a;
+		s.dsr = d.b;
+		s.whole = whole_stepping(d.a, d.b, &s.in_step, &s.out_step);
+		// reference CDSPFracInterpolator.h:736-760
+		s.bank = s.whole ? &design_frac_bank(s.out_step, 1, 2, d.c, d.i0 != 0) :
+			&design_frac_bank(-1, 3, 8, d.c, d.i0 != 0);
+		s.flen = s.bank->filter_len;
+		s.fl2 = s.flen / 2;
+		s.fll = s.fl2 - 1;
+	}
+	else
+	{
+		s.hb_n = select_hb_filter(d.a, d.i0, d.i1 != 0, &s.hb_taps, &s.hb_att);
+	}
+	s.clear();
+	return s;
+}
+
+void StagePlan::clear()
+{
+	m = 0;
+	done = 0;
+	poly = PolyState();
+}
+
+long long StagePlan::total(long long mm) const
+{
+	switch (desc.kind)
+	{
+	case kConv:
+	{
+		// the stage swallows `latency` virtual samples, then keeps every down-th
+		const long long v = (long long) cg.up * mm - cg.latency;
+		return v <= 0 ? 0 : (v + cg.down - 1) / cg.down;
+	}
+	case kFrac:
+	{
+		// whole stepping: output j sits at input position floor(j*In/Out) and is emitted once
+		// fl2 further input samples exist
+		const long long lim = mm - fl2 - 1;
+		if (lim < 0) return 0;
+		return ((lim + 1) * out_step - 1) / in_step + 1;
+	}
+	case kHBUp:
+		return mm > hb_n ? 2 * (mm - hb_n) : 0;
+	case kHBDown:
+	{
+		const long long v = mm / 2 - hb_n + 1;
+		return v > 0 ? v : 0;
+	}
+	}
+	return 0;
+}
+
+void StagePlan::step(int l, long long* a, long long* b, PolyState* ps)
+{
+	m += l;
+	*a = done;
+	if (desc.kind == kFrac && !whole)
+	{
+		// literal restatement of the position counter (reference
+		// CDSPFracInterpolator.h:1153-1168) and of its per-call re-base (:907-919)
+		if (ps) *ps = poly;
+		long long n = 0;
+		PolyState st = poly;
+		while (m - st.rpos - fl2 > 0)
+		{
+			n++;
+			st.in_counter++;
+			const double nxt = ((double) st.in_counter + st.pos_shift) * ssr / dsr;
+			const int ni = (int) nxt;
+			st.rpos += ni - st.in_pos_int;
+			st.in_pos_int = ni;
+			st.pos_frac = nxt - ni;
+		}
+		if (st.in_counter > 1000)
+		{
+			st.in_counter = 0;
+			st.in_pos_int = 0;
+			st.pos_shift = st.pos_frac * dsr / ssr;
+		}
+		poly = st;
+		done += n;
+		*b = done;
+		return;
+	}
+	const long long t = total(m);
+	if (t > done) done = t;
+	*b = done;
+}
+
+int StagePlan::max_out_len(int maxin) const
+{
+	switch (desc.kind)
+	{
+	case kConv: // reference CDSPBlockConvolver.h:208-213
+		return (int) (((long long) maxin * cg.up + cg.down - 1) / cg.down);
+	case kFrac: // reference CDSPFracInterpolator.h:826-832
+		return (int) std::ceil(maxin * dsr / ssr) + 1;
+	case kHBUp: // reference CDSPHBUpsampler.h:647-652
+		return maxin * 2;
+	case kHBDown: // reference CDSPHBDownsampler.h:115-120
+		return (maxin + 1) >> 1;
+	}
+	return 0;
+}
+
+int StagePlan::in_len_before_out_pos(int pos) const
+{
+	switch (desc.kind)
+	{
+	case kConv: // reference CDSPBlockConvolver.h:192-196
+		return (int) ((cg.latency + (double) pos * cg.down) / cg.up + 0.0 * cg.down / cg.up);
+	case kFrac: // reference CDSPFracInterpolator.h:802-815
+		if (whole) return fl2 + (int) ((0 + (double) pos * in_step) / out_step);
+		return fl2 + (int) (0.0 + pos * ssr / dsr);
+	case kHBUp: // reference CDSPHBUpsampler.h:632-635
+		return hb_n + (int) ((0 + 0.0 + pos) * 0.5);
+	case kHBDown: // reference CDSPHBDownsampler.h:100-103
+		return 2 * hb_n - 1 + (int) ((0 + 0.0 + pos) * 2.0);
+	}
+	return 0;
+}
+
+int StagePlan::history() const
+{
+	switch (desc.kind)
+	{
+	case kConv:
+		// the earliest block the next call can touch starts less than 2*in_len virtual samples
+		// before the stream end and reaches bl2-in_len further back
+		return (cg.in_len + cg.bl2) / cg.up + 4;
+	case kFrac:
+		return 2 * flen + 4;
+	case kHBUp:
+		return 2 * hb_n + 4;
+	case kHBDown:
+		return 4 * hb_n + 4;
+	}
+	return 0;
+}
+
+std::string StagePlan::describe() const
+{
+	char buf[256];
+	switch (desc.kind)
+	{
+	case kConv:
+		snprintf(buf, sizeof(buf), "BlockConvolver: flt_len=%d in_len=%d io=%d/%d fft=%d/%d "
+			"latency=%d nfreq=%.6g tb=%.6g gain=%.6g\n", lp->kernel_len, cg.in_len, cg.up,
+			cg.down, cg.n_in, cg.n_out, cg.latency, desc.a, desc.b, desc.d);
+		break;
+	case kFrac:
+		snprintf(buf, sizeof(buf), "FracInterpolator: %.10g->%.10g whole=%d step=%d/%d taps=%d "
+			"fracs=%d order=%d\n", ssr, dsr, whole ? 1 : 0, in_step, out_step, flen, bank->fracs,
+			whole ? 0 : 2);
+		break;
+	case kHBUp:
+		snprintf(buf, sizeof(buf), "HBUpsampler: sti=%d third=%d taps=%d att=%.2f\n", desc.i0,
+			desc.i1, hb_n, hb_att);
+		break;
+	case kHBDown:
+		snprintf(buf, sizeof(buf), "HBDownsampler: sti=%d third=%d taps=%d att=%.2f\n", desc.i0,
+			desc.i1, hb_n, hb_att);
+		break;
+	}
+	return buf;
+}
+
+void ChainPlan::init(const std::vector<StageDesc>& descs, int maxin)
+{
+	stages.clear();
+	stage_max_in.clear();
+	max_in = maxin;
+	int mo = maxin;
+	for (const StageDesc& d : descs)
+	{
+		stages.push_back(make_stage_plan(d));
+		stage_max_in.push_back(mo);
+		mo = stages.back().max_out_len(mo);
+	}
+	max_out_len = mo;
+}
+
+void ChainPlan::clear()
+{
+	for (StagePlan& s : stages) s.clear();
+}
+
+int ChainPlan::in_len_before_out_pos(int pos) const
+{
+	int r = pos;
+	for (size_t i = stages.size(); i-- > 0;) r = stages[i].in_len_before_out_pos(r);
+	return r;
+}
+
+int ChainPlan::input_required(int nout) const
+{
+	return nout < 1 ? 0 : in_len_before_out_pos(nout - 1) + 1;
+}
+
+std::string ChainPlan::describe() const
+{
+	std::string s;
+	for (const StagePlan& st : stages) s += st.describe();
+	return s;
+}
+
+} // namespace r8bhip

@@ -1,0 +1,107 @@
+// r8b_plan.h -- host-side schedule of a resampler chain.
+//
+// All control flow on the resampling path is data independent: how many
+// samples each stage emits per process() call, and which absolute stream positions they are,
+// depends only on the rates, the filter geometry and the number of samples fed so far.  The plan
+// keeps that integer state for ONE stream; every channel of a batch follows it, and the kernels
+// are addressed by absolute stream position.
+//
+// Per stage the plan answers: after M input samples in total, how many output samples has the
+// reference's stage emitted (`total`)?  The closed forms restate
+//   CDSPBlockConvolver::process      reference CDSPBlockConvolver.h:252-354 (+ geometry :62-185)
+//   CDSPFracInterpolator::process    reference CDSPFracInterpolator.h:861-922, 991-1060, 1069-1179
+//   CDSPHBUpsampler::process         reference CDSPHBUpsampler.h:674-732
+//   CDSPHBDownsampler::process       reference CDSPHBDownsampler.h:137-239
+// and were checked call by call against the compiled reference (tests/test_plan.py).
+#ifndef R8B_PLAN_H
+#define R8B_PLAN_H
+
+#include <string>
+#include <vector>
+
+#include "r8b_design.h"
+
+namespace r8bhip {
+
+// Geometry of one overlap-save block convolver (reference CDSPBlockConvolver.h:62-185).
+struct ConvGeom
+{
+	int up = 1, down = 1;
+	int fl2 = 0;        // filter half length == filter latency
+	int bl2 = 0;        // BlockLen2: length of the circular block (virtual, upsampled rate)
+	int in_len = 0;     // InputLen: new virtual samples per block
+	int prev_len = 0;   // PrevInputLen (input-rate samples when up is 2^k, virtual otherwise)
+	int latency = 0;    // samples (virtual rate, before decimation) the stage swallows
+	int n_in = 0;       // length of the forward real FFT
+	int n_out = 0;      // length of the inverse real FFT
+	bool up_pow2 = true;   // up-sampling by spectrum replication (else explicit zero stuffing)
+	bool down_pow2 = false; // decimation by spectrum truncation (else strided pick)
+};
+
+// State of a CDSPFracInterpolator's non-whole-stepping position counter
+// (reference CDSPFracInterpolator.h:907-919, 1153-1168).
+struct PolyState
+{
+	long long rpos = 0;     // absolute integer input position of the next output
+	double pos_frac = 0.0;  // InPosFrac
+	int in_counter = 0;     // InCounter
+	int in_pos_int = 0;     // InPosInt
+	double pos_shift = 0.0; // InPosShift
+};
+
+struct StagePlan
+{
+	StageDesc desc;
+	// conv
+	ConvGeom cg;
+	const LpFilter* lp = nullptr;
+	// frac
+	bool whole = false;
+	int in_step = 0, out_step = 0;
+	const FracBank* bank = nullptr;
+	int flen = 0, fl2 = 0, fll = 0;
+	double ssr = 0, dsr = 0;
+	PolyState poly;      // state at the start of the next call
+	// half-band
+	const double* hb_taps = nullptr;
+	int hb_n = 0;
+	double hb_att = 0;
+
+	// stream counters
+	long long m = 0;     // input samples received so far
+	long long done = 0;  // output samples emitted so far
+
+	void clear();
+	// Feeds l more input samples; returns the absolute range [*a, *b) of output samples the
+	// reference's stage returns from this call.  For the polynomial interpolator *ps receives
+	// the counter state the call starts from.
+	void step(int l, long long* a, long long* b, PolyState* ps);
+	int max_out_len(int maxin) const;
+	int in_len_before_out_pos(int pos) const;
+	// number of input samples preceding position m that the next call may still read
+	int history() const;
+	std::string describe() const;
+
+private:
+	long long total(long long mm) const;
+};
+
+StagePlan make_stage_plan(const StageDesc& d);
+
+struct ChainPlan
+{
+	std::vector<StagePlan> stages;
+	int max_in = 0;
+	int max_out_len = 0;             // CDSPResampler::getMaxOutLen(0)
+	std::vector<int> stage_max_in;   // max new samples per call entering each stage
+
+	void init(const std::vector<StageDesc>& descs, int maxin);
+	void clear();
+	int in_len_before_out_pos(int pos) const; // reference CDSPResampler.h:406-421
+	int input_required(int nout) const;        // reference CDSPResampler.h:476-484
+	std::string describe() const;
+};
+
+} // namespace r8bhip
+
+#endif

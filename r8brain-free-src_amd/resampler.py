@@ -1,0 +1,227 @@
+"""Host-side mirror of the reference's front-end over the C ABI (include/r8bsrc.h).
+
+Names, arguments and behaviour follow r8b::CDSPResampler (reference CDSPResampler.h:117-120,
+406-421, 476-519, 521-529, 559-575, 592-651) and its presets CDSPResampler16 / 16IR / 24
+(:729-810), so the parity tests read like calls into the reference.  `BatchResampler` is the
+N-channel object the throughput numbers are quoted on: process() takes torch CUDA tensors (device
+memory and streams are the only things torch is used for).
+
+`lib=` lets the tests bind another library that exports the same ABI; the default is the HIP
+library and nothing else.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+fprLinearPhase = 0
+
+
+def _dptr(a):
+    return a.ctypes.data_as(_capi.dp)
+
+
+class _Base:
+    def __init__(self, lib):
+        self._lib = lib if lib is not None else _capi.load()
+        self._h = None
+
+    def _err(self):
+        return self._lib.r8b_last_error().decode()
+
+
+class BatchResampler(_Base):
+    """`nch` independent CDSPResampler streams sharing one schedule (C ABI part 2)."""
+
+    def __init__(self, SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand=2.0,
+                 ReqAtten=206.91, nch=1, device=-1, lib=None, stage=None):
+        super().__init__(lib)
+        self.nch = int(nch)
+        self.MaxInLen = int(aMaxInLen)
+        if stage is not None:
+            kind, a, b, c, d, i0, i1 = stage
+            self._h = self._lib.r8b_batch_create_stage(int(kind), a, b, c, d, int(i0), int(i1),
+                                                       self.MaxInLen, self.nch, int(device))
+        else:
+            self._h = self._lib.r8b_batch_create(SrcSampleRate, DstSampleRate, self.MaxInLen,
+                                                 ReqTransBand, ReqAtten, self.nch, int(device))
+        if not self._h:
+            raise RuntimeError(self._err())
+        self.max_out_len = self._lib.r8b_batch_max_out_len(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.r8b_batch_delete(self._h)
+            self._h = None
+
+    def getMaxOutLen(self, MaxInLen=0):
+        return self.max_out_len
+
+    def getInLenBeforeOutPos(self, ReqOutPos):
+        return self._lib.r8b_batch_inlen_before_outpos(self._h, int(ReqOutPos))
+
+    def getInputRequiredForOutput(self, ReqOutSamples):
+        return self._lib.r8b_batch_inlen(self._h, int(ReqOutSamples))
+
+    def clear(self):
+        self._lib.r8b_batch_clear(self._h)
+
+    def describe(self):
+        n = self._lib.r8b_batch_describe(self._h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self._lib.r8b_batch_describe(self._h, buf, n + 1)
+        return buf.value.decode()
+
+    def set_option(self, name, value):
+        if self._lib.r8b_batch_set_option(self._h, name.encode(), int(value)) != 0:
+            raise KeyError(name)
+
+    def process_ptr(self, d_in, in_stride, l, d_out, out_stride, stream=0):
+        """Raw device-pointer entry (r8b_batch_process)."""
+        n = self._lib.r8b_batch_process(self._h, C.c_void_p(d_in), in_stride, int(l),
+                                        C.c_void_p(d_out), out_stride, C.c_void_p(stream))
+        if n < 0:
+            raise RuntimeError(self._err())
+        return n
+
+    def process(self, x, out=None):
+        """x: float64 CUDA tensor [nch, l] (row stride >= l); returns a view [nch, n] of `out`
+        (allocated [nch, max_out_len] if not given).  Enqueues on torch's current stream."""
+        import torch
+        assert x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.shape[0] == self.nch
+        assert x.stride(1) == 1
+        l = x.shape[1]
+        if out is None:
+            out = torch.empty((self.nch, max(self.max_out_len, 1)), dtype=torch.float64,
+                              device=x.device)
+        assert out.is_cuda and out.dtype == torch.float64 and out.stride(1) == 1
+        assert out.shape[0] == self.nch and out.shape[1] >= self.max_out_len
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        n = self.process_ptr(x.data_ptr(), x.stride(0), l, out.data_ptr(), out.stride(0), stream)
+        return out[:, :n]
+
+    def process_host(self, x):
+        """x: float64 numpy [nch, l]; synchronous; returns numpy [nch, n]."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.ndim == 2 and x.shape[0] == self.nch
+        l = x.shape[1]
+        cap = max(self.max_out_len, 1)
+        out = np.empty((self.nch, cap), dtype=np.float64)
+        n = self._lib.r8b_batch_process_host(self._h, _dptr(x), l, l, _dptr(out), cap)
+        if n < 0:
+            raise RuntimeError(self._err())
+        return out[:, :n].copy()
+
+
+class CDSPResampler(_Base):
+    """Single stream through the reference's own five C-ABI symbols is `DLLResampler`; this class
+    mirrors the C++ front-end, i.e. arbitrary ReqAtten (the DLL only offers three presets)."""
+
+    def __init__(self, SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand=2.0,
+                 ReqAtten=206.91, ReqPhase=fprLinearPhase, lib=None, device=-1):
+        if ReqPhase != fprLinearPhase:
+            raise NotImplementedError("minimum-phase filters are out of scope (SURVEY.md 8f)")
+        super().__init__(lib)
+        self._b = BatchResampler(SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand, ReqAtten,
+                                 nch=1, device=device, lib=self._lib)
+        self.SrcSampleRate, self.DstSampleRate = SrcSampleRate, DstSampleRate
+        self.MaxInLen = int(aMaxInLen)
+
+    def getInLenBeforeOutPos(self, ReqOutPos):
+        return self._b.getInLenBeforeOutPos(ReqOutPos)
+
+    def getInputRequiredForOutput(self, ReqOutSamples):
+        return self._b.getInputRequiredForOutput(ReqOutSamples)
+
+    def getInLenBeforeOutStart(self, ReqOutPos=0):
+        """reference CDSPResampler.h:443-464: feed one zero sample at a time until the output
+        length passes ReqOutPos, then clear().  (Legacy/test helper; slow by design.)"""
+        inc = 0
+        outc = 0
+        one = np.zeros(1)
+        while True:
+            outc += len(self.process(one))
+            if outc > ReqOutPos:
+                self.clear()
+                return inc
+            inc += 1
+
+    def getMaxOutLen(self, MaxInLen=0):
+        return self._b.max_out_len
+
+    def getLatency(self):
+        return 0
+
+    def clear(self):
+        self._b.clear()
+
+    def process(self, ip0):
+        x = np.ascontiguousarray(ip0, dtype=np.float64).reshape(1, -1)
+        if self.SrcSampleRate == self.DstSampleRate:
+            return x[0].copy()
+        return self._b.process_host(x)[0]
+
+    def oneshot(self, ip, oplen):
+        """reference CDSPResampler.h:592-651."""
+        ip = np.asarray(ip, dtype=np.float64)
+        out = []
+        got = 0
+        pos = 0
+        while got < oplen:
+            if pos < len(ip):
+                blk = ip[pos:pos + self.MaxInLen]
+                pos += len(blk)
+            else:
+                blk = np.zeros(self.MaxInLen)
+            y = self.process(blk)
+            y = y[:oplen - got]
+            out.append(y)
+            got += len(y)
+        self.clear()
+        return np.concatenate(out) if out else np.zeros(0)
+
+
+class CDSPResampler16(CDSPResampler):
+    def __init__(self, SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand=2.0, **kw):
+        super().__init__(SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand, 136.45, **kw)
+
+
+class CDSPResampler16IR(CDSPResampler):
+    def __init__(self, SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand=2.0, **kw):
+        super().__init__(SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand, 109.56, **kw)
+
+
+class CDSPResampler24(CDSPResampler):
+    def __init__(self, SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand=2.0, **kw):
+        super().__init__(SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand, 180.15, **kw)
+
+
+class DLLResampler(_Base):
+    """The five drop-in symbols exactly as a C host would call them (reference DLL/r8bsrc.h)."""
+
+    r8brr16, r8brr16IR, r8brr24 = 0, 1, 2
+
+    def __init__(self, SrcSampleRate, DstSampleRate, MaxInLen, ReqTransBand=2.0, Res=2, lib=None):
+        super().__init__(lib)
+        self._h = self._lib.r8b_create(SrcSampleRate, DstSampleRate, int(MaxInLen), ReqTransBand,
+                                       int(Res))
+        if not self._h:
+            raise RuntimeError(self._err())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.r8b_delete(self._h)
+            self._h = None
+
+    def inlen(self, n):
+        return self._lib.r8b_inlen(self._h, int(n))
+
+    def clear(self):
+        self._lib.r8b_clear(self._h)
+
+    def process(self, ip0):
+        x = np.ascontiguousarray(ip0, dtype=np.float64)
+        op = _capi.dp()
+        n = self._lib.r8b_process(self._h, _dptr(x), len(x), C.byref(op))
+        return np.ctypeslib.as_array(op, shape=(n,)).copy() if n > 0 else np.zeros(0)

@@ -1,0 +1,54 @@
+"""Shared parity cases and the stream comparison helper used by the emulation tier (CPU) and the
+GPU tier.  Tolerance: direct parity vs the oracle on identical input, RMS <= 1e-15
+and peak <= 1e-13 on +-1.0 full-scale noise (the reference's own cross-build noise floor is
+3e-16 / 2.3e-15)."""
+import numpy as np
+
+import r8b_oracle as O
+
+RMS_TOL = 1e-15
+PEAK_TOL = 1e-13
+
+# (src, dst, maxin, chunk, n_in, tb, atten)
+STREAM_CASES = [
+    (44100.0, 96000.0, 4096, 4096, 4096 * 4, 2.0, 180.15),      # cfg2 topology
+    (96000.0, 44100.0, 4096, 1000, 4096 * 4, 2.0, 180.15),      # cfg3 topology, ragged chunks
+    (44100.0, 2822400.0, 1024, 1024, 4096, 2.0, 180.15),        # cfg5: convolver + 5 half-band up
+    (176400.0, 44100.0, 4096, 1000, 30000, 2.0, 180.15),        # half-band down + 2^k-down convolver
+    (2822400.0, 176400.0, 4096, 4096, 65536, 2.0, 180.15),      # sacd.cpp second pass
+    (44100.0, 44101.0, 1024, 100, 5000, 2.0, 180.15),           # polynomial-interpolated bank
+    (44100.0, 96000.0, 1024, 1, 1800, 2.0, 180.15),             # one sample per call
+    (48000.0, 44111.0, 512, 512, 5000, 2.0, 136.45),            # 16-bit preset, non-whole step
+    (64000.0, 48000.0, 1024, 333, 15000, 2.0, 180.15),          # 3/4: up 3, down 4
+    (44100.0, 132300.0, 1024, 1024, 15000, 2.0, 180.15),        # 3x up (zero stuffing)
+    (48000.0, 32000.0, 1024, 1024, 15000, 2.0, 180.15),         # 2/3: up 2, strided down 3
+    (11025.0, 96000.0, 512, 512, 3000, 2.0, 136.45),            # intermediate interpolation chain
+    (96000.0, 11025.0, 512, 512, 30000, 2.0, 136.45),           # deep decimation
+    (44100.0, 192000.0, 512, 512, 6000, 2.0, 180.15),           # interp -> convolver -> half-band
+    (96000.0, 48000.0, 512, 512, 9000, 5.0, 109.56),            # 1/2 via one convolver, 16IR preset
+    (44100.0, 48000.0, 512, 512, 9000, 0.5, 109.56),            # narrow transition band (long filter)
+    (44100.0, 88200.0, 512, 512, 6000, 45.0, 49.0),             # widest band, lowest attenuation
+    (44100.0, 44100.0, 512, 512, 1024, 2.0, 180.15),            # Src == Dst passthrough
+]
+
+
+def make_input(nch, n, seed0=1):
+    return np.stack([O.splitmix_uniform(seed0 + c, n) for c in range(nch)])
+
+
+def compare_stream(batch, src, dst, maxin, chunk, n, tb, att, nch, x=None):
+    """Feeds x (nch x n) through `batch` (anything with process_host) and through one oracle per
+    channel, call by call; asserts equal counts and returns the worst (rms, peak) difference."""
+    x = make_input(nch, n) if x is None else x
+    oracles = [O.OracleResampler(src, dst, maxin, tb, att) for _ in range(nch)]
+    worst_rms = worst_peak = 0.0
+    for i in range(0, n, chunk):
+        y = batch.process_host(x[:, i:i + chunk])
+        for c in range(nch):
+            yo = oracles[c].process(x[c, i:i + chunk]) if src != dst else x[c, i:i + chunk]
+            assert len(yo) == y.shape[1], (i, len(yo), y.shape)
+            if len(yo):
+                d = y[c] - yo
+                worst_rms = max(worst_rms, float(np.sqrt(np.mean(d * d))))
+                worst_peak = max(worst_peak, float(np.abs(d).max()))
+    return worst_rms, worst_peak

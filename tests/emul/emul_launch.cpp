@@ -1,0 +1,149 @@
+// tests/emul/emul_launch.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Host stand-in for r8b_kernels.hip so that the engine's schedule and the kernels' index
+// arithmetic can be unit-tested in a container without a GPU: it includes the very same
+// r8b_kernel_phases.h and runs every phase for tid = 0..nthr-1 in a loop, one loop per
+// barrier-separated phase ("device memory" is host memory).  It is built only by
+// tests/emul/Makefile into tests/emul/_build/libr8bsrc_emul.so and loaded only by tests/ --
+// never by the package, bench.py or __graft_entry__.  It is NOT a CPU fallback of the product:
+// libr8bsrc_hip.so does not contain it and fails loudly without a HIP device.
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#define R8B_HD inline
+#include "r8b_kernel_phases.h"
+
+namespace r8bhip {
+
+void launch_conv(const ConvLaunch& L, void*)
+{
+	std::vector<double> lds((size_t) (L.n_in + L.n_out) + 2);
+	// 16-byte alignment for the cd views
+	double* base = lds.data();
+	if (((size_t) base & 15) != 0) base++;
+	const int nthr = L.threads;
+	for (int ch = 0; ch < L.nch; ch++)
+		for (int bx = 0; bx < L.nblk; bx++)
+		{
+			double* ra = base;
+			cd* za = reinterpret_cast<cd*>(ra);
+			double* rb = ra + L.n_in;
+			cd* zb = reinterpret_cast<cd*>(rb);
+			const long long k = L.k0 + bx;
+			for (int t = 0; t < nthr; t++) conv_load(L, ra, k, ch, t, nthr);
+			const int N = L.n_in / 2;
+			int n = N;
+			for (int p = 0; p < L.n_fwd; p++)
+			{
+				for (int t = 0; t < nthr; t++)
+					fft_pass(za, N, n, L.fwd_radix[p], false, L.tw, L.tw_len, t, nthr);
+				n /= L.fwd_radix[p];
+			}
+			for (int t = 0; t < nthr; t++) conv_spectral(L, za, zb, t, nthr);
+			const int N2 = L.n_out / 2;
+			n = 1;
+			for (int p = 0; p < L.n_inv; p++)
+			{
+				n *= L.inv_radix[p];
+				for (int t = 0; t < nthr; t++)
+					fft_pass(zb, N2, n, L.inv_radix[p], true, L.tw, L.tw_len, t, nthr);
+			}
+			for (int t = 0; t < nthr; t++) conv_store(L, rb, k, ch, t, nthr);
+		}
+}
+
+void launch_whole(const WholeLaunch& L, void*)
+{
+	std::vector<double> xs((size_t) L.span_max);
+	const int nthr = 256;
+	const long long n = L.b - L.a;
+	const int tiles = (int) ((n + L.tile - 1) / L.tile);
+	for (int ch = 0; ch < L.nch; ch++)
+		for (int bx = 0; bx < tiles; bx++)
+		{
+			const long long j0 = L.a + (long long) bx * L.tile;
+			long long j1 = j0 + L.tile;
+			if (j1 > L.b) j1 = L.b;
+			long long lo;
+			int len;
+			whole_tile_span(L, j0, j1, &lo, &len);
+			if (len > L.span_max) throw std::runtime_error("emul: whole-step tile overflows LDS");
+			for (int t = 0; t < nthr; t++) whole_load(L, xs.data(), lo, len, ch, t, nthr);
+			for (int t = 0; t < nthr; t++) whole_compute(L, xs.data(), lo, j0, j1, ch, t, nthr);
+		}
+}
+
+void launch_poly(const PolyLaunch& L, void*)
+{
+	for (int ch = 0; ch < L.nch; ch++)
+		for (long long i = 0; L.a + i < L.b; i++) dst_store(L.dst, ch, L.a + i, poly_one(L, ch, i));
+}
+
+void launch_hbup(const HBLaunch& L, void*)
+{
+	const int nthr = 256, T = L.ntaps;
+	std::vector<double> xs((size_t) (L.tile + 2 * T));
+	const long long nb = L.a / 2, ne = (L.b + 1) / 2;
+	const int tiles = (int) ((ne - nb + L.tile - 1) / L.tile);
+	for (int ch = 0; ch < L.nch; ch++)
+		for (int bx = 0; bx < tiles; bx++)
+		{
+			const long long n0 = nb + (long long) bx * L.tile;
+			long long n1 = n0 + L.tile;
+			if (n1 > ne) n1 = ne;
+			const long long lo = n0 - (T - 1);
+			const int len = (int) (n1 - n0) + 2 * T - 1;
+			for (int i = 0; i < len; i++) xs[(size_t) i] = src_load(L.src, ch, lo + i);
+			for (int t = 0; t < nthr; t++) hbup_compute(L, xs.data(), n0, n1, ch, t, nthr);
+		}
+}
+
+void launch_hbdown(const HBLaunch& L, void*)
+{
+	const int nthr = 256, T = L.ntaps;
+	std::vector<double> xs((size_t) (2 * L.tile + 4 * T));
+	const long long n = L.b - L.a;
+	const int tiles = (int) ((n + L.tile - 1) / L.tile);
+	for (int ch = 0; ch < L.nch; ch++)
+		for (int bx = 0; bx < tiles; bx++)
+		{
+			const long long n0 = L.a + (long long) bx * L.tile;
+			long long n1 = n0 + L.tile;
+			if (n1 > L.b) n1 = L.b;
+			const long long lo = 2 * n0 - (2 * T - 1);
+			const int len = (int) (2 * (n1 - n0 - 1) + 1) + 2 * (2 * T - 1);
+			for (int i = 0; i < len; i++) xs[(size_t) i] = src_load(L.src, ch, lo + i);
+			for (int t = 0; t < nthr; t++) hbdown_compute(L, xs.data(), n0, n1, ch, t, nthr);
+		}
+}
+
+void launch_tail(const TailLaunch& L, void*)
+{
+	for (int ch = 0; ch < L.nch; ch++)
+		for (long long i = L.p0; i < L.p1; i++)
+			L.ring[(long long) ch * L.ring_stride + (i & L.ring_mask)] =
+				L.cur[(long long) ch * L.cur_stride + (i - L.cur_base)];
+}
+
+void dev_select(int) {}
+
+void* dev_alloc(size_t bytes)
+{
+	void* p = nullptr;
+	if (bytes == 0) bytes = 8;
+	if (posix_memalign(&p, 64, bytes) != 0) throw std::runtime_error("emul: out of memory");
+	memset(p, 0, bytes);
+	return p;
+}
+
+void dev_free(void* p) { free(p); }
+void dev_zero(void* p, size_t bytes, void*) { memset(p, 0, bytes); }
+void dev_upload(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+void dev_upload_async(void* dst, const void* src, size_t bytes, void*) { memcpy(dst, src, bytes); }
+void dev_download(void* dst, const void* src, size_t bytes, void*) { memcpy(dst, src, bytes); }
+void dev_sync(void*) {}
+void dev_check_last(const char*) {}
+
+} // namespace r8bhip

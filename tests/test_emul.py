@@ -1,0 +1,81 @@
+"""CPU tier: the engine's schedule (rings, block anchoring, per-call ranges) and the kernels' index
+arithmetic, exercised WITHOUT a GPU by tests/emul/ (the same r8b_kernel_phases.h run thread by
+thread on the host; test infrastructure, not part of the product) and compared with the oracle.
+The GPU tier (test_gpu_parity.py) repeats these cases on the real HIP path."""
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import r8b_oracle as O
+from cases import STREAM_CASES, RMS_TOL, PEAK_TOL, compare_stream, make_input
+from conftest import ROOT
+
+r8b = importlib.import_module("r8brain-free-src_amd")
+
+
+@pytest.fixture(scope="module")
+def emul():
+    d = os.path.join(ROOT, "tests", "emul")
+    subprocess.run(["make"], cwd=d, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return r8b.bind(os.path.join(d, "_build", "libr8bsrc_emul.so"))
+
+
+@pytest.mark.parametrize("case", STREAM_CASES)
+def test_emulated_engine_matches_oracle(emul, case):
+    src, dst, maxin, chunk, n, tb, att = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, lib=emul)
+    rms, pk = compare_stream(b, src, dst, maxin, chunk, n, tb, att, 2)
+    assert rms <= RMS_TOL and pk <= PEAK_TOL, (rms, pk)
+
+
+@pytest.mark.parametrize("radix,threads", [(2, 64), (4, 256), (16, 128)])
+def test_emulated_transform_plans(emul, radix, threads):
+    """every radix mix of the in-LDS FFT gives the same stream"""
+    src, dst, maxin, chunk, n, tb, att = STREAM_CASES[0]
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=1, lib=emul)
+    b.set_option("conv_radix", radix)
+    b.set_option("conv_threads", threads)
+    rms, pk = compare_stream(b, src, dst, maxin, chunk, n, tb, att, 1)
+    assert rms <= RMS_TOL and pk <= PEAK_TOL, (rms, pk)
+
+
+def test_emulated_chunk_invariance_is_bitwise(emul):
+    """blocks are anchored to absolute stream positions, so -- like the reference --
+    the stream does not depend on how the input is cut into calls"""
+    x = make_input(1, 9000, 11)
+    ref = None
+    for chunk in (1024, 1000, 777, 64):
+        b = r8b.BatchResampler(44100.0, 96000.0, 1024, 2.0, 180.15, nch=1, lib=emul)
+        y = np.concatenate([b.process_host(x[:, i:i + chunk])[0] for i in range(0, 9000, chunk)])
+        if ref is None:
+            ref = y
+        else:
+            assert np.array_equal(y, ref)
+
+
+def test_emulated_clear(emul):
+    x = make_input(2, 5000, 5)
+    b = r8b.BatchResampler(96000.0, 44100.0, 1024, 2.0, 180.15, nch=2, lib=emul)
+    y1 = np.concatenate([b.process_host(x[:, i:i + 1000]) for i in range(0, 5000, 1000)], axis=1)
+    b.clear()
+    y2 = np.concatenate([b.process_host(x[:, i:i + 1000]) for i in range(0, 5000, 1000)], axis=1)
+    assert np.array_equal(y1, y2)
+
+
+def test_emulated_dll_abi(emul):
+    """r8b_create ... r8b_process called the way a C host calls the reference DLL"""
+    x = O.splitmix_uniform(9, 4096)
+    d = r8b.DLLResampler(44100.0, 96000.0, 1024, 2.0, r8b.DLLResampler.r8brr24, lib=emul)
+    o = O.OracleResampler(44100.0, 96000.0, 1024, 2.0, 180.15)
+    assert d.inlen(1) == o.input_required(1)
+    for i in range(0, 4096, 1024):
+        a = d.process(x[i:i + 1024])
+        b = o.process(x[i:i + 1024])
+        assert len(a) == len(b)
+        if len(a):
+            assert np.abs(a - b).max() <= PEAK_TOL
+    d.clear()
+    assert len(d.process(x[:1024])) == 0
