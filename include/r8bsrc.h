@@ -120,6 +120,15 @@ R8BSRC_DECL int r8b_batch_describe(CR8BBatch b, char* buf, int cap);
  * ("fuse", "conv_threads", ...).  Returns 0 if the knob exists. */
 R8BSRC_DECL int r8b_batch_set_option(CR8BBatch b, const char* name, int value);
 
+/* Instrumentation: with option "timing" = 1 every stage launch is bracketed by HIP events on the
+ * caller's stream.  r8b_batch_stage_timing waits for the pending events of `stage` and returns
+ * the accumulated kernel milliseconds and launch count since the previous query (then resets),
+ * the per-channel input/output sample counts those launches covered, and the kernel's name.
+ * 0 on success. */
+R8BSRC_DECL int r8b_batch_stage_count(CR8BBatch b);
+R8BSRC_DECL int r8b_batch_stage_timing(CR8BBatch b, int stage, double* ms_sum, int* launches,
+	long long* in_samples, long long* out_samples, char* kernel, int cap);
+
 /* Last error message of the calling thread ("" if none). */
 R8BSRC_DECL const char* r8b_last_error(void);
 

@@ -204,6 +204,29 @@ R8BSRC_DECL int r8b_batch_set_option(CR8BBatch b, const char* name, int value)
 	return ((Batch*) b)->eng->set_option(name, value) ? 0 : -1;
 }
 
+R8BSRC_DECL int r8b_batch_stage_count(CR8BBatch b)
+{
+	return (int) ((Batch*) b)->eng->plan().stages.size();
+}
+
+R8BSRC_DECL int r8b_batch_stage_timing(CR8BBatch b, int stage, double* ms_sum, int* launches,
+	long long* in_samples, long long* out_samples, char* kernel, int cap)
+{
+	try
+	{
+		std::string name;
+		if (!((Batch*) b)->eng->stage_timing((size_t) stage, ms_sum, launches, &name,
+			in_samples, out_samples)) return -1;
+		copy_text(name, kernel, cap);
+		return 0;
+	}
+	catch (const std::exception& e)
+	{
+		set_err("r8b_batch_stage_timing", e);
+		return -1;
+	}
+}
+
 // ---------------------------------------------------------------- drop-in single-stream ABI
 
 R8BSRC_DECL CR8BResampler r8b_create(double SrcSampleRate, double DstSampleRate, int MaxInLen,

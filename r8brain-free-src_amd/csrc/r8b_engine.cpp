@@ -109,6 +109,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["conv_threads"] = 256;
 	opt_["whole_tile"] = 1024;
 	opt_["hb_tile"] = 1024;
+	opt_["timing"] = 0;
 	dev_.resize(plan_.stages.size());
 	for (size_t s = 0; s < plan_.stages.size(); s++)
 	{
@@ -147,6 +148,12 @@ Engine::~Engine()
 {
 	for (StageDev& d : dev_)
 	{
+		for (auto& pr : d.pending)
+		{
+			dev_event_destroy(pr.first);
+			dev_event_destroy(pr.second);
+		}
+		for (void* e : d.free_events) dev_event_destroy(e);
 		dev_free(d.ring);
 		dev_free(d.H);
 		dev_free(d.tw);
@@ -173,6 +180,51 @@ bool Engine::set_option(const std::string& name, int value)
 	if (it == opt_.end()) return false;
 	it->second = value;
 	plan_transforms();
+	return true;
+}
+
+void* Engine::get_event(StageDev& d)
+{
+	if (!d.free_events.empty())
+	{
+		void* e = d.free_events.back();
+		d.free_events.pop_back();
+		return e;
+	}
+	return dev_event_create();
+}
+
+bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::string* kernel,
+	long long* in_samples, long long* out_samples)
+{
+	if (stage >= dev_.size()) return false;
+	StageDev& d = dev_[stage];
+	for (auto& pr : d.pending)
+	{
+		d.ms_sum += dev_event_elapsed_ms(pr.first, pr.second);
+		d.launches++;
+		d.free_events.push_back(pr.first);
+		d.free_events.push_back(pr.second);
+	}
+	d.pending.clear();
+	if (ms_sum) *ms_sum = d.ms_sum;
+	if (launches) *launches = d.launches;
+	if (in_samples) *in_samples = d.t_in;
+	if (out_samples) *out_samples = d.t_out;
+	if (kernel)
+	{
+		const StagePlan& sp = plan_.stages[stage];
+		switch (sp.desc.kind)
+		{
+		case kConv: *kernel = "k_conv"; break;
+		case kFrac: *kernel = sp.whole ? "k_whole" : "k_poly"; break;
+		case kHBUp: *kernel = "k_hbup"; break;
+		case kHBDown: *kernel = "k_hbdown"; break;
+		}
+	}
+	d.ms_sum = 0.0;
+	d.launches = 0;
+	d.t_in = d.t_out = 0;
 	return true;
 }
 
@@ -323,7 +375,21 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 			dst.mask = dev_[s + 1].ring_size - 1;
 			dst.off = 0;
 		}
-		if (b > a) launch_stage(s, m_prev, a, b, ps, src, dst, stream);
+		if (b > a)
+		{
+			if (opt_.at("timing"))
+			{
+				void* e0 = get_event(dev_[s]);
+				void* e1 = get_event(dev_[s]);
+				dev_event_record(e0, stream);
+				launch_stage(s, m_prev, a, b, ps, src, dst, stream);
+				dev_event_record(e1, stream);
+				dev_[s].pending.emplace_back(e0, e1);
+				dev_[s].t_in += n;
+				dev_[s].t_out += b - a;
+			}
+			else launch_stage(s, m_prev, a, b, ps, src, dst, stream);
+		}
 		if (s == 0)
 		{
 			// keep the tail of the caller's buffer as history for the next call

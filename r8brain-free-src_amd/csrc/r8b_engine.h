@@ -10,6 +10,7 @@
 #define R8B_ENGINE_H
 
 #include <map>
+#include <utility>
 #include <string>
 #include <vector>
 
@@ -32,6 +33,11 @@ public:
 	void clear();
 	bool set_option(const std::string& name, int value);
 
+	// per-stage kernel time accumulated since the last call (only while option "timing" is 1):
+	// resolves pending events, returns total milliseconds and the number of launches
+	bool stage_timing(size_t stage, double* ms_sum, int* launches, std::string* kernel,
+		long long* in_samples, long long* out_samples);
+
 	const ChainPlan& plan() const { return plan_; }
 	int channels() const { return nch_; }
 	int device() const { return device_; }
@@ -46,7 +52,13 @@ private:
 		int tw_len = 0;
 		double* table = nullptr;
 		std::vector<int> fwd_radix, inv_radix;
+		std::vector<std::pair<void*, void*>> pending; // (start, stop) events not yet read
+		std::vector<void*> free_events;
+		double ms_sum = 0.0;
+		int launches = 0;
+		long long t_in = 0, t_out = 0; // per-channel samples in/out over the timed launches
 	};
+	void* get_event(StageDev& d);
 
 	void plan_transforms();
 	void launch_stage(size_t s, long long m_prev, long long a, long long b, const PolyState& ps,

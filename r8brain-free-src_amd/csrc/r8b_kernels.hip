@@ -261,4 +261,29 @@ void dev_check_last(const char* what)
 	check(hipGetLastError(), what);
 }
 
+void* dev_event_create()
+{
+	hipEvent_t e;
+	check(hipEventCreate(&e), "hipEventCreate");
+	return e;
+}
+
+void dev_event_destroy(void* ev)
+{
+	if (ev) (void) hipEventDestroy((hipEvent_t) ev);
+}
+
+void dev_event_record(void* ev, void* stream)
+{
+	check(hipEventRecord((hipEvent_t) ev, (hipStream_t) stream), "hipEventRecord");
+}
+
+float dev_event_elapsed_ms(void* start, void* stop)
+{
+	float ms = 0.f;
+	check(hipEventSynchronize((hipEvent_t) stop), "hipEventSynchronize");
+	check(hipEventElapsedTime(&ms, (hipEvent_t) start, (hipEvent_t) stop), "hipEventElapsedTime");
+	return ms;
+}
+
 } // namespace r8bhip

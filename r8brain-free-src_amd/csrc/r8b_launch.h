@@ -129,6 +129,11 @@ void dev_download(void* dst, const void* src, size_t bytes, void* stream); // sy
 void dev_upload_async(void* dst, const void* src, size_t bytes, void* stream);
 void dev_sync(void* stream);
 void dev_check_last(const char* what);
+// events for the optional per-stage timing (hipEvent_t on the launching stream)
+void* dev_event_create();
+void dev_event_destroy(void* ev);
+void dev_event_record(void* ev, void* stream);
+float dev_event_elapsed_ms(void* start, void* stop); // waits for `stop`
 
 } // namespace r8bhip
 

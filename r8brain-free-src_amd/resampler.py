@@ -77,6 +77,20 @@ class BatchResampler(_Base):
         if self._lib.r8b_batch_set_option(self._h, name.encode(), int(value)) != 0:
             raise KeyError(name)
 
+    def stage_timings(self):
+        """[(kernel name, total ms, launches, samples in, samples out)] per stage since the last
+        query (needs set_option("timing", 1)); sample counts are per channel; waits for the
+        recorded events."""
+        res = []
+        for s in range(self._lib.r8b_batch_stage_count(self._h)):
+            ms, n = C.c_double(), C.c_int()
+            si, so = C.c_longlong(), C.c_longlong()
+            name = C.create_string_buffer(64)
+            if self._lib.r8b_batch_stage_timing(self._h, s, ms, n, si, so, name, 64) != 0:
+                raise RuntimeError(self._err())
+            res.append((name.value.decode(), ms.value, n.value, si.value, so.value))
+        return res
+
     def process_ptr(self, d_in, in_stride, l, d_out, out_stride, stream=0):
         """Raw device-pointer entry (r8b_batch_process)."""
         n = self._lib.r8b_batch_process(self._h, C.c_void_p(d_in), in_stride, int(l),

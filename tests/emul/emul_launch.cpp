@@ -145,5 +145,9 @@ void dev_upload_async(void* dst, const void* src, size_t bytes, void*) { memcpy(
 void dev_download(void* dst, const void* src, size_t bytes, void*) { memcpy(dst, src, bytes); }
 void dev_sync(void*) {}
 void dev_check_last(const char*) {}
+void* dev_event_create() { return nullptr; }
+void dev_event_destroy(void*) {}
+void dev_event_record(void*, void*) {}
+float dev_event_elapsed_ms(void*, void*) { return 0.f; }
 
 } // namespace r8bhip
