@@ -72,7 +72,8 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(_HERE, LIB_NAME)
+    # R8B_HIP_LIB: kernel-tuning experiments load an alternative BUILD of the same HIP library
+    return os.environ.get("R8B_HIP_LIB") or os.path.join(_HERE, LIB_NAME)
 
 
 def load():

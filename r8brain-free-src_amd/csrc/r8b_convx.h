@@ -1,0 +1,642 @@
+// r8b_convx.h -- the fast path: one workgroup = one overlap-save block of one channel, with
+// compile-time transform sizes, and (MODE 1) the whole-step polyphase interpolator of the NEXT
+// stage fused behind the inverse transform, so that the 2x-rate convolver output never leaves LDS.
+//
+// Covers block convolvers with a 2^k-point geometry, up-sampling 1 or 2 and no decimation -- the
+// first stage of every up-sampling and mild down-sampling chain of the reference
+// (CDSPResampler.h:218-330) including BASELINE configs 1-5.  Everything else takes the generic
+// kernels of r8b_kernel_phases.h.
+//
+// Differences from the generic convolver kernel, all about where cycles and LDS bytes go:
+//  * LDS holds ONE complex work array (in-place transforms), padded by one complex every 16 so
+//    that both the stride-q passes and the contiguous-per-thread passes are bank-conflict free;
+//  * the spectral stage runs in place: each thread first pulls its forward bins into registers,
+//    then (after a barrier) writes the backward-transform inputs they determine;
+//  * the last backward pass keeps its results in registers across a barrier and then writes the
+//    block's VALID outputs only, rotated so that they form one linear run y[0..in_len) in LDS;
+//  * twiddles of pass p+1 are fetched from the L2-resident table BEFORE the barrier that ends
+//    pass p, so their latency overlaps the barrier wait;
+//  * MODE 1: thread t < OutStep keeps polyphase row (t*InStep mod OutStep) in registers and
+//    produces outputs j = t (mod OutStep) of the block, reading y straight from LDS.  In this
+//    mode consecutive blocks start blk_stride = in_len - flen (rounded to the up factor) virtual
+//    samples apart instead of in_len, i.e. their valid output ranges overlap by one interpolator
+//    filter length, so every tap window lies inside one block and nothing is exchanged between
+//    workgroups (cost: < 1 % more blocks).
+//
+// Reference semantics reproduced: CDSPBlockConvolver.h:252-354, 512-593, 606-629;
+// CDSPRealFFT.h:289-385; CDSPFracInterpolator.h:991-1060.
+#ifndef R8B_CONVX_H
+#define R8B_CONVX_H
+
+#include "r8b_kernel_phases.h"
+
+namespace r8bhip {
+
+static const int kConvxThreads = 256;
+
+// offset (doubles, multiple of 2) of the one-sample-shifted copy y1[u] = y[u + 1] of the linear run
+// = 16 (mod 32) doubles, i.e. half a 256-byte LDS bank row away from y: a wave reads even window
+// starts from y and odd ones from y1 at nearly the same index, and must not hit the same banks
+R8B_HD int cx_y1_offset(int in_len) { return ((in_len + 8 + 31) & ~31) + 16; }
+
+// padded complex index: one spare slot after every 16
+R8B_HD int cpad(int e) { return e + (e >> 4); }
+// padded index of real sample i when the reals are viewed as packed complex pairs
+R8B_HD int rpad(int i) { return i + ((i >> 5) << 1); }
+
+constexpr int convx_lds_doubles(int logn2) { return 2 * ((1 << logn2) + ((1 << logn2) >> 4)); }
+// LDS doubles a workgroup needs: the padded work array, which the linear output run (and in
+// fused mode its one-sample-shifted copy) aliases once the last backward pass sits in registers
+inline int convx_lds_need(int logn2, int in_len, int mode)
+{
+	const int work = convx_lds_doubles(logn2);
+	const int y1 = ((in_len + 8 + 31) & ~31) + 16;
+	const int run = mode == 1 ? y1 + in_len + 16 : in_len + 8;
+	return work > run ? work : run;
+}
+
+// log2 radix of the pass that touches the full length (first DIF pass / last DIT pass): sized so
+// that one butterfly per thread covers the array when possible
+constexpr int big_pass_bits(int logn)
+{
+	return logn - 8 < 1 ? 1 : (logn - 8 > 4 ? 4 : logn - 8);
+}
+
+// number of remaining passes and their log2 radices (as even as possible, each <= 4)
+constexpr int rest_passes(int logn) { return (logn - big_pass_bits(logn) + 3) / 4; }
+constexpr int rest_bits(int logn, int i)
+{
+	const int bits = logn - big_pass_bits(logn), np = rest_passes(logn);
+	return (bits + np - 1 - i) / np;
+}
+
+// per-thread state that lives in registers across barriers
+template<int LOGN, int UPLOG>
+struct ConvxState
+{
+	static constexpr int N = 1 << LOGN, N2 = N << UPLOG;
+	static constexpr int SP = (N / 2 + 1 + kConvxThreads - 1) / kConvxThreads;
+	static constexpr int RL = 1 << big_pass_bits(LOGN + UPLOG);
+	static constexpr int FIN = (N2 / RL + kConvxThreads - 1) / kConvxThreads;
+	cd tw[6];
+	cd sp[SP][2];
+	double fr[FIN][RL], fi[FIN][RL];
+	double row[32];
+};
+
+// ---- transform passes over the padded array -------------------------------------------------
+
+// Twiddles of a radix-R butterfly are w^(j*i), i = 1..R-1.  Only the "base" powers
+// i in {1,2,3} and {4,8,12} are fetched (6 values for R = 16, 4 for R = 8, 3 for R = 4); the
+// others are products base[i & 3] * base[i & 12], formed on the fly: 24 registers instead of 60.
+template<int R>
+R8B_HD void tw_fetch(cd* twr, const cd* tw, int tw_len, int n, int j)
+{
+	const int ts = tw_len / n * j;
+	twr[0] = tw[ts];
+	if constexpr (R >= 4)
+	{
+		twr[1] = tw[ts * 2];
+		twr[2] = tw[ts * 3];
+	}
+	if constexpr (R >= 8) twr[3] = tw[ts * 4];
+	if constexpr (R >= 16)
+	{
+		twr[4] = tw[ts * 8];
+		twr[5] = tw[ts * 12];
+	}
+}
+
+// w^(j*i) from the base set (i is a compile-time constant after unrolling)
+R8B_HD cd tw_get(const cd* twr, int i)
+{
+	const int lo = i & 3, hi = i >> 2;
+	if (hi == 0) return twr[lo - 1];
+	if (lo == 0) return twr[2 + hi];
+	const cd a = twr[lo - 1], b = twr[2 + hi];
+	cd r;
+	r.re = a.re * b.re - a.im * b.im;
+	r.im = a.re * b.im + a.im * b.re;
+	return r;
+}
+
+template<int R, bool TW>
+R8B_HD void xdif(cd* buf, int n, int b, const cd* twr)
+{
+	const int q = n / R;
+	const int blk = b / q, j = b - blk * q;
+	const int e0 = blk * n + j;
+	double vr[R], vi[R];
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		const cd v = buf[cpad(e0 + p * q)];
+		vr[p] = v.re;
+		vi[p] = v.im;
+	}
+	dif_regs<R>(vr, vi);
+	if constexpr (TW)
+	{
+#pragma unroll
+		for (int p = 1; p < R; p++)
+		{
+			const cd w = tw_get(twr, bitrev_c<R>(p));
+			const double tr = vr[p] * w.re - vi[p] * w.im;
+			const double ti = vr[p] * w.im + vi[p] * w.re;
+			vr[p] = tr;
+			vi[p] = ti;
+		}
+	}
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		cd v;
+		v.re = vr[p];
+		v.im = vi[p];
+		buf[cpad(e0 + p * q)] = v;
+	}
+}
+
+// backward butterfly; results stay in vr/vi (the caller stores them)
+template<int R, bool TW>
+R8B_HD void xdit_regs(const cd* buf, int n, int b, const cd* twr, double* vr, double* vi)
+{
+	const int q = n / R;
+	const int blk = b / q, j = b - blk * q;
+	const int e0 = blk * n + j;
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		const cd v = buf[cpad(e0 + p * q)];
+		vr[p] = v.re;
+		vi[p] = v.im;
+	}
+	if constexpr (TW)
+	{
+#pragma unroll
+		for (int p = 1; p < R; p++)
+		{
+			const cd w = tw_get(twr, bitrev_c<R>(p));
+			const double tr = vr[p] * w.re + vi[p] * w.im;
+			const double ti = vi[p] * w.re - vr[p] * w.im;
+			vr[p] = tr;
+			vi[p] = ti;
+		}
+	}
+	dit_regs<R>(vr, vi);
+}
+
+template<int R, bool TW>
+R8B_HD void xdit(cd* buf, int n, int b, const cd* twr)
+{
+	double vr[R], vi[R];
+	xdit_regs<R, TW>(buf, n, b, twr, vr, vi);
+	const int q = n / R;
+	const int blk = b / q, j = b - blk * q;
+	const int e0 = blk * n + j;
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		cd v;
+		v.re = vr[p];
+		v.im = vi[p];
+		buf[cpad(e0 + p * q)] = v;
+	}
+}
+
+// one full pass with sub-length n = 2^LOGSUB and radix 2^RB over an array of 2^LOGTOT complex.
+// Twiddles come from `twr` when each thread owns exactly one butterfly (prefetched by the
+// caller), otherwise they are fetched in place.
+template<int LOGTOT, int LOGSUB, int RB, bool INV>
+R8B_HD void xpass(cd* buf, const cd* twr, const cd* tw, int tw_len, int tid)
+{
+	constexpr int R = 1 << RB, n = 1 << LOGSUB, nb = (1 << LOGTOT) / R;
+	constexpr bool TW = LOGSUB > RB;
+	constexpr bool PRE = nb <= kConvxThreads;
+	for (int b = tid; b < nb; b += kConvxThreads)
+	{
+		if constexpr (TW && !PRE)
+		{
+			cd loc[6];
+			tw_fetch<R>(loc, tw, tw_len, n, b & (n / R - 1));
+			if constexpr (INV) xdit<R, TW>(buf, n, b, loc);
+			else xdif<R, TW>(buf, n, b, loc);
+		}
+		else
+		{
+			if constexpr (INV) xdit<R, TW>(buf, n, b, twr);
+			else xdif<R, TW>(buf, n, b, twr);
+		}
+	}
+}
+
+template<int LOGTOT, int LOGSUB, int RB>
+R8B_HD void xprefetch(cd* twr, const cd* tw, int tw_len, int tid)
+{
+	constexpr int R = 1 << RB, n = 1 << LOGSUB, nb = (1 << LOGTOT) / R;
+	if constexpr (LOGSUB > RB && nb <= kConvxThreads)
+	{
+		if (tid < nb) tw_fetch<R>(twr, tw, tw_len, n, tid & (n / R - 1));
+	}
+}
+
+// ---- forward: DIF, first pass big_pass_bits, then the rest -----------------------------------
+// The kernel body calls these in order with a barrier after each; `FwdPass<LOGN, I>` is pass I.
+
+template<int LOGN, int I>
+struct FwdPass
+{
+	static constexpr int B0 = big_pass_bits(LOGN);
+	static constexpr int NP = 1 + rest_passes(LOGN);
+	// sub-length and radix bits of pass I
+	static constexpr int sub()
+	{
+		int s = LOGN;
+		if (I >= 1) s -= B0;
+		for (int i = 0; i + 1 < I; i++) s -= rest_bits(LOGN, i);
+		return s;
+	}
+	static constexpr int rb() { return I == 0 ? B0 : rest_bits(LOGN, I - 1); }
+	static R8B_HD void prefetch(cd* twr, const cd* tw, int tw_len, int tid)
+	{
+		xprefetch<LOGN, sub(), rb()>(twr, tw, tw_len, tid);
+	}
+	static R8B_HD void run(cd* buf, const cd* twr, const cd* tw, int tw_len, int tid)
+	{
+		xpass<LOGN, sub(), rb(), false>(buf, twr, tw, tw_len, tid);
+	}
+};
+
+// ---- backward: DIT, rest passes (sub-length growing), last pass big_pass_bits ------------------
+
+template<int LOGN2, int I>
+struct InvPass
+{
+	static constexpr int BL = big_pass_bits(LOGN2);
+	static constexpr int NR = rest_passes(LOGN2); // passes before the last one
+	static constexpr int rb() { return I < NR ? rest_bits(LOGN2, NR - 1 - I) : BL; }
+	static constexpr int sub()
+	{
+		int s = 0;
+		for (int i = 0; i <= I && i < NR; i++) s += rest_bits(LOGN2, NR - 1 - i);
+		if (I >= NR) s += BL;
+		return s;
+	}
+	static R8B_HD void prefetch(cd* twr, const cd* tw, int tw_len, int tid)
+	{
+		xprefetch<LOGN2, sub(), rb()>(twr, tw, tw_len, tid);
+	}
+	static R8B_HD void run(cd* buf, const cd* twr, const cd* tw, int tw_len, int tid)
+	{
+		xpass<LOGN2, sub(), rb(), true>(buf, twr, tw, tw_len, tid);
+	}
+};
+
+// ---- phases ------------------------------------------------------------------------------------
+
+// K1: block input as packed complex pairs in the padded array
+template<int LOGN>
+R8B_HD void cx_load(const ConvLaunch& L, double* buf, long long k, int ch, int tid)
+{
+	constexpr int NIN = 2 << LOGN;
+	const int iln = L.in_len / L.up;
+	const long long base = k * (long long) (L.blk_stride / L.up);
+	// all loads of a thread are issued before the first one is waited for
+	double v[NIN / kConvxThreads];
+#pragma unroll
+	for (int m = 0; m < NIN / kConvxThreads; m++)
+	{
+		const int i = tid + m * kConvxThreads;
+		const long long pos = i < iln ? base + i : base + i - NIN;
+		v[m] = src_load(L.src, ch, pos);
+	}
+#pragma unroll
+	for (int m = 0; m < NIN / kConvxThreads; m++) buf[rpad(tid + m * kConvxThreads)] = v[m];
+}
+
+// slot -> forward bin handled by that slot.  Slots 0..N/2-1 take bins in bit-reversed order, so
+// that consecutive lanes touch consecutive LDS words of the bit-reversed spectrum instead of
+// one bank; slot N/2 takes bin N/2; larger slots are idle (returned bin > N/2).
+template<int LOGN>
+R8B_HD int cx_spec_bin(int slot)
+{
+	constexpr int N = 1 << LOGN;
+	if (slot < N / 2) return bitrev_n(slot, LOGN - 1);
+	return slot == N / 2 ? N / 2 : N;
+}
+
+// spectral stage, part 1: forward bins (kf, N-kf) -> registers
+template<int LOGN, int UPLOG>
+R8B_HD void cx_spec_read(const cd* buf, ConvxState<LOGN, UPLOG>& st, int tid)
+{
+	constexpr int N = 1 << LOGN;
+#pragma unroll
+	for (int s = 0; s < ConvxState<LOGN, UPLOG>::SP; s++)
+	{
+		const int kf = cx_spec_bin<LOGN>(tid + s * kConvxThreads);
+		if (kf <= N / 2)
+		{
+			st.sp[s][0] = buf[cpad(bitrev_n(kf & (N - 1), LOGN))];
+			st.sp[s][1] = buf[cpad(bitrev_n((N - kf) & (N - 1), LOGN))];
+		}
+	}
+}
+
+// spectral stage, part 2: from the held pair to the 2 (1:1) or 4 (2x) backward inputs.
+// Everything between the forward bins and the backward inputs -- real-FFT unpacking, spectrum
+// replication (K3), multiplication by the zero-phase kernel (K4), packing for the half-length
+// backward transform -- is linear in (Z1, conj Z1, Z2, conj Z2), so the host folds it into
+// complex constants per slot (Engine::spectral_constants); the kernel is two complex
+// multiply-adds per backward input.  Table layout: constant c of slot s at spec[c * slots + s].
+template<int LOGN, int UPLOG>
+R8B_HD void cx_spec_write(const ConvLaunch& L, cd* buf, const ConvxState<LOGN, UPLOG>& st, int tid)
+{
+	constexpr int N = 1 << LOGN, LOGN2 = LOGN + UPLOG;
+	constexpr int SLOTS = N / 2 + 1;
+#pragma unroll
+	for (int s = 0; s < ConvxState<LOGN, UPLOG>::SP; s++)
+	{
+		const int slot = tid + s * kConvxThreads;
+		const int kf = cx_spec_bin<LOGN>(slot);
+		if (kf > N / 2) continue;
+		const cd z1 = st.sp[s][0], z2 = st.sp[s][1];
+		const cd* c = L.spec + slot;
+		// out = a * (p.re, sp * p.im) + b * (q.re, sq * q.im)
+#define R8B_CMADD(out, a, p, sp, b, q, sq) \
+		{ \
+			const cd ca = (a), cb = (b); \
+			const double pi_ = (sp) * (p).im, qi_ = (sq) * (q).im; \
+			(out).re = ca.re * (p).re - ca.im * pi_ + cb.re * (q).re - cb.im * qi_; \
+			(out).im = ca.re * pi_ + ca.im * (p).re + cb.re * qi_ + cb.im * (q).re; \
+		}
+		cd o;
+		if constexpr (UPLOG == 0)
+		{
+			R8B_CMADD(o, c[0], z1, 1.0, c[SLOTS], z2, -1.0)            // Z'[kf]
+			buf[cpad(bitrev_n(kf, LOGN2))] = o;
+			if (kf != 0 && kf != N / 2)
+			{
+				R8B_CMADD(o, c[2 * SLOTS], z1, -1.0, c[3 * SLOTS], z2, 1.0) // Z'[N-kf]
+				buf[cpad(bitrev_n(N - kf, LOGN2))] = o;
+			}
+		}
+		else
+		{
+			R8B_CMADD(o, c[0], z1, 1.0, c[SLOTS], z2, -1.0)            // Z'[kf]
+			buf[cpad(bitrev_n(kf, LOGN2))] = o;
+			R8B_CMADD(o, c[4 * SLOTS], z1, -1.0, c[5 * SLOTS], z2, 1.0) // Z'[N-kf]
+			buf[cpad(bitrev_n(N - kf, LOGN2))] = o;
+			if (kf != 0)
+			{
+				R8B_CMADD(o, c[2 * SLOTS], z1, -1.0, c[3 * SLOTS], z2, 1.0) // Z'[2N-kf]
+				buf[cpad(bitrev_n(2 * N - kf, LOGN2))] = o;
+				R8B_CMADD(o, c[6 * SLOTS], z1, 1.0, c[7 * SLOTS], z2, -1.0) // Z'[N+kf]
+				buf[cpad(bitrev_n(N + kf, LOGN2))] = o;
+			}
+		}
+#undef R8B_CMADD
+	}
+}
+
+// last backward pass, part 1: butterflies into registers
+template<int LOGN, int UPLOG>
+R8B_HD void cx_final_compute(const ConvLaunch& L, const cd* buf, ConvxState<LOGN, UPLOG>& st,
+	int tid)
+{
+	constexpr int LOGN2 = LOGN + UPLOG, RB = big_pass_bits(LOGN2), R = 1 << RB;
+	constexpr int nb = (1 << LOGN2) / R;
+	typedef ConvxState<LOGN, UPLOG> St;
+#pragma unroll
+	for (int f = 0; f < St::FIN; f++)
+	{
+		const int b = tid + f * kConvxThreads;
+		if (b >= nb) continue;
+		if constexpr (nb > kConvxThreads)
+		{
+			cd loc[6];
+			tw_fetch<R>(loc, L.tw, L.tw_len, 1 << LOGN2, b);
+			xdit_regs<R, true>(buf, 1 << LOGN2, b, loc, st.fr[f], st.fi[f]);
+		}
+		else xdit_regs<R, true>(buf, 1 << LOGN2, b, st.tw, st.fr[f], st.fi[f]);
+	}
+}
+
+// last backward pass, part 2: the block's valid outputs as one linear run y[u], u in [0, in_len),
+// y[u] = convolver output at time t0 + u, t0 = k*in_len - fl2 (reals, unpadded, at `y`)
+template<int LOGN, int UPLOG>
+R8B_HD void cx_final_store(const ConvLaunch& L, double* y, const ConvxState<LOGN, UPLOG>& st,
+	long long k, bool zero_negative, int tid)
+{
+	constexpr int LOGN2 = LOGN + UPLOG, RB = big_pass_bits(LOGN2), R = 1 << RB;
+	constexpr int nb = (1 << LOGN2) / R, q = nb;
+	typedef ConvxState<LOGN, UPLOG> St;
+	const int mask = (2 << LOGN2) - 1;
+	double* const y1 = y + cx_y1_offset(L.in_len);
+#pragma unroll
+	for (int f = 0; f < St::FIN; f++)
+	{
+		const int b = tid + f * kConvxThreads;
+		if (b >= nb) continue;
+#pragma unroll
+		for (int p = 0; p < R; p++)
+		{
+			const int e = b + p * q; // complex index: reals 2e, 2e+1 at circular positions c
+			const int u0 = (2 * e + L.fl2) & mask, u1 = (2 * e + 1 + L.fl2) & mask;
+			double v0 = st.fr[f][p], v1 = st.fi[f][p];
+			if (zero_negative && k == 0)
+			{
+				// the stream starts at t = 0: earlier convolver outputs do not exist for the
+				// next stage (its history is zero), reference CDSPFracInterpolator.h:834-859
+				if (u0 < L.fl2) v0 = 0.0;
+				if (u1 < L.fl2) v1 = 0.0;
+			}
+			if (u0 < L.in_len)
+			{
+				y[u0] = v0;
+				if (zero_negative && u0 > 0) y1[u0 - 1] = v0; // shifted copy (fused mode only)
+			}
+			if (u1 < L.in_len)
+			{
+				y[u1] = v1;
+				if (zero_negative && u1 > 0) y1[u1 - 1] = v1;
+			}
+		}
+	}
+	// zero extension read (times zero taps) by the padded polyphase rows
+	if (tid < 8) y[L.in_len + tid] = 0.0;
+	else if (zero_negative && tid < 24) y1[L.in_len - 1 + (tid - 8)] = 0.0;
+}
+
+// MODE 0: K7, write the block's valid outputs that fall into [a, b)
+R8B_HD void cx_store_conv(const ConvLaunch& L, const double* y, long long k, int ch, int tid)
+{
+	const long long t0 = k * (long long) L.blk_stride - L.fl2;
+	for (int u = tid; u < L.in_len; u += kConvxThreads)
+	{
+		const long long q = t0 + u;
+		if (q >= L.a && q < L.b) dst_store(L.dst, ch, q, y[u]);
+	}
+}
+
+R8B_HD long long ceil_div_pos(long long a, long long b) { return a <= 0 ? 0 : (a + b - 1) / b; }
+
+// MODE 1: K8 on the block's linear run.  Thread t owns outputs j = t (mod OutStep) whose tap
+// window [r-fll, r+fl2] lies inside [t0, t0+in_len); r = floor(j*In/Out).
+template<int FLENP>
+R8B_HD void cx_whole_row(const ConvxLaunch& X, double* row, int tid)
+{
+	// X.wtab is the bank transposed and permuted by the host for this access: tap i of the row
+	// thread t uses (phase t*InStep mod OutStep) sits at wtab[i * OutStep + t], so a wave reads
+	// 64 consecutive doubles per tap.  Rows shorter than FLENP are padded with zero taps (the
+	// run y[] is zero-extended to match).
+	const int t = tid < X.out_step ? tid : 0;
+#pragma unroll
+	for (int i = 0; i < FLENP; i++) row[i] = i < X.flen ? X.wtab[(long) i * X.out_step + t] : 0.0;
+}
+
+template<int FLEN>
+R8B_HD void cx_whole_compute(const ConvxLaunch& X, const double* y, const double* row, long long k,
+	int ch, int tid)
+{
+	const ConvLaunch& L = X.c;
+	if (tid >= X.out_step) return;
+	const SpanInfo& B = X.blk[k - L.k0];
+	// first j >= jlo with j = tid (mod OutStep)
+	int d = tid - B.jlo_mod;
+	if (d < 0) d += X.out_step;
+	long long j = B.jlo + d;
+	const long long jhi = B.jhi;
+	if (j >= jhi) return;
+	// The run is kept twice in LDS, y and y shifted by one sample (cx_y1_offset), so that every
+	// tap window starts 16-byte aligned in one of the copies and is read with ds_read_b128
+	// (256 B/clk); unaligned 8-byte pairs would compile to ds_read2_b64 at half that rate.
+	const double* y1 = y + cx_y1_offset(L.in_len);
+	int u = B.u_lo + (int) ((unsigned) (B.ph_lo + d * X.in_step) / (unsigned) X.out_step);
+#if defined(R8B_X_PAIR) && R8B_X_PAIR
+	// two outputs per iteration: twice the LDS reads in flight, four independent FMA chains
+	for (; j + X.out_step < jhi; j += 2 * X.out_step, u += 2 * X.in_step)
+	{
+		const int u2 = u + X.in_step;
+		const cd* xa = reinterpret_cast<const cd*>((u & 1) ? y1 + (u - 1) : y + u);
+		const cd* xb = reinterpret_cast<const cd*>((u2 & 1) ? y1 + (u2 - 1) : y + u2);
+		double s0 = 0.0, s1 = 0.0, t0s = 0.0, t1s = 0.0;
+#pragma unroll
+		for (int i = 0; i < FLEN / 2; i++)
+		{
+			const cd va = xa[i], vb = xb[i];
+			s0 += row[2 * i] * va.re;
+			t0s += row[2 * i] * vb.re;
+			s1 += row[2 * i + 1] * va.im;
+			t1s += row[2 * i + 1] * vb.im;
+		}
+		dst_store(X.wdst, ch, j, s0 + s1);
+		dst_store(X.wdst, ch, j + X.out_step, t0s + t1s);
+	}
+#endif
+	for (; j < jhi; j += X.out_step, u += X.in_step)
+	{
+		const cd* x = reinterpret_cast<const cd*>((u & 1) ? y1 + (u - 1) : y + u);
+		double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+		for (int i = 0; i < FLEN / 2; i++)
+		{
+			const cd v = x[i];
+			s0 += row[2 * i] * v.re;
+			s1 += row[2 * i + 1] * v.im;
+		}
+		dst_store(X.wdst, ch, j, s0 + s1);
+	}
+}
+
+// ---- the kernel body as a sequence of barrier-separated phases ----------------------------------
+//
+// `Exec::phase(f)` runs f(tid, state) for every thread of the workgroup and ends with a barrier:
+// on the GPU it is `f(threadIdx.x, st); __syncthreads();` (r8b_kernels.hip), in the host
+// emulation of tests/emul it is a loop over tid.  Writing the sequence once keeps both in step.
+
+template<int LOGN, int UPLOG, int I, class Exec>
+R8B_HD void cx_fwd_seq(Exec& ex, const ConvLaunch& L, cd* buf)
+{
+	typedef ConvxState<LOGN, UPLOG> St;
+	constexpr int NP = FwdPass<LOGN, 0>::NP;
+	ex.phase([&](int tid, St& st)
+	{
+		FwdPass<LOGN, I>::run(buf, st.tw, L.tw, L.tw_len, tid);
+		if constexpr (I + 1 < NP) FwdPass<LOGN, I + 1>::prefetch(st.tw, L.tw, L.tw_len, tid);
+	});
+	if constexpr (I + 1 < NP) cx_fwd_seq<LOGN, UPLOG, I + 1>(ex, L, buf);
+}
+
+// backward passes 0 .. NR-1 (the last one, NR, is split into compute/store by the caller)
+template<int LOGN, int UPLOG, int I, class Exec>
+R8B_HD void cx_inv_seq(Exec& ex, const ConvLaunch& L, cd* buf)
+{
+	typedef ConvxState<LOGN, UPLOG> St;
+	constexpr int LOGN2 = LOGN + UPLOG, NR = InvPass<LOGN2, 0>::NR;
+	if constexpr (I < NR)
+	{
+		ex.phase([&](int tid, St& st)
+		{
+			InvPass<LOGN2, I>::run(buf, st.tw, L.tw, L.tw_len, tid);
+			InvPass<LOGN2, I + 1>::prefetch(st.tw, L.tw, L.tw_len, tid);
+		});
+		cx_inv_seq<LOGN, UPLOG, I + 1>(ex, L, buf);
+	}
+}
+
+template<int LOGN, int UPLOG, int MODE, int FLENP, class Exec>
+R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k, int ch)
+{
+	typedef ConvxState<LOGN, UPLOG> St;
+	constexpr int LOGN2 = LOGN + UPLOG;
+	const ConvLaunch& L = X.c;
+	cd* const buf = reinterpret_cast<cd*>(rbuf);
+#ifndef R8B_X_SKIP
+#define R8B_X_SKIP 0 // timing ablations only (bit mask of phases left out; results are wrong)
+#endif
+	ex.phase([&](int tid, St& st)
+	{
+		FwdPass<LOGN, 0>::prefetch(st.tw, L.tw, L.tw_len, tid);
+		if (!(R8B_X_SKIP & 32)) cx_load<LOGN>(L, rbuf, k, ch, tid);
+	});
+	if (!(R8B_X_SKIP & 1)) cx_fwd_seq<LOGN, UPLOG, 0>(ex, L, buf);
+	if (!(R8B_X_SKIP & 2))
+	{
+	ex.phase([&](int tid, St& st) { cx_spec_read<LOGN, UPLOG>(buf, st, tid); });
+	ex.phase([&](int tid, St& st)
+	{
+		cx_spec_write<LOGN, UPLOG>(L, buf, st, tid);
+		InvPass<LOGN2, 0>::prefetch(st.tw, L.tw, L.tw_len, tid);
+	});
+	}
+	if (!(R8B_X_SKIP & 4)) cx_inv_seq<LOGN, UPLOG, 0>(ex, L, buf);
+	ex.phase([&](int tid, St& st)
+	{
+		if (!(R8B_X_SKIP & 8)) cx_final_compute<LOGN, UPLOG>(L, buf, st, tid);
+#if defined(R8B_X_ROWLATE) && !R8B_X_ROWLATE
+		if constexpr (MODE == 1) cx_whole_row<FLENP>(X, st.row, tid);
+#endif
+	});
+	ex.phase([&](int tid, St& st)
+	{
+		if (!(R8B_X_SKIP & 128)) cx_final_store<LOGN, UPLOG>(L, rbuf, st, k, MODE == 1, tid);
+#if !defined(R8B_X_ROWLATE) || R8B_X_ROWLATE
+		if constexpr (MODE == 1)
+		{
+			if (!(R8B_X_SKIP & 256)) cx_whole_row<FLENP>(X, st.row, tid);
+		}
+#endif
+	});
+	ex.phase([&](int tid, St& st)
+	{
+		if constexpr (MODE == 1)
+		{
+			if (!(R8B_X_SKIP & 16)) cx_whole_compute<FLENP>(X, rbuf, st.row, k, ch, tid);
+		}
+		else cx_store_conv(L, rbuf, k, ch, tid);
+	});
+}
+
+} // namespace r8bhip
+
+#endif

@@ -2,8 +2,10 @@
 // r8b_launch.h.
 #include "r8b_engine.h"
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
+#include <complex>
 #include <stdexcept>
 
 namespace r8bhip {
@@ -72,6 +74,88 @@ std::vector<double> kernel_spectrum(const LpFilter& f, int bl2, double scale)
 	return H;
 }
 
+std::vector<double> spectral_constants(const std::vector<double>& H, const std::vector<double>& tw,
+	int bl2, int n_in, int up)
+{
+	typedef std::complex<long double> C;
+	const int N = n_in / 2, N2 = N * up;
+	const int slots = N / 2 + 1;
+	int logn = 0;
+	while ((1 << logn) < N) logn++;
+	const int nconst = up == 1 ? 4 : 8;
+	std::vector<double> out((size_t) nconst * slots * 2, 0.0);
+	auto W = [&](long long e) // exp(-2 pi i e / bl2)
+	{
+		e &= bl2 - 1;
+		return C(tw[(size_t) e * 2], tw[(size_t) e * 2 + 1]);
+	};
+	auto put = [&](int c, int slot, C v)
+	{
+		out[((size_t) c * slots + slot) * 2] = (double) v.real();
+		out[((size_t) c * slots + slot) * 2 + 1] = (double) v.imag();
+	};
+	const C I(0.0L, 1.0L);
+	const int tsf = bl2 / (2 * N), tsh = bl2 / (2 * N2);
+	for (int slot = 0; slot < slots; slot++)
+	{
+		int kf = N / 2;
+		if (slot < N / 2)
+		{
+			kf = 0;
+			for (int b = 0; b < logn - 1; b++)
+				if (slot & (1 << b)) kf |= 1 << (logn - 2 - b);
+		}
+		// R[kf] = A Z1 + B conj(Z2),  R[N-kf] = conj(B) conj(Z1) + conj(A) Z2
+		const C w = W((long long) kf * tsf);
+		const C A = 0.5L * (C(1.0L) - I * w), B = 0.5L * (C(1.0L) + I * w);
+		auto cw = [&](int k) { return std::conj(W((long long) k * tsh)); }; // conj(w_{2 N2}^k)
+		if (up == 1)
+		{
+			const long double ha = H[(size_t) kf], hb = H[(size_t) (N - kf)];
+			// Z'[kf] = ha (1 + i cw) R + hb (1 - i cw) conj(R[N-kf])
+			C f = ha * (C(1.0L) + I * cw(kf)), g = hb * (C(1.0L) - I * cw(kf));
+			put(0, slot, f * A + g * B);
+			put(1, slot, f * B + g * A);
+			// Z'[N-kf] = hb (1 + i cw2) R[N-kf] + ha (1 - i cw2) conj(R)
+			f = hb * (C(1.0L) + I * cw(N - kf));
+			g = ha * (C(1.0L) - I * cw(N - kf));
+			put(2, slot, f * std::conj(B) + g * std::conj(A));
+			put(3, slot, f * std::conj(A) + g * std::conj(B));
+		}
+		else
+		{
+			// zero-stuffed spectrum: bins kf / 2N-kf carry R / conj R, bins N-kf / N+kf carry
+			// R[N-kf] / its conjugate
+			long double ha = H[(size_t) kf], hb = H[(size_t) (2 * N - kf)];
+			C c1 = C(ha + hb) + I * cw(kf) * C(ha - hb);
+			put(0, slot, c1 * A);
+			put(1, slot, c1 * B);
+			C d1 = C(hb + ha) + I * cw(2 * N - kf) * C(hb - ha);
+			put(2, slot, d1 * std::conj(A));
+			put(3, slot, d1 * std::conj(B));
+			if (kf != 0)
+			{
+				ha = H[(size_t) (N - kf)];
+				hb = H[(size_t) (N + kf)];
+				C c2 = C(ha + hb) + I * cw(N - kf) * C(ha - hb);
+				put(4, slot, c2 * std::conj(B));
+				put(5, slot, c2 * std::conj(A));
+				C d2 = C(hb + ha) + I * cw(N + kf) * C(hb - ha);
+				put(6, slot, d2 * B);
+				put(7, slot, d2 * A);
+			}
+			else
+			{
+				// bin N is its own partner: Z'[N] = 2 H[N] R[N]
+				const C c2 = C(2.0L * H[(size_t) N]);
+				put(4, slot, c2 * std::conj(B));
+				put(5, slot, c2 * std::conj(A));
+			}
+		}
+	}
+	return out;
+}
+
 std::vector<int> plan_radices(int N, int max_radix)
 {
 	std::vector<int> r;
@@ -110,6 +194,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["whole_tile"] = 1024;
 	opt_["hb_tile"] = 1024;
 	opt_["timing"] = 0;
+	opt_["fast_conv"] = 1; // compile-time-sized convolver kernel when the geometry allows
+	opt_["fuse"] = 1;      // ... with the whole-step interpolator behind it fused in
 	dev_.resize(plan_.stages.size());
 	for (size_t s = 0; s < plan_.stages.size(); s++)
 	{
@@ -133,12 +219,30 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 			d.tw_len = g.bl2;
 			d.tw = (cd*) dev_alloc(tw.size() * sizeof(double));
 			dev_upload(d.tw, tw.data(), tw.size() * sizeof(double));
+			if (convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
+			{
+				const std::vector<double> sc = spectral_constants(H, tw, g.bl2, g.n_in, g.up);
+				d.spec = (cd*) dev_alloc(sc.size() * sizeof(double));
+				dev_upload(d.spec, sc.data(), sc.size() * sizeof(double));
+			}
 		}
 		else if (sp.desc.kind == kFrac)
 		{
 			const std::vector<double>& t = sp.bank->table;
 			d.table = (double*) dev_alloc(t.size() * sizeof(double));
 			dev_upload(d.table, t.data(), t.size() * sizeof(double));
+			if (sp.whole)
+			{
+				std::vector<double> w((size_t) sp.flen * sp.out_step);
+				for (int r = 0; r < sp.out_step; r++)
+				{
+					const int ph = (int) (((long long) r * sp.in_step) % sp.out_step);
+					for (int i = 0; i < sp.flen; i++)
+						w[(size_t) i * sp.out_step + r] = t[(size_t) ph * sp.flen + i];
+				}
+				d.wtab = (double*) dev_alloc(w.size() * sizeof(double));
+				dev_upload(d.wtab, w.data(), w.size() * sizeof(double));
+			}
 		}
 	}
 	plan_transforms();
@@ -157,7 +261,9 @@ Engine::~Engine()
 		dev_free(d.ring);
 		dev_free(d.H);
 		dev_free(d.tw);
+		dev_free(d.spec);
 		dev_free(d.table);
+		dev_free(d.wtab);
 	}
 }
 
@@ -216,7 +322,11 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 		const StagePlan& sp = plan_.stages[stage];
 		switch (sp.desc.kind)
 		{
-		case kConv: *kernel = "k_conv"; break;
+		case kConv:
+			*kernel = fuse_with_next(stage) ? "k_convx_whole" : (opt_.at("fast_conv") &&
+				convx_geometry_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2) ?
+				"k_convx" : "k_conv");
+			break;
 		case kFrac: *kernel = sp.whole ? "k_whole" : "k_poly"; break;
 		case kHBUp: *kernel = "k_hbup"; break;
 		case kHBDown: *kernel = "k_hbdown"; break;
@@ -246,25 +356,21 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 	case kConv:
 	{
 		const ConvGeom& g = sp.cg;
-		ConvLaunch L;
-		L.up = g.up; L.down = g.down; L.fl2 = g.fl2; L.bl2 = g.bl2; L.in_len = g.in_len;
-		L.n_in = g.n_in; L.n_out = g.n_out;
-		L.up_pow2 = g.up_pow2 ? 1 : 0;
-		L.down_pow2 = g.down_pow2 ? 1 : 0;
-		L.n_fwd = (int) d.fwd_radix.size();
-		L.n_inv = (int) d.inv_radix.size();
-		if (L.n_fwd > kMaxPasses || L.n_inv > kMaxPasses)
-			throw std::runtime_error("transform plan too deep");
-		for (int i = 0; i < L.n_fwd; i++) L.fwd_radix[i] = d.fwd_radix[(size_t) i];
-		for (int i = 0; i < L.n_inv; i++) L.inv_radix[i] = d.inv_radix[(size_t) i];
-		L.H = d.H; L.tw = d.tw; L.tw_len = d.tw_len;
+		ConvxLaunch X;
+		ConvLaunch& L = X.c;
+		fill_conv(s, L, src);
 		L.k0 = ((long long) g.down * a + g.fl2) / g.in_len;
 		const long long k1 = ((long long) g.down * (b - 1) + g.fl2) / g.in_len;
 		L.nblk = (int) (k1 - L.k0 + 1);
-		L.a = a; L.b = b; L.nch = nch_;
-		L.threads = opt_.at("conv_threads");
-		L.src = src; L.dst = dst;
-		launch_conv(L, stream);
+		L.a = a; L.b = b;
+		L.dst = dst;
+		if (opt_.at("fast_conv") && convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
+		{
+			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0;
+			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
+			launch_convx(X, 0, stream);
+		}
+		else launch_conv(L, stream);
 		break;
 	}
 	case kFrac:
@@ -344,6 +450,10 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 		long long a, b;
 		PolyState ps;
 		sp.step(n, &a, &b, &ps);
+		const bool fused = fuse_with_next(s);
+		long long wa = 0, wb = 0;
+		if (fused) plan_.stages[s + 1].step((int) (b - a), &wa, &wb, nullptr);
+		const size_t last = fused ? s + 1 : s; // stage whose output this launch produces
 		SrcView src;
 		src.ring = dev_[s].ring;
 		src.ring_stride = dev_[s].ring_size;
@@ -361,34 +471,40 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 			src.cur_base = LLONG_MAX;
 		}
 		DstView dst;
-		if (s + 1 == ns)
+		if (last + 1 == ns)
 		{
 			dst.p = d_out;
 			dst.stride = out_stride;
 			dst.mask = -1;
-			dst.off = -a;
+			dst.off = -(fused ? wa : a);
 		}
 		else
 		{
-			dst.p = dev_[s + 1].ring;
-			dst.stride = dev_[s + 1].ring_size;
-			dst.mask = dev_[s + 1].ring_size - 1;
+			dst.p = dev_[last + 1].ring;
+			dst.stride = dev_[last + 1].ring_size;
+			dst.mask = dev_[last + 1].ring_size - 1;
 			dst.off = 0;
 		}
-		if (b > a)
+		const bool work = fused ? wb > wa : b > a;
+		if (work)
 		{
-			if (opt_.at("timing"))
+			const bool timing = opt_.at("timing") != 0;
+			void *e0 = nullptr, *e1 = nullptr;
+			if (timing)
 			{
-				void* e0 = get_event(dev_[s]);
-				void* e1 = get_event(dev_[s]);
+				e0 = get_event(dev_[s]);
+				e1 = get_event(dev_[s]);
 				dev_event_record(e0, stream);
-				launch_stage(s, m_prev, a, b, ps, src, dst, stream);
+			}
+			if (fused) launch_fused(s, wa, wb, src, dst, stream);
+			else launch_stage(s, m_prev, a, b, ps, src, dst, stream);
+			if (timing)
+			{
 				dev_event_record(e1, stream);
 				dev_[s].pending.emplace_back(e0, e1);
 				dev_[s].t_in += n;
-				dev_[s].t_out += b - a;
+				dev_[s].t_out += fused ? wb - wa : b - a;
 			}
-			else launch_stage(s, m_prev, a, b, ps, src, dst, stream);
 		}
 		if (s == 0)
 		{
@@ -404,9 +520,103 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 			T.nch = nch_;
 			launch_tail(T, stream);
 		}
-		n = (int) (b - a);
+		n = (int) (fused ? wb - wa : b - a);
+		if (fused) s++;
 	}
 	return n;
+}
+
+bool Engine::fuse_with_next(size_t s) const
+{
+	if (!opt_.at("fuse") || !opt_.at("fast_conv") || s + 1 >= plan_.stages.size()) return false;
+	const StagePlan& c = plan_.stages[s];
+	const StagePlan& w = plan_.stages[s + 1];
+	if (c.desc.kind != kConv || w.desc.kind != kFrac || !w.whole) return false;
+	if (!convx_geometry_ok(c.cg.n_in, c.cg.n_out, c.cg.up, c.cg.down, c.cg.up_pow2)) return false;
+	return w.out_step <= 256 && w.flen <= 32 && c.cg.in_len >= 4 * w.flen;
+}
+
+void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
+{
+	const StagePlan& sp = plan_.stages[s];
+	const StageDev& d = dev_[s];
+	const ConvGeom& g = sp.cg;
+	L.up = g.up; L.down = g.down; L.fl2 = g.fl2; L.bl2 = g.bl2; L.in_len = g.in_len;
+	L.n_in = g.n_in; L.n_out = g.n_out;
+	L.blk_stride = g.in_len;
+	L.up_pow2 = g.up_pow2 ? 1 : 0;
+	L.down_pow2 = g.down_pow2 ? 1 : 0;
+	L.n_fwd = (int) d.fwd_radix.size();
+	L.n_inv = (int) d.inv_radix.size();
+	if (L.n_fwd > kMaxPasses || L.n_inv > kMaxPasses)
+		throw std::runtime_error("transform plan too deep");
+	for (int i = 0; i < L.n_fwd; i++) L.fwd_radix[i] = d.fwd_radix[(size_t) i];
+	for (int i = 0; i < L.n_inv; i++) L.inv_radix[i] = d.inv_radix[(size_t) i];
+	L.H = d.H; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec;
+	L.nch = nch_;
+	L.threads = opt_.at("conv_threads");
+	L.src = src;
+}
+
+static long long ceil_div_nonneg(long long a, long long b) { return a <= 0 ? 0 : (a + b - 1) / b; }
+
+void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& src,
+	const DstView& dst, void* stream)
+{
+	const StagePlan& c = plan_.stages[s];
+	const StagePlan& w = plan_.stages[s + 1];
+	ConvxLaunch X;
+	fill_conv(s, X.c, src);
+	X.c.a = 0; X.c.b = 0;
+	X.c.dst = dst; // unused in fused mode
+	X.in_step = w.in_step; X.out_step = w.out_step; X.flen = w.flen;
+	X.fl2w = w.fl2; X.fllw = w.fll;
+	X.table = dev_[s + 1].table;
+	X.wtab = dev_[s + 1].wtab;
+	X.wa = wa; X.wb = wb;
+	X.wdst = dst;
+	const int in_len = c.cg.in_len, fl2c = c.cg.fl2, up = c.cg.up;
+	const long long In = w.in_step, Out = w.out_step;
+	// Blocks start S virtual samples apart with S = in_len - (interpolator taps, rounded up to
+	// the up factor): the valid ranges [k*S - fl2, k*S - fl2 + in_len) of consecutive blocks
+	// overlap by at least flen-1 convolver outputs, so each interpolator tap window lies inside
+	// one block.  An output belongs to the FIRST block that contains its window.  That block's
+	// input is complete whenever the reference has emitted the output (its latency covers one
+	// whole block of in_len >= S samples), so block contents -- and therefore the stream -- do
+	// not depend on how the input is cut into calls.
+	const long long S = in_len - (w.flen + up - 1) / up * up;
+	X.c.blk_stride = (int) S;
+	auto owner = [&](long long j) // first block whose valid range ends after the window of j
+	{
+		const long long v = j * In / Out + w.fl2 + fl2c - in_len;
+		return v < 0 ? 0 : v / S + 1;
+	};
+	const long long kfirst = owner(wa), klast = owner(wb - 1);
+	for (long long k0 = kfirst; k0 <= klast; k0 += kConvxMaxBlocks)
+	{
+		const long long k1 = std::min(klast, k0 + kConvxMaxBlocks - 1);
+		X.c.k0 = k0;
+		X.c.nblk = (int) (k1 - k0 + 1);
+		for (int i = 0; i < X.c.nblk; i++)
+		{
+			const long long k = k0 + i;
+			const long long t0 = k * S - fl2c;          // first valid time of block k
+			const long long e_prev = t0 - S + in_len;   // end of block k-1's valid range
+			const long long e_this = t0 + in_len;
+			SpanInfo& B = X.blk[i];
+			long long jlo = k == 0 ? 0 : ceil_div_nonneg((e_prev - w.fl2) * Out, In);
+			long long jhi = ceil_div_nonneg((e_this - w.fl2) * Out, In);
+			if (jlo < wa) jlo = wa;
+			if (jhi > wb) jhi = wb;
+			if (jhi < jlo) jhi = jlo;
+			B.jlo = jlo; B.jhi = jhi;
+			B.jlo_mod = (int) (jlo % Out);
+			B.ph_lo = (int) ((jlo * In) % Out);
+			B.u_lo = (int) (jlo * In / Out - w.fll - t0);
+			B.pad = 0;
+		}
+		launch_convx(X, 1, stream);
+	}
 }
 
 } // namespace r8bhip

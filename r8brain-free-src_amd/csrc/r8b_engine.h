@@ -49,8 +49,10 @@ private:
 		long long ring_size = 0;
 		double* H = nullptr;
 		cd* tw = nullptr;
+		cd* spec = nullptr; // fast-path spectral constants
 		int tw_len = 0;
 		double* table = nullptr;
+		double* wtab = nullptr; // whole-step bank, transposed per residue class (fused kernel)
 		std::vector<int> fwd_radix, inv_radix;
 		std::vector<std::pair<void*, void*>> pending; // (start, stop) events not yet read
 		std::vector<void*> free_events;
@@ -61,6 +63,10 @@ private:
 	void* get_event(StageDev& d);
 
 	void plan_transforms();
+	bool fuse_with_next(size_t s) const;
+	void fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const;
+	void launch_fused(size_t s, long long wa, long long wb, const SrcView& src,
+		const DstView& dst, void* stream);
 	void launch_stage(size_t s, long long m_prev, long long a, long long b, const PolyState& ps,
 		const SrcView& src, const DstView& dst, void* stream);
 
@@ -75,6 +81,13 @@ private:
 std::vector<double> make_twiddles(int len);
 // zero-phase kernel spectrum H[m] = sum_t h[t] cos(2 pi m t / bl2), m = 0..bl2/2, times `scale`
 std::vector<double> kernel_spectrum(const LpFilter& f, int bl2, double scale);
+// constants of the fast path's spectral stage (r8b_convx.h cx_spec_write) for a block convolver
+// with forward complex length N = n_in/2 and backward length N2 = N*up (up in {1,2}): per slot
+// s (bin kf = bitrev(s) for s < N/2, kf = N/2 for s == N/2) 4 (up 1) or 8 (up 2) complex values,
+// constant c of slot s at [c*(N/2+1) + s]; interleaved (re, im).  H is the scaled kernel
+// spectrum (kernel_spectrum), tw the exp(-2 pi i e / bl2) table.
+std::vector<double> spectral_constants(const std::vector<double>& H, const std::vector<double>& tw,
+	int bl2, int n_in, int up);
 // radices (each in {2,4,8,16}, <= max_radix) whose product is N, largest first
 std::vector<int> plan_radices(int N, int max_radix);
 

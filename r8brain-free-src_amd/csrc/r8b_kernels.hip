@@ -13,6 +13,7 @@
 
 #define R8B_HD __device__ __forceinline__
 #include "r8b_kernel_phases.h"
+#include "r8b_convx.h"
 
 namespace r8bhip {
 
@@ -133,6 +134,82 @@ __global__ void k_tail(const TailLaunch L)
 			L.cur[(long long) ch * L.cur_stride + (i - L.cur_base)];
 }
 
+// ------------------------------------------------------------------ fast path (r8b_convx.h)
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory,
+// i.e. drains vmcnt before every barrier; the phases exchange data through LDS exclusively, and
+// the table fetches a phase issues for the NEXT phase must stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+template<int LOGN, int UPLOG>
+struct GpuExec
+{
+	ConvxState<LOGN, UPLOG> st;
+#ifdef R8B_X_TRACE // tuning aid: cycle stamps of one workgroup's phases, printed by the kernel
+	long long ts[24];
+	int nts = 0;
+#endif
+	template<class F>
+	__device__ __forceinline__ void phase(F f)
+	{
+		f((int) threadIdx.x, st);
+		lds_barrier();
+#ifdef R8B_X_TRACE
+		if (nts < 24) ts[nts++] = (long long) __builtin_readcyclecounter();
+#endif
+	}
+};
+
+template<int LOGN, int UPLOG, int MODE, int FLENP>
+#ifndef R8B_CONVX_MINWAVES
+#define R8B_CONVX_MINWAVES 3
+#endif
+__global__ __launch_bounds__(kConvxThreads, R8B_CONVX_MINWAVES) void k_convx(const ConvxLaunch X)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	GpuExec<LOGN, UPLOG> ex;
+#ifdef R8B_X_TRACE
+	const long long t_begin = (long long) __builtin_readcyclecounter();
+#endif
+	convx_body<LOGN, UPLOG, MODE, FLENP>(ex, X, reinterpret_cast<double*>(smem),
+		X.c.k0 + blockIdx.x, (int) blockIdx.y);
+#ifdef R8B_X_TRACE
+	if (threadIdx.x == 0 && blockIdx.x == 6 && blockIdx.y == 300)
+	{
+		printf("trace ch %d:", (int) blockIdx.y);
+		long long prev = t_begin;
+		for (int i = 0; i < ex.nts; i++)
+		{
+			printf(" %lld", ex.ts[i] - prev);
+			prev = ex.ts[i];
+		}
+		printf("\n");
+	}
+#endif
+}
+
+template<int LOGN, int UPLOG, int MODE, int FLENP>
+void launch_convx_t(const ConvxLaunch& X, hipStream_t stream)
+{
+	static bool attr_done = false;
+	auto kern = k_convx<LOGN, UPLOG, MODE, FLENP>;
+	// work array; the linear output run (in_len + 8 doubles) aliases its start
+	const size_t lds = (size_t) convx_lds_need(LOGN + UPLOG, X.c.in_len, MODE) * sizeof(double);
+	if (!attr_done)
+	{
+		check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+			hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(k_convx)");
+		attr_done = true;
+	}
+	hipLaunchKernelGGL(kern, dim3((unsigned) X.c.nblk, (unsigned) X.c.nch), dim3(kConvxThreads),
+		lds, stream, X);
+	check(hipGetLastError(), "launch k_convx");
+}
+
 bool g_attr_done = false;
 
 void set_lds_attrs()
@@ -191,6 +268,25 @@ void launch_hbdown(const HBLaunch& L, void* stream)
 	hipLaunchKernelGGL(k_hbdown, dim3(tiles, (unsigned) L.nch), dim3(256),
 		(size_t) (2 * L.tile + 4 * L.ntaps) * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_hbdown");
+}
+
+void launch_convx(const ConvxLaunch& X, int mode, void* stream)
+{
+	int logn = 0;
+	while ((2 << logn) < X.c.n_in) logn++;
+	const int up = X.c.up;
+	const bool wide = X.flen > 24;
+#define R8B_CONVX_DISPATCH(LN, UL) \
+	if (logn == LN && up == (1 << UL)) \
+	{ \
+		if (mode == 0) launch_convx_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
+		else if (wide) launch_convx_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
+		else launch_convx_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
+		return; \
+	}
+	R8B_CONVX_GEOMS(R8B_CONVX_DISPATCH)
+#undef R8B_CONVX_DISPATCH
+	throw std::runtime_error("launch_convx: geometry not instantiated");
 }
 
 void launch_tail(const TailLaunch& L, void* stream)

@@ -41,6 +41,9 @@ struct ConvLaunch
 {
 	// geometry (r8b_plan.h ConvGeom)
 	int up, down, fl2, bl2, in_len, n_in, n_out;
+	// virtual samples between the starts of consecutive blocks: in_len (the reference's own block
+	// anchoring, reference CDSPBlockConvolver.h:283-305) except in the fused fast path
+	int blk_stride;
 	int up_pow2, down_pow2;
 	// transform plan: radices of the forward passes in execution order (sub-length N, N/r0, ...)
 	// and of the backward passes in execution order (sub-length grows to N2)
@@ -49,6 +52,7 @@ struct ConvLaunch
 	int inv_radix[kMaxPasses];
 	const double* H; // bl2/2+1 reals: zero-phase kernel spectrum / bl2
 	const cd* tw;    // tw_len complex: exp(-2 pi i e / tw_len)
+	const cd* spec;  // fast path only: per-slot spectral-stage constants (r8b_convx.h)
 	int tw_len;
 	// work: blocks [k0, k0+nblk) x channels [0, nch); outputs clipped to [a, b)
 	long long k0;
@@ -111,6 +115,49 @@ struct TailLaunch
 	int nch;
 };
 
+// fast path (r8b_convx.h): power-of-two block convolver, optionally fused with the whole-step
+// interpolator that follows it
+// Interpolator outputs one block owns, precomputed by the host so that the kernel needs no 64-bit
+// divisions: outputs [jlo, jhi); for j = jlo + d the tap window starts at index
+// u_lo + (ph_lo + d*in_step) / out_step of the block's linear run.
+struct SpanInfo
+{
+	long long jlo, jhi;
+	int jlo_mod; // jlo mod out_step
+	int u_lo;
+	int ph_lo;   // (jlo * in_step) mod out_step
+	int pad;
+};
+
+static const int kConvxMaxBlocks = 24; // blocks per fused launch (longer calls are split)
+
+struct ConvxLaunch
+{
+	ConvLaunch c;        // geometry, tables, block range, conv output range [c.a, c.b), src, dst
+	// MODE 1 (fused whole-step interpolator); c.dst is unused then
+	int in_step, out_step, flen, fl2w, fllw;
+	const double* table; // out_step rows x flen (boundary kernel)
+	const double* wtab;  // flen x out_step: wtab[i*out_step + t] = table[(t*in_step % out_step)*flen + i]
+	long long wa, wb;    // interpolator outputs to produce
+	DstView wdst;
+	SpanInfo blk[kConvxMaxBlocks]; // per block c.k0 + i
+};
+
+// geometries the fast path is instantiated for: (log2 of the forward complex length, up shift)
+#define R8B_CONVX_GEOMS(M) M(8, 1) M(9, 0) M(9, 1) M(10, 0) M(10, 1) M(11, 0) M(11, 1) M(12, 0)
+
+inline bool convx_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
+{
+	if (!up_pow2 || down != 1 || (up != 1 && up != 2) || n_out != n_in * up) return false;
+	int logn = 0;
+	while ((2 << logn) < n_in) logn++;
+	if ((2 << logn) != n_in) return false;
+#define R8B_CONVX_CHECK(LN, UL) if (logn == LN && up == (1 << UL)) return true;
+	R8B_CONVX_GEOMS(R8B_CONVX_CHECK)
+#undef R8B_CONVX_CHECK
+	return false;
+}
+
 // launchers (asynchronous on `stream`, a hipStream_t)
 void launch_conv(const ConvLaunch& L, void* stream);
 void launch_whole(const WholeLaunch& L, void* stream);
@@ -118,6 +165,8 @@ void launch_poly(const PolyLaunch& L, void* stream);
 void launch_hbup(const HBLaunch& L, void* stream);
 void launch_hbdown(const HBLaunch& L, void* stream);
 void launch_tail(const TailLaunch& L, void* stream);
+// mode 0: convolver output to X.c.dst; mode 1: fused interpolator output to X.wdst
+void launch_convx(const ConvxLaunch& X, int mode, void* stream);
 
 // memory helpers; all throw std::runtime_error with the HIP error text on failure
 void dev_select(int device);          // -1 keeps the current device

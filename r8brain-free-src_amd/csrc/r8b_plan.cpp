@@ -181,7 +181,9 @@ int StagePlan::history() const
 	case kConv:
 		// the earliest block the next call can touch starts less than 2*in_len virtual samples
 		// before the stream end and reaches bl2-in_len further back
-		return (cg.in_len + cg.bl2) / cg.up + 4;
+		// (+ up to one interpolator filter length when the next stage is fused in and starts a
+		// little earlier than this stage's own next output)
+		return (cg.in_len + cg.bl2) / cg.up + 64;
 	case kFrac:
 		return 2 * flen + 4;
 	case kHBUp:

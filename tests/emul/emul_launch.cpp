@@ -8,12 +8,14 @@
 // never by the package, bench.py or __graft_entry__.  It is NOT a CPU fallback of the product:
 // libr8bsrc_hip.so does not contain it and fails loudly without a HIP device.
 #include <cstdlib>
+#include <limits>
 #include <cstring>
 #include <stdexcept>
 #include <vector>
 
 #define R8B_HD inline
 #include "r8b_kernel_phases.h"
+#include "r8b_convx.h"
 
 namespace r8bhip {
 
@@ -117,6 +119,53 @@ void launch_hbdown(const HBLaunch& L, void*)
 			for (int i = 0; i < len; i++) xs[(size_t) i] = src_load(L.src, ch, lo + i);
 			for (int t = 0; t < nthr; t++) hbdown_compute(L, xs.data(), n0, n1, ch, t, nthr);
 		}
+}
+
+template<int LOGN, int UPLOG>
+struct EmulExec
+{
+	std::vector<ConvxState<LOGN, UPLOG>> st;
+	EmulExec() : st((size_t) kConvxThreads) {}
+	template<class F>
+	void phase(F f)
+	{
+		for (int t = 0; t < kConvxThreads; t++) f(t, st[(size_t) t]);
+	}
+};
+
+template<int LOGN, int UPLOG, int MODE, int FLENP>
+void emul_convx_t(const ConvxLaunch& X)
+{
+	std::vector<double> lds((size_t) convx_lds_need(LOGN + UPLOG, X.c.in_len, MODE) + 2);
+	double* base = lds.data();
+	if (((size_t) base & 15) != 0) base++;
+	for (int ch = 0; ch < X.c.nch; ch++)
+		for (int bx = 0; bx < X.c.nblk; bx++)
+		{
+			// poison the LDS (pad slots are never written by the kernel and must never matter)
+			for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
+			EmulExec<LOGN, UPLOG> ex;
+			convx_body<LOGN, UPLOG, MODE, FLENP>(ex, X, base, X.c.k0 + bx, ch);
+		}
+}
+
+void launch_convx(const ConvxLaunch& X, int mode, void*)
+{
+	int logn = 0;
+	while ((2 << logn) < X.c.n_in) logn++;
+	const int up = X.c.up;
+	const bool wide = X.flen > 24;
+#define R8B_CONVX_DISPATCH(LN, UL) \
+	if (logn == LN && up == (1 << UL)) \
+	{ \
+		if (mode == 0) emul_convx_t<LN, UL, 0, 24>(X); \
+		else if (wide) emul_convx_t<LN, UL, 1, 32>(X); \
+		else emul_convx_t<LN, UL, 1, 24>(X); \
+		return; \
+	}
+	R8B_CONVX_GEOMS(R8B_CONVX_DISPATCH)
+#undef R8B_CONVX_DISPATCH
+	throw std::runtime_error("emul launch_convx: geometry not instantiated");
 }
 
 void launch_tail(const TailLaunch& L, void*)
