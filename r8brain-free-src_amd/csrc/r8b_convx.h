@@ -78,7 +78,10 @@ struct ConvxState
 	static constexpr int SP = (N / 2 + 1 + kConvxThreads - 1) / kConvxThreads;
 	static constexpr int RL = 1 << big_pass_bits(LOGN + UPLOG);
 	static constexpr int FIN = (N2 / RL + kConvxThreads - 1) / kConvxThreads;
+	static constexpr int RF = 1 << big_pass_bits(LOGN); // radix of the first forward pass
 	cd tw[6];
+	cd tw0[RF > 8 ? 6 : (RF > 4 ? 4 : 3)]; // first-pass twiddles: same for every block
+	cd pre[RF];                            // inputs of the NEXT block's first-pass butterfly
 	cd sp[SP][2];
 	double fr[FIN][RL], fi[FIN][RL];
 	double row[32];
@@ -294,24 +297,82 @@ struct InvPass
 
 // ---- phases ------------------------------------------------------------------------------------
 
-// K1: block input as packed complex pairs in the padded array
-template<int LOGN>
-R8B_HD void cx_load(const ConvLaunch& L, double* buf, long long k, int ch, int tid)
+// two consecutive samples at an even position as one aligned 16-byte load through a selected
+// address (the host sets ConvLaunch::vec_ok only when every position used here is even and the
+// buffers are 16-byte aligned)
+R8B_HD cd src_load2(const SrcView& s, int ch, long long pos)
 {
-	constexpr int NIN = 2 << LOGN;
+	const double* pr = s.ring + ((long long) ch * s.ring_stride + (pos & s.ring_mask));
+	const double* pc = s.cur + ((long long) ch * s.cur_stride + (pos - s.cur_base));
+	const cd v = *reinterpret_cast<const cd*>(pos >= s.cur_base ? pc : pr);
+	cd r;
+	r.re = pos < 0 ? 0.0 : v.re;
+	r.im = pos < 0 ? 0.0 : v.im;
+	return r;
+}
+
+// K1: the block's input goes from global memory straight into the registers of the first
+// forward pass (thread b owns butterfly b: complex elements b + p*N/R, i.e. real samples
+// 2e, 2e+1 of the circular block).  Issued one block ahead, at the start of the long
+// interpolation phase of the previous block, so that HBM latency is off the critical path.
+template<int LOGN, int UPLOG>
+R8B_HD void cx_prefetch(const ConvLaunch& L, ConvxState<LOGN, UPLOG>& st, long long k, int ch, int tid)
+{
+	constexpr int R = ConvxState<LOGN, UPLOG>::RF, N = 1 << LOGN, nb = N / R, NIN = 2 * N;
+	if (tid >= nb) return;
 	const int iln = L.in_len / L.up;
 	const long long base = k * (long long) (L.blk_stride / L.up);
-	// all loads of a thread are issued before the first one is waited for
-	double v[NIN / kConvxThreads];
 #pragma unroll
-	for (int m = 0; m < NIN / kConvxThreads; m++)
+	for (int p = 0; p < R; p++)
 	{
-		const int i = tid + m * kConvxThreads;
+		const int i = 2 * (tid + p * nb);
 		const long long pos = i < iln ? base + i : base + i - NIN;
-		v[m] = src_load(L.src, ch, pos);
+		if (L.vec_ok) st.pre[p] = src_load2(L.src, ch, pos);
+		else
+		{
+			// odd geometry or unaligned caller buffer: the two samples may even sit on different
+			// sides of the fresh/history split
+			const long long pos1 = i + 1 < iln ? base + i + 1 : base + i + 1 - NIN;
+			st.pre[p].re = src_load(L.src, ch, pos);
+			st.pre[p].im = src_load(L.src, ch, pos1);
+		}
+	}
+}
+
+// first forward pass: inputs from the prefetch registers, results into the padded LDS array
+template<int LOGN, int UPLOG>
+R8B_HD void cx_first_pass(cd* buf, const ConvxState<LOGN, UPLOG>& st, int tid)
+{
+	constexpr int R = ConvxState<LOGN, UPLOG>::RF, N = 1 << LOGN, q = N / R;
+	if (tid >= q) return;
+	double vr[R], vi[R];
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		vr[p] = st.pre[p].re;
+		vi[p] = st.pre[p].im;
+	}
+	dif_regs<R>(vr, vi);
+	if constexpr (LOGN > big_pass_bits(LOGN))
+	{
+#pragma unroll
+		for (int p = 1; p < R; p++)
+		{
+			const cd w = tw_get(st.tw0, bitrev_c<R>(p));
+			const double tr = vr[p] * w.re - vi[p] * w.im;
+			const double ti = vr[p] * w.im + vi[p] * w.re;
+			vr[p] = tr;
+			vi[p] = ti;
+		}
 	}
 #pragma unroll
-	for (int m = 0; m < NIN / kConvxThreads; m++) buf[rpad(tid + m * kConvxThreads)] = v[m];
+	for (int p = 0; p < R; p++)
+	{
+		cd v;
+		v.re = vr[p];
+		v.im = vi[p];
+		buf[cpad(tid + p * q)] = v;
+	}
 }
 
 // slot -> forward bin handled by that slot.  Slots 0..N/2-1 take bins in bit-reversed order, so
@@ -584,55 +645,43 @@ R8B_HD void cx_inv_seq(Exec& ex, const ConvLaunch& L, cd* buf)
 	}
 }
 
+// One workgroup = one block of one channel.  (A persistent variant that walks several blocks and
+// prefetches the next block's input during the output phase was tried: the loop-carried state
+// pushes hipcc into heavy SGPR/VGPR spilling, 3x slower.  Latency hiding is left to the 3-4
+// workgroups resident per CU.)
 template<int LOGN, int UPLOG, int MODE, int FLENP, class Exec>
 R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k, int ch)
 {
 	typedef ConvxState<LOGN, UPLOG> St;
 	constexpr int LOGN2 = LOGN + UPLOG;
+	constexpr int NPF = FwdPass<LOGN, 0>::NP;
 	const ConvLaunch& L = X.c;
 	cd* const buf = reinterpret_cast<cd*>(rbuf);
-#ifndef R8B_X_SKIP
-#define R8B_X_SKIP 0 // timing ablations only (bit mask of phases left out; results are wrong)
-#endif
 	ex.phase([&](int tid, St& st)
 	{
-		FwdPass<LOGN, 0>::prefetch(st.tw, L.tw, L.tw_len, tid);
-		if (!(R8B_X_SKIP & 32)) cx_load<LOGN>(L, rbuf, k, ch, tid);
+		cx_prefetch<LOGN, UPLOG>(L, st, k, ch, tid);
+		if (tid < (1 << LOGN) / St::RF)
+			tw_fetch<St::RF>(st.tw0, L.tw, L.tw_len, 1 << LOGN, tid);
+		if constexpr (NPF > 1) FwdPass<LOGN, 1>::prefetch(st.tw, L.tw, L.tw_len, tid);
+		cx_first_pass<LOGN, UPLOG>(buf, st, tid);
 	});
-	if (!(R8B_X_SKIP & 1)) cx_fwd_seq<LOGN, UPLOG, 0>(ex, L, buf);
-	if (!(R8B_X_SKIP & 2))
-	{
+	if constexpr (NPF > 1) cx_fwd_seq<LOGN, UPLOG, 1>(ex, L, buf);
 	ex.phase([&](int tid, St& st) { cx_spec_read<LOGN, UPLOG>(buf, st, tid); });
 	ex.phase([&](int tid, St& st)
 	{
 		cx_spec_write<LOGN, UPLOG>(L, buf, st, tid);
 		InvPass<LOGN2, 0>::prefetch(st.tw, L.tw, L.tw_len, tid);
 	});
-	}
-	if (!(R8B_X_SKIP & 4)) cx_inv_seq<LOGN, UPLOG, 0>(ex, L, buf);
+	cx_inv_seq<LOGN, UPLOG, 0>(ex, L, buf);
+	ex.phase([&](int tid, St& st) { cx_final_compute<LOGN, UPLOG>(L, buf, st, tid); });
 	ex.phase([&](int tid, St& st)
 	{
-		if (!(R8B_X_SKIP & 8)) cx_final_compute<LOGN, UPLOG>(L, buf, st, tid);
-#if defined(R8B_X_ROWLATE) && !R8B_X_ROWLATE
+		cx_final_store<LOGN, UPLOG>(L, rbuf, st, k, MODE == 1, tid);
 		if constexpr (MODE == 1) cx_whole_row<FLENP>(X, st.row, tid);
-#endif
 	});
 	ex.phase([&](int tid, St& st)
 	{
-		if (!(R8B_X_SKIP & 128)) cx_final_store<LOGN, UPLOG>(L, rbuf, st, k, MODE == 1, tid);
-#if !defined(R8B_X_ROWLATE) || R8B_X_ROWLATE
-		if constexpr (MODE == 1)
-		{
-			if (!(R8B_X_SKIP & 256)) cx_whole_row<FLENP>(X, st.row, tid);
-		}
-#endif
-	});
-	ex.phase([&](int tid, St& st)
-	{
-		if constexpr (MODE == 1)
-		{
-			if (!(R8B_X_SKIP & 16)) cx_whole_compute<FLENP>(X, rbuf, st.row, k, ch, tid);
-		}
+		if constexpr (MODE == 1) cx_whole_compute<FLENP>(X, rbuf, st.row, k, ch, tid);
 		else cx_store_conv(L, rbuf, k, ch, tid);
 	});
 }

@@ -544,6 +544,10 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	L.up = g.up; L.down = g.down; L.fl2 = g.fl2; L.bl2 = g.bl2; L.in_len = g.in_len;
 	L.n_in = g.n_in; L.n_out = g.n_out;
 	L.blk_stride = g.in_len;
+	// aligned 16-byte loads of sample pairs need even positions on every side of the selection
+	L.vec_ok = (src.cur == nullptr || (((size_t) src.cur & 15) == 0 && (src.cur_stride & 1) == 0 &&
+		(src.cur_base & 1) == 0)) && (src.ring_stride & 1) == 0 && ((g.in_len / g.up) & 1) == 0 &&
+		((g.in_len / g.up) & 1) == 0 ? 1 : 0;
 	L.up_pow2 = g.up_pow2 ? 1 : 0;
 	L.down_pow2 = g.down_pow2 ? 1 : 0;
 	L.n_fwd = (int) d.fwd_radix.size();
@@ -584,8 +588,11 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	// input is complete whenever the reference has emitted the output (its latency covers one
 	// whole block of in_len >= S samples), so block contents -- and therefore the stream -- do
 	// not depend on how the input is cut into calls.
-	const long long S = in_len - (w.flen + up - 1) / up * up;
+	long long S = in_len - (w.flen + up - 1) / up * up;
+	// keep block starts on even input positions (pairs of samples load as 16 bytes)
+	while ((S / up) & 1) S -= up;
 	X.c.blk_stride = (int) S;
+	if (((S / up) & 1) != 0) X.c.vec_ok = 0;
 	auto owner = [&](long long j) // first block whose valid range ends after the window of j
 	{
 		const long long v = j * In / Out + w.fl2 + fl2c - in_len;

@@ -44,6 +44,8 @@ struct ConvLaunch
 	// virtual samples between the starts of consecutive blocks: in_len (the reference's own block
 	// anchoring, reference CDSPBlockConvolver.h:283-305) except in the fused fast path
 	int blk_stride;
+	// fast path: the source admits aligned 16-byte loads of sample pairs (even positions)
+	int vec_ok;
 	int up_pow2, down_pow2;
 	// transform plan: radices of the forward passes in execution order (sub-length N, N/r0, ...)
 	// and of the backward passes in execution order (sub-length grows to N2)

@@ -131,6 +131,7 @@ struct EmulExec
 	{
 		for (int t = 0; t < kConvxThreads; t++) f(t, st[(size_t) t]);
 	}
+
 };
 
 template<int LOGN, int UPLOG, int MODE, int FLENP>
