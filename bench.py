@@ -32,6 +32,22 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def channel_shard(total_channels, rank, world):
+    """Contiguous channel block [lo, hi) owned by `rank`: channels never interact, so a batch that
+    is sharded this way needs no data-path collective."""
+    lo = total_channels * rank // world
+    hi = total_channels * (rank + 1) // world
+    return lo, hi
+
+
+def kernel_ms(timings, steps):
+    """ms per step per kernel name (stages that run the same kernel are summed)."""
+    out = {}
+    for name, ms, launches, _, _ in timings:
+        out[name] = round(out.get(name, 0.0) + ms / max(steps, 1), 4)
+    return out
+
+
 def cpu_baseline(src, dst, L, gpu_sample=None):
     """Reference CPU path on a bounded sample (~20 CPU-seconds) of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -108,7 +124,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     r8b = importlib.import_module("r8brain-free-src_amd")
-    C, L = args.channels, args.block
+    # weak scaling: --channels per GPU; the global batch is channels*world, rank r owns
+    # channel_shard(channels*world, r, world)
+    lo, hi = channel_shard(args.channels * world, rank, world)
+    C, L = hi - lo, args.block
     rs = r8b.BatchResampler(args.src, args.dst, L, 2.0, 180.15, nch=C, device=local_rank)
     for o in args.opt:
         k, v = o.split("=")
@@ -184,8 +203,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "alg_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(avg_ms, 4),
                          "launches": launches,
-                         "kernels_ms_per_step": {t[0]: round(t[1] / max(t[2], 1), 4)
-                                                 for t in timings},
+                         "kernels_ms_per_step": kernel_ms(timings, args.steps),
                          "path_frac": round(path_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                                             4)},
         }

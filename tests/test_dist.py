@@ -1,0 +1,78 @@
+"""CPU tier, 2 processes over gloo: the multi-GPU path of bench.py shards CHANNELS across ranks
+with no data-path collective (channels are independent streams, reference README.md:53-55).
+Checked here without GPUs: every rank derives its shard from (rank, world) alone, shards are
+disjoint and cover the batch, each rank's per-call output counts (host plan through the C ABI) are
+identical -- so the only cross-rank traffic bench.py needs is the barrier and the MAX of the timed
+region, which are exercised with the same torch.distributed calls."""
+import importlib
+import os
+import socket
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import bench
+    r8b = importlib.import_module("r8brain-free-src_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = 2048
+    lo, hi = bench.channel_shard(total, rank, world)
+    lib = r8b.load()
+    p = lib.r8b_plan_create(44100.0, 96000.0, 16384, 2.0, 180.15)
+    counts = [lib.r8b_plan_step(p, 16384) for _ in range(4)]
+    t = torch.tensor([float(hi - lo), float(sum(counts)), 0.001 * (rank + 1)], dtype=torch.float64)
+    gathered = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    dist.barrier()
+    tmax = t[2:3].clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        q.put(([(float(g[0]), float(g[1])) for g in gathered], float(tmax), (lo, hi)))
+    dist.destroy_process_group()
+
+
+def test_channel_sharding_two_ranks():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    per_rank, tmax, shard0 = res
+    assert sum(n for n, _ in per_rank) == 2048 and all(n == 1024 for n, _ in per_rank)
+    assert per_rank[0][1] == per_rank[1][1] > 0     # same schedule on every rank
+    assert abs(tmax - 0.002) < 1e-12                 # MAX over ranks
+    assert shard0 == (0, 1024)
+
+
+def test_channel_shard_function():
+    sys.path.insert(0, ROOT)
+    import bench
+    for total, world in [(8192, 8), (1000, 3), (7, 8), (1, 1)]:
+        cover = []
+        for r in range(world):
+            lo, hi = bench.channel_shard(total, r, world)
+            assert 0 <= lo <= hi <= total
+            cover += list(range(lo, hi))
+        assert cover == list(range(total))

@@ -213,3 +213,21 @@ def test_hip_full_size_properties(torch, cfg):
     yc = np.concatenate([b2.process_host(np.full((1, L), 0.5))[0] for _ in range(calls + 2)])
     tail = yc[len(yc) // 2:]
     assert len(tail) > 100 and peak(tail - 0.5) <= (5e-9 if dst > 1e6 else 2e-12)
+
+
+def test_cxx_frontend(torch, tmp_path):
+    """include/r8b/CDSPResampler.h + the five DLL symbols from a C++ host, the way the reference's
+    example.cpp uses its classes; compared with the oracle"""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "cxx_frontend")
+    libdir = os.path.dirname(r8b.lib_path())
+    subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cxx_frontend.cpp"),
+                    "-L" + libdir, "-lr8bsrc_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, stdout=subprocess.PIPE, text=True).stdout.split("\n")
+    assert out[0].split()[1] == out[0].split()[2]
+    vals = np.array([float.fromhex(l) for l in out if l.startswith(("0x", "-0x"))])
+    o = O.OracleResampler(44100.0, 96000.0, 1024, 2.0, 180.15)
+    x = O.splitmix_uniform(7, 1024 * 6)
+    yo = np.concatenate([o.process(x[i:i + 1024]) for i in range(0, len(x), 1024)])
+    assert len(vals) == len(yo) and rms(vals - yo) <= RMS_TOL and peak(vals - yo) <= PEAK_TOL
