@@ -57,13 +57,19 @@ inline int convx_lds_need(int logn2, int in_len, int mode)
 
 // log2 radix of the pass that touches the full length (first DIF pass / last DIT pass): sized so
 // that one butterfly per thread covers the array when possible
+#ifndef R8B_CX_MAXBITS
+#define R8B_CX_MAXBITS 4 // largest log2 radix of a pass (4: radix 16, fewest LDS round trips)
+#endif
 constexpr int big_pass_bits(int logn)
 {
-	return logn - 8 < 1 ? 1 : (logn - 8 > 4 ? 4 : logn - 8);
+	return logn - 8 < 1 ? 1 : (logn - 8 > R8B_CX_MAXBITS ? R8B_CX_MAXBITS : logn - 8);
 }
 
-// number of remaining passes and their log2 radices (as even as possible, each <= 4)
-constexpr int rest_passes(int logn) { return (logn - big_pass_bits(logn) + 3) / 4; }
+// number of remaining passes and their log2 radices (as even as possible, each <= R8B_CX_MAXBITS)
+constexpr int rest_passes(int logn)
+{
+	return (logn - big_pass_bits(logn) + R8B_CX_MAXBITS - 1) / R8B_CX_MAXBITS;
+}
 constexpr int rest_bits(int logn, int i)
 {
 	const int bits = logn - big_pass_bits(logn), np = rest_passes(logn);
@@ -321,7 +327,7 @@ R8B_HD void cx_prefetch(const ConvLaunch& L, ConvxState<LOGN, UPLOG>& st, long l
 	constexpr int R = ConvxState<LOGN, UPLOG>::RF, N = 1 << LOGN, nb = N / R, NIN = 2 * N;
 	if (tid >= nb) return;
 	const int iln = L.in_len / L.up;
-	const long long base = k * (long long) (L.blk_stride / L.up);
+	const long long base = (k * (long long) L.blk_stride + L.blk_offset) / L.up;
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
@@ -482,17 +488,28 @@ R8B_HD void cx_final_compute(const ConvLaunch& L, const cd* buf, ConvxState<LOGN
 	}
 }
 
+// first time (virtual rate) of block k's valid output run
+R8B_HD long long cx_block_t0(const ConvLaunch& L, long long k)
+{
+	return k * (long long) L.blk_stride + L.blk_offset - L.fl2;
+}
+
 // last backward pass, part 2: the block's valid outputs as one linear run y[u], u in [0, in_len),
-// y[u] = convolver output at time t0 + u, t0 = k*in_len - fl2 (reals, unpadded, at `y`)
-template<int LOGN, int UPLOG>
+// y[u] = convolver output at time t0 + u (reals, unpadded, at `y`).  COPIES == 2 also writes the
+// one-sample-shifted copy y1; ZERO_NEG clears the outputs at negative times (a stage's stream
+// starts at t = 0: for the next stage earlier samples do not exist, its history is zero --
+// reference CDSPFracInterpolator.h:834-859).
+template<int LOGN, int UPLOG, int COPIES, bool ZERO_NEG>
 R8B_HD void cx_final_store(const ConvLaunch& L, double* y, const ConvxState<LOGN, UPLOG>& st,
-	long long k, bool zero_negative, int tid)
+	long long k, int tid)
 {
 	constexpr int LOGN2 = LOGN + UPLOG, RB = big_pass_bits(LOGN2), R = 1 << RB;
 	constexpr int nb = (1 << LOGN2) / R, q = nb;
 	typedef ConvxState<LOGN, UPLOG> St;
 	const int mask = (2 << LOGN2) - 1;
 	double* const y1 = y + cx_y1_offset(L.in_len);
+	const long long t0 = cx_block_t0(L, k);
+	const int nzero = !ZERO_NEG || t0 >= 0 ? 0 : (-t0 > L.in_len ? L.in_len : (int) -t0);
 #pragma unroll
 	for (int f = 0; f < St::FIN; f++)
 	{
@@ -503,35 +520,28 @@ R8B_HD void cx_final_store(const ConvLaunch& L, double* y, const ConvxState<LOGN
 		{
 			const int e = b + p * q; // complex index: reals 2e, 2e+1 at circular positions c
 			const int u0 = (2 * e + L.fl2) & mask, u1 = (2 * e + 1 + L.fl2) & mask;
-			double v0 = st.fr[f][p], v1 = st.fi[f][p];
-			if (zero_negative && k == 0)
-			{
-				// the stream starts at t = 0: earlier convolver outputs do not exist for the
-				// next stage (its history is zero), reference CDSPFracInterpolator.h:834-859
-				if (u0 < L.fl2) v0 = 0.0;
-				if (u1 < L.fl2) v1 = 0.0;
-			}
+			const double v0 = u0 < nzero ? 0.0 : st.fr[f][p], v1 = u1 < nzero ? 0.0 : st.fi[f][p];
 			if (u0 < L.in_len)
 			{
 				y[u0] = v0;
-				if (zero_negative && u0 > 0) y1[u0 - 1] = v0; // shifted copy (fused mode only)
+				if (COPIES == 2 && u0 > 0) y1[u0 - 1] = v0;
 			}
 			if (u1 < L.in_len)
 			{
 				y[u1] = v1;
-				if (zero_negative && u1 > 0) y1[u1 - 1] = v1;
+				if (COPIES == 2 && u1 > 0) y1[u1 - 1] = v1;
 			}
 		}
 	}
 	// zero extension read (times zero taps) by the padded polyphase rows
 	if (tid < 8) y[L.in_len + tid] = 0.0;
-	else if (zero_negative && tid < 24) y1[L.in_len - 1 + (tid - 8)] = 0.0;
+	else if (COPIES == 2 && tid < 24) y1[L.in_len - 1 + (tid - 8)] = 0.0;
 }
 
 // MODE 0: K7, write the block's valid outputs that fall into [a, b)
 R8B_HD void cx_store_conv(const ConvLaunch& L, const double* y, long long k, int ch, int tid)
 {
-	const long long t0 = k * (long long) L.blk_stride - L.fl2;
+	const long long t0 = cx_block_t0(L, k);
 	for (int u = tid; u < L.in_len; u += kConvxThreads)
 	{
 		const long long q = t0 + u;
@@ -645,6 +655,32 @@ R8B_HD void cx_inv_seq(Exec& ex, const ConvLaunch& L, cd* buf)
 	}
 }
 
+// MODE 2: K8 on the matrix cores.  Outputs j = OutStep*g + ph (group g, phase ph) read
+// y[InStep*g + r_ph - fll + i], r_ph = floor(ph*InStep/OutStep): for a tile of 16 phases x 16
+// groups this is D[16x16] = A[16xK] * B[Kx16] with B[c][n] = y[InStep*n + c0 + c] and the banded,
+// group-independent A[m][c] = T[ph0+m][c - (r_(ph0+m) - r_ph0)] (zero outside the 24 taps), K
+// <= 40.  v_mfma_f64_16x16x4_f64 runs it on the MFMA pipe next to the other workgroups' FFT
+// VALU work, and every convolver output is read from LDS ~2.5 times instead of 24.  A block
+// covers exactly 16 groups (blk_stride = 16*InStep); wave w takes phase tiles w, w+4, ...
+// Operand layout (cdna_hip_programming.md section 3): lane l supplies A[l&15][l>>4] and
+// B[l>>4][l&15]; D register i of lane l is row (l>>4) + 4*i, column l&15.
+R8B_HD int cx_mfma_b_index(const ConvxLaunch& X, int p, int lane)
+{
+	return X.mf_boff[p] + X.in_step * (lane & 15) + (lane >> 4);
+}
+
+R8B_HD void cx_mfma_store(const ConvxLaunch& X, long long k, int ch, int p, int lane, const double* d)
+{
+	const long long jb = (long long) X.out_step * (16 * k + (lane & 15));
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+	{
+		const int ph = 16 * p + (lane >> 4) + 4 * i;
+		const long long j = jb + ph;
+		if (ph < X.out_step && j >= X.wa && j < X.wb) dst_store(X.wdst, ch, j, d[i]);
+	}
+}
+
 // One workgroup = one block of one channel.  (A persistent variant that walks several blocks and
 // prefetches the next block's input during the output phase was tried: the loop-carried state
 // pushes hipcc into heavy SGPR/VGPR spilling, 3x slower.  Latency hiding is left to the 3-4
@@ -676,14 +712,19 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 	ex.phase([&](int tid, St& st) { cx_final_compute<LOGN, UPLOG>(L, buf, st, tid); });
 	ex.phase([&](int tid, St& st)
 	{
-		cx_final_store<LOGN, UPLOG>(L, rbuf, st, k, MODE == 1, tid);
+		cx_final_store<LOGN, UPLOG, MODE == 1 ? 2 : 1, MODE != 0>(L, rbuf, st, k, tid);
 		if constexpr (MODE == 1) cx_whole_row<FLENP>(X, st.row, tid);
 	});
-	ex.phase([&](int tid, St& st)
+	// K steps: 10 cover 24 taps + the 14-sample phase spread of a tile, 12 cover 32 taps
+	if constexpr (MODE == 2) ex.template mfma_interp<(FLENP > 24 ? 12 : 10)>(X, rbuf, k, ch);
+	else
 	{
-		if constexpr (MODE == 1) cx_whole_compute<FLENP>(X, rbuf, st.row, k, ch, tid);
-		else cx_store_conv(L, rbuf, k, ch, tid);
-	});
+		ex.phase([&](int tid, St& st)
+		{
+			if constexpr (MODE == 1) cx_whole_compute<FLENP>(X, rbuf, st.row, k, ch, tid);
+			else cx_store_conv(L, rbuf, k, ch, tid);
+		});
+	}
 }
 
 } // namespace r8bhip

@@ -196,6 +196,11 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["timing"] = 0;
 	opt_["fast_conv"] = 1; // compile-time-sized convolver kernel when the geometry allows
 	opt_["fuse"] = 1;      // ... with the whole-step interpolator behind it fused in
+	opt_["fuse_hb"] = 1;   // runs of half-band up-samplers as one kernel
+	// fused interpolator on the matrix cores (when a block holds 16 output groups): measured equal
+	// to the vector-ALU form on cfg2 (0.357 vs 0.362 ms: 10x fewer LDS reads, 13 % more FFT
+	// blocks), so the simpler form stays the default
+	opt_["mfma_interp"] = 0;
 	dev_.resize(plan_.stages.size());
 	for (size_t s = 0; s < plan_.stages.size(); s++)
 	{
@@ -246,6 +251,63 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 		}
 	}
 	plan_transforms();
+	for (size_t s = 0; s + 1 < plan_.stages.size(); s++)
+		if (fuse_with_next(s)) prepare_mfma(s);
+}
+
+// Geometry and A fragments of the matrix-core interpolator (r8b_convx.h, MODE 2) for the fused
+// pair (convolver s, whole-step interpolator s+1); leaves mf_ok false when a block cannot hold 16
+// groups of outputs.
+void Engine::prepare_mfma(size_t s)
+{
+	const StagePlan& c = plan_.stages[s];
+	const StagePlan& w = plan_.stages[s + 1];
+	StageDev& d = dev_[s + 1];
+	const int In = w.in_step, Out = w.out_step, up = c.cg.up;
+	auto r_of = [&](int ph) { return (int) ((long long) ph * In / Out); };
+	const int tiles = (Out + 15) / 16;
+	if (tiles > 16) return;
+	// first valid time of block k is k*16*In - fll - e, e chosen so that the block's first fresh
+	// input sample sits on an even input position (16-byte loads)
+	const int align = 2 * up;
+	const int boff = (c.cg.fl2 - w.fll) / align * align;
+	if (boff < 0) return;
+	const int e = c.cg.fl2 - w.fll - boff;
+	int span = 0;
+	for (int p = 0; p < tiles; p++)
+	{
+		const int last = std::min(16 * p + 15, Out - 1);
+		span = std::max(span, r_of(last) - r_of(16 * p) + w.flen);
+	}
+	// the kernel unrolls a fixed number of K steps: 10 (<= 24 taps) or 12 (<= 32 taps)
+	const int ksteps = w.flen > 24 ? 12 : 10;
+	if ((span + 3) / 4 > ksteps) return;
+	// everything a block reads must lie inside its valid run (+8 zero-extension doubles)
+	const int max_index = r_of(16 * (tiles - 1)) + e + In * 15 + 3 + 4 * (ksteps - 1);
+	if (max_index >= c.cg.in_len + 8 || 16 * In > c.cg.in_len) return;
+	if (w.fll + e + 15 * In + r_of(Out - 1) + w.fl2 + 1 > c.cg.in_len) return;
+	std::vector<double> at((size_t) tiles * ksteps * 64, 0.0);
+	const std::vector<double>& T = w.bank->table;
+	for (int p = 0; p < tiles; p++)
+	{
+		d.mf_boff[p] = r_of(16 * p) + e;
+		for (int st = 0; st < ksteps; st++)
+			for (int lane = 0; lane < 64; lane++)
+			{
+				const int ph = 16 * p + (lane & 15), col = 4 * st + (lane >> 4);
+				if (ph >= Out) continue;
+				const int idx = col - (r_of(ph) - r_of(16 * p));
+				if (idx < 0 || idx >= w.flen) continue;
+				const int row = (int) (((long long) ph * In) % Out);
+				at[((size_t) p * ksteps + st) * 64 + lane] = T[(size_t) row * w.flen + idx];
+			}
+	}
+	d.mf_atab = (double*) dev_alloc(at.size() * sizeof(double));
+	dev_upload(d.mf_atab, at.data(), at.size() * sizeof(double));
+	d.mf_ksteps = ksteps;
+	d.mf_tiles = tiles;
+	d.mf_e = e;
+	d.mf_ok = true;
 }
 
 Engine::~Engine()
@@ -264,6 +326,7 @@ Engine::~Engine()
 		dev_free(d.spec);
 		dev_free(d.table);
 		dev_free(d.wtab);
+		dev_free(d.mf_atab);
 	}
 }
 
@@ -328,7 +391,7 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 				"k_convx" : "k_conv");
 			break;
 		case kFrac: *kernel = sp.whole ? "k_whole" : "k_poly"; break;
-		case kHBUp: *kernel = "k_hbup"; break;
+		case kHBUp: *kernel = group_len(stage) > 1 ? "k_hbcascade" : "k_hbup"; break;
 		case kHBDown: *kernel = "k_hbdown"; break;
 		}
 	}
@@ -450,10 +513,19 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 		long long a, b;
 		PolyState ps;
 		sp.step(n, &a, &b, &ps);
-		const bool fused = fuse_with_next(s);
-		long long wa = 0, wb = 0;
-		if (fused) plan_.stages[s + 1].step((int) (b - a), &wa, &wb, nullptr);
-		const size_t last = fused ? s + 1 : s; // stage whose output this launch produces
+		// stages [s, s+glen) are executed by one launch: convolver + whole-step interpolator, or a
+		// run of half-band up-samplers
+		const int glen = group_len(s);
+		const bool fused = glen > 1;
+		long long wa = a, wb = b;
+		for (int g = 1; g < glen; g++)
+		{
+			long long ga, gb;
+			plan_.stages[s + g].step((int) (wb - wa), &ga, &gb, nullptr);
+			wa = ga;
+			wb = gb;
+		}
+		const size_t last = s + glen - 1; // stage whose output this launch produces
 		SrcView src;
 		src.ring = dev_[s].ring;
 		src.ring_stride = dev_[s].ring_size;
@@ -496,7 +568,8 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 				e1 = get_event(dev_[s]);
 				dev_event_record(e0, stream);
 			}
-			if (fused) launch_fused(s, wa, wb, src, dst, stream);
+			if (fused && sp.desc.kind == kConv) launch_fused(s, wa, wb, src, dst, stream);
+			else if (fused) launch_cascade(s, glen, wa, wb, src, dst, stream);
 			else launch_stage(s, m_prev, a, b, ps, src, dst, stream);
 			if (timing)
 			{
@@ -521,9 +594,51 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 			launch_tail(T, stream);
 		}
 		n = (int) (fused ? wb - wa : b - a);
-		if (fused) s++;
+		s += glen - 1;
 	}
 	return n;
+}
+
+int Engine::group_len(size_t s) const
+{
+	if (fuse_with_next(s)) return 2;
+	if (opt_.at("fuse_hb") && plan_.stages[s].desc.kind == kHBUp)
+	{
+		int n = 1;
+		while (s + n < plan_.stages.size() && plan_.stages[s + n].desc.kind == kHBUp &&
+			n < kMaxCascade) n++;
+		return n;
+	}
+	return 1;
+}
+
+void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, const SrcView& src,
+	const DstView& dst, void* stream)
+{
+	HBCascadeLaunch L;
+	L.nst = glen;
+	for (int g = 0; g < kMaxCascade; g++)
+	{
+		L.ntaps[g] = 0;
+		for (int k = 0; k < 14; k++) L.taps[g][k] = 0.0;
+	}
+	for (int g = 0; g < glen; g++)
+	{
+		const StagePlan& sp = plan_.stages[s + g];
+		if (sp.hb_n > 14) throw std::runtime_error("half-band filter too long");
+		// rounded up to the unrolled widths of the kernel (extra taps are zero)
+		L.ntaps[g] = sp.hb_n <= 4 ? 4 : (sp.hb_n <= 8 ? 8 : 14);
+		for (int k = 0; k < sp.hb_n; k++) L.taps[g][k] = sp.hb_taps[k];
+	}
+	L.a = fa; L.b = fb;
+	// last-stage outputs per workgroup: a multiple of 2^glen, about 4096
+	int tile = 1 << glen;
+	while (tile < 4096) tile <<= 1;
+	L.tile = tile;
+	L.buf = tile / 2 + 96; // largest intermediate stream of a tile (input of the last stage)
+	L.nch = nch_;
+	L.src = src; L.dst = dst;
+	launch_hbcascade(L, stream);
 }
 
 bool Engine::fuse_with_next(size_t s) const
@@ -544,6 +659,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	L.up = g.up; L.down = g.down; L.fl2 = g.fl2; L.bl2 = g.bl2; L.in_len = g.in_len;
 	L.n_in = g.n_in; L.n_out = g.n_out;
 	L.blk_stride = g.in_len;
+	L.blk_offset = 0;
 	// aligned 16-byte loads of sample pairs need even positions on every side of the selection
 	L.vec_ok = (src.cur == nullptr || (((size_t) src.cur & 15) == 0 && (src.cur_stride & 1) == 0 &&
 		(src.cur_base & 1) == 0)) && (src.ring_stride & 1) == 0 && ((g.in_len / g.up) & 1) == 0 &&
@@ -581,6 +697,28 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	X.wdst = dst;
 	const int in_len = c.cg.in_len, fl2c = c.cg.fl2, up = c.cg.up;
 	const long long In = w.in_step, Out = w.out_step;
+	X.c.blk_offset = 0;
+	X.mf_atab = nullptr; X.mf_ksteps = 0; X.mf_tiles = 0;
+	for (int i = 0; i < 16; i++) X.mf_boff[i] = 0;
+	const StageDev& dw = dev_[s + 1];
+	if (opt_.at("mfma_interp") && dw.mf_ok)
+	{
+		// matrix-core interpolation: block k = output groups [16k, 16k+16), i.e. outputs
+		// [16*Out*k, 16*Out*(k+1)); its run starts at time 16*In*k - fll - e
+		X.c.blk_stride = (int) (16 * In);
+		X.c.blk_offset = fl2c - w.fll - dw.mf_e;
+		X.mf_atab = dw.mf_atab; X.mf_ksteps = dw.mf_ksteps; X.mf_tiles = dw.mf_tiles;
+		for (int i = 0; i < 16; i++) X.mf_boff[i] = dw.mf_boff[i];
+		const long long per = 16 * Out;
+		const long long kfirst = wa / per, klast = (wb - 1) / per;
+		for (long long k0 = kfirst; k0 <= klast; k0 += kConvxMaxBlocks)
+		{
+			X.c.k0 = k0;
+			X.c.nblk = (int) (std::min(klast, k0 + kConvxMaxBlocks - 1) - k0 + 1);
+			launch_convx(X, 2, stream);
+		}
+		return;
+	}
 	// Blocks start S virtual samples apart with S = in_len - (interpolator taps, rounded up to
 	// the up factor): the valid ranges [k*S - fl2, k*S - fl2 + in_len) of consecutive blocks
 	// overlap by at least flen-1 convolver outputs, so each interpolator tap window lies inside

@@ -53,6 +53,11 @@ private:
 		int tw_len = 0;
 		double* table = nullptr;
 		double* wtab = nullptr; // whole-step bank, transposed per residue class (fused kernel)
+		// matrix-core interpolation (fused mode 2): banded A fragments and tile geometry
+		double* mf_atab = nullptr;
+		int mf_ksteps = 0, mf_tiles = 0, mf_e = 0;
+		int mf_boff[16] = {};
+		bool mf_ok = false;
 		std::vector<int> fwd_radix, inv_radix;
 		std::vector<std::pair<void*, void*>> pending; // (start, stop) events not yet read
 		std::vector<void*> free_events;
@@ -64,6 +69,10 @@ private:
 
 	void plan_transforms();
 	bool fuse_with_next(size_t s) const;
+	void prepare_mfma(size_t s);
+	int group_len(size_t s) const;
+	void launch_cascade(size_t s, int glen, long long fa, long long fb, const SrcView& src,
+		const DstView& dst, void* stream);
 	void fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const;
 	void launch_fused(size_t s, long long wa, long long wb, const SrcView& src,
 		const DstView& dst, void* stream);

@@ -524,6 +524,98 @@ R8B_HD void hbdown_compute(const HBLaunch& L, const double* xs, long long n0, lo
 	}
 }
 
+// ------------------------------------------------------------------------------------ half-band cascade
+//
+// Tile of last-stage outputs [q0, q1).  Working backwards, stage s (0-based) must produce its
+// outputs [lo[s], hi[s]) and reads its input over [in_lo[s], in_hi[s]):
+//   y[2n] = x[n], y[2n+1] = sum_k f[k] (x[n+1+k] + x[n-k])  (reference CDSPHBUpsampler.h:773-786)
+// so in_lo = floor(lo/2) - (T-1), in_hi = floor((hi-1)/2) + T + 1.  Stage s+1's input range is
+// stage s's output range.
+
+struct HBCRanges
+{
+	long long lo[kMaxCascade], hi[kMaxCascade]; // outputs of stage s
+	long long in_lo, in_hi;                      // input of stage 0
+};
+
+R8B_HD long long floor_half(long long v) { return v >> 1; } // arithmetic shift == floor for negatives
+
+R8B_HD void hbc_ranges(const HBCascadeLaunch& L, long long q0, long long q1, HBCRanges& R)
+{
+	long long lo = q0, hi = q1;
+	for (int s = L.nst - 1; s >= 0; s--)
+	{
+		R.lo[s] = lo;
+		R.hi[s] = hi;
+		const int T = L.ntaps[s];
+		const long long ilo = floor_half(lo) - (T - 1), ihi = floor_half(hi - 1) + T + 1;
+		lo = ilo;
+		hi = ihi;
+	}
+	R.in_lo = lo;
+	R.in_hi = hi;
+}
+
+R8B_HD void hbc_load(const HBCascadeLaunch& L, const HBCRanges& R, double* buf, int ch, int tid,
+	int nthr)
+{
+	const int len = (int) (R.in_hi - R.in_lo);
+	for (int i = tid; i < len; i += nthr) buf[i] = src_load(L.src, ch, R.in_lo + i);
+}
+
+// one stage: input x[] (LDS, xin[0] = stream position in_lo) -> outputs [lo, hi) either into LDS
+// (yout[0] = position lo) or, for the last stage, to the destination.  TP = tap count rounded up
+// (4, 8 or 14): L.ntaps[] already holds the rounded count (so the input ranges cover the wider
+// window) and the extra taps are zero.
+template<int TP>
+R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, int s, const double* xin, long long in_lo,
+	long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr)
+{
+	double f[TP];
+#pragma unroll
+	for (int k = 0; k < TP; k++) f[k] = L.taps[s][k];
+	const long long n0 = floor_half(lo);
+	const int cnt = (int) (floor_half(hi - 1) + 1 - n0);
+	const int xoff = (int) (n0 - in_lo);  // index of x[n0] in xin
+	const int qoff = (int) (2 * n0 - lo); // index of output 2*n0 relative to lo (0 or -1)
+	const int nout = (int) (hi - lo);
+	for (int i = tid; i < cnt; i += nthr)
+	{
+		const double* x = xin + xoff + i; // x[0] == stream x[n0 + i]
+		double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+		for (int k = 0; k < TP; k += 2)
+		{
+			a0 += f[k] * (x[1 + k] + x[-k]);
+			a1 += f[k + 1] * (x[2 + k] + x[-k - 1]);
+		}
+		const long long q = 2 * (n0 + i);
+		// a stage's stream starts at position 0: earlier outputs do not exist for the next stage
+		const double ev = q < 0 ? 0.0 : x[0];
+		const double od = q + 1 < 0 ? 0.0 : a0 + a1;
+		const int o = qoff + 2 * i;
+		if (last)
+		{
+			if (o >= 0 && o < nout) dst_store(L.dst, ch, q, ev);
+			if (o + 1 >= 0 && o + 1 < nout) dst_store(L.dst, ch, q + 1, od);
+		}
+		else
+		{
+			if (o >= 0 && o < nout) yout[o] = ev;
+			if (o + 1 >= 0 && o + 1 < nout) yout[o + 1] = od;
+		}
+	}
+}
+
+R8B_HD void hbc_stage(const HBCascadeLaunch& L, int s, const double* xin, long long in_lo,
+	long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr)
+{
+	const int T = L.ntaps[s];
+	if (T <= 4) hbc_stage_t<4>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
+	else if (T <= 8) hbc_stage_t<8>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
+	else hbc_stage_t<14>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
+}
+
 } // namespace r8bhip
 
 #endif

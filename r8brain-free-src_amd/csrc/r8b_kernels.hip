@@ -124,6 +124,35 @@ __global__ void k_hbdown(const HBLaunch L)
 	hbdown_compute(L, xs, n0, n1, ch, tid, nthr);
 }
 
+// ------------------------------------------------------------------ half-band cascade (cfg5: 5 stages, 32x)
+__global__ void k_hbcascade(const HBCascadeLaunch L)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	double* const b0 = reinterpret_cast<double*>(smem);
+	double* const b1 = b0 + L.buf;
+	const int tid = threadIdx.x, nthr = blockDim.x;
+	const int ch = blockIdx.y;
+	const long long q0 = L.a + (long long) blockIdx.x * L.tile;
+	long long q1 = q0 + L.tile;
+	if (q1 > L.b) q1 = L.b;
+	HBCRanges R;
+	hbc_ranges(L, q0, q1, R);
+	hbc_load(L, R, b0, ch, tid, nthr);
+	__syncthreads();
+	double* xin = b0;
+	double* yout = b1;
+	long long in_lo = R.in_lo;
+	for (int s = 0; s < L.nst; s++)
+	{
+		hbc_stage(L, s, xin, in_lo, R.lo[s], R.hi[s], yout, s + 1 == L.nst, ch, tid, nthr);
+		__syncthreads();
+		in_lo = R.lo[s];
+		double* t = xin;
+		xin = yout;
+		yout = t;
+	}
+}
+
 // ------------------------------------------------------------------ history tail of the caller's buffer
 __global__ void k_tail(const TailLaunch L)
 {
@@ -153,6 +182,31 @@ struct GpuExec
 	long long ts[24];
 	int nts = 0;
 #endif
+	// MODE 2 output phase: every wave runs its phase tiles on the matrix cores
+	template<int KS>
+	__device__ __forceinline__ void mfma_interp(const ConvxLaunch& X, const double* y, long long k, int ch)
+	{
+		typedef double d4 __attribute__((ext_vector_type(4)));
+		const int wave = (int) threadIdx.x >> 6, lane = (int) threadIdx.x & 63;
+		for (int p = wave; p < X.mf_tiles; p += kConvxThreads / 64)
+		{
+			// all operand fetches of the tile first (A fragments from L2, B from LDS), then the
+			// K steps back to back on the matrix pipe
+			const double* at = X.mf_atab + (long) p * KS * 64 + lane;
+			const double* bp = y + cx_mfma_b_index(X, p, lane);
+			double a[KS], b[KS];
+#pragma unroll
+			for (int s = 0; s < KS; s++) a[s] = at[s * 64];
+#pragma unroll
+			for (int s = 0; s < KS; s++) b[s] = bp[4 * s];
+			d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+			for (int s = 0; s < KS; s++)
+				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
+			const double d[4] = { acc[0], acc[1], acc[2], acc[3] };
+			cx_mfma_store(X, k, ch, p, lane, d);
+		}
+	}
 	template<class F>
 	__device__ __forceinline__ void phase(F f)
 	{
@@ -280,6 +334,8 @@ void launch_convx(const ConvxLaunch& X, int mode, void* stream)
 	if (logn == LN && up == (1 << UL)) \
 	{ \
 		if (mode == 0) launch_convx_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
+		else if (mode == 2 && wide) launch_convx_t<LN, UL, 2, 32>(X, (hipStream_t) stream); \
+		else if (mode == 2) launch_convx_t<LN, UL, 2, 24>(X, (hipStream_t) stream); \
 		else if (wide) launch_convx_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
 		else launch_convx_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
 		return; \
@@ -287,6 +343,16 @@ void launch_convx(const ConvxLaunch& X, int mode, void* stream)
 	R8B_CONVX_GEOMS(R8B_CONVX_DISPATCH)
 #undef R8B_CONVX_DISPATCH
 	throw std::runtime_error("launch_convx: geometry not instantiated");
+}
+
+void launch_hbcascade(const HBCascadeLaunch& L, void* stream)
+{
+	const long long n = L.b - L.a;
+	if (n <= 0) return;
+	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
+	hipLaunchKernelGGL(k_hbcascade, dim3(tiles, (unsigned) L.nch), dim3(256),
+		(size_t) 2 * L.buf * sizeof(double), (hipStream_t) stream, L);
+	check(hipGetLastError(), "launch k_hbcascade");
 }
 
 void launch_tail(const TailLaunch& L, void* stream)

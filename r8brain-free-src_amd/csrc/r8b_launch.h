@@ -44,6 +44,7 @@ struct ConvLaunch
 	// virtual samples between the starts of consecutive blocks: in_len (the reference's own block
 	// anchoring, reference CDSPBlockConvolver.h:283-305) except in the fused fast path
 	int blk_stride;
+	int blk_offset; // virtual position of block 0's first fresh sample (0 except fused MFMA mode)
 	// fast path: the source admits aligned 16-byte loads of sample pairs (even positions)
 	int vec_ok;
 	int up_pow2, down_pow2;
@@ -105,6 +106,23 @@ struct HBLaunch
 	DstView dst;
 };
 
+// A run of consecutive 2x half-band up-samplers executed by one kernel: every intermediate stream
+// stays in LDS, only the first stage's input is read and the last stage's output written.
+static const int kMaxCascade = 8;
+
+struct HBCascadeLaunch
+{
+	int nst;                       // stages in the run
+	int ntaps[kMaxCascade];
+	double taps[kMaxCascade][14];
+	long long a, b;                // outputs of the LAST stage to produce
+	int tile;                      // last-stage outputs per workgroup (multiple of 2^nst)
+	int buf;                       // doubles per LDS buffer (two buffers): tile/2 + slack
+	int nch;
+	SrcView src;                   // input stream of the first stage
+	DstView dst;
+};
+
 struct TailLaunch
 {
 	const double* cur;
@@ -142,7 +160,12 @@ struct ConvxLaunch
 	const double* wtab;  // flen x out_step: wtab[i*out_step + t] = table[(t*in_step % out_step)*flen + i]
 	long long wa, wb;    // interpolator outputs to produce
 	DstView wdst;
-	SpanInfo blk[kConvxMaxBlocks]; // per block c.k0 + i
+	SpanInfo blk[kConvxMaxBlocks]; // per block c.k0 + i (mode 1)
+	// mode 2 (interpolation on the matrix cores, r8b_convx.h): A fragments [tile][step][64 lanes],
+	// K steps of 4, phase tiles, and per tile the run index of B[0][0]
+	const double* mf_atab;
+	int mf_ksteps, mf_tiles;
+	int mf_boff[16];
 };
 
 // geometries the fast path is instantiated for: (log2 of the forward complex length, up shift)
@@ -166,8 +189,10 @@ void launch_whole(const WholeLaunch& L, void* stream);
 void launch_poly(const PolyLaunch& L, void* stream);
 void launch_hbup(const HBLaunch& L, void* stream);
 void launch_hbdown(const HBLaunch& L, void* stream);
+void launch_hbcascade(const HBCascadeLaunch& L, void* stream);
 void launch_tail(const TailLaunch& L, void* stream);
-// mode 0: convolver output to X.c.dst; mode 1: fused interpolator output to X.wdst
+// mode 0: convolver output to X.c.dst; mode 1 / 2: fused interpolator output to X.wdst (FIR on
+// the vector ALU / on the matrix cores)
 void launch_convx(const ConvxLaunch& X, int mode, void* stream);
 
 // memory helpers; all throw std::runtime_error with the HIP error text on failure

@@ -187,7 +187,8 @@ int StagePlan::history() const
 	case kFrac:
 		return 2 * flen + 4;
 	case kHBUp:
-		return 2 * hb_n + 4;
+		// (+ what the later stages of a fused half-band run lag behind this stage's own output)
+		return 2 * hb_n + 96;
 	case kHBDown:
 		return 4 * hb_n + 4;
 	}

@@ -30,6 +30,8 @@ STREAM_CASES = [
     (44100.0, 88200.0, 512, 512, 6000, 45.0, 49.0),             # widest band, lowest attenuation
     (44100.0, 44100.0, 512, 512, 1024, 2.0, 180.15),            # Src == Dst passthrough
     (44100.0, 96000.0, 70000, 70000, 140000, 2.0, 180.15),      # > 24 FFT blocks per call (split launches)
+    (44100.0, 529200.0, 512, 300, 3000, 2.0, 180.15),           # 3x convolver + two third-band half-bands
+    (44100.0, 705600.0, 256, 256, 1024, 2.0, 136.45),           # 2x + three half-bands, 16-bit preset
 ]
 
 

@@ -7,6 +7,7 @@
 // tests/emul/Makefile into tests/emul/_build/libr8bsrc_emul.so and loaded only by tests/ --
 // never by the package, bench.py or __graft_entry__.  It is NOT a CPU fallback of the product:
 // libr8bsrc_hip.so does not contain it and fails loudly without a HIP device.
+#include <algorithm>
 #include <cstdlib>
 #include <limits>
 #include <cstring>
@@ -126,6 +127,36 @@ struct EmulExec
 {
 	std::vector<ConvxState<LOGN, UPLOG>> st;
 	EmulExec() : st((size_t) kConvxThreads) {}
+	// MODE 2 output phase with a software model of v_mfma_f64_16x16x4_f64: lane l supplies
+	// A[l&15][l>>4] and B[l>>4][l&15]; D register i of lane l is row (l>>4)+4i, column l&15
+	template<int KS>
+	void mfma_interp(const ConvxLaunch& X, const double* y, long long k, int ch)
+	{
+		if (X.mf_ksteps != KS) throw std::runtime_error("emul: K steps mismatch");
+		for (int wave = 0; wave < kConvxThreads / 64; wave++)
+			for (int p = wave; p < X.mf_tiles; p += kConvxThreads / 64)
+			{
+				double D[16][16] = {};
+				for (int s = 0; s < X.mf_ksteps; s++)
+				{
+					double A[16][4], B[4][16];
+					for (int lane = 0; lane < 64; lane++)
+					{
+						A[lane & 15][lane >> 4] = X.mf_atab[((long) p * X.mf_ksteps + s) * 64 + lane];
+						B[lane >> 4][lane & 15] = y[cx_mfma_b_index(X, p, lane) + 4 * s];
+					}
+					for (int m = 0; m < 16; m++)
+						for (int n = 0; n < 16; n++)
+							for (int c = 0; c < 4; c++) D[m][n] += A[m][c] * B[c][n];
+				}
+				for (int lane = 0; lane < 64; lane++)
+				{
+					double d[4];
+					for (int i = 0; i < 4; i++) d[i] = D[(lane >> 4) + 4 * i][lane & 15];
+					cx_mfma_store(X, k, ch, p, lane, d);
+				}
+			}
+	}
 	template<class F>
 	void phase(F f)
 	{
@@ -160,6 +191,8 @@ void launch_convx(const ConvxLaunch& X, int mode, void*)
 	if (logn == LN && up == (1 << UL)) \
 	{ \
 		if (mode == 0) emul_convx_t<LN, UL, 0, 24>(X); \
+		else if (mode == 2 && wide) emul_convx_t<LN, UL, 2, 32>(X); \
+		else if (mode == 2) emul_convx_t<LN, UL, 2, 24>(X); \
 		else if (wide) emul_convx_t<LN, UL, 1, 32>(X); \
 		else emul_convx_t<LN, UL, 1, 24>(X); \
 		return; \
@@ -167,6 +200,39 @@ void launch_convx(const ConvxLaunch& X, int mode, void*)
 	R8B_CONVX_GEOMS(R8B_CONVX_DISPATCH)
 #undef R8B_CONVX_DISPATCH
 	throw std::runtime_error("emul launch_convx: geometry not instantiated");
+}
+
+void launch_hbcascade(const HBCascadeLaunch& L, void*)
+{
+	const int nthr = 256;
+	std::vector<double> lds((size_t) 2 * L.buf);
+	const long long n = L.b - L.a;
+	if (n <= 0) return;
+	const int tiles = (int) ((n + L.tile - 1) / L.tile);
+	for (int ch = 0; ch < L.nch; ch++)
+		for (int bx = 0; bx < tiles; bx++)
+		{
+			for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
+			const long long q0 = L.a + (long long) bx * L.tile;
+			long long q1 = q0 + L.tile;
+			if (q1 > L.b) q1 = L.b;
+			HBCRanges R;
+			hbc_ranges(L, q0, q1, R);
+			if (R.in_hi - R.in_lo > L.buf) throw std::runtime_error("emul: cascade LDS");
+			double* xin = lds.data();
+			double* yout = xin + L.buf;
+			for (int t = 0; t < nthr; t++) hbc_load(L, R, xin, ch, t, nthr);
+			long long in_lo = R.in_lo;
+			for (int s = 0; s < L.nst; s++)
+			{
+				if (s + 1 < L.nst && R.hi[s] - R.lo[s] > L.buf)
+					throw std::runtime_error("emul: cascade LDS");
+				for (int t = 0; t < nthr; t++)
+					hbc_stage(L, s, xin, in_lo, R.lo[s], R.hi[s], yout, s + 1 == L.nst, ch, t, nthr);
+				in_lo = R.lo[s];
+				std::swap(xin, yout);
+			}
+		}
 }
 
 void launch_tail(const TailLaunch& L, void*)

@@ -79,3 +79,14 @@ def test_emulated_dll_abi(emul):
             assert np.abs(a - b).max() <= PEAK_TOL
     d.clear()
     assert len(d.process(x[:1024])) == 0
+
+
+@pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[6], STREAM_CASES[15]])
+def test_emulated_matrix_core_interpolator(emul, case):
+    """option mfma_interp: the fused interpolator as 16x16x4 fp64 matrix tiles (software model of
+    the instruction in tests/emul) gives the same stream"""
+    src, dst, maxin, chunk, n, tb, att = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, lib=emul)
+    b.set_option("mfma_interp", 1)
+    rms, pk = compare_stream(b, src, dst, maxin, chunk, n, tb, att, 2)
+    assert rms <= RMS_TOL and pk <= PEAK_TOL, (rms, pk)

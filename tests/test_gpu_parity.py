@@ -231,3 +231,17 @@ def test_cxx_frontend(torch, tmp_path):
     x = O.splitmix_uniform(7, 1024 * 6)
     yo = np.concatenate([o.process(x[i:i + 1024]) for i in range(0, len(x), 1024)])
     assert len(vals) == len(yo) and rms(vals - yo) <= RMS_TOL and peak(vals - yo) <= PEAK_TOL
+
+
+@pytest.mark.parametrize("opts", [{"mfma_interp": 1}, {"fuse": 0}, {"fuse": 0, "fast_conv": 0},
+                                  {"fuse_hb": 0}])
+@pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[1], STREAM_CASES[2], STREAM_CASES[6]])
+def test_hip_alternative_kernel_paths(torch, case, opts):
+    """every kernel path behind the engine options (matrix-core interpolator, unfused fast
+    convolver, generic kernels, unfused half-bands) produces the same stream"""
+    src, dst, maxin, chunk, n, tb, att = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, device=0)
+    for k, v in opts.items():
+        b.set_option(k, v)
+    r, p = compare_stream(b, src, dst, maxin, chunk, n, tb, att, 2)
+    assert r <= RMS_TOL and p <= PEAK_TOL, (r, p)
