@@ -186,6 +186,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	: nch_(nch), device_(device)
 {
 	if (nch < 1) throw std::runtime_error("channel count must be >= 1");
+	if (nch > 65535) throw std::runtime_error("channel count must be <= 65535 per batch object "
+		"(grid y dimension); split larger batches");
 	if (maxin < 1) throw std::runtime_error("MaxInLen must be >= 1");
 	dev_select(device);
 	plan_.init(descs, maxin);
@@ -585,7 +587,7 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 			TailLaunch T;
 			T.cur = d_in; T.cur_stride = in_stride; T.cur_base = m_prev;
 			T.p1 = sp.m;
-			T.p0 = sp.m - dev_[0].ring_size;
+			T.p0 = sp.m - sp.history(); // only what a later call can still read
 			if (T.p0 < m_prev) T.p0 = m_prev;
 			T.ring = dev_[0].ring;
 			T.ring_stride = dev_[0].ring_size;
