@@ -583,27 +583,6 @@ R8B_HD void cx_whole_compute(const ConvxLaunch& X, const double* y, const double
 	// (256 B/clk); unaligned 8-byte pairs would compile to ds_read2_b64 at half that rate.
 	const double* y1 = y + cx_y1_offset(L.in_len);
 	int u = B.u_lo + (int) ((unsigned) (B.ph_lo + d * X.in_step) / (unsigned) X.out_step);
-#if defined(R8B_X_PAIR) && R8B_X_PAIR
-	// two outputs per iteration: twice the LDS reads in flight, four independent FMA chains
-	for (; j + X.out_step < jhi; j += 2 * X.out_step, u += 2 * X.in_step)
-	{
-		const int u2 = u + X.in_step;
-		const cd* xa = reinterpret_cast<const cd*>((u & 1) ? y1 + (u - 1) : y + u);
-		const cd* xb = reinterpret_cast<const cd*>((u2 & 1) ? y1 + (u2 - 1) : y + u2);
-		double s0 = 0.0, s1 = 0.0, t0s = 0.0, t1s = 0.0;
-#pragma unroll
-		for (int i = 0; i < FLEN / 2; i++)
-		{
-			const cd va = xa[i], vb = xb[i];
-			s0 += row[2 * i] * va.re;
-			t0s += row[2 * i] * vb.re;
-			s1 += row[2 * i + 1] * va.im;
-			t1s += row[2 * i + 1] * vb.im;
-		}
-		dst_store(X.wdst, ch, j, s0 + s1);
-		dst_store(X.wdst, ch, j + X.out_step, t0s + t1s);
-	}
-#endif
 	for (; j < jhi; j += X.out_step, u += X.in_step)
 	{
 		const cd* x = reinterpret_cast<const cd*>((u & 1) ? y1 + (u - 1) : y + u);

@@ -33,11 +33,6 @@ struct alignas(16) cd
 
 R8B_HD double src_load(const SrcView& s, int ch, long long pos)
 {
-#if defined(R8B_X_SRCSEL) && !R8B_X_SRCSEL
-	if (pos < 0) return 0.0;
-	if (pos >= s.cur_base) return s.cur[(long long) ch * s.cur_stride + (pos - s.cur_base)];
-	return s.ring[(long long) ch * s.ring_stride + (pos & s.ring_mask)];
-#endif
 	// one load through a selected address (no branches: a thread's loads stay in flight together)
 	const double* pr = s.ring + ((long long) ch * s.ring_stride + (pos & s.ring_mask));
 	const double* pc = s.cur + ((long long) ch * s.cur_stride + (pos - s.cur_base));

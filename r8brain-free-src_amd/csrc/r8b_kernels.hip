@@ -178,10 +178,6 @@ template<int LOGN, int UPLOG>
 struct GpuExec
 {
 	ConvxState<LOGN, UPLOG> st;
-#ifdef R8B_X_TRACE // tuning aid: cycle stamps of one workgroup's phases, printed by the kernel
-	long long ts[24];
-	int nts = 0;
-#endif
 	// MODE 2 output phase: every wave runs its phase tiles on the matrix cores
 	template<int KS>
 	__device__ __forceinline__ void mfma_interp(const ConvxLaunch& X, const double* y, long long k, int ch)
@@ -212,9 +208,6 @@ struct GpuExec
 	{
 		f((int) threadIdx.x, st);
 		lds_barrier();
-#ifdef R8B_X_TRACE
-		if (nts < 24) ts[nts++] = (long long) __builtin_readcyclecounter();
-#endif
 	}
 };
 
@@ -226,24 +219,8 @@ __global__ __launch_bounds__(kConvxThreads, R8B_CONVX_MINWAVES) void k_convx(con
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	GpuExec<LOGN, UPLOG> ex;
-#ifdef R8B_X_TRACE
-	const long long t_begin = (long long) __builtin_readcyclecounter();
-#endif
 	convx_body<LOGN, UPLOG, MODE, FLENP>(ex, X, reinterpret_cast<double*>(smem),
 		X.c.k0 + blockIdx.x, (int) blockIdx.y);
-#ifdef R8B_X_TRACE
-	if (threadIdx.x == 0 && blockIdx.x == 6 && blockIdx.y == 300)
-	{
-		printf("trace ch %d:", (int) blockIdx.y);
-		long long prev = t_begin;
-		for (int i = 0; i < ex.nts; i++)
-		{
-			printf(" %lld", ex.ts[i] - prev);
-			prev = ex.ts[i];
-		}
-		printf("\n");
-	}
-#endif
 }
 
 template<int LOGN, int UPLOG, int MODE, int FLENP>
