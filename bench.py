@@ -110,8 +110,8 @@ def cpu_baseline(src, dst, L, gpu_sample=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
     ap.add_argument("--block", type=int, default=16384, help="input samples per channel per step")
     ap.add_argument("--src", type=float, default=44100.0)

@@ -695,6 +695,18 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 		if constexpr (MODE == 1) cx_whole_row<FLENP>(X, st.row, tid);
 	});
 	// K steps: 10 cover 24 taps + the 14-sample phase spread of a tile, 12 cover 32 taps
+	// history for the next call (stage 0 only): the first block's workgroup copies the tail of
+	// the caller's buffer into the other history ring; issued before the output phase, the
+	// stores need no wait
+	if (L.tail_ring != nullptr && k == L.k0)
+	{
+		ex.each([&](int tid, St&)
+		{
+			for (long long i = L.tail_p0 + tid; i < L.tail_p1; i += kConvxThreads)
+				L.tail_ring[(long long) ch * L.src.ring_stride + (i & L.src.ring_mask)] =
+					src_load(L.src, ch, i);
+		});
+	}
 	if constexpr (MODE == 2) ex.template mfma_interp<(FLENP > 24 ? 12 : 10)>(X, rbuf, k, ch);
 	else
 	{

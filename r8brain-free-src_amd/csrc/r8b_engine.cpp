@@ -199,6 +199,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["fast_conv"] = 1; // compile-time-sized convolver kernel when the geometry allows
 	opt_["fuse"] = 1;      // ... with the whole-step interpolator behind it fused in
 	opt_["fuse_hb"] = 1;   // runs of half-band up-samplers as one kernel
+	opt_["fold_tail"] = 1; // fast convolver at stage 0 keeps the input history itself
 	// fused interpolator on the matrix cores (when a block holds 16 output groups): measured equal
 	// to the vector-ALU form on cfg2 (0.357 vs 0.362 ms: 10x fewer LDS reads, 13 % more FFT
 	// blocks), so the simpler form stays the default
@@ -211,6 +212,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 		const long long hist = sp.history();
 		d.ring_size = pow2_at_least(s == 0 ? hist : hist + plan_.stage_max_in[s]);
 		d.ring = (double*) dev_alloc((size_t) d.ring_size * (size_t) nch * sizeof(double));
+		if (s == 0)
+			d.ring_alt = (double*) dev_alloc((size_t) d.ring_size * (size_t) nch * sizeof(double));
 		if (sp.desc.kind == kConv)
 		{
 			const ConvGeom& g = sp.cg;
@@ -323,6 +326,7 @@ Engine::~Engine()
 		}
 		for (void* e : d.free_events) dev_event_destroy(e);
 		dev_free(d.ring);
+		dev_free(d.ring_alt);
 		dev_free(d.H);
 		dev_free(d.tw);
 		dev_free(d.spec);
@@ -434,8 +438,13 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
 			launch_convx(X, 0, stream);
+			if (L.tail_ring != nullptr) tail_done_ = true;
 		}
-		else launch_conv(L, stream);
+		else
+		{
+			L.tail_ring = nullptr;
+			launch_conv(L, stream);
+		}
 		break;
 	}
 	case kFrac:
@@ -500,7 +509,8 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 		// Src == Dst: the reference hands the input back (reference CDSPResampler.h:534-535);
 		// the batch entry copies it into the caller's output buffer
 		TailLaunch T;
-		T.cur = d_in; T.cur_stride = in_stride; T.cur_base = 0;
+		T.src.ring = d_in; T.src.ring_stride = 0; T.src.ring_mask = 0;
+		T.src.cur = d_in; T.src.cur_stride = in_stride; T.src.cur_base = 0;
 		T.p0 = 0; T.p1 = l;
 		T.ring = d_out; T.ring_stride = out_stride; T.ring_mask = -1;
 		T.nch = nch_;
@@ -560,6 +570,7 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 			dst.off = 0;
 		}
 		const bool work = fused ? wb > wa : b > a;
+		if (s == 0) tail_done_ = false;
 		if (work)
 		{
 			const bool timing = opt_.at("timing") != 0;
@@ -583,17 +594,23 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 		}
 		if (s == 0)
 		{
-			// keep the tail of the caller's buffer as history for the next call
-			TailLaunch T;
-			T.cur = d_in; T.cur_stride = in_stride; T.cur_base = m_prev;
-			T.p1 = sp.m;
-			T.p0 = sp.m - sp.history(); // only what a later call can still read
-			if (T.p0 < m_prev) T.p0 = m_prev;
-			T.ring = dev_[0].ring;
-			T.ring_stride = dev_[0].ring_size;
-			T.ring_mask = dev_[0].ring_size - 1;
-			T.nch = nch_;
-			launch_tail(T, stream);
+			// History for the next call: the last history() samples of the stream go into the
+			// OTHER ring (this call's kernels may still be reading the current one).  The fast
+			// convolver does the copy itself (tail_done_); otherwise a copy kernel.
+			if (!tail_done_)
+			{
+				TailLaunch T;
+				T.src = src;
+				T.p1 = sp.m;
+				T.p0 = sp.m - sp.history();
+				if (T.p0 < 0) T.p0 = 0;
+				T.ring = dev_[0].ring_alt;
+				T.ring_stride = dev_[0].ring_size;
+				T.ring_mask = dev_[0].ring_size - 1;
+				T.nch = nch_;
+				launch_tail(T, stream);
+			}
+			std::swap(dev_[0].ring, dev_[0].ring_alt);
 		}
 		n = (int) (fused ? wb - wa : b - a);
 		s += glen - 1;
@@ -678,6 +695,16 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	L.nch = nch_;
 	L.threads = opt_.at("conv_threads");
 	L.src = src;
+	L.tail_ring = nullptr; L.tail_p0 = L.tail_p1 = 0;
+	if (s == 0 && opt_.at("fold_tail"))
+	{
+		// stage 0 on the fast path: let the kernel keep the history (see process())
+		const StagePlan& sp0 = plan_.stages[0];
+		L.tail_ring = dev_[0].ring_alt;
+		L.tail_p1 = sp0.m;
+		L.tail_p0 = sp0.m - sp0.history();
+		if (L.tail_p0 < 0) L.tail_p0 = 0;
+	}
 }
 
 static long long ceil_div_nonneg(long long a, long long b) { return a <= 0 ? 0 : (a + b - 1) / b; }
@@ -718,6 +745,8 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			X.c.k0 = k0;
 			X.c.nblk = (int) (std::min(klast, k0 + kConvxMaxBlocks - 1) - k0 + 1);
 			launch_convx(X, 2, stream);
+			if (X.c.tail_ring != nullptr) tail_done_ = true;
+			X.c.tail_ring = nullptr; // once per call
 		}
 		return;
 	}
@@ -763,6 +792,8 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			B.pad = 0;
 		}
 		launch_convx(X, 1, stream);
+		if (X.c.tail_ring != nullptr) tail_done_ = true;
+		X.c.tail_ring = nullptr; // once per call
 	}
 }
 

@@ -46,6 +46,7 @@ private:
 	struct StageDev
 	{
 		double* ring = nullptr; // input ring of this stage, nch x ring_size
+		double* ring_alt = nullptr; // stage 0 only: second history ring (calls alternate)
 		long long ring_size = 0;
 		double* H = nullptr;
 		cd* tw = nullptr;
@@ -84,6 +85,7 @@ private:
 	int device_;
 	std::vector<StageDev> dev_;
 	std::map<std::string, int> opt_;
+	bool tail_done_ = false; // stage-0 history already written by the convolver kernel
 };
 
 // complex twiddle table exp(-2 pi i e / len), exact on the axes; interleaved (re, im)

@@ -159,8 +159,7 @@ __global__ void k_tail(const TailLaunch L)
 	const long long i = L.p0 + (long long) blockIdx.x * blockDim.x + threadIdx.x;
 	const int ch = blockIdx.y;
 	if (i < L.p1)
-		L.ring[(long long) ch * L.ring_stride + (i & L.ring_mask)] =
-			L.cur[(long long) ch * L.cur_stride + (i - L.cur_base)];
+		L.ring[(long long) ch * L.ring_stride + (i & L.ring_mask)] = src_load(L.src, ch, i);
 }
 
 // ------------------------------------------------------------------ fast path (r8b_convx.h)
@@ -202,6 +201,11 @@ struct GpuExec
 			const double d[4] = { acc[0], acc[1], acc[2], acc[3] };
 			cx_mfma_store(X, k, ch, p, lane, d);
 		}
+	}
+	template<class F>
+	__device__ __forceinline__ void each(F f) // no barrier
+	{
+		f((int) threadIdx.x, st);
 	}
 	template<class F>
 	__device__ __forceinline__ void phase(F f)

@@ -47,6 +47,10 @@ struct ConvLaunch
 	int blk_offset; // virtual position of block 0's first fresh sample (0 except fused MFMA mode)
 	// fast path: the source admits aligned 16-byte loads of sample pairs (even positions)
 	int vec_ok;
+	// fast path at stage 0: the workgroups of the first block also copy stream positions
+	// [tail_p0, tail_p1) into the history ring the NEXT call reads (null: nothing to copy)
+	double* tail_ring;
+	long long tail_p0, tail_p1;
 	int up_pow2, down_pow2;
 	// transform plan: radices of the forward passes in execution order (sub-length N, N/r0, ...)
 	// and of the backward passes in execution order (sub-length grows to N2)
@@ -125,9 +129,7 @@ struct HBCascadeLaunch
 
 struct TailLaunch
 {
-	const double* cur;
-	long long cur_stride;
-	long long cur_base; // absolute position of cur[0]
+	SrcView src;        // where the stream is read (history ring and/or the caller's buffer)
 	long long p0, p1;   // positions [p0, p1) to copy into the ring
 	double* ring;
 	long long ring_stride;

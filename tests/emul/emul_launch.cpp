@@ -162,6 +162,11 @@ struct EmulExec
 	{
 		for (int t = 0; t < kConvxThreads; t++) f(t, st[(size_t) t]);
 	}
+	template<class F>
+	void each(F f)
+	{
+		for (int t = 0; t < kConvxThreads; t++) f(t, st[(size_t) t]);
+	}
 
 };
 
@@ -239,8 +244,7 @@ void launch_tail(const TailLaunch& L, void*)
 {
 	for (int ch = 0; ch < L.nch; ch++)
 		for (long long i = L.p0; i < L.p1; i++)
-			L.ring[(long long) ch * L.ring_stride + (i & L.ring_mask)] =
-				L.cur[(long long) ch * L.cur_stride + (i - L.cur_base)];
+			L.ring[(long long) ch * L.ring_stride + (i & L.ring_mask)] = src_load(L.src, ch, i);
 }
 
 void dev_select(int) {}
