@@ -33,8 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def channel_shard(total_channels, rank, world):
-    """Contiguous channel block [lo, hi) owned by `rank`: channels never interact, so a batch that
-    is sharded this way needs no data-path collective."""
+    """Contiguous channel block [lo, hi) owned by `rank` (r8brain-free-src_amd/sharding.py)."""
     lo = total_channels * rank // world
     hi = total_channels * (rank + 1) // world
     return lo, hi

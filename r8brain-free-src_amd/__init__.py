@@ -9,5 +9,6 @@ CDSPResampler24, DLLResampler (see resampler.py) and `load()` (the ctypes handle
 libr8bsrc_hip.so).  Everything computes on the GPU through the C ABI of include/r8bsrc.h.
 """
 from ._capi import load, lib_path, bind, PROTOTYPES  # noqa: F401
+from .sharding import channel_shard, scatter_channels, gather_channels, ShardedBatchResampler  # noqa: F401
 from .resampler import (BatchResampler, CDSPResampler, CDSPResampler16, CDSPResampler16IR,  # noqa: F401
                         CDSPResampler24, DLLResampler, fprLinearPhase)

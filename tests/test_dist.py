@@ -40,6 +40,14 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(gathered, t)
     dist.barrier()
+    # scatter a batch that lives on rank 0, "resample" the shard (x2 stand-in), gather it back
+    full = torch.arange(10 * 6, dtype=torch.float64).reshape(10, 6) if rank == 0 else None
+    sh = r8b.ShardedBatchResampler(lambda nch: type("P", (), {"process": staticmethod(lambda x: 2.0 * x)})(), 10)
+    back = sh.process_from_root(full, 6, root=0, device="cpu")
+    if rank == 0:
+        assert torch.equal(back, 2.0 * full)
+    else:
+        assert back is None
     tmax = t[2:3].clone()
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     if rank == 0:
