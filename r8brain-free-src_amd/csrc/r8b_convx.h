@@ -604,26 +604,66 @@ R8B_HD void cx_whole_compute(const ConvxLaunch& X, const double* y, const double
 // on the GPU it is `f(threadIdx.x, st); __syncthreads();` (r8b_kernels.hip), in the host
 // emulation of tests/emul it is a loop over tid.  Writing the sequence once keeps both in step.
 
+// Two consecutive "rest" passes of equal radix with one butterfly per thread are wave-local: the
+// sub-blocks a wave's butterflies read in the second pass are exactly the ones it wrote in the
+// first (butterfly b works inside sub-block b / (sub-block size / radix) in both), so they run in
+// one phase with a wave-level ordering point instead of a workgroup barrier.
+template<int LOGTOT, int RBA, int RBB>
+constexpr bool cx_wave_local() { return RBA == RBB && ((1 << LOGTOT) >> RBA) <= kConvxThreads; }
+
 template<int LOGN, int UPLOG, int I, class Exec>
 R8B_HD void cx_fwd_seq(Exec& ex, const ConvLaunch& L, cd* buf)
 {
 	typedef ConvxState<LOGN, UPLOG> St;
 	constexpr int NP = FwdPass<LOGN, 0>::NP;
-	ex.phase([&](int tid, St& st)
+	if constexpr (I >= 1 && I + 2 == NP &&
+		cx_wave_local<LOGN, FwdPass<LOGN, I>::rb(), FwdPass<LOGN, I + 1>::rb()>())
 	{
-		FwdPass<LOGN, I>::run(buf, st.tw, L.tw, L.tw_len, tid);
-		if constexpr (I + 1 < NP) FwdPass<LOGN, I + 1>::prefetch(st.tw, L.tw, L.tw_len, tid);
-	});
-	if constexpr (I + 1 < NP) cx_fwd_seq<LOGN, UPLOG, I + 1>(ex, L, buf);
+		// (the last forward pass has no twiddles, so st.tw serves the first of the pair)
+		ex.wave_phase2(
+			[&](int tid, St& st) { FwdPass<LOGN, I>::run(buf, st.tw, L.tw, L.tw_len, tid); },
+			[&](int tid, St& st) { FwdPass<LOGN, I + 1>::run(buf, st.tw, L.tw, L.tw_len, tid); });
+	}
+	else
+	{
+		ex.phase([&](int tid, St& st)
+		{
+			FwdPass<LOGN, I>::run(buf, st.tw, L.tw, L.tw_len, tid);
+			if constexpr (I + 1 < NP) FwdPass<LOGN, I + 1>::prefetch(st.tw, L.tw, L.tw_len, tid);
+		});
+		if constexpr (I + 1 < NP) cx_fwd_seq<LOGN, UPLOG, I + 1>(ex, L, buf);
+	}
 }
 
 // backward passes 0 .. NR-1 (the last one, NR, is split into compute/store by the caller)
+template<int LOGN, int UPLOG>
+constexpr bool cx_inv_pair_local()
+{
+	constexpr int LOGN2 = LOGN + UPLOG;
+	if constexpr (InvPass<LOGN2, 0>::NR == 2)
+		return cx_wave_local<LOGN2, InvPass<LOGN2, 0>::rb(), InvPass<LOGN2, 1>::rb()>();
+	else
+		return false;
+}
+
 template<int LOGN, int UPLOG, int I, class Exec>
 R8B_HD void cx_inv_seq(Exec& ex, const ConvLaunch& L, cd* buf)
 {
 	typedef ConvxState<LOGN, UPLOG> St;
 	constexpr int LOGN2 = LOGN + UPLOG, NR = InvPass<LOGN2, 0>::NR;
-	if constexpr (I < NR)
+	if constexpr (I == 0 && cx_inv_pair_local<LOGN, UPLOG>())
+	{
+		// pass 0 (sub-length = radix) has no twiddles: st.tw already holds pass 1's (fetched by
+		// the caller), and the last pass's are fetched behind the pair
+		ex.wave_phase2(
+			[&](int tid, St& st) { InvPass<LOGN2, 0>::run(buf, st.tw, L.tw, L.tw_len, tid); },
+			[&](int tid, St& st)
+			{
+				InvPass<LOGN2, 1>::run(buf, st.tw, L.tw, L.tw_len, tid);
+				InvPass<LOGN2, 2>::prefetch(st.tw, L.tw, L.tw_len, tid);
+			});
+	}
+	else if constexpr (I < NR)
 	{
 		ex.phase([&](int tid, St& st)
 		{
@@ -685,7 +725,10 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 	ex.phase([&](int tid, St& st)
 	{
 		cx_spec_write<LOGN, UPLOG>(L, buf, st, tid);
-		InvPass<LOGN2, 0>::prefetch(st.tw, L.tw, L.tw_len, tid);
+		if constexpr (cx_inv_pair_local<LOGN, UPLOG>())
+			InvPass<LOGN2, 1>::prefetch(st.tw, L.tw, L.tw_len, tid);
+		else
+			InvPass<LOGN2, 0>::prefetch(st.tw, L.tw, L.tw_len, tid);
 	});
 	cx_inv_seq<LOGN, UPLOG, 0>(ex, L, buf);
 	ex.phase([&](int tid, St& st) { cx_final_compute<LOGN, UPLOG>(L, buf, st, tid); });

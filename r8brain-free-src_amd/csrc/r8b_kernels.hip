@@ -202,6 +202,20 @@ struct GpuExec
 			cx_mfma_store(X, k, ch, p, lane, d);
 		}
 	}
+	// two wave-local steps in one phase: the second reads LDS words written by other lanes of the
+	// SAME wave in the first; LDS serves a wave's accesses in issue order, so only the compiler
+	// must be kept from reordering them
+	template<class FA, class FB>
+	__device__ __forceinline__ void wave_phase2(FA fa, FB fb)
+	{
+		const int ltid = (int) ((threadIdx.x + 64u * ((blockIdx.x + blockIdx.y) & 3u)) & (kConvxThreads - 1));
+		fa(ltid, st);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+		fb(ltid, st);
+		lds_barrier();
+	}
 	template<class F>
 	__device__ __forceinline__ void each(F f) // no barrier
 	{

@@ -162,6 +162,17 @@ struct EmulExec
 	{
 		for (int t = 0; t < kConvxThreads; t++) f(t, st[(size_t) t]);
 	}
+	// wave-local pair: all lanes of a wave finish the first step before any starts the second;
+	// waves run one after the other (they must not depend on each other inside the pair)
+	template<class FA, class FB>
+	void wave_phase2(FA fa, FB fb)
+	{
+		for (int w = 0; w < kConvxThreads / 64; w++)
+		{
+			for (int t = 64 * w; t < 64 * w + 64; t++) fa(t, st[(size_t) t]);
+			for (int t = 64 * w; t < 64 * w + 64; t++) fb(t, st[(size_t) t]);
+		}
+	}
 	template<class F>
 	void each(F f)
 	{
