@@ -736,6 +736,7 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 	{
 		cx_final_store<LOGN, UPLOG, MODE == 1 ? 2 : 1, MODE != 0>(L, rbuf, st, k, tid);
 		if constexpr (MODE == 1) cx_whole_row<FLENP>(X, st.row, tid);
+		if constexpr (MODE == 2) ex.template mfma_prefetch<(FLENP > 24 ? 12 : 10)>(X);
 	});
 	// K steps: 10 cover 24 taps + the 14-sample phase spread of a tile, 12 cover 32 taps
 	// history for the next call (stage 0 only): the first block's workgroup copies the tail of

@@ -177,7 +177,21 @@ template<int LOGN, int UPLOG>
 struct GpuExec
 {
 	ConvxState<LOGN, UPLOG> st;
-	// MODE 2 output phase: every wave runs its phase tiles on the matrix cores
+	// MODE 2 output phase: every wave runs its phase tiles on the matrix cores.  The A fragments
+	// (L2) of a tile are fetched one tile ahead -- the first tile's before the barrier that ends
+	// the last FFT phase (mfma_prefetch) -- so only LDS reads and MFMAs are on the critical path.
+	double mf_a[12];
+	template<int KS>
+	__device__ __forceinline__ void mfma_prefetch(const ConvxLaunch& X)
+	{
+		const int wave = (int) threadIdx.x >> 6, lane = (int) threadIdx.x & 63;
+		if (wave < X.mf_tiles)
+		{
+			const double* at = X.mf_atab + (long) wave * KS * 64 + lane;
+#pragma unroll
+			for (int s = 0; s < KS; s++) mf_a[s] = at[s * 64];
+		}
+	}
 	template<int KS>
 	__device__ __forceinline__ void mfma_interp(const ConvxLaunch& X, const double* y, long long k, int ch)
 	{
@@ -185,15 +199,19 @@ struct GpuExec
 		const int wave = (int) threadIdx.x >> 6, lane = (int) threadIdx.x & 63;
 		for (int p = wave; p < X.mf_tiles; p += kConvxThreads / 64)
 		{
-			// all operand fetches of the tile first (A fragments from L2, B from LDS), then the
-			// K steps back to back on the matrix pipe
-			const double* at = X.mf_atab + (long) p * KS * 64 + lane;
 			const double* bp = y + cx_mfma_b_index(X, p, lane);
 			double a[KS], b[KS];
 #pragma unroll
-			for (int s = 0; s < KS; s++) a[s] = at[s * 64];
+			for (int s = 0; s < KS; s++) a[s] = mf_a[s];
 #pragma unroll
 			for (int s = 0; s < KS; s++) b[s] = bp[4 * s];
+			const int pn = p + kConvxThreads / 64;
+			if (pn < X.mf_tiles)
+			{
+				const double* at = X.mf_atab + (long) pn * KS * 64 + lane;
+#pragma unroll
+				for (int s = 0; s < KS; s++) mf_a[s] = at[s * 64];
+			}
 			d4 acc = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
 			for (int s = 0; s < KS; s++)

@@ -130,6 +130,8 @@ struct EmulExec
 	// MODE 2 output phase with a software model of v_mfma_f64_16x16x4_f64: lane l supplies
 	// A[l&15][l>>4] and B[l>>4][l&15]; D register i of lane l is row (l>>4)+4i, column l&15
 	template<int KS>
+	void mfma_prefetch(const ConvxLaunch&) {}
+	template<int KS>
 	void mfma_interp(const ConvxLaunch& X, const double* y, long long k, int ch)
 	{
 		if (X.mf_ksteps != KS) throw std::runtime_error("emul: K steps mismatch");
