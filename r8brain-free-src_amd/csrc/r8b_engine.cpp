@@ -211,9 +211,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 		StageDev& d = dev_[s];
 		const long long hist = sp.history();
 		d.ring_size = pow2_at_least(s == 0 ? hist : hist + plan_.stage_max_in[s]);
-		d.ring = (double*) dev_alloc((size_t) d.ring_size * (size_t) nch * sizeof(double));
-		if (s == 0)
-			d.ring_alt = (double*) dev_alloc((size_t) d.ring_size * (size_t) nch * sizeof(double));
+		// rings are allocated on first use (ensure_ring): the ring between two fused stages is
+		// never touched and would be the largest allocation (cfg2: 512 MB)
 		if (sp.desc.kind == kConv)
 		{
 			const ConvGeom& g = sp.cg;
@@ -356,6 +355,15 @@ bool Engine::set_option(const std::string& name, int value)
 	it->second = value;
 	plan_transforms();
 	return true;
+}
+
+void Engine::ensure_ring(size_t s)
+{
+	StageDev& d = dev_[s];
+	if (d.ring != nullptr) return;
+	const size_t bytes = (size_t) d.ring_size * (size_t) nch_ * sizeof(double);
+	d.ring = (double*) dev_alloc(bytes);
+	if (s == 0) d.ring_alt = (double*) dev_alloc(bytes);
 }
 
 void* Engine::get_event(StageDev& d)
@@ -538,6 +546,8 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 			wb = gb;
 		}
 		const size_t last = s + glen - 1; // stage whose output this launch produces
+		ensure_ring(s);
+		if (last + 1 < ns) ensure_ring(last + 1);
 		SrcView src;
 		src.ring = dev_[s].ring;
 		src.ring_stride = dev_[s].ring_size;

@@ -69,6 +69,7 @@ private:
 	void* get_event(StageDev& d);
 
 	void plan_transforms();
+	void ensure_ring(size_t s);
 	bool fuse_with_next(size_t s) const;
 	void prepare_mfma(size_t s);
 	int group_len(size_t s) const;

@@ -177,6 +177,7 @@ template<int LOGN, int UPLOG>
 struct GpuExec
 {
 	ConvxState<LOGN, UPLOG> st;
+	unsigned rot = 0; // per-workgroup rotation of the logical wave roles
 	// MODE 2 output phase: every wave runs its phase tiles on the matrix cores.  The A fragments
 	// (L2) of a tile are fetched one tile ahead -- the first tile's before the barrier that ends
 	// the last FFT phase (mfma_prefetch) -- so only LDS reads and MFMAs are on the critical path.
@@ -226,7 +227,7 @@ struct GpuExec
 	template<class FA, class FB>
 	__device__ __forceinline__ void wave_phase2(FA fa, FB fb)
 	{
-		const int ltid = (int) ((threadIdx.x + 64u * ((blockIdx.x + blockIdx.y) & 3u)) & (kConvxThreads - 1));
+		const int ltid = (int) ((threadIdx.x + 64u * rot) & (kConvxThreads - 1));
 		fa(ltid, st);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
 		__builtin_amdgcn_wave_barrier();
@@ -245,7 +246,7 @@ struct GpuExec
 		// Logical thread id rotated by whole waves per workgroup: the phases that keep only the
 		// first one or two logical waves busy (radix-16 passes, interpolation) then land on
 		// different SIMDs for the workgroups sharing a CU (measured +3.5 %).
-		f((int) ((threadIdx.x + 64u * ((blockIdx.x + blockIdx.y) & 3u)) & (kConvxThreads - 1)), st);
+		f((int) ((threadIdx.x + 64u * rot) & (kConvxThreads - 1)), st);
 		lds_barrier();
 	}
 };
@@ -257,9 +258,26 @@ template<int LOGN, int UPLOG, int MODE, int FLENP>
 __global__ __launch_bounds__(kConvxThreads, R8B_CONVX_MINWAVES) void k_convx(const ConvxLaunch X)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
+	// XCD-aware work mapping: the dispatcher hands consecutive workgroup ids to the 8 XCDs round
+	// robin, each XCD with its own L2.  Consecutive blocks of a channel share PrevInputLen input
+	// samples (overlap-save), so channel c is served by XCD c % 8 and an XCD walks the blocks of
+	// one channel back to back: the overlap is re-read from that XCD's L2 instead of HBM.
+	const unsigned w = blockIdx.x, nblk = (unsigned) X.c.nblk, nch = (unsigned) X.c.nch;
+	unsigned blk, ch;
+	if ((nch & 7u) == 0)
+	{
+		const unsigned i = w >> 3;
+		blk = i % nblk;
+		ch = ((i / nblk) << 3) + (w & 7u);
+	}
+	else
+	{
+		blk = w % nblk;
+		ch = w / nblk;
+	}
 	GpuExec<LOGN, UPLOG> ex;
-	convx_body<LOGN, UPLOG, MODE, FLENP>(ex, X, reinterpret_cast<double*>(smem),
-		X.c.k0 + blockIdx.x, (int) blockIdx.y);
+	ex.rot = (blk + ch) & 3u;
+	convx_body<LOGN, UPLOG, MODE, FLENP>(ex, X, reinterpret_cast<double*>(smem), X.c.k0 + blk, (int) ch);
 }
 
 template<int LOGN, int UPLOG, int MODE, int FLENP>
@@ -275,7 +293,7 @@ void launch_convx_t(const ConvxLaunch& X, hipStream_t stream)
 			hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(k_convx)");
 		attr_done = true;
 	}
-	hipLaunchKernelGGL(kern, dim3((unsigned) X.c.nblk, (unsigned) X.c.nch), dim3(kConvxThreads),
+	hipLaunchKernelGGL(kern, dim3((unsigned) X.c.nblk * (unsigned) X.c.nch), dim3(kConvxThreads),
 		lds, stream, X);
 	check(hipGetLastError(), "launch k_convx");
 }
