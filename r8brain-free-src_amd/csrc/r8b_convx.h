@@ -47,8 +47,14 @@ R8B_HD int rpad(int i) { return i + ((i >> 5) << 1); }
 constexpr int convx_lds_doubles(int logn2) { return 2 * ((1 << logn2) + ((1 << logn2) >> 4)); }
 // LDS doubles a workgroup needs: the padded work array, which the linear output run (and in
 // fused mode its one-sample-shifted copy) aliases once the last backward pass sits in registers
+#ifdef R8B_CX_ONECOPY
+static const bool kCxOneCopy = true;
+#else
+static const bool kCxOneCopy = false;
+#endif
 inline int convx_lds_need(int logn2, int in_len, int mode)
 {
+	if (kCxOneCopy && mode == 1) mode = 0;
 	const int work = convx_lds_doubles(logn2);
 	const int y1 = ((in_len + 8 + 31) & ~31) + 16;
 	const int run = mode == 1 ? y1 + in_len + 16 : in_len + 8;
@@ -583,6 +589,24 @@ R8B_HD void cx_whole_compute(const ConvxLaunch& X, const double* y, const double
 	// (256 B/clk); unaligned 8-byte pairs would compile to ds_read2_b64 at half that rate.
 	const double* y1 = y + cx_y1_offset(L.in_len);
 	int u = B.u_lo + (int) ((unsigned) (B.ph_lo + d * X.in_step) / (unsigned) X.out_step);
+#ifdef R8B_CX_ONECOPY
+	// experiment: single copy of the run, every tap one 8-byte LDS read (R8B_LDS_WINDOW supplied
+	// by the includer: inline-asm ds_read_b64 on the GPU, plain loads in the emulation)
+	for (; j < jhi; j += X.out_step, u += X.in_step)
+	{
+		double v[FLEN];
+		R8B_LDS_WINDOW(FLEN, v, y + u);
+		double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+		for (int i = 0; i < FLEN; i += 2)
+		{
+			s0 += row[i] * v[i];
+			s1 += row[i + 1] * v[i + 1];
+		}
+		dst_store(X.wdst, ch, j, s0 + s1);
+	}
+	return;
+#endif
 	for (; j < jhi; j += X.out_step, u += X.in_step)
 	{
 		const cd* x = reinterpret_cast<const cd*>((u & 1) ? y1 + (u - 1) : y + u);
@@ -734,7 +758,7 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 	ex.phase([&](int tid, St& st) { cx_final_compute<LOGN, UPLOG>(L, buf, st, tid); });
 	ex.phase([&](int tid, St& st)
 	{
-		cx_final_store<LOGN, UPLOG, MODE == 1 ? 2 : 1, MODE != 0>(L, rbuf, st, k, tid);
+		cx_final_store<LOGN, UPLOG, (MODE == 1 && !kCxOneCopy) ? 2 : 1, MODE != 0>(L, rbuf, st, k, tid);
 		if constexpr (MODE == 1) cx_whole_row<FLENP>(X, st.row, tid);
 		if constexpr (MODE == 2) ex.template mfma_prefetch<(FLENP > 24 ? 12 : 10)>(X);
 	});

@@ -275,6 +275,9 @@ __global__ __launch_bounds__(kConvxThreads, R8B_CONVX_MINWAVES) void k_convx(con
 		blk = w % nblk;
 		ch = w / nblk;
 	}
+	// wave-uniform by construction; tell the compiler (keeps block/channel arithmetic on the SALU)
+	blk = (unsigned) __builtin_amdgcn_readfirstlane((int) blk);
+	ch = (unsigned) __builtin_amdgcn_readfirstlane((int) ch);
 	GpuExec<LOGN, UPLOG> ex;
 	ex.rot = (blk + ch) & 3u;
 	convx_body<LOGN, UPLOG, MODE, FLENP>(ex, X, reinterpret_cast<double*>(smem), X.c.k0 + blk, (int) ch);
