@@ -13,7 +13,8 @@
 //  * the spectral stage runs in place: each thread first pulls its forward bins into registers,
 //    then (after a barrier) writes the backward-transform inputs they determine;
 //  * the last backward pass keeps its results in registers across a barrier and then writes the
-//    block's VALID outputs only, rotated so that they form one linear run y[0..in_len) in LDS;
+//    block's VALID outputs only, rotated so that they form one linear run y[0..in_len) in LDS
+//    (aliasing the work array: 34.8 KB of LDS per workgroup for the 2048-point backward FFT);
 //  * twiddles of pass p+1 are fetched from the L2-resident table BEFORE the barrier that ends
 //    pass p, so their latency overlaps the barrier wait;
 //  * MODE 1: thread t < OutStep keeps polyphase row (t*InStep mod OutStep) in registers and
@@ -34,37 +35,26 @@ namespace r8bhip {
 
 static const int kConvxThreads = 256;
 
-// offset (doubles, multiple of 2) of the one-sample-shifted copy y1[u] = y[u + 1] of the linear run
-// = 16 (mod 32) doubles, i.e. half a 256-byte LDS bank row away from y: a wave reads even window
-// starts from y and odd ones from y1 at nearly the same index, and must not hit the same banks
-R8B_HD int cx_y1_offset(int in_len) { return ((in_len + 8 + 31) & ~31) + 16; }
-
 // padded complex index: one spare slot after every 16
 R8B_HD int cpad(int e) { return e + (e >> 4); }
 // padded index of real sample i when the reals are viewed as packed complex pairs
 R8B_HD int rpad(int i) { return i + ((i >> 5) << 1); }
 
 constexpr int convx_lds_doubles(int logn2) { return 2 * ((1 << logn2) + ((1 << logn2) >> 4)); }
-// LDS doubles a workgroup needs: the padded work array, which the linear output run (and in
-// fused mode its one-sample-shifted copy) aliases once the last backward pass sits in registers
-#ifdef R8B_CX_ONECOPY
-static const bool kCxOneCopy = true;
-#else
-static const bool kCxOneCopy = false;
-#endif
-inline int convx_lds_need(int logn2, int in_len, int mode)
+// LDS doubles a workgroup needs: the padded work array, which the linear output run aliases once the
+// last backward pass sits in registers
+inline int convx_lds_need(int logn2, int in_len, int /*mode*/)
 {
-	if (kCxOneCopy && mode == 1) mode = 0;
 	const int work = convx_lds_doubles(logn2);
-	const int y1 = ((in_len + 8 + 31) & ~31) + 16;
-	const int run = mode == 1 ? y1 + in_len + 16 : in_len + 8;
+	const int run = in_len + 8;
 	return work > run ? work : run;
 }
 
 // log2 radix of the pass that touches the full length (first DIF pass / last DIT pass): sized so
 // that one butterfly per thread covers the array when possible
 #ifndef R8B_CX_MAXBITS
-#define R8B_CX_MAXBITS 4 // largest log2 radix of a pass (4: radix 16, fewest LDS round trips)
+#define R8B_CX_MAXBITS 3 // largest log2 radix of a pass: radix 8 keeps the kernel under 128 VGPRs (4
+                         // workgroups per CU); radix 16 saves an LDS round trip but allows only 3
 #endif
 constexpr int big_pass_bits(int logn)
 {
@@ -501,11 +491,11 @@ R8B_HD long long cx_block_t0(const ConvLaunch& L, long long k)
 }
 
 // last backward pass, part 2: the block's valid outputs as one linear run y[u], u in [0, in_len),
-// y[u] = convolver output at time t0 + u (reals, unpadded, at `y`).  COPIES == 2 also writes the
-// one-sample-shifted copy y1; ZERO_NEG clears the outputs at negative times (a stage's stream
+// y[u] = convolver output at time t0 + u (reals, unpadded, at `y`).  ZERO_NEG clears the outputs
+// at negative times (a stage's stream
 // starts at t = 0: for the next stage earlier samples do not exist, its history is zero --
 // reference CDSPFracInterpolator.h:834-859).
-template<int LOGN, int UPLOG, int COPIES, bool ZERO_NEG>
+template<int LOGN, int UPLOG, bool ZERO_NEG>
 R8B_HD void cx_final_store(const ConvLaunch& L, double* y, const ConvxState<LOGN, UPLOG>& st,
 	long long k, int tid)
 {
@@ -513,7 +503,6 @@ R8B_HD void cx_final_store(const ConvLaunch& L, double* y, const ConvxState<LOGN
 	constexpr int nb = (1 << LOGN2) / R, q = nb;
 	typedef ConvxState<LOGN, UPLOG> St;
 	const int mask = (2 << LOGN2) - 1;
-	double* const y1 = y + cx_y1_offset(L.in_len);
 	const long long t0 = cx_block_t0(L, k);
 	const int nzero = !ZERO_NEG || t0 >= 0 ? 0 : (-t0 > L.in_len ? L.in_len : (int) -t0);
 #pragma unroll
@@ -527,21 +516,12 @@ R8B_HD void cx_final_store(const ConvLaunch& L, double* y, const ConvxState<LOGN
 			const int e = b + p * q; // complex index: reals 2e, 2e+1 at circular positions c
 			const int u0 = (2 * e + L.fl2) & mask, u1 = (2 * e + 1 + L.fl2) & mask;
 			const double v0 = u0 < nzero ? 0.0 : st.fr[f][p], v1 = u1 < nzero ? 0.0 : st.fi[f][p];
-			if (u0 < L.in_len)
-			{
-				y[u0] = v0;
-				if (COPIES == 2 && u0 > 0) y1[u0 - 1] = v0;
-			}
-			if (u1 < L.in_len)
-			{
-				y[u1] = v1;
-				if (COPIES == 2 && u1 > 0) y1[u1 - 1] = v1;
-			}
+			if (u0 < L.in_len) y[u0] = v0;
+			if (u1 < L.in_len) y[u1] = v1;
 		}
 	}
 	// zero extension read (times zero taps) by the padded polyphase rows
 	if (tid < 8) y[L.in_len + tid] = 0.0;
-	else if (COPIES == 2 && tid < 24) y1[L.in_len - 1 + (tid - 8)] = 0.0;
 }
 
 // MODE 0: K7, write the block's valid outputs that fall into [a, b)
@@ -584,14 +564,11 @@ R8B_HD void cx_whole_compute(const ConvxLaunch& X, const double* y, const double
 	long long j = B.jlo + d;
 	const long long jhi = B.jhi;
 	if (j >= jhi) return;
-	// The run is kept twice in LDS, y and y shifted by one sample (cx_y1_offset), so that every
-	// tap window starts 16-byte aligned in one of the copies and is read with ds_read_b128
-	// (256 B/clk); unaligned 8-byte pairs would compile to ds_read2_b64 at half that rate.
-	const double* y1 = y + cx_y1_offset(L.in_len);
+	// Every tap is one 8-byte LDS read.  R8B_LDS_WINDOW is supplied by the includer: on the GPU
+	// inline-asm ds_read_b64 (256 B/clk; left to the compiler, unaligned pairs become
+	// ds_read2_b64 at half that rate, and an aligned two-copy layout costs a second 21 KB of LDS,
+	// i.e. one resident workgroup per CU), in the host emulation plain loads.
 	int u = B.u_lo + (int) ((unsigned) (B.ph_lo + d * X.in_step) / (unsigned) X.out_step);
-#ifdef R8B_CX_ONECOPY
-	// experiment: single copy of the run, every tap one 8-byte LDS read (R8B_LDS_WINDOW supplied
-	// by the includer: inline-asm ds_read_b64 on the GPU, plain loads in the emulation)
 	for (; j < jhi; j += X.out_step, u += X.in_step)
 	{
 		double v[FLEN];
@@ -602,21 +579,6 @@ R8B_HD void cx_whole_compute(const ConvxLaunch& X, const double* y, const double
 		{
 			s0 += row[i] * v[i];
 			s1 += row[i + 1] * v[i + 1];
-		}
-		dst_store(X.wdst, ch, j, s0 + s1);
-	}
-	return;
-#endif
-	for (; j < jhi; j += X.out_step, u += X.in_step)
-	{
-		const cd* x = reinterpret_cast<const cd*>((u & 1) ? y1 + (u - 1) : y + u);
-		double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-		for (int i = 0; i < FLEN / 2; i++)
-		{
-			const cd v = x[i];
-			s0 += row[2 * i] * v.re;
-			s1 += row[2 * i + 1] * v.im;
 		}
 		dst_store(X.wdst, ch, j, s0 + s1);
 	}
@@ -758,7 +720,7 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 	ex.phase([&](int tid, St& st) { cx_final_compute<LOGN, UPLOG>(L, buf, st, tid); });
 	ex.phase([&](int tid, St& st)
 	{
-		cx_final_store<LOGN, UPLOG, (MODE == 1 && !kCxOneCopy) ? 2 : 1, MODE != 0>(L, rbuf, st, k, tid);
+		cx_final_store<LOGN, UPLOG, MODE != 0>(L, rbuf, st, k, tid);
 		if constexpr (MODE == 1) cx_whole_row<FLENP>(X, st.row, tid);
 		if constexpr (MODE == 2) ex.template mfma_prefetch<(FLENP > 24 ? 12 : 10)>(X);
 	});

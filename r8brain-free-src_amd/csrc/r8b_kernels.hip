@@ -12,6 +12,32 @@
 #include <string>
 
 #define R8B_HD __device__ __forceinline__
+// 8 consecutive doubles from LDS as 8 separate ds_read_b64 (the compiler would pair them into
+// ds_read2_b64, half the LDS rate); completion is awaited by the wait statement naming the
+// registers (cdna_hip_programming.md 5.7, form ii)
+#define R8B_LDS_READ8(v, o, a) \
+	asm volatile("ds_read_b64 %0, %8 offset:%9\n\tds_read_b64 %1, %8 offset:%10\n\t" \
+		"ds_read_b64 %2, %8 offset:%11\n\tds_read_b64 %3, %8 offset:%12\n\t" \
+		"ds_read_b64 %4, %8 offset:%13\n\tds_read_b64 %5, %8 offset:%14\n\t" \
+		"ds_read_b64 %6, %8 offset:%15\n\tds_read_b64 %7, %8 offset:%16" \
+		: "=v"(v[o]), "=v"(v[o + 1]), "=v"(v[o + 2]), "=v"(v[o + 3]), "=v"(v[o + 4]), \
+		  "=v"(v[o + 5]), "=v"(v[o + 6]), "=v"(v[o + 7]) \
+		: "v"(a), "i"(8 * (o)), "i"(8 * (o) + 8), "i"(8 * (o) + 16), "i"(8 * (o) + 24), \
+		  "i"(8 * (o) + 32), "i"(8 * (o) + 40), "i"(8 * (o) + 48), "i"(8 * (o) + 56) : "memory")
+#define R8B_LDS_WINDOW(N, v, p) \
+	{ \
+		const unsigned a_ = (unsigned) (unsigned long long) (p); \
+		R8B_LDS_READ8(v, 0, a_); R8B_LDS_READ8(v, 8, a_); R8B_LDS_READ8(v, 16, a_); \
+		if constexpr ((N) > 24) R8B_LDS_READ8(v, 24, a_); \
+		asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), \
+			"+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), \
+			"+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])); \
+		asm volatile("" : "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]), "+v"(v[20]), \
+			"+v"(v[21]), "+v"(v[22]), "+v"(v[23])); \
+		if constexpr ((N) > 24) asm volatile("" : "+v"(v[(N) - 8]), "+v"(v[(N) - 7]), \
+			"+v"(v[(N) - 6]), "+v"(v[(N) - 5]), "+v"(v[(N) - 4]), "+v"(v[(N) - 3]), \
+			"+v"(v[(N) - 2]), "+v"(v[(N) - 1])); \
+	}
 #include "r8b_kernel_phases.h"
 #include "r8b_convx.h"
 
