@@ -199,6 +199,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["fast_conv"] = 1; // compile-time-sized convolver kernel when the geometry allows
 	opt_["fuse"] = 1;      // ... with the whole-step interpolator behind it fused in
 	opt_["fuse_hb"] = 1;   // runs of half-band up-samplers as one kernel
+	opt_["poly_tiled"] = 1; // polynomial interpolator: 16 channels share each coefficient fetch
 	opt_["fold_tail"] = 1; // fast convolver at stage 0 keeps the input history itself
 	// fused interpolator on the matrix cores (when a block holds 16 output groups): measured equal
 	// to the vector-ALU form on cfg2 (0.357 vs 0.362 ms: 10x fewer LDS reads, 13 % more FFT
@@ -483,6 +484,10 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			L.rpos0 = ps.rpos; L.fpos0 = ps.pos_frac;
 			L.counter0 = ps.in_counter; L.pos_int0 = ps.in_pos_int; L.shift = ps.pos_shift;
 			L.a = a; L.b = b; L.nch = nch_;
+			// tile of 64 outputs spans at most 64*Src/Dst + taps input samples (+ slack for the
+			// counter's rounding)
+			L.span_max = opt_.at("poly_tiled") ?
+				(int) std::ceil(64.0 * sp.ssr / sp.dsr) + sp.flen + 4 : 0;
 			L.src = src; L.dst = dst;
 			launch_poly(L, stream);
 		}

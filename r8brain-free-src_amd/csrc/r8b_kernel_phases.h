@@ -487,6 +487,84 @@ R8B_HD double poly_one(const PolyLaunch& L, int ch, long long i)
 	return s;
 }
 
+// Tiled form: a workgroup takes kPolyTC channels x kPolyTO consecutive outputs.  All channels
+// follow the same position schedule, so the interpolated taps c0 + c1 x + c2 x^2 (reference
+// CDSPFracInterpolator.h:1088-1150) depend on the output index only: they are evaluated once per
+// output into LDS (cf[o * flen + t], plus the x-row offset of output o) and shared by the 16
+// channels; each channel's input span is staged in LDS (row pitch odd against bank conflicts).
+static const int kPolyTC = 16; // channels per workgroup (lanes 0..15 of each 16-lane group)
+static const int kPolyTO = 64; // outputs per workgroup
+
+R8B_HD int poly_pitch(int span) { return span | 1; }
+
+R8B_HD int poly_lds_doubles(int span_max, int flen)
+{
+	return (span_max | 1) * kPolyTC + kPolyTO * flen + kPolyTO;
+}
+
+// input span [lo, lo + len) needed by outputs i0 .. i1-1 of this call
+R8B_HD void poly_tile_span(const PolyLaunch& L, long long i0, long long i1, long long* lo, int* len)
+{
+	long long r0, r1;
+	double f;
+	poly_position(L, i0, &r0, &f);
+	poly_position(L, i1 - 1, &r1, &f);
+	*lo = r0 - L.fll;
+	*len = (int) (r1 + L.fl2 - *lo + 1);
+}
+
+R8B_HD void poly_tile_load(const PolyLaunch& L, double* xs, int pitch, long long lo, int len, int ch0,
+	int tid, int nthr)
+{
+	for (int c = 0; c < kPolyTC && ch0 + c < L.nch; c++)
+		for (int i = tid; i < len; i += nthr) xs[c * pitch + i] = src_load(L.src, ch0 + c, lo + i);
+}
+
+R8B_HD void poly_tile_coefs(const PolyLaunch& L, double* cf, double* xoff, long long lo, long long i0,
+	long long i1, int tid, int nthr)
+{
+	const int nout = (int) (i1 - i0);
+	for (int idx = tid; idx < nout * L.flen; idx += nthr)
+	{
+		const int o = idx / L.flen, t = idx - o * L.flen;
+		long long rpos;
+		double fpos;
+		poly_position(L, i0 + o, &rpos, &fpos);
+		double x, x2;
+		int fti;
+		{
+#pragma clang fp contract(off)
+			x = fpos * L.fracs;
+			fti = (int) x;
+			x -= fti;
+			x2 = x * x;
+		}
+		const double* c = L.table + ((long) fti * L.flen + t) * 3;
+		cf[idx] = c[0] + c[1] * x + c[2] * x2;
+		if (t == 0) xoff[o] = (double) (rpos - L.fll - lo);
+	}
+}
+
+R8B_HD void poly_tile_compute(const PolyLaunch& L, const double* xs, int pitch, const double* cf,
+	const double* xoff, long long i0, long long i1, int ch0, int tid, int nthr)
+{
+	const int c = tid % kPolyTC;
+	if (ch0 + c >= L.nch) return;
+	for (long long i = i0 + tid / kPolyTC; i < i1; i += nthr / kPolyTC)
+	{
+		const int o = (int) (i - i0);
+		const double* k = cf + o * L.flen;
+		const double* xv = xs + c * pitch + (int) xoff[o];
+		double s0 = 0.0, s1 = 0.0;
+		for (int t = 0; t < L.flen; t += 2)
+		{
+			s0 += k[t] * xv[t];
+			s1 += k[t + 1] * xv[t + 1];
+		}
+		dst_store(L.dst, ch0 + c, L.a + i, s0 + s1);
+	}
+}
+
 // ------------------------------------------------------------------------------------ half-band
 
 // 2x up: tile of input indices [n0, n1); xs holds x[n0 - T + 1 .. n1 + T - 1 + 1)

@@ -114,6 +114,28 @@ __global__ void k_poly(const PolyLaunch L)
 	if (L.a + i < L.b) dst_store(L.dst, ch, L.a + i, poly_one(L, ch, i));
 }
 
+__global__ void k_poly_tiled(const PolyLaunch L)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	double* const xs = reinterpret_cast<double*>(smem);
+	const int tid = threadIdx.x, nthr = blockDim.x;
+	const int ch0 = (int) blockIdx.y * kPolyTC;
+	const long long n = L.b - L.a;
+	const long long i0 = (long long) blockIdx.x * kPolyTO;
+	long long i1 = i0 + kPolyTO;
+	if (i1 > n) i1 = n;
+	long long lo;
+	int len;
+	poly_tile_span(L, i0, i1, &lo, &len);
+	const int pitch = poly_pitch(L.span_max);
+	double* const cf = xs + pitch * kPolyTC;
+	double* const xoff = cf + kPolyTO * L.flen;
+	poly_tile_load(L, xs, pitch, lo, len, ch0, tid, nthr);
+	poly_tile_coefs(L, cf, xoff, lo, i0, i1, tid, nthr);
+	__syncthreads();
+	poly_tile_compute(L, xs, pitch, cf, xoff, i0, i1, ch0, tid, nthr);
+}
+
 // ------------------------------------------------------------------ half-band stages
 __global__ void k_hbup(const HBLaunch L)
 {
@@ -364,6 +386,16 @@ void launch_whole(const WholeLaunch& L, void* stream)
 void launch_poly(const PolyLaunch& L, void* stream)
 {
 	const long long n = L.b - L.a;
+	if (L.span_max > 0)
+	{
+		// x rows (poly_pitch) + interpolated taps + row offsets: poly_lds_doubles()
+		const size_t lds = ((size_t) (L.span_max | 1) * kPolyTC + (size_t) kPolyTO * L.flen +
+			kPolyTO) * sizeof(double);
+		hipLaunchKernelGGL(k_poly_tiled, dim3((unsigned) ((n + kPolyTO - 1) / kPolyTO),
+			(unsigned) ((L.nch + kPolyTC - 1) / kPolyTC)), dim3(256), lds, (hipStream_t) stream, L);
+		check(hipGetLastError(), "launch k_poly_tiled");
+		return;
+	}
 	hipLaunchKernelGGL(k_poly, dim3((unsigned) ((n + 255) / 256), (unsigned) L.nch), dim3(256), 0,
 		(hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_poly");

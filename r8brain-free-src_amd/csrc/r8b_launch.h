@@ -95,6 +95,7 @@ struct PolyLaunch
 	double shift;
 	long long a, b;
 	int nch;
+	int span_max; // tiled kernel: LDS doubles per channel row (max input span of an output tile)
 	SrcView src;
 	DstView dst;
 };

@@ -82,6 +82,30 @@ void launch_whole(const WholeLaunch& L, void*)
 
 void launch_poly(const PolyLaunch& L, void*)
 {
+	if (L.span_max > 0)
+	{
+		const int nthr = 256, pitch = poly_pitch(L.span_max);
+		std::vector<double> xs((size_t) poly_lds_doubles(L.span_max, L.flen));
+		double* const cf = xs.data() + pitch * kPolyTC;
+		double* const xoff = cf + kPolyTO * L.flen;
+		const long long n = L.b - L.a;
+		for (int by = 0; by < (L.nch + kPolyTC - 1) / kPolyTC; by++)
+			for (long long i0 = 0; i0 < n; i0 += kPolyTO)
+			{
+				for (double& v : xs) v = std::numeric_limits<double>::quiet_NaN();
+				const long long i1 = std::min(n, i0 + kPolyTO);
+				long long lo;
+				int len;
+				poly_tile_span(L, i0, i1, &lo, &len);
+				if (len > L.span_max) throw std::runtime_error("emul: poly tile span overflows LDS");
+				for (int t = 0; t < nthr; t++)
+					poly_tile_load(L, xs.data(), pitch, lo, len, by * kPolyTC, t, nthr);
+				for (int t = 0; t < nthr; t++) poly_tile_coefs(L, cf, xoff, lo, i0, i1, t, nthr);
+				for (int t = 0; t < nthr; t++)
+					poly_tile_compute(L, xs.data(), pitch, cf, xoff, i0, i1, by * kPolyTC, t, nthr);
+			}
+		return;
+	}
 	for (int ch = 0; ch < L.nch; ch++)
 		for (long long i = 0; L.a + i < L.b; i++) dst_store(L.dst, ch, L.a + i, poly_one(L, ch, i));
 }
