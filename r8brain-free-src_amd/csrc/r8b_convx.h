@@ -34,6 +34,7 @@
 namespace r8bhip {
 
 static const int kConvxThreads = 256;
+static const int kConvxRunPad = 32; // zeros behind the linear output run (see cx_final_store)
 
 // padded complex index: one spare slot after every 16
 R8B_HD int cpad(int e) { return e + (e >> 4); }
@@ -46,7 +47,7 @@ constexpr int convx_lds_doubles(int logn2) { return 2 * ((1 << logn2) + ((1 << l
 inline int convx_lds_need(int logn2, int in_len, int /*mode*/)
 {
 	const int work = convx_lds_doubles(logn2);
-	const int run = in_len + 8;
+	const int run = in_len + kConvxRunPad;
 	return work > run ? work : run;
 }
 
@@ -76,15 +77,22 @@ constexpr int rest_bits(int logn, int i)
 template<int LOGN, int UPLOG>
 struct ConvxState
 {
-	static constexpr int N = 1 << LOGN, N2 = N << UPLOG;
-	static constexpr int SP = (N / 2 + 1 + kConvxThreads - 1) / kConvxThreads;
-	static constexpr int RL = 1 << big_pass_bits(LOGN + UPLOG);
+	// UPLOG = 1: 2x up-sampling, 0: 1:1, -1: 2x decimation (backward transform of half the length)
+	static constexpr bool DOWN = UPLOG < 0;
+	static constexpr int N = 1 << LOGN, LOGN2 = LOGN + UPLOG, N2 = 1 << LOGN2;
+	// spectral slots: one per forward bin pair (kf, N-kf), or when decimating per backward pair
+	// (k, N2-k), which needs four forward bins
+	static constexpr int SLOTS = (DOWN ? N2 : N) / 2 + 1;
+	static constexpr int SP = (SLOTS + kConvxThreads - 1) / kConvxThreads;
+	static constexpr int NSP = DOWN ? 4 : 2;
+	static constexpr int RL = 1 << big_pass_bits(LOGN2);
 	static constexpr int FIN = (N2 / RL + kConvxThreads - 1) / kConvxThreads;
 	static constexpr int RF = 1 << big_pass_bits(LOGN); // radix of the first forward pass
+	static constexpr int FF = (N / RF + kConvxThreads - 1) / kConvxThreads; // its butterflies/thread
 	cd tw[6];
 	cd tw0[RF > 8 ? 6 : (RF > 4 ? 4 : 3)]; // first-pass twiddles: same for every block
-	cd pre[RF];                            // inputs of the NEXT block's first-pass butterfly
-	cd sp[SP][2];
+	cd pre[FF][RF];                        // inputs of the block's first-pass butterflies
+	cd sp[SP][NSP];
 	double fr[FIN][RL], fi[FIN][RL];
 	double row[32];
 };
@@ -320,60 +328,80 @@ R8B_HD cd src_load2(const SrcView& s, int ch, long long pos)
 template<int LOGN, int UPLOG>
 R8B_HD void cx_prefetch(const ConvLaunch& L, ConvxState<LOGN, UPLOG>& st, long long k, int ch, int tid)
 {
-	constexpr int R = ConvxState<LOGN, UPLOG>::RF, N = 1 << LOGN, nb = N / R, NIN = 2 * N;
-	if (tid >= nb) return;
+	typedef ConvxState<LOGN, UPLOG> St;
+	constexpr int R = St::RF, N = 1 << LOGN, nb = N / R, NIN = 2 * N;
 	const int iln = L.in_len / L.up;
 	const long long base = (k * (long long) L.blk_stride + L.blk_offset) / L.up;
 #pragma unroll
-	for (int p = 0; p < R; p++)
+	for (int f = 0; f < St::FF; f++)
 	{
-		const int i = 2 * (tid + p * nb);
-		const long long pos = i < iln ? base + i : base + i - NIN;
-		if (L.vec_ok) st.pre[p] = src_load2(L.src, ch, pos);
-		else
+		const int b = tid + f * kConvxThreads;
+		if (b >= nb) continue;
+#pragma unroll
+		for (int p = 0; p < R; p++)
 		{
-			// odd geometry or unaligned caller buffer: the two samples may even sit on different
-			// sides of the fresh/history split
-			const long long pos1 = i + 1 < iln ? base + i + 1 : base + i + 1 - NIN;
-			st.pre[p].re = src_load(L.src, ch, pos);
-			st.pre[p].im = src_load(L.src, ch, pos1);
+			const int i = 2 * (b + p * nb);
+			const long long pos = i < iln ? base + i : base + i - NIN;
+			if (L.vec_ok) st.pre[f][p] = src_load2(L.src, ch, pos);
+			else
+			{
+				// odd geometry or unaligned caller buffer: the two samples may even sit on
+				// different sides of the fresh/history split
+				const long long pos1 = i + 1 < iln ? base + i + 1 : base + i + 1 - NIN;
+				st.pre[f][p].re = src_load(L.src, ch, pos);
+				st.pre[f][p].im = src_load(L.src, ch, pos1);
+			}
 		}
 	}
 }
 
 // first forward pass: inputs from the prefetch registers, results into the padded LDS array
 template<int LOGN, int UPLOG>
-R8B_HD void cx_first_pass(cd* buf, const ConvxState<LOGN, UPLOG>& st, int tid)
+R8B_HD void cx_first_pass(const ConvLaunch& L, cd* buf, const ConvxState<LOGN, UPLOG>& st, int tid)
 {
-	constexpr int R = ConvxState<LOGN, UPLOG>::RF, N = 1 << LOGN, q = N / R;
-	if (tid >= q) return;
-	double vr[R], vi[R];
+	typedef ConvxState<LOGN, UPLOG> St;
+	constexpr int R = St::RF, N = 1 << LOGN, q = N / R;
 #pragma unroll
-	for (int p = 0; p < R; p++)
+	for (int f = 0; f < St::FF; f++)
 	{
-		vr[p] = st.pre[p].re;
-		vi[p] = st.pre[p].im;
-	}
-	dif_regs<R>(vr, vi);
-	if constexpr (LOGN > big_pass_bits(LOGN))
-	{
+		const int b = tid + f * kConvxThreads;
+		if (b >= q) continue;
+		double vr[R], vi[R];
 #pragma unroll
-		for (int p = 1; p < R; p++)
+		for (int p = 0; p < R; p++)
 		{
-			const cd w = tw_get(st.tw0, bitrev_c<R>(p));
-			const double tr = vr[p] * w.re - vi[p] * w.im;
-			const double ti = vr[p] * w.im + vi[p] * w.re;
-			vr[p] = tr;
-			vi[p] = ti;
+			vr[p] = st.pre[f][p].re;
+			vi[p] = st.pre[f][p].im;
 		}
-	}
+		dif_regs<R>(vr, vi);
+		if constexpr (LOGN > big_pass_bits(LOGN))
+		{
+			// one butterfly per thread: twiddles prefetched into st.tw0; more: fetched here
+			cd loc[6];
+			const cd* twr = st.tw0;
+			if constexpr (St::FF > 1)
+			{
+				tw_fetch<R>(loc, L.tw, L.tw_len, N, b);
+				twr = loc;
+			}
 #pragma unroll
-	for (int p = 0; p < R; p++)
-	{
-		cd v;
-		v.re = vr[p];
-		v.im = vi[p];
-		buf[cpad(tid + p * q)] = v;
+			for (int p = 1; p < R; p++)
+			{
+				const cd w = tw_get(twr, bitrev_c<R>(p));
+				const double tr = vr[p] * w.re - vi[p] * w.im;
+				const double ti = vr[p] * w.im + vi[p] * w.re;
+				vr[p] = tr;
+				vi[p] = ti;
+			}
+		}
+#pragma unroll
+		for (int p = 0; p < R; p++)
+		{
+			cd v;
+			v.re = vr[p];
+			v.im = vi[p];
+			buf[cpad(b + p * q)] = v;
+		}
 	}
 }
 
@@ -393,6 +421,24 @@ template<int LOGN, int UPLOG>
 R8B_HD void cx_spec_read(const cd* buf, ConvxState<LOGN, UPLOG>& st, int tid)
 {
 	constexpr int N = 1 << LOGN;
+	if constexpr (UPLOG < 0)
+	{
+		// decimating: slot -> backward pair (k, N2-k), fed by forward bins k, N-k, N2-k, N-N2+k
+		constexpr int LOGN2 = LOGN + UPLOG, N2 = 1 << LOGN2;
+#pragma unroll
+		for (int s = 0; s < ConvxState<LOGN, UPLOG>::SP; s++)
+		{
+			const int k = cx_spec_bin<LOGN2>(tid + s * kConvxThreads);
+			if (k <= N2 / 2)
+			{
+				st.sp[s][0] = buf[cpad(bitrev_n(k, LOGN))];
+				st.sp[s][1] = buf[cpad(bitrev_n((N - k) & (N - 1), LOGN))];
+				st.sp[s][2] = buf[cpad(bitrev_n(N2 - k, LOGN))];
+				st.sp[s][3] = buf[cpad(bitrev_n(N - N2 + k, LOGN))];
+			}
+		}
+		return;
+	}
 #pragma unroll
 	for (int s = 0; s < ConvxState<LOGN, UPLOG>::SP; s++)
 	{
@@ -415,50 +461,86 @@ template<int LOGN, int UPLOG>
 R8B_HD void cx_spec_write(const ConvLaunch& L, cd* buf, const ConvxState<LOGN, UPLOG>& st, int tid)
 {
 	constexpr int N = 1 << LOGN, LOGN2 = LOGN + UPLOG;
-	constexpr int SLOTS = N / 2 + 1;
-#pragma unroll
-	for (int s = 0; s < ConvxState<LOGN, UPLOG>::SP; s++)
-	{
-		const int slot = tid + s * kConvxThreads;
-		const int kf = cx_spec_bin<LOGN>(slot);
-		if (kf > N / 2) continue;
-		const cd z1 = st.sp[s][0], z2 = st.sp[s][1];
-		const cd* c = L.spec + slot;
-		// out = a * (p.re, sp * p.im) + b * (q.re, sq * q.im)
+	constexpr int SLOTS = ConvxState<LOGN, UPLOG>::SLOTS;
+	// out = a * (p.re, sp * p.im) + b * (q.re, sq * q.im)
 #define R8B_CMADD(out, a, p, sp, b, q, sq) \
-		{ \
-			const cd ca = (a), cb = (b); \
-			const double pi_ = (sp) * (p).im, qi_ = (sq) * (q).im; \
-			(out).re = ca.re * (p).re - ca.im * pi_ + cb.re * (q).re - cb.im * qi_; \
-			(out).im = ca.re * pi_ + ca.im * (p).re + cb.re * qi_ + cb.im * (q).re; \
-		}
-		cd o;
-		if constexpr (UPLOG == 0)
-		{
-			R8B_CMADD(o, c[0], z1, 1.0, c[SLOTS], z2, -1.0)            // Z'[kf]
-			buf[cpad(bitrev_n(kf, LOGN2))] = o;
-			if (kf != 0 && kf != N / 2)
-			{
-				R8B_CMADD(o, c[2 * SLOTS], z1, -1.0, c[3 * SLOTS], z2, 1.0) // Z'[N-kf]
-				buf[cpad(bitrev_n(N - kf, LOGN2))] = o;
-			}
-		}
-		else
-		{
-			R8B_CMADD(o, c[0], z1, 1.0, c[SLOTS], z2, -1.0)            // Z'[kf]
-			buf[cpad(bitrev_n(kf, LOGN2))] = o;
-			R8B_CMADD(o, c[4 * SLOTS], z1, -1.0, c[5 * SLOTS], z2, 1.0) // Z'[N-kf]
-			buf[cpad(bitrev_n(N - kf, LOGN2))] = o;
-			if (kf != 0)
-			{
-				R8B_CMADD(o, c[2 * SLOTS], z1, -1.0, c[3 * SLOTS], z2, 1.0) // Z'[2N-kf]
-				buf[cpad(bitrev_n(2 * N - kf, LOGN2))] = o;
-				R8B_CMADD(o, c[6 * SLOTS], z1, 1.0, c[7 * SLOTS], z2, -1.0) // Z'[N+kf]
-				buf[cpad(bitrev_n(N + kf, LOGN2))] = o;
-			}
-		}
-#undef R8B_CMADD
+	{ \
+		const cd ca = (a), cb = (b); \
+		const double pi_ = (sp) * (p).im, qi_ = (sq) * (q).im; \
+		(out).re = ca.re * (p).re - ca.im * pi_ + cb.re * (q).re - cb.im * qi_; \
+		(out).im = ca.re * pi_ + ca.im * (p).re + cb.re * qi_ + cb.im * (q).re; \
 	}
+	if constexpr (UPLOG < 0)
+	{
+		// Z'[k]    = c0 Z1 + c1 conj Z2 + c2 conj Z3 + c3 Z4
+		// Z'[N2-k] = c4 conj Z1 + c5 Z2 + c6 Z3 + c7 conj Z4
+		// (slot k = 0 has one output, the sum of both forms: its Nyquist fix-up needs Z[N2] and
+		// Z[N-N2] plain and conjugated, reference CDSPBlockConvolver.h:329-342)
+		constexpr int N2 = 1 << LOGN2;
+#pragma unroll
+		for (int s = 0; s < ConvxState<LOGN, UPLOG>::SP; s++)
+		{
+			const int slot = tid + s * kConvxThreads;
+			const int k = cx_spec_bin<LOGN2>(slot);
+			if (k > N2 / 2) continue;
+			const cd z1 = st.sp[s][0], z2 = st.sp[s][1], z3 = st.sp[s][2], z4 = st.sp[s][3];
+			const cd* c = L.spec + slot;
+			cd o1, o2, t;
+			R8B_CMADD(o1, c[0], z1, 1.0, c[SLOTS], z2, -1.0)
+			R8B_CMADD(t, c[2 * SLOTS], z3, -1.0, c[3 * SLOTS], z4, 1.0)
+			o1.re += t.re;
+			o1.im += t.im;
+			R8B_CMADD(o2, c[4 * SLOTS], z1, -1.0, c[5 * SLOTS], z2, 1.0)
+			R8B_CMADD(t, c[6 * SLOTS], z3, 1.0, c[7 * SLOTS], z4, -1.0)
+			o2.re += t.re;
+			o2.im += t.im;
+			if (k == 0)
+			{
+				o1.re += o2.re;
+				o1.im += o2.im;
+			}
+			buf[cpad(bitrev_n(k, LOGN2))] = o1;
+			if (k != 0 && k != N2 / 2) buf[cpad(bitrev_n(N2 - k, LOGN2))] = o2;
+		}
+	}
+	else
+	{
+#pragma unroll
+		for (int s = 0; s < ConvxState<LOGN, UPLOG>::SP; s++)
+		{
+			const int slot = tid + s * kConvxThreads;
+			const int kf = cx_spec_bin<LOGN>(slot);
+			if (kf > N / 2) continue;
+			const cd z1 = st.sp[s][0], z2 = st.sp[s][1];
+			const cd* c = L.spec + slot;
+			cd o;
+			if constexpr (UPLOG == 0)
+			{
+				R8B_CMADD(o, c[0], z1, 1.0, c[SLOTS], z2, -1.0)            // Z'[kf]
+				buf[cpad(bitrev_n(kf, LOGN2))] = o;
+				if (kf != 0 && kf != N / 2)
+				{
+					R8B_CMADD(o, c[2 * SLOTS], z1, -1.0, c[3 * SLOTS], z2, 1.0) // Z'[N-kf]
+					buf[cpad(bitrev_n(N - kf, LOGN2))] = o;
+				}
+			}
+			else
+			{
+				R8B_CMADD(o, c[0], z1, 1.0, c[SLOTS], z2, -1.0)            // Z'[kf]
+				buf[cpad(bitrev_n(kf, LOGN2))] = o;
+				R8B_CMADD(o, c[4 * SLOTS], z1, -1.0, c[5 * SLOTS], z2, 1.0) // Z'[N-kf]
+				buf[cpad(bitrev_n(N - kf, LOGN2))] = o;
+				if (kf != 0)
+				{
+					R8B_CMADD(o, c[2 * SLOTS], z1, -1.0, c[3 * SLOTS], z2, 1.0) // Z'[2N-kf]
+					buf[cpad(bitrev_n(2 * N - kf, LOGN2))] = o;
+					R8B_CMADD(o, c[6 * SLOTS], z1, 1.0, c[7 * SLOTS], z2, -1.0) // Z'[N+kf]
+					buf[cpad(bitrev_n(N + kf, LOGN2))] = o;
+				}
+			}
+		}
+	}
+#undef R8B_CMADD
 }
 
 // last backward pass, part 1: butterflies into registers
@@ -502,9 +584,14 @@ R8B_HD void cx_final_store(const ConvLaunch& L, double* y, const ConvxState<LOGN
 	constexpr int LOGN2 = LOGN + UPLOG, RB = big_pass_bits(LOGN2), R = 1 << RB;
 	constexpr int nb = (1 << LOGN2) / R, q = nb;
 	typedef ConvxState<LOGN, UPLOG> St;
+	static_assert(UPLOG >= 0 || !ZERO_NEG, "the decimating form has no fused interpolator");
 	const int mask = (2 << LOGN2) - 1;
 	const long long t0 = cx_block_t0(L, k);
-	const int nzero = !ZERO_NEG || t0 >= 0 ? 0 : (-t0 > L.in_len ? L.in_len : (int) -t0);
+	// decimating: the backward transform's real sample e sits at circular time e * down, the run
+	// holds the in_len / down outputs of the block and starts fl2 / down samples before time 0
+	const int fl2 = UPLOG < 0 ? L.fl2 >> -UPLOG : L.fl2;
+	const int in_len = UPLOG < 0 ? L.in_len >> -UPLOG : L.in_len;
+	const int nzero = !ZERO_NEG || t0 >= 0 ? 0 : (-t0 > in_len ? in_len : (int) -t0);
 #pragma unroll
 	for (int f = 0; f < St::FIN; f++)
 	{
@@ -514,23 +601,33 @@ R8B_HD void cx_final_store(const ConvLaunch& L, double* y, const ConvxState<LOGN
 		for (int p = 0; p < R; p++)
 		{
 			const int e = b + p * q; // complex index: reals 2e, 2e+1 at circular positions c
-			const int u0 = (2 * e + L.fl2) & mask, u1 = (2 * e + 1 + L.fl2) & mask;
+			const int u0 = (2 * e + fl2) & mask, u1 = (2 * e + 1 + fl2) & mask;
 			const double v0 = u0 < nzero ? 0.0 : st.fr[f][p], v1 = u1 < nzero ? 0.0 : st.fi[f][p];
-			if (u0 < L.in_len) y[u0] = v0;
-			if (u1 < L.in_len) y[u1] = v1;
+			if (u0 < in_len) y[u0] = v0;
+			if (u1 < in_len) y[u1] = v1;
 		}
 	}
-	// zero extension read (times zero taps) by the padded polyphase rows
-	if (tid < 8) y[L.in_len + tid] = 0.0;
+	// zero extension read (times zero taps) by the padded polyphase rows: a window starts at most at
+	// in_len - flen and is FLENP <= 32 long, flen >= 6
+	if (tid < kConvxRunPad) y[in_len + tid] = 0.0;
 }
 
-// MODE 0: K7, write the block's valid outputs that fall into [a, b)
+// MODE 0: K7, write the block's valid outputs that fall into [a, b).  Decimating: output q sits at
+// virtual time q * down; the block's first one is (block start) / down - floor(fl2 / down), both
+// in_len and the block starts being multiples of down (reference CDSPBlockConvolver.h:150-165).
+template<int UPLOG>
 R8B_HD void cx_store_conv(const ConvLaunch& L, const double* y, long long k, int ch, int tid)
 {
-	const long long t0 = cx_block_t0(L, k);
-	for (int u = tid; u < L.in_len; u += kConvxThreads)
+	long long q0 = cx_block_t0(L, k);
+	int n = L.in_len;
+	if constexpr (UPLOG < 0)
 	{
-		const long long q = t0 + u;
+		q0 = ((k * (long long) L.blk_stride + L.blk_offset) >> -UPLOG) - (L.fl2 >> -UPLOG);
+		n >>= -UPLOG;
+	}
+	for (int u = tid; u < n; u += kConvxThreads)
+	{
+		const long long q = q0 + u;
 		if (q >= L.a && q < L.b) dst_store(L.dst, ch, q, y[u]);
 	}
 }
@@ -701,10 +798,13 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 	ex.phase([&](int tid, St& st)
 	{
 		cx_prefetch<LOGN, UPLOG>(L, st, k, ch, tid);
-		if (tid < (1 << LOGN) / St::RF)
-			tw_fetch<St::RF>(st.tw0, L.tw, L.tw_len, 1 << LOGN, tid);
+		if constexpr (St::FF == 1)
+		{
+			if (tid < (1 << LOGN) / St::RF)
+				tw_fetch<St::RF>(st.tw0, L.tw, L.tw_len, 1 << LOGN, tid);
+		}
 		if constexpr (NPF > 1) FwdPass<LOGN, 1>::prefetch(st.tw, L.tw, L.tw_len, tid);
-		cx_first_pass<LOGN, UPLOG>(buf, st, tid);
+		cx_first_pass<LOGN, UPLOG>(L, buf, st, tid);
 	});
 	if constexpr (NPF > 1) cx_fwd_seq<LOGN, UPLOG, 1>(ex, L, buf);
 	ex.phase([&](int tid, St& st) { cx_spec_read<LOGN, UPLOG>(buf, st, tid); });
@@ -743,7 +843,7 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 		ex.phase([&](int tid, St& st)
 		{
 			if constexpr (MODE == 1) cx_whole_compute<FLENP>(X, rbuf, st.row, k, ch, tid);
-			else cx_store_conv(L, rbuf, k, ch, tid);
+			else cx_store_conv<UPLOG>(L, rbuf, k, ch, tid);
 		});
 	}
 }

@@ -156,6 +156,118 @@ std::vector<double> spectral_constants(const std::vector<double>& H, const std::
 	return out;
 }
 
+// The same for the 2x-decimating convolver (r8b_convx.h, UPLOG < 0): slot -> backward pair
+// (k, N2-k), N2 = N / down, fed by the forward bins idx = {k, N-k, N2-k, N-N2+k}:
+//   Z'[k]    = c0 Z1 + c1 conj Z2 + c2 conj Z3 + c3 Z4      (form 1)
+//   Z'[N2-k] = c4 conj Z1 + c5 Z2 + c6 Z3 + c7 conj Z4      (form 2; slot k = 0: added to Z'[0])
+// The constants are read off a long-double model of the chain real-FFT unpacking -> kernel
+// multiplication -> Nyquist fix-up of the shortened transform (reference
+// CDSPBlockConvolver.h:329-342) -> packing, by probing it with unit inputs: a real-linear map of
+// one complex input is a*z + b*conj(z) with a = (F(1) - i F(i)) / 2, b = (F(1) + i F(i)) / 2.
+std::vector<double> spectral_constants_down(const std::vector<double>& H,
+	const std::vector<double>& tw, int bl2, int n_in, int down)
+{
+	typedef std::complex<long double> C;
+	const int N = n_in / 2, N2 = N / down;
+	const int slots = N2 / 2 + 1;
+	int logn2 = 0;
+	while ((1 << logn2) < N2) logn2++;
+	std::vector<double> out((size_t) 8 * slots * 2, 0.0);
+	const C I(0.0L, 1.0L);
+	auto W = [&](long long e) // exp(-2 pi i e / bl2)
+	{
+		e &= bl2 - 1;
+		return C(tw[(size_t) e * 2], tw[(size_t) e * 2 + 1]);
+	};
+	long double hmax = 0.0L;
+	for (double h : H) hmax = std::max(hmax, (long double) std::fabs(h));
+	for (int slot = 0; slot < slots; slot++)
+	{
+		int k = N2 / 2;
+		if (slot < N2 / 2)
+		{
+			k = 0;
+			for (int b = 0; b < logn2 - 1; b++)
+				if (slot & (1 << b)) k |= 1 << (logn2 - 2 - b);
+		}
+		const int idx[4] = { k, (N - k) & (N - 1), N2 - k, (N - N2 + k) & (N - 1) };
+		// the model, with the forward transform being zero except Z[pe] = pv
+		int pe = 0;
+		C pv;
+		auto Z = [&](int j) { return j == pe ? pv : C(0.0L); };
+		auto X = [&](int m) // bin m of the bl2-point real spectrum, 0 <= m <= N
+		{
+			const C z1 = Z(m & (N - 1)), z2 = std::conj(Z((N - m) & (N - 1)));
+			return 0.5L * (z1 + z2) + W((long long) m * (bl2 / (2 * N))) * ((z1 - z2) / (2.0L * I));
+		};
+		auto Y = [&](int m) // product spectrum handed to the backward transform, 0 <= m <= N2
+		{
+			const C x = X(m);
+			if (m == N2) return C((long double) H[(size_t) m] * (x.real() + x.imag()));
+			return (long double) H[(size_t) m] * x;
+		};
+		auto Zp = [&](int m) // packed input m of the N2-point backward transform
+		{
+			const C sa = Y(m), sb = std::conj(Y(N2 - m));
+			return (sa + sb) + I * std::conj(W((long long) m * (bl2 / (2 * N2)))) * (sa - sb);
+		};
+		const int nout = k != 0 && k != N2 / 2 ? 2 : 1;
+		for (int o = 0; o < nout; o++)
+		{
+			const int m = o == 0 ? k : N2 - k;
+			for (int u = 0; u < 4; u++)
+			{
+				bool seen = false;
+				for (int v = 0; v < u; v++) seen = seen || idx[v] == idx[u];
+				if (seen) continue;
+				pe = idx[u];
+				pv = C(1.0L);
+				const C f1 = Zp(m);
+				pv = I;
+				const C fi = Zp(m);
+				const C coef[2] = { 0.5L * (f1 - I * fi), 0.5L * (f1 + I * fi) }; // plain, conj
+				for (int cj = 0; cj < 2; cj++)
+				{
+					if (std::abs(coef[cj]) <= 1e-19L * hmax) continue;
+					// where does element idx[u] appear plain (cj = 0) / conjugated (cj = 1)?
+					// form 1: plain at positions 0, 3; form 2: plain at positions 1, 2
+					int where = -1;
+					for (int form = 0; form < 2 && where < 0; form++)
+					{
+						if (k != 0 && form != o) continue;
+						for (int pos = 0; pos < 4 && where < 0; pos++)
+						{
+							const bool plain = form == 0 ? (pos == 0 || pos == 3) :
+								(pos == 1 || pos == 2);
+							if (idx[pos] == idx[u] && plain == (cj == 0)) where = form * 4 + pos;
+						}
+					}
+					if (where < 0)
+						throw std::logic_error("spectral_constants_down: term does not fit");
+					out[((size_t) where * slots + slot) * 2] = (double) coef[cj].real();
+					out[((size_t) where * slots + slot) * 2 + 1] = (double) coef[cj].imag();
+				}
+			}
+		}
+	}
+	return out;
+}
+
+// LDS of the fast path: one padded complex array of n elements (r8b_convx.h, convx_lds_doubles)
+static size_t convx_work_bytes(int n) { return (size_t) 2 * (n + (n >> 4)) * sizeof(double); }
+
+// LDS of the generic convolver kernel: forward and backward arrays side by side; transforms of
+// equal length can share one array (each spectral slot rewrites exactly the two bins it read)
+static bool generic_conv_two_arrays(const ConvGeom& g)
+{
+	return (size_t) (g.n_in + g.n_out) * sizeof(double) <= 160 * 1024;
+}
+static bool generic_conv_fits(const ConvGeom& g)
+{
+	return generic_conv_two_arrays(g) ||
+		(g.n_in == g.n_out && (size_t) g.n_in * sizeof(double) <= 160 * 1024);
+}
+
 std::vector<int> plan_radices(int N, int max_radix)
 {
 	std::vector<int> r;
@@ -219,7 +331,10 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 			const ConvGeom& g = sp.cg;
 			if (g.n_in < 32 || g.n_out < 32)
 				throw std::runtime_error("block convolver transform too short");
-			if ((size_t) (g.n_in + g.n_out) * sizeof(double) > 160 * 1024)
+			// the generic kernel keeps both transforms' arrays in LDS, the fast path works in place
+			const bool fast_ok = convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2) &&
+				convx_work_bytes(std::max(g.n_in, g.n_out) / 2) <= 160 * 1024;
+			if (!generic_conv_fits(g) && !fast_ok)
 				throw std::runtime_error("low-pass filter too long for the LDS-resident "
 					"block convolver (transition band too narrow)");
 			const std::vector<double> H = kernel_spectrum(*sp.lp, g.bl2, 1.0 / g.bl2);
@@ -231,7 +346,9 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 			dev_upload(d.tw, tw.data(), tw.size() * sizeof(double));
 			if (convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
 			{
-				const std::vector<double> sc = spectral_constants(H, tw, g.bl2, g.n_in, g.up);
+				const std::vector<double> sc = g.down > 1 ?
+					spectral_constants_down(H, tw, g.bl2, g.n_in, g.down) :
+					spectral_constants(H, tw, g.bl2, g.n_in, g.up);
 				d.spec = (cd*) dev_alloc(sc.size() * sizeof(double));
 				dev_upload(d.spec, sc.data(), sc.size() * sizeof(double));
 			}
@@ -401,9 +518,9 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 		switch (sp.desc.kind)
 		{
 		case kConv:
-			*kernel = fuse_with_next(stage) ? "k_convx_whole" : (opt_.at("fast_conv") &&
-				convx_geometry_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2) ?
-				"k_convx" : "k_conv");
+			*kernel = fuse_with_next(stage) ? "k_convx_whole" :
+				((opt_.at("fast_conv") || !generic_conv_fits(sp.cg)) && convx_geometry_ok(
+				sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2) ? "k_convx" : "k_conv");
 			break;
 		case kFrac: *kernel = sp.whole ? "k_whole" : "k_poly"; break;
 		case kHBUp: *kernel = group_len(stage) > 1 ? "k_hbcascade" : "k_hbup"; break;
@@ -442,7 +559,8 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		L.nblk = (int) (k1 - L.k0 + 1);
 		L.a = a; L.b = b;
 		L.dst = dst;
-		if (opt_.at("fast_conv") && convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
+		if ((opt_.at("fast_conv") || !generic_conv_fits(g)) &&
+			convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
 		{
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
@@ -680,7 +798,7 @@ bool Engine::fuse_with_next(size_t s) const
 	if (!opt_.at("fuse") || !opt_.at("fast_conv") || s + 1 >= plan_.stages.size()) return false;
 	const StagePlan& c = plan_.stages[s];
 	const StagePlan& w = plan_.stages[s + 1];
-	if (c.desc.kind != kConv || w.desc.kind != kFrac || !w.whole) return false;
+	if (c.desc.kind != kConv || w.desc.kind != kFrac || !w.whole || c.cg.down != 1) return false;
 	if (!convx_geometry_ok(c.cg.n_in, c.cg.n_out, c.cg.up, c.cg.down, c.cg.up_pow2)) return false;
 	return w.out_step <= 256 && w.flen <= 32 && c.cg.in_len >= 4 * w.flen;
 }
@@ -698,6 +816,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	L.vec_ok = (src.cur == nullptr || (((size_t) src.cur & 15) == 0 && (src.cur_stride & 1) == 0 &&
 		(src.cur_base & 1) == 0)) && (src.ring_stride & 1) == 0 && ((g.in_len / g.up) & 1) == 0 &&
 		((g.in_len / g.up) & 1) == 0 ? 1 : 0;
+	L.inplace = generic_conv_two_arrays(g) ? 0 : 1;
 	L.up_pow2 = g.up_pow2 ? 1 : 0;
 	L.down_pow2 = g.down_pow2 ? 1 : 0;
 	L.n_fwd = (int) d.fwd_radix.size();

@@ -59,7 +59,7 @@ __global__ void k_conv(const ConvLaunch L)
 	extern __shared__ __align__(16) unsigned char smem[];
 	double* const ra = reinterpret_cast<double*>(smem);
 	cd* const za = reinterpret_cast<cd*>(smem);
-	double* const rb = ra + L.n_in;
+	double* const rb = ra + (L.inplace ? 0 : L.n_in);
 	cd* const zb = reinterpret_cast<cd*>(rb);
 	const int tid = threadIdx.x, nthr = blockDim.x;
 	const long long k = L.k0 + blockIdx.x;
@@ -303,7 +303,10 @@ template<int LOGN, int UPLOG, int MODE, int FLENP>
 #ifndef R8B_CONVX_MINWAVES
 #define R8B_CONVX_MINWAVES 3
 #endif
-__global__ __launch_bounds__(kConvxThreads, R8B_CONVX_MINWAVES) void k_convx(const ConvxLaunch X)
+// (the 8192 / 4096-point arrays leave room for one / two workgroups per CU anyway: no point in
+// capping the registers below that)
+__global__ __launch_bounds__(kConvxThreads, (LOGN + (UPLOG > 0 ? UPLOG : 0) >= 13 ? 1 :
+	(LOGN + (UPLOG > 0 ? UPLOG : 0) == 12 ? 2 : R8B_CONVX_MINWAVES))) void k_convx(const ConvxLaunch X)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	// XCD-aware work mapping: the dispatcher hands consecutive workgroup ids to the 8 XCDs round
@@ -336,8 +339,8 @@ void launch_convx_t(const ConvxLaunch& X, hipStream_t stream)
 {
 	static bool attr_done = false;
 	auto kern = k_convx<LOGN, UPLOG, MODE, FLENP>;
-	// work array; the linear output run (in_len + 8 doubles) aliases its start
-	const size_t lds = (size_t) convx_lds_need(LOGN + UPLOG, X.c.in_len, MODE) * sizeof(double);
+	// work array; the linear output run (in_len + kConvxRunPad doubles) aliases its start
+	const size_t lds = (size_t) convx_lds_need(UPLOG > 0 ? LOGN + UPLOG : LOGN, X.c.in_len, MODE) * sizeof(double);
 	if (!attr_done)
 	{
 		check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -367,7 +370,7 @@ void set_lds_attrs()
 void launch_conv(const ConvLaunch& L, void* stream)
 {
 	set_lds_attrs();
-	const size_t lds = (size_t) (L.n_in + L.n_out) * sizeof(double);
+	const size_t lds = (size_t) (L.inplace ? L.n_in : L.n_in + L.n_out) * sizeof(double);
 	hipLaunchKernelGGL(k_conv, dim3((unsigned) L.nblk, (unsigned) L.nch), dim3((unsigned) L.threads),
 		lds, (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_conv");
@@ -425,6 +428,17 @@ void launch_convx(const ConvxLaunch& X, int mode, void* stream)
 	while ((2 << logn) < X.c.n_in) logn++;
 	const int up = X.c.up;
 	const bool wide = X.flen > 24;
+#define R8B_CONVX_DISPATCH_DOWN(LN, DL) \
+	if (logn == LN && X.c.down == (1 << DL)) \
+	{ \
+		launch_convx_t<LN, -DL, 0, 24>(X, (hipStream_t) stream); \
+		return; \
+	}
+	if (X.c.down > 1)
+	{
+		R8B_CONVX_GEOMS_DOWN(R8B_CONVX_DISPATCH_DOWN)
+	}
+#undef R8B_CONVX_DISPATCH_DOWN
 #define R8B_CONVX_DISPATCH(LN, UL) \
 	if (logn == LN && up == (1 << UL)) \
 	{ \

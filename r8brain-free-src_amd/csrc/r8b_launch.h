@@ -47,6 +47,7 @@ struct ConvLaunch
 	int blk_offset; // virtual position of block 0's first fresh sample (0 except fused MFMA mode)
 	// fast path: the source admits aligned 16-byte loads of sample pairs (even positions)
 	int vec_ok;
+	int inplace; // generic kernel: backward transform in the forward array (n_in == n_out only)
 	// fast path at stage 0: the workgroups of the first block also copy stream positions
 	// [tail_p0, tail_p1) into the history ring the NEXT call reads (null: nothing to copy)
 	double* tail_ring;
@@ -171,15 +172,26 @@ struct ConvxLaunch
 	int mf_boff[16];
 };
 
-// geometries the fast path is instantiated for: (log2 of the forward complex length, up shift)
-#define R8B_CONVX_GEOMS(M) M(8, 1) M(9, 0) M(9, 1) M(10, 0) M(10, 1) M(11, 0) M(11, 1) M(12, 0)
+// geometries the fast path is instantiated for: (log2 of the forward complex length, up shift), and
+// for the 2x-decimating convolver (log2 of the forward complex length, down shift)
+#define R8B_CONVX_GEOMS(M) M(8, 1) M(9, 0) M(9, 1) M(10, 0) M(10, 1) M(11, 0) M(11, 1) M(12, 0) \
+	M(12, 1) M(13, 0)
+#define R8B_CONVX_GEOMS_DOWN(M) M(8, 1) M(9, 1) M(10, 1) M(11, 1) M(12, 1) M(13, 1)
 
 inline bool convx_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
 {
-	if (!up_pow2 || down != 1 || (up != 1 && up != 2) || n_out != n_in * up) return false;
+	if (!up_pow2 || (down != 1 && down != 2) || (up != 1 && up != 2)) return false;
+	if (down == 2 ? (up != 1 || n_out * 2 != n_in) : n_out != n_in * up) return false;
 	int logn = 0;
 	while ((2 << logn) < n_in) logn++;
 	if ((2 << logn) != n_in) return false;
+	if (down == 2)
+	{
+#define R8B_CONVX_CHECK(LN, DL) if (logn == LN && down == (1 << DL)) return true;
+		R8B_CONVX_GEOMS_DOWN(R8B_CONVX_CHECK)
+#undef R8B_CONVX_CHECK
+		return false;
+	}
 #define R8B_CONVX_CHECK(LN, UL) if (logn == LN && up == (1 << UL)) return true;
 	R8B_CONVX_GEOMS(R8B_CONVX_CHECK)
 #undef R8B_CONVX_CHECK

@@ -32,6 +32,16 @@ STREAM_CASES = [
     (44100.0, 96000.0, 70000, 70000, 140000, 2.0, 180.15),      # > 24 FFT blocks per call (split launches)
     (44100.0, 529200.0, 512, 300, 3000, 2.0, 180.15),           # 3x convolver + two third-band half-bands
     (44100.0, 705600.0, 256, 256, 1024, 2.0, 136.45),           # 2x + three half-bands, 16-bit preset
+    # narrowest transition band at 24-bit attenuation: 16384-point blocks, in-place kernels only
+    (44100.0, 96000.0, 2048, 2048, 36000, 0.5, 180.15),         # 8192 -> 16384-point transforms, fused
+    (44100.0, 88200.0, 2048, 1500, 36000, 0.5, 180.15),         # same, convolver only
+    (192000.0, 44100.0, 4096, 4096, 72000, 0.5, 180.15),        # 16384 -> 16384, fused
+    (176400.0, 44100.0, 4096, 3000, 72000, 0.5, 180.15),        # 16384 -> 8192 (2x decimating)
+    (192000.0, 44100.0, 4096, 4096, 40000, 1.0, 180.15),        # 8192 -> 8192
+    (88200.0, 44100.0, 1024, 700, 12000, 2.0, 180.15),          # 2x decimating convolver alone
+    (20.0, 21.0, 300, 300, 6000, 1.0, 49.0),                    # 8-tap interpolator rows (zero padding)
+    (32000.0, 96000.0, 2048, 2048, 30000, 1.0, 180.15),         # 3x zero stuffing, 16384-point, in place
+    (96000.0, 32000.0, 4096, 4096, 60000, 1.0, 180.15),         # strided 3x decimation, 16384-point
 ]
 
 

@@ -34,7 +34,7 @@ void launch_conv(const ConvLaunch& L, void*)
 		{
 			double* ra = base;
 			cd* za = reinterpret_cast<cd*>(ra);
-			double* rb = ra + L.n_in;
+			double* rb = ra + (L.inplace ? 0 : L.n_in);
 			cd* zb = reinterpret_cast<cd*>(rb);
 			const long long k = L.k0 + bx;
 			for (int t = 0; t < nthr; t++) conv_load(L, ra, k, ch, t, nthr);
@@ -212,7 +212,7 @@ struct EmulExec
 template<int LOGN, int UPLOG, int MODE, int FLENP>
 void emul_convx_t(const ConvxLaunch& X)
 {
-	std::vector<double> lds((size_t) convx_lds_need(LOGN + UPLOG, X.c.in_len, MODE) + 2);
+	std::vector<double> lds((size_t) convx_lds_need(UPLOG > 0 ? LOGN + UPLOG : LOGN, X.c.in_len, MODE) + 2);
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
 	for (int ch = 0; ch < X.c.nch; ch++)
@@ -231,6 +231,17 @@ void launch_convx(const ConvxLaunch& X, int mode, void*)
 	while ((2 << logn) < X.c.n_in) logn++;
 	const int up = X.c.up;
 	const bool wide = X.flen > 24;
+#define R8B_CONVX_DISPATCH_DOWN(LN, DL) \
+	if (logn == LN && X.c.down == (1 << DL)) \
+	{ \
+		emul_convx_t<LN, -DL, 0, 24>(X); \
+		return; \
+	}
+	if (X.c.down > 1)
+	{
+		R8B_CONVX_GEOMS_DOWN(R8B_CONVX_DISPATCH_DOWN)
+	}
+#undef R8B_CONVX_DISPATCH_DOWN
 #define R8B_CONVX_DISPATCH(LN, UL) \
 	if (logn == LN && up == (1 << UL)) \
 	{ \

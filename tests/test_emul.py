@@ -90,3 +90,10 @@ def test_emulated_matrix_core_interpolator(emul, case):
     b.set_option("mfma_interp", 1)
     rms, pk = compare_stream(b, src, dst, maxin, chunk, n, tb, att, 2)
     assert rms <= RMS_TOL and pk <= PEAK_TOL, (rms, pk)
+
+
+def test_unsupported_geometry_fails_loudly(emul):
+    """A radix-3 convolver whose 32768-point block does not fit LDS: creation must fail with a
+    message, not fall back to anything."""
+    with pytest.raises(RuntimeError, match="too long"):
+        r8b.BatchResampler(32000.0, 96000.0, 1024, 0.5, 218.0, nch=1, lib=emul)
