@@ -101,6 +101,29 @@ R8BSRC_DECL int r8b_batch_process(CR8BBatch b, const double* d_in, long long in_
 R8BSRC_DECL int r8b_batch_process_host(CR8BBatch b, const double* in, long long in_stride, int l,
 	double* out, long long out_stride);
 
+/* PCM boundary next to the hot path (the reference's command-line tool does
+ * this on the host through CWaveFile, call sites bench/r8bfreesrc.cpp:103,134): one process()
+ * step whose input and output are DEVICE buffers of PCM samples, converted by ingest / egress
+ * kernels on `stream`, so that 2-4 bytes per sample cross PCIe and the HBM edge instead of 8.
+ *   interleaved != 0: frame-major, sample (frame f, channel c) is element f*stride + c
+ *                     (stride >= channel count; the usual WAV layout has stride == channels)
+ *   interleaved == 0: planar, element c*stride + f
+ * Strides are in samples.  Integer formats decode as value / 2^(bits-1) and encode as
+ * round-to-nearest-even of v * 2^(bits-1), saturated, without dither; R8B_PCM_S24 is packed
+ * 3-byte little-endian.  Returns the output frames produced, or -1 on error. */
+enum r8b_pcm_format
+{
+	R8B_PCM_F64 = 0,
+	R8B_PCM_F32 = 1,
+	R8B_PCM_S16 = 2,
+	R8B_PCM_S24 = 3,
+	R8B_PCM_S32 = 4
+};
+R8BSRC_DECL int r8b_batch_process_pcm(CR8BBatch b, const void* d_in, int in_format,
+	int in_interleaved, long long in_stride, int l, void* d_out, int out_format,
+	int out_interleaved, long long out_stride, void* stream);
+R8BSRC_DECL int r8b_pcm_sample_bytes(int format);
+
 /* Single DSP stage as a batch object (the reference's CDSPProcessor boundary,
  * CDSPProcessor.h:64-127), used by the stage-level parity tests:
  *   kind 0: CDSPBlockConvolver(getLPFilter(a=ReqNormFreq, b=ReqTransBand, c=ReqAtten, linear,

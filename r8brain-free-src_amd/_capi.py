@@ -32,6 +32,10 @@ PROTOTYPES = [
                                     C.c_longlong, C.c_void_p]),
     ("r8b_batch_process_host", C.c_int, [C.c_void_p, dp, C.c_longlong, C.c_int, dp,
                                          C.c_longlong]),
+    ("r8b_batch_process_pcm", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_longlong,
+                                        C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong,
+                                        C.c_void_p]),
+    ("r8b_pcm_sample_bytes", C.c_int, [C.c_int]),
     ("r8b_batch_create_stage", C.c_void_p, [C.c_int, C.c_double, C.c_double, C.c_double,
                                             C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int]),

@@ -98,6 +98,43 @@ int batch_process_host(Batch* h, const double* in, long long in_stride, int l, d
 	return n;
 }
 
+// PCM boundary: ingest kernel -> staging rows -> the resampler -> staging rows -> egress kernel, all
+// on `stream`, nothing synchronises
+int batch_process_pcm(Batch* h, const void* d_in, int in_fmt, int in_interleaved,
+	long long in_stride, int l, void* d_out, int out_fmt, int out_interleaved, long long out_stride,
+	void* stream)
+{
+	h->need_staging();
+	Engine& e = *h->eng;
+	if (l < 0 || l > h->in_cap) throw std::runtime_error("input length exceeds MaxInLen");
+	auto valid = [](int f) { return f >= kPcmF64 && f <= kPcmS32; };
+	if (!valid(in_fmt) || !valid(out_fmt)) throw std::runtime_error("unknown PCM sample format");
+	if (l == 0) return 0;
+	PcmLaunch P;
+	P.pcm = const_cast<void*>(d_in);
+	P.fmt = in_fmt;
+	P.interleaved = in_interleaved ? 1 : 0;
+	P.pcm_stride = in_stride;
+	P.planar = h->d_in;
+	P.planar_stride = h->in_cap;
+	P.nch = e.channels();
+	P.n = l;
+	launch_pcm_in(P, stream);
+	const int n = e.process(h->d_in, h->in_cap, l, h->d_out, h->out_cap, stream);
+	if (n > 0)
+	{
+		P.pcm = d_out;
+		P.fmt = out_fmt;
+		P.interleaved = out_interleaved ? 1 : 0;
+		P.pcm_stride = out_stride;
+		P.planar = h->d_out;
+		P.planar_stride = h->out_cap;
+		P.n = n;
+		launch_pcm_out(P, stream);
+	}
+	return n;
+}
+
 } // namespace
 
 extern "C" {
@@ -192,6 +229,35 @@ R8BSRC_DECL int r8b_batch_process_host(CR8BBatch b, const double* in, long long 
 		set_err("r8b_batch_process_host", e);
 		return -1;
 	}
+}
+
+R8BSRC_DECL int r8b_batch_process_pcm(CR8BBatch b, const void* d_in, int in_format,
+	int in_interleaved, long long in_stride, int l, void* d_out, int out_format,
+	int out_interleaved, long long out_stride, void* stream)
+{
+	try
+	{
+		return batch_process_pcm((Batch*) b, d_in, in_format, in_interleaved, in_stride, l, d_out,
+			out_format, out_interleaved, out_stride, stream);
+	}
+	catch (const std::exception& e)
+	{
+		set_err("r8b_batch_process_pcm", e);
+		return -1;
+	}
+}
+
+R8BSRC_DECL int r8b_pcm_sample_bytes(int format)
+{
+	switch (format)
+	{
+	case kPcmF64: return 8;
+	case kPcmF32: return 4;
+	case kPcmS16: return 2;
+	case kPcmS24: return 3;
+	case kPcmS32: return 4;
+	}
+	return 0;
 }
 
 R8BSRC_DECL int r8b_batch_describe(CR8BBatch b, char* buf, int cap)

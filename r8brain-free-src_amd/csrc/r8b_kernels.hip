@@ -40,6 +40,7 @@
 	}
 #include "r8b_kernel_phases.h"
 #include "r8b_convx.h"
+#include "r8b_pcm.h"
 
 namespace r8bhip {
 
@@ -208,6 +209,37 @@ __global__ void k_tail(const TailLaunch L)
 	const int ch = blockIdx.y;
 	if (i < L.p1)
 		L.ring[(long long) ch * L.ring_stride + (i & L.ring_mask)] = src_load(L.src, ch, i);
+}
+
+// ------------------------------------------------------------------ PCM ingest / egress (r8b_pcm.h)
+__global__ __launch_bounds__(256) void k_pcm_in(const PcmLaunch L)
+{
+	__shared__ double tile[kPcmTile * kPcmPitch];
+	const long long f0 = (long long) blockIdx.x * kPcmTile;
+	const int c0 = (int) blockIdx.y * kPcmTile;
+	if (!L.interleaved)
+	{
+		pcm_in_direct(L, f0, c0, threadIdx.x, 256);
+		return;
+	}
+	pcm_in_gather(L, tile, f0, c0, threadIdx.x, 256);
+	__syncthreads();
+	pcm_in_scatter(L, tile, f0, c0, threadIdx.x, 256);
+}
+
+__global__ __launch_bounds__(256) void k_pcm_out(const PcmLaunch L)
+{
+	__shared__ double tile[kPcmTile * kPcmPitch];
+	const long long f0 = (long long) blockIdx.x * kPcmTile;
+	const int c0 = (int) blockIdx.y * kPcmTile;
+	if (!L.interleaved)
+	{
+		pcm_out_direct(L, f0, c0, threadIdx.x, 256);
+		return;
+	}
+	pcm_out_gather(L, tile, f0, c0, threadIdx.x, 256);
+	__syncthreads();
+	pcm_out_scatter(L, tile, f0, c0, threadIdx.x, 256);
 }
 
 // ------------------------------------------------------------------ fast path (r8b_convx.h)
@@ -472,6 +504,19 @@ void launch_tail(const TailLaunch& L, void* stream)
 		(hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_tail");
 }
+
+static void launch_pcm(const PcmLaunch& L, bool in, void* stream)
+{
+	if (L.n <= 0 || L.nch <= 0) return;
+	const dim3 grid((unsigned) ((L.n + kPcmTile - 1) / kPcmTile),
+		(unsigned) ((L.nch + kPcmTile - 1) / kPcmTile));
+	if (in) hipLaunchKernelGGL(k_pcm_in, grid, dim3(256), 0, (hipStream_t) stream, L);
+	else hipLaunchKernelGGL(k_pcm_out, grid, dim3(256), 0, (hipStream_t) stream, L);
+	check(hipGetLastError(), in ? "launch k_pcm_in" : "launch k_pcm_out");
+}
+
+void launch_pcm_in(const PcmLaunch& L, void* stream) { launch_pcm(L, true, stream); }
+void launch_pcm_out(const PcmLaunch& L, void* stream) { launch_pcm(L, false, stream); }
 
 // ------------------------------------------------------------------ memory helpers
 

@@ -139,6 +139,23 @@ struct TailLaunch
 	int nch;
 };
 
+// PCM sample formats of the ingest/egress kernels (r8b_pcm.h); values are part of the C ABI
+// (include/r8bsrc.h, enum r8b_pcm_format)
+enum PcmFormat { kPcmF64 = 0, kPcmF32 = 1, kPcmS16 = 2, kPcmS24 = 3, kPcmS32 = 4 };
+
+struct PcmLaunch
+{
+	void* pcm;              // PCM buffer (read by the ingest kernel, written by the egress kernel)
+	int fmt;                // PcmFormat
+	int interleaved;        // 1: frame-major, sample (f, c) at element f * pcm_stride + c
+	                        // 0: planar, at element c * pcm_stride + f
+	long long pcm_stride;   // in samples
+	double* planar;         // the resampler's rows: (c, f) at planar[c * planar_stride + f]
+	long long planar_stride;
+	int nch;
+	long long n;            // frames
+};
+
 // fast path (r8b_convx.h): power-of-two block convolver, optionally fused with the whole-step
 // interpolator that follows it
 // Interpolator outputs one block owns, precomputed by the host so that the kernel needs no 64-bit
@@ -206,6 +223,8 @@ void launch_hbup(const HBLaunch& L, void* stream);
 void launch_hbdown(const HBLaunch& L, void* stream);
 void launch_hbcascade(const HBCascadeLaunch& L, void* stream);
 void launch_tail(const TailLaunch& L, void* stream);
+void launch_pcm_in(const PcmLaunch& L, void* stream);  // PCM -> planar fp64
+void launch_pcm_out(const PcmLaunch& L, void* stream); // planar fp64 -> PCM
 // mode 0: convolver output to X.c.dst; mode 1 / 2: fused interpolator output to X.wdst (FIR on
 // the vector ALU / on the matrix cores)
 void launch_convx(const ConvxLaunch& X, int mode, void* stream);

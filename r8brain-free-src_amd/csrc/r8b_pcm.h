@@ -1,0 +1,167 @@
+// r8b_pcm.h -- PCM ingest/egress next to the hot path: interleaved or planar
+// int16 / packed int24 / int32 / float32 / float64 samples <-> the planar fp64 rows the resampler
+// works on, so that 2-4 bytes per sample cross PCIe and the HBM edge instead of 8.
+//
+// The reference has no such code in-tree: its command-line tool converts through CWaveFile (the
+// external "libvox", absent from the repository; call sites bench/r8bfreesrc.cpp:103,134), and
+// oneshot<Tin,Tout> (CDSPResampler.h:592-651) only casts.  The conventions here are the usual PCM
+// ones and are part of this library's interface (include/r8bsrc.h):
+//   decode: integer / 2^(bits-1); float32 widened exactly
+//   encode: v * 2^(bits-1), round to nearest even, saturate to [-2^(bits-1), 2^(bits-1)-1]
+//           (no dither); float32 by round-to-nearest conversion; NaN encodes as 0 in the integer
+//           formats
+// Phases are shared with the host emulation of tests/emul like every other kernel.
+#ifndef R8B_PCM_H
+#define R8B_PCM_H
+
+#include <math.h>
+
+#include "r8b_kernel_phases.h"
+
+namespace r8bhip {
+
+R8B_HD int pcm_bytes(int fmt)
+{
+	switch (fmt)
+	{
+	case kPcmF64: return 8;
+	case kPcmF32: return 4;
+	case kPcmS16: return 2;
+	case kPcmS24: return 3;
+	case kPcmS32: return 4;
+	}
+	return 0;
+}
+
+R8B_HD double pcm_decode(const unsigned char* p, int fmt)
+{
+	switch (fmt)
+	{
+	case kPcmF64: return *reinterpret_cast<const double*>(p);
+	case kPcmF32: return (double) *reinterpret_cast<const float*>(p);
+	case kPcmS16: return (double) *reinterpret_cast<const short*>(p) * (1.0 / 32768.0);
+	case kPcmS24:
+	{
+		// packed little-endian, no alignment: three byte loads
+		int v = (int) p[0] | ((int) p[1] << 8) | ((int) (signed char) p[2] << 16);
+		return (double) v * (1.0 / 8388608.0);
+	}
+	case kPcmS32: return (double) *reinterpret_cast<const int*>(p) * (1.0 / 2147483648.0);
+	}
+	return 0.0;
+}
+
+R8B_HD double pcm_quantize(double v, double scale)
+{
+	double q = rint(v * scale); // round half to even in both the HIP and the host build
+	if (!(q >= -scale)) q = q != q ? 0.0 : -scale;
+	if (q > scale - 1.0) q = scale - 1.0;
+	return q;
+}
+
+R8B_HD void pcm_encode(unsigned char* p, int fmt, double v)
+{
+	switch (fmt)
+	{
+	case kPcmF64: *reinterpret_cast<double*>(p) = v; break;
+	case kPcmF32: *reinterpret_cast<float*>(p) = (float) v; break;
+	case kPcmS16: *reinterpret_cast<short*>(p) = (short) (int) pcm_quantize(v, 32768.0); break;
+	case kPcmS24:
+	{
+		const int q = (int) pcm_quantize(v, 8388608.0);
+		p[0] = (unsigned char) (q & 255);
+		p[1] = (unsigned char) ((q >> 8) & 255);
+		p[2] = (unsigned char) ((q >> 16) & 255);
+		break;
+	}
+	case kPcmS32: *reinterpret_cast<int*>(p) = (int) (long long) pcm_quantize(v, 2147483648.0); break;
+	}
+}
+
+// byte offset of (frame f, channel c) in the PCM buffer
+R8B_HD long long pcm_offset(const PcmLaunch& L, long long f, int c)
+{
+	const long long e = L.interleaved ? f * L.pcm_stride + c : (long long) c * L.pcm_stride + f;
+	return e * pcm_bytes(L.fmt);
+}
+
+// A workgroup converts a tile of kPcmTile frames x kPcmTile channels.  Interleaved buffers are
+// frame-major, the planar rows channel-major: the tile goes through LDS (pitch kPcmTile + 1) so
+// that both sides are accessed with the fastest index on consecutive lanes.
+static const int kPcmTile = 64;
+static const int kPcmPitch = kPcmTile + 1;
+
+// PCM -> tile (interleaved) : lanes walk channels
+R8B_HD void pcm_in_gather(const PcmLaunch& L, double* tile, long long f0, int c0, int tid, int nthr)
+{
+	const unsigned char* src = static_cast<const unsigned char*>(L.pcm);
+	for (int e = tid; e < kPcmTile * kPcmTile; e += nthr)
+	{
+		const int c = e & (kPcmTile - 1), f = e >> 6;
+		if (f0 + f < L.n && c0 + c < L.nch)
+			tile[c * kPcmPitch + f] = pcm_decode(src + pcm_offset(L, f0 + f, c0 + c), L.fmt);
+	}
+}
+
+// tile -> planar rows : lanes walk frames
+R8B_HD void pcm_in_scatter(const PcmLaunch& L, const double* tile, long long f0, int c0, int tid,
+	int nthr)
+{
+	for (int e = tid; e < kPcmTile * kPcmTile; e += nthr)
+	{
+		const int f = e & (kPcmTile - 1), c = e >> 6;
+		if (f0 + f < L.n && c0 + c < L.nch)
+			L.planar[(long long) (c0 + c) * L.planar_stride + f0 + f] = tile[c * kPcmPitch + f];
+	}
+}
+
+// planar PCM -> planar rows, no transposition
+R8B_HD void pcm_in_direct(const PcmLaunch& L, long long f0, int c0, int tid, int nthr)
+{
+	const unsigned char* src = static_cast<const unsigned char*>(L.pcm);
+	for (int e = tid; e < kPcmTile * kPcmTile; e += nthr)
+	{
+		const int f = e & (kPcmTile - 1), c = e >> 6;
+		if (f0 + f < L.n && c0 + c < L.nch)
+			L.planar[(long long) (c0 + c) * L.planar_stride + f0 + f] =
+				pcm_decode(src + pcm_offset(L, f0 + f, c0 + c), L.fmt);
+	}
+}
+
+R8B_HD void pcm_out_gather(const PcmLaunch& L, double* tile, long long f0, int c0, int tid, int nthr)
+{
+	for (int e = tid; e < kPcmTile * kPcmTile; e += nthr)
+	{
+		const int f = e & (kPcmTile - 1), c = e >> 6;
+		if (f0 + f < L.n && c0 + c < L.nch)
+			tile[c * kPcmPitch + f] = L.planar[(long long) (c0 + c) * L.planar_stride + f0 + f];
+	}
+}
+
+R8B_HD void pcm_out_scatter(const PcmLaunch& L, const double* tile, long long f0, int c0, int tid,
+	int nthr)
+{
+	unsigned char* dst = static_cast<unsigned char*>(L.pcm);
+	for (int e = tid; e < kPcmTile * kPcmTile; e += nthr)
+	{
+		const int c = e & (kPcmTile - 1), f = e >> 6;
+		if (f0 + f < L.n && c0 + c < L.nch)
+			pcm_encode(dst + pcm_offset(L, f0 + f, c0 + c), L.fmt, tile[c * kPcmPitch + f]);
+	}
+}
+
+R8B_HD void pcm_out_direct(const PcmLaunch& L, long long f0, int c0, int tid, int nthr)
+{
+	unsigned char* dst = static_cast<unsigned char*>(L.pcm);
+	for (int e = tid; e < kPcmTile * kPcmTile; e += nthr)
+	{
+		const int f = e & (kPcmTile - 1), c = e >> 6;
+		if (f0 + f < L.n && c0 + c < L.nch)
+			pcm_encode(dst + pcm_offset(L, f0 + f, c0 + c), L.fmt,
+				L.planar[(long long) (c0 + c) * L.planar_stride + f0 + f]);
+	}
+}
+
+} // namespace r8bhip
+
+#endif

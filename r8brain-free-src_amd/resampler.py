@@ -18,6 +18,10 @@ from . import _capi
 fprLinearPhase = 0
 
 
+# r8b_pcm_format (include/r8bsrc.h)
+PCM_F64, PCM_F32, PCM_S16, PCM_S24, PCM_S32 = 0, 1, 2, 3, 4
+
+
 def _dptr(a):
     return a.ctypes.data_as(_capi.dp)
 
@@ -114,6 +118,43 @@ class BatchResampler(_Base):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         n = self.process_ptr(x.data_ptr(), x.stride(0), l, out.data_ptr(), out.stride(0), stream)
         return out[:, :n]
+
+    def process_pcm_ptr(self, d_in, in_format, in_interleaved, in_stride, l, d_out, out_format,
+                        out_interleaved, out_stride, stream=0):
+        """Raw device-pointer PCM entry (r8b_batch_process_pcm); strides in samples."""
+        n = self._lib.r8b_batch_process_pcm(self._h, C.c_void_p(d_in), int(in_format),
+                                            int(bool(in_interleaved)), in_stride, int(l),
+                                            C.c_void_p(d_out), int(out_format),
+                                            int(bool(out_interleaved)), out_stride,
+                                            C.c_void_p(stream))
+        if n < 0:
+            raise RuntimeError(self._err())
+        return n
+
+    def process_pcm(self, x, out_format=None, out=None):
+        """Interleaved PCM in, interleaved PCM out, both CUDA tensors.  x: [frames, nch] of
+        int16 / int32 / float32 / float64, or uint8 [frames, nch, 3] for packed 24-bit.  Returns
+        a view [n, nch(, 3)] of `out` (allocated [max_out_len, nch(, 3)] if not given) in
+        `out_format` (default: the input's).  Enqueues on torch's current stream."""
+        import torch
+        fmt_of = {torch.float64: PCM_F64, torch.float32: PCM_F32, torch.int16: PCM_S16,
+                  torch.int32: PCM_S32, torch.uint8: PCM_S24}
+        dtype_of = {v: k for k, v in fmt_of.items()}
+        assert x.is_cuda and x.is_contiguous() and x.shape[1] == self.nch
+        in_format = fmt_of[x.dtype]
+        assert (x.dim() == 3 and x.shape[2] == 3) if in_format == PCM_S24 else x.dim() == 2
+        if out_format is None:
+            out_format = in_format
+        tail = (3,) if out_format == PCM_S24 else ()
+        if out is None:
+            out = torch.empty((max(self.max_out_len, 1), self.nch) + tail,
+                              dtype=dtype_of[out_format], device=x.device)
+        assert out.is_cuda and out.is_contiguous() and out.dtype == dtype_of[out_format]
+        assert out.shape[0] >= self.max_out_len and tuple(out.shape[1:]) == (self.nch,) + tail
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        n = self.process_pcm_ptr(x.data_ptr(), in_format, True, self.nch, x.shape[0],
+                                 out.data_ptr(), out_format, True, self.nch, stream)
+        return out[:n]
 
     def process_host(self, x):
         """x: float64 numpy [nch, l]; synchronous; returns numpy [nch, n]."""

@@ -19,6 +19,7 @@
 #define R8B_LDS_WINDOW(N, v, p) { for (int i_ = 0; i_ < (N); i_++) (v)[i_] = (p)[i_]; }
 #include "r8b_kernel_phases.h"
 #include "r8b_convx.h"
+#include "r8b_pcm.h"
 
 namespace r8bhip {
 
@@ -296,6 +297,39 @@ void launch_tail(const TailLaunch& L, void*)
 		for (long long i = L.p0; i < L.p1; i++)
 			L.ring[(long long) ch * L.ring_stride + (i & L.ring_mask)] = src_load(L.src, ch, i);
 }
+
+static void emul_pcm(const PcmLaunch& L, bool in)
+{
+	std::vector<double> tile((size_t) kPcmTile * kPcmPitch);
+	const int nthr = 256;
+	for (int c0 = 0; c0 < L.nch; c0 += kPcmTile)
+		for (long long f0 = 0; f0 < L.n; f0 += kPcmTile)
+		{
+			for (double& v : tile) v = std::numeric_limits<double>::quiet_NaN();
+			if (!L.interleaved)
+			{
+				for (int t = 0; t < nthr; t++)
+				{
+					if (in) pcm_in_direct(L, f0, c0, t, nthr);
+					else pcm_out_direct(L, f0, c0, t, nthr);
+				}
+				continue;
+			}
+			for (int t = 0; t < nthr; t++)
+			{
+				if (in) pcm_in_gather(L, tile.data(), f0, c0, t, nthr);
+				else pcm_out_gather(L, tile.data(), f0, c0, t, nthr);
+			}
+			for (int t = 0; t < nthr; t++)
+			{
+				if (in) pcm_in_scatter(L, tile.data(), f0, c0, t, nthr);
+				else pcm_out_scatter(L, tile.data(), f0, c0, t, nthr);
+			}
+		}
+}
+
+void launch_pcm_in(const PcmLaunch& L, void*) { emul_pcm(L, true); }
+void launch_pcm_out(const PcmLaunch& L, void*) { emul_pcm(L, false); }
 
 void dev_select(int) {}
 

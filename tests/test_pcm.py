@@ -1,0 +1,170 @@
+"""PCM ingest/egress kernels next to the hot path (r8b_pcm.h): interleaved or
+planar int16 / packed int24 / int32 / float32 / float64 buffers in and out of r8b_batch_process_pcm.
+
+Checked against numpy restatements of the documented conventions (decode = value / 2^(bits-1);
+encode = round-half-even of v * 2^(bits-1), saturated) applied around the fp64 path itself:
+bit-exact for the integer formats.  CPU tier: host emulation (its "device memory" is host memory,
+so numpy buffers are passed as device pointers); GPU tier: torch tensors."""
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import r8b_oracle as O
+from conftest import ROOT
+
+r8b = importlib.import_module("r8brain-free-src_amd")
+
+BITS = {r8b.PCM_S16: 16, r8b.PCM_S24: 24, r8b.PCM_S32: 32}
+
+
+def np_decode(raw, fmt):
+    """raw: integer/float array of sample values (int24 already as int32 values)."""
+    if fmt in BITS:
+        return raw.astype(np.float64) / float(1 << (BITS[fmt] - 1))
+    return raw.astype(np.float64)
+
+
+def np_encode(v, fmt):
+    if fmt in BITS:
+        s = float(1 << (BITS[fmt] - 1))
+        q = np.rint(v * s)  # half to even
+        q = np.where(np.isnan(q), 0.0, q)
+        return np.clip(q, -s, s - 1.0).astype(np.int64)
+    if fmt == r8b.PCM_F32:
+        return v.astype(np.float32)
+    return v
+
+
+def pack24(vals):
+    """int values [..] -> uint8 [.., 3], little-endian two's complement."""
+    u = (vals.astype(np.int64) & 0xFFFFFF).astype(np.uint32)
+    return np.stack([(u & 255), (u >> 8) & 255, (u >> 16) & 255], axis=-1).astype(np.uint8)
+
+
+def unpack24(b):
+    u = b[..., 0].astype(np.int64) | (b[..., 1].astype(np.int64) << 8) | (b[..., 2].astype(np.int64) << 16)
+    return np.where(u >= 1 << 23, u - (1 << 24), u)
+
+
+NP_DTYPE = {r8b.PCM_F64: np.float64, r8b.PCM_F32: np.float32, r8b.PCM_S16: np.int16,
+            r8b.PCM_S32: np.int32}
+
+
+def make_pcm(fmt, frames, nch, seed):
+    """Random full-range samples as (storage array [frames, nch(,3)], sample values)."""
+    u = np.stack([O.splitmix_uniform(seed + c, frames) for c in range(nch)], axis=1)
+    if fmt in BITS:
+        vals = np_encode(u, fmt)
+        store = pack24(vals) if fmt == r8b.PCM_S24 else vals.astype(NP_DTYPE[fmt])
+        return np.ascontiguousarray(store), vals
+    store = u.astype(NP_DTYPE[fmt])
+    return np.ascontiguousarray(store), store
+
+
+def values_of(store, fmt):
+    return unpack24(store) if fmt == r8b.PCM_S24 else store
+
+
+@pytest.fixture(scope="module")
+def emul():
+    d = os.path.join(ROOT, "tests", "emul")
+    subprocess.run(["make"], cwd=d, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return r8b.bind(os.path.join(d, "_build", "libr8bsrc_emul.so"))
+
+
+CASES = [(r8b.PCM_S16, r8b.PCM_S16, 2), (r8b.PCM_S24, r8b.PCM_S24, 3), (r8b.PCM_S32, r8b.PCM_F32, 70),
+         (r8b.PCM_F32, r8b.PCM_S24, 5), (r8b.PCM_S16, r8b.PCM_F64, 65), (r8b.PCM_F64, r8b.PCM_S32, 1)]
+
+
+def run_emul(lib, fin, fout, nch, interleaved, src=44100.0, dst=48000.0):
+    frames, chunk = 3000, 1000
+    store, vals = make_pcm(fin, frames, nch, 11)
+    x = np_decode(vals, fin)  # [frames, nch]
+    a = r8b.BatchResampler(src, dst, chunk, 2.0, 136.45, nch=nch, lib=lib)
+    b = r8b.BatchResampler(src, dst, chunk, 2.0, 136.45, nch=nch, lib=lib)
+    cap = a.max_out_len
+    tail = (3,) if fout == r8b.PCM_S24 else ()
+    odt = np.uint8 if fout == r8b.PCM_S24 else NP_DTYPE[fout]
+    for i in range(0, frames, chunk):
+        want = b.process_host(np.ascontiguousarray(x[i:i + chunk].T))  # [nch, n]
+        if interleaved:
+            inp = np.ascontiguousarray(store[i:i + chunk])
+            out = np.zeros((cap, nch) + tail, dtype=odt)
+            n = a.process_pcm_ptr(inp.ctypes.data, fin, True, nch, chunk, out.ctypes.data, fout,
+                                  True, nch)
+            got = values_of(out[:n], fout)
+            ref = np_encode(want.T, fout)
+        else:
+            inp = np.ascontiguousarray(np.moveaxis(store[i:i + chunk], 1, 0))  # [nch, l(,3)]
+            out = np.zeros((nch, cap) + tail, dtype=odt)
+            n = a.process_pcm_ptr(inp.ctypes.data, fin, False, chunk, chunk, out.ctypes.data, fout,
+                                  False, cap)
+            got = values_of(out[:, :n], fout)
+            ref = np_encode(want, fout)
+        assert n == want.shape[1]
+        assert np.array_equal(got, ref), (fin, fout, nch, interleaved, i)
+
+
+@pytest.mark.parametrize("fin,fout,nch", CASES)
+@pytest.mark.parametrize("interleaved", [True, False])
+def test_pcm_emulated(emul, fin, fout, nch, interleaved):
+    run_emul(emul, fin, fout, nch, interleaved)
+
+
+def test_pcm_rounding_and_saturation(emul):
+    """Src == Dst passes samples through: the codec alone.  Half-way cases round to even, values
+    beyond full scale saturate, NaN encodes as 0."""
+    v = np.array([0.5 / 32768, 1.5 / 32768, 2.5 / 32768, -0.5 / 32768, -1.5 / 32768, 1.0, -1.0,
+                  2.0, -3.0, np.nan, 32766.5 / 32768, 0.25 / 32768])
+    a = r8b.BatchResampler(48000.0, 48000.0, len(v), 2.0, 136.45, nch=1, lib=emul)
+    out = np.zeros((len(v), 1), dtype=np.int16)
+    x = np.ascontiguousarray(v[:, None])
+    n = a.process_pcm_ptr(x.ctypes.data, r8b.PCM_F64, True, 1, len(v), out.ctypes.data,
+                          r8b.PCM_S16, True, 1)
+    assert n == len(v)
+    assert out[:, 0].tolist() == [0, 2, 2, 0, -2, 32767, -32768, 32767, -32768, 0, 32766, 0]
+    assert np.array_equal(out[:, 0], np_encode(v, r8b.PCM_S16))
+    with pytest.raises(RuntimeError, match="format"):
+        a.process_pcm_ptr(x.ctypes.data, 9, True, 1, 4, out.ctypes.data, r8b.PCM_S16, True, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fin,fout,nch", CASES)
+def test_pcm_gpu(fin, fout, nch):
+    import torch
+    frames, chunk = 3000, 1000
+    store, vals = make_pcm(fin, frames, nch, 11)
+    x = np_decode(vals, fin)
+    a = r8b.BatchResampler(44100.0, 48000.0, chunk, 2.0, 136.45, nch=nch)
+    b = r8b.BatchResampler(44100.0, 48000.0, chunk, 2.0, 136.45, nch=nch)
+    for i in range(0, frames, chunk):
+        want = b.process_host(np.ascontiguousarray(x[i:i + chunk].T))
+        t = torch.from_numpy(np.ascontiguousarray(store[i:i + chunk])).cuda()
+        y = a.process_pcm(t, out_format=fout)
+        torch.cuda.synchronize()
+        got = values_of(y.cpu().numpy(), fout)
+        assert got.shape[0] == want.shape[1]
+        assert np.array_equal(got, np_encode(want.T, fout)), (fin, fout, nch, i)
+
+
+@pytest.mark.gpu
+def test_pcm_gpu_full_size_roundtrip():
+    """1024 channels x 16384 frames of int16 through 44100 -> 96000: the egress of the fp64 result
+    equals the numpy encoding of the fp64 path's own output (bit-exact), at BASELINE's size."""
+    import torch
+    nch, L = 1024, 16384
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    x16 = torch.randint(-32768, 32767, (L, nch), generator=g, dtype=torch.int16, device="cuda")
+    a = r8b.BatchResampler(44100.0, 96000.0, L, 2.0, 180.15, nch=nch)
+    b = r8b.BatchResampler(44100.0, 96000.0, L, 2.0, 180.15, nch=nch)
+    xf = (x16.to(torch.float64) / 32768.0).t().contiguous()
+    for _ in range(2):
+        y16 = a.process_pcm(x16)
+        yf = b.process(xf)
+        assert y16.shape[0] == yf.shape[1]
+        ref = torch.clamp(torch.round(yf * 32768.0), -32768, 32767).to(torch.int16).t()
+        assert torch.equal(y16, ref)
