@@ -124,6 +124,17 @@ R8BSRC_DECL int r8b_batch_process_pcm(CR8BBatch b, const void* d_in, int in_form
 	int out_interleaved, long long out_stride, void* stream);
 R8BSRC_DECL int r8b_pcm_sample_bytes(int format);
 
+/* Checkpoint / resume of the streaming state of all channels (the reference
+ * keeps this state inside each CDSPProcessor and offers only clear()).  The blob is host memory:
+ * the schedule's counters plus every history ring.  r8b_batch_state_size() is the size a save
+ * would need right now; save returns the bytes written; load accepts only a blob saved by an
+ * object created with the same parameters and options, after which the stream continues
+ * bit-identically.  Both wait for `stream` (the stream the process calls were enqueued on).
+ * Return -1 on error. */
+R8BSRC_DECL long long r8b_batch_state_size(CR8BBatch b);
+R8BSRC_DECL long long r8b_batch_state_save(CR8BBatch b, void* buf, long long cap, void* stream);
+R8BSRC_DECL int r8b_batch_state_load(CR8BBatch b, const void* buf, long long size, void* stream);
+
 /* Single DSP stage as a batch object (the reference's CDSPProcessor boundary,
  * CDSPProcessor.h:64-127), used by the stage-level parity tests:
  *   kind 0: CDSPBlockConvolver(getLPFilter(a=ReqNormFreq, b=ReqTransBand, c=ReqAtten, linear,

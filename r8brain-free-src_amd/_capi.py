@@ -36,6 +36,9 @@ PROTOTYPES = [
                                         C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_longlong,
                                         C.c_void_p]),
     ("r8b_pcm_sample_bytes", C.c_int, [C.c_int]),
+    ("r8b_batch_state_size", C.c_longlong, [C.c_void_p]),
+    ("r8b_batch_state_save", C.c_longlong, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    ("r8b_batch_state_load", C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     ("r8b_batch_create_stage", C.c_void_p, [C.c_int, C.c_double, C.c_double, C.c_double,
                                             C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                                             C.c_int]),

@@ -260,6 +260,38 @@ R8BSRC_DECL int r8b_pcm_sample_bytes(int format)
 	return 0;
 }
 
+R8BSRC_DECL long long r8b_batch_state_size(CR8BBatch b)
+{
+	return (long long) ((Batch*) b)->eng->state_size();
+}
+
+R8BSRC_DECL long long r8b_batch_state_save(CR8BBatch b, void* buf, long long cap, void* stream)
+{
+	try
+	{
+		return (long long) ((Batch*) b)->eng->save_state(buf, cap < 0 ? 0 : (size_t) cap, stream);
+	}
+	catch (const std::exception& e)
+	{
+		set_err("r8b_batch_state_save", e);
+		return -1;
+	}
+}
+
+R8BSRC_DECL int r8b_batch_state_load(CR8BBatch b, const void* buf, long long size, void* stream)
+{
+	try
+	{
+		((Batch*) b)->eng->load_state(buf, size < 0 ? 0 : (size_t) size, stream);
+		return 0;
+	}
+	catch (const std::exception& e)
+	{
+		set_err("r8b_batch_state_load", e);
+		return -1;
+	}
+}
+
 R8BSRC_DECL int r8b_batch_describe(CR8BBatch b, char* buf, int cap)
 {
 	return copy_text(((Batch*) b)->eng->plan().describe(), buf, cap);

@@ -6,6 +6,7 @@
 #include <climits>
 #include <cmath>
 #include <complex>
+#include <cstring>
 #include <stdexcept>
 
 namespace r8bhip {
@@ -538,6 +539,123 @@ void Engine::clear()
 	// ring contents need no reset: positions restart at 0 and every position >= 0 is rewritten
 	// before it is read again, positions < 0 read as zero by construction
 	plan_.clear();
+}
+
+// ---- checkpoint -------------------------------------------------------------------------------
+// blob: StateHeader, then per stage a StageState followed by the stage's input ring (nch x
+// ring_size doubles) when that ring exists (the ring between two fused stages never does)
+namespace {
+struct StateHeader
+{
+	char magic[8];
+	unsigned long long config;
+	long long nstages, nch;
+};
+struct StageState
+{
+	long long m, done, rpos, ring_size, has_ring;
+	double pos_frac, pos_shift;
+	long long in_counter, in_pos_int;
+};
+}
+
+unsigned long long Engine::config_hash() const
+{
+	// FNV-1a over everything that shapes the rings and the schedule
+	std::string key = plan_.describe();
+	key += "|maxin=" + std::to_string(plan_.max_in) + "|nch=" + std::to_string(nch_);
+	for (const auto& kv : opt_)
+		if (kv.first != "timing") key += "|" + kv.first + "=" + std::to_string(kv.second);
+	unsigned long long h = 1469598103934665603ull;
+	for (unsigned char c : key)
+	{
+		h ^= c;
+		h *= 1099511628211ull;
+	}
+	return h;
+}
+
+size_t Engine::state_size() const
+{
+	size_t n = sizeof(StateHeader);
+	for (const StageDev& d : dev_)
+	{
+		n += sizeof(StageState);
+		if (d.ring != nullptr) n += (size_t) d.ring_size * (size_t) nch_ * sizeof(double);
+	}
+	return n;
+}
+
+size_t Engine::save_state(void* buf, size_t cap, void* stream)
+{
+	const size_t need = state_size();
+	if (cap < need) throw std::runtime_error("state buffer too small");
+	dev_select(device_);
+	dev_sync(stream);
+	unsigned char* p = static_cast<unsigned char*>(buf);
+	StateHeader h;
+	std::memcpy(h.magic, "R8BHIPS1", 8);
+	h.config = config_hash();
+	h.nstages = (long long) dev_.size();
+	h.nch = nch_;
+	std::memcpy(p, &h, sizeof(h));
+	p += sizeof(h);
+	for (size_t s = 0; s < dev_.size(); s++)
+	{
+		const StagePlan& sp = plan_.stages[s];
+		const StageDev& d = dev_[s];
+		StageState st;
+		st.m = sp.m; st.done = sp.done;
+		st.rpos = sp.poly.rpos; st.pos_frac = sp.poly.pos_frac; st.pos_shift = sp.poly.pos_shift;
+		st.in_counter = sp.poly.in_counter; st.in_pos_int = sp.poly.in_pos_int;
+		st.ring_size = d.ring_size;
+		st.has_ring = d.ring != nullptr ? 1 : 0;
+		std::memcpy(p, &st, sizeof(st));
+		p += sizeof(st);
+		if (d.ring != nullptr)
+		{
+			const size_t bytes = (size_t) d.ring_size * (size_t) nch_ * sizeof(double);
+			dev_download(p, d.ring, bytes, stream);
+			p += bytes;
+		}
+	}
+	return need;
+}
+
+void Engine::load_state(const void* buf, size_t size, void* stream)
+{
+	const unsigned char* p = static_cast<const unsigned char*>(buf);
+	const unsigned char* const end = p + size;
+	StateHeader h;
+	if (size < sizeof(h)) throw std::runtime_error("state blob truncated");
+	std::memcpy(&h, p, sizeof(h));
+	p += sizeof(h);
+	if (std::memcmp(h.magic, "R8BHIPS1", 8) != 0) throw std::runtime_error("not a state blob");
+	if (h.config != config_hash() || h.nstages != (long long) dev_.size() || h.nch != nch_)
+		throw std::runtime_error("state blob was saved by a differently configured resampler");
+	dev_select(device_);
+	dev_sync(stream);
+	for (size_t s = 0; s < dev_.size(); s++)
+	{
+		StagePlan& sp = plan_.stages[s];
+		StageDev& d = dev_[s];
+		StageState st;
+		if ((size_t) (end - p) < sizeof(st)) throw std::runtime_error("state blob truncated");
+		std::memcpy(&st, p, sizeof(st));
+		p += sizeof(st);
+		if (st.ring_size != d.ring_size) throw std::runtime_error("state blob ring size mismatch");
+		sp.m = st.m; sp.done = st.done;
+		sp.poly.rpos = st.rpos; sp.poly.pos_frac = st.pos_frac; sp.poly.pos_shift = st.pos_shift;
+		sp.poly.in_counter = (int) st.in_counter; sp.poly.in_pos_int = (int) st.in_pos_int;
+		if (st.has_ring)
+		{
+			const size_t bytes = (size_t) d.ring_size * (size_t) nch_ * sizeof(double);
+			if ((size_t) (end - p) < bytes) throw std::runtime_error("state blob truncated");
+			ensure_ring(s);
+			dev_upload(d.ring, p, bytes);
+			p += bytes;
+		}
+	}
 }
 
 void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,

@@ -38,6 +38,15 @@ public:
 	bool stage_timing(size_t stage, double* ms_sum, int* launches, std::string* kernel,
 		long long* in_samples, long long* out_samples);
 
+	// Checkpoint of the streaming state of all channels: the plan's counters
+	// and the contents of every history ring, as one host blob.  load_state() accepts only a blob
+	// saved by an object of the same configuration (rates, filter parameters, MaxInLen, channel
+	// count, engine options); a stream resumed from it continues bit-identically.  Both wait for
+	// `stream`, the stream the process() calls were enqueued on.
+	size_t state_size() const;
+	size_t save_state(void* buf, size_t cap, void* stream);
+	void load_state(const void* buf, size_t size, void* stream);
+
 	const ChainPlan& plan() const { return plan_; }
 	int channels() const { return nch_; }
 	int device() const { return device_; }
@@ -67,6 +76,7 @@ private:
 		long long t_in = 0, t_out = 0; // per-channel samples in/out over the timed launches
 	};
 	void* get_event(StageDev& d);
+	unsigned long long config_hash() const;
 
 	void plan_transforms();
 	void ensure_ring(size_t s);

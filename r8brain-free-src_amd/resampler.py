@@ -119,6 +119,24 @@ class BatchResampler(_Base):
         n = self.process_ptr(x.data_ptr(), x.stride(0), l, out.data_ptr(), out.stride(0), stream)
         return out[:, :n]
 
+    def state_dict(self, stream=0):
+        """Checkpoint of the streaming state of all channels as one numpy uint8 blob
+        (r8b_batch_state_save); waits for `stream`."""
+        size = self._lib.r8b_batch_state_size(self._h)
+        buf = np.empty(size, dtype=np.uint8)
+        n = self._lib.r8b_batch_state_save(self._h, C.c_void_p(buf.ctypes.data), size,
+                                           C.c_void_p(stream))
+        if n < 0:
+            raise RuntimeError(self._err())
+        return buf[:n]
+
+    def load_state_dict(self, blob, stream=0):
+        """Resume from a blob of state_dict() taken from an equally configured object."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        if self._lib.r8b_batch_state_load(self._h, C.c_void_p(blob.ctypes.data), blob.size,
+                                          C.c_void_p(stream)) < 0:
+            raise RuntimeError(self._err())
+
     def process_pcm_ptr(self, d_in, in_format, in_interleaved, in_stride, l, d_out, out_format,
                         out_interleaved, out_stride, stream=0):
         """Raw device-pointer PCM entry (r8b_batch_process_pcm); strides in samples."""

@@ -97,3 +97,43 @@ def test_unsupported_geometry_fails_loudly(emul):
     message, not fall back to anything."""
     with pytest.raises(RuntimeError, match="too long"):
         r8b.BatchResampler(32000.0, 96000.0, 1024, 0.5, 218.0, nch=1, lib=emul)
+
+
+CKPT_CASES = [(44100.0, 96000.0), (96000.0, 44100.0), (44100.0, 44101.0), (44100.0, 2822400.0),
+              (176400.0, 44100.0), (48000.0, 32000.0)]
+
+
+def checkpoint_roundtrip(make, src, dst):
+    """Stream A runs straight through; stream B is checkpointed mid-way, the blob is loaded into
+    a fresh object C, and C's continuation must equal A's bit for bit."""
+    nch, chunk, n = 3, 700, 700 * 9
+    x = make_input(nch, n)
+    a, b, c = make(), make(), make()
+    ya = [a.process_host(x[:, i:i + chunk]) for i in range(0, n, chunk)]
+    for i in range(0, 4 * chunk, chunk):
+        b.process_host(x[:, i:i + chunk])
+    blob = b.state_dict()
+    c.process_host(x[:, :chunk] * 0.5)  # c has seen unrelated input before the load
+    c.load_state_dict(blob)
+    for k, i in enumerate(range(4 * chunk, n, chunk)):
+        yc = c.process_host(x[:, i:i + chunk])
+        assert yc.shape == ya[4 + k].shape and np.array_equal(yc, ya[4 + k]), (src, dst, k)
+    return blob
+
+
+@pytest.mark.parametrize("src,dst", CKPT_CASES)
+def test_emulated_checkpoint_resume(emul, src, dst):
+    checkpoint_roundtrip(lambda: r8b.BatchResampler(src, dst, 700, 2.0, 136.45, nch=3, lib=emul),
+                         src, dst)
+
+
+def test_emulated_checkpoint_rejects_other_configuration(emul):
+    a = r8b.BatchResampler(44100.0, 96000.0, 700, 2.0, 136.45, nch=3, lib=emul)
+    a.process_host(make_input(3, 700))
+    blob = a.state_dict()
+    for other in (r8b.BatchResampler(44100.0, 96000.0, 700, 2.0, 136.45, nch=2, lib=emul),
+                  r8b.BatchResampler(44100.0, 88200.0, 700, 2.0, 136.45, nch=3, lib=emul)):
+        with pytest.raises(RuntimeError, match="differently configured|ring size"):
+            other.load_state_dict(blob)
+    with pytest.raises(RuntimeError, match="truncated"):
+        a.load_state_dict(blob[:100])

@@ -245,3 +245,15 @@ def test_hip_alternative_kernel_paths(torch, case, opts):
         b.set_option(k, v)
     r, p = compare_stream(b, src, dst, maxin, chunk, n, tb, att, 2)
     assert r <= RMS_TOL and p <= PEAK_TOL, (r, p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,dst", [(44100.0, 96000.0), (44100.0, 44101.0), (44100.0, 2822400.0),
+                                     (176400.0, 44100.0)])
+def test_gpu_checkpoint_resume(src, dst):
+    """r8b_batch_state_save / _load: a stream resumed from a checkpoint in a fresh object continues
+    bit-identically (same procedure as the emulation tier)."""
+    from test_emul import checkpoint_roundtrip
+    blob = checkpoint_roundtrip(lambda: r8b.BatchResampler(src, dst, 700, 2.0, 136.45, nch=3),
+                                src, dst)
+    assert blob.size > 64
