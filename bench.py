@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--dst", type=float, default=96000.0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value")
+    ap.add_argument("--pcm", choices=["s16", "s24", "s32", "f32"], default=None,
+                    help="side measurement: interleaved PCM in/out through the ingest/egress "
+                         "kernels (r8b_batch_process_pcm) instead of planar fp64; not the headline")
     args = ap.parse_args()
 
     import numpy as np
@@ -161,11 +164,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.pcm:
+        fmt = {"s16": r8b.PCM_S16, "s24": r8b.PCM_S24, "s32": r8b.PCM_S32, "f32": r8b.PCM_F32}[args.pcm]
+        dt_ = {"s16": torch.int16, "s24": torch.uint8, "s32": torch.int32, "f32": torch.float32}[args.pcm]
+        tail = (3,) if args.pcm == "s24" else ()
+        if args.pcm == "f32":
+            pin = [(x.t().contiguous()).to(torch.float32) for x in xin]
+        else:
+            pin = [torch.randint(0, 255, (L, C) + tail, generator=g, device=dev,
+                                 dtype=torch.int32).to(dt_) for _ in range(nbuf)]
+        pouts = [torch.empty((rs.max_out_len, C) + tail, dtype=dt_, device=dev) for _ in range(2)]
+
     def run(k0, k):
         n_out = 0
         for i in range(k0, k0 + k):
-            y = rs.process(xin[i % nbuf], out=outs[i % 2])
-            n_out += y.shape[1]
+            if args.pcm:
+                n_out += rs.process_pcm(pin[i % nbuf], out_format=fmt, out=pouts[i % 2]).shape[0]
+            else:
+                n_out += rs.process(xin[i % nbuf], out=outs[i % 2]).shape[1]
         return n_out
 
     run(0, args.warmup)
@@ -208,7 +224,8 @@ def main():
             "config": {"workload": "CDSPResampler24 %g->%g, %d channels/GPU x %d-sample blocks, "
                                    "fp64, inputs and outputs resident in HBM" %
                                    (args.src, args.dst, C, L),
-                       "channels_per_gpu": C, "block": L, "out_msamples_per_s":
+                       "channels_per_gpu": C, "block": L, "io": args.pcm or "f64 planar",
+                       "out_msamples_per_s":
                            round(n_out * C * world / dt / 1e6, 3),
                        "chain": rs.describe().strip().split("\n")},
             "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2),
