@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--pcm", choices=["s16", "s24", "s32", "f32"], default=None,
                     help="side measurement: interleaved PCM in/out through the ingest/egress "
                          "kernels (r8b_batch_process_pcm) instead of planar fp64; not the headline")
+    ap.add_argument("--planar", action="store_true",
+                    help="with --pcm: planar [channel][frame] buffers, decoded/encoded inside the "
+                         "first/last stage kernels")
     args = ap.parse_args()
 
     import numpy as np
@@ -169,17 +172,19 @@ def main():
         dt_ = {"s16": torch.int16, "s24": torch.uint8, "s32": torch.int32, "f32": torch.float32}[args.pcm]
         tail = (3,) if args.pcm == "s24" else ()
         if args.pcm == "f32":
-            pin = [(x.t().contiguous()).to(torch.float32) for x in xin]
+            pin = [(x if args.planar else x.t().contiguous()).to(torch.float32) for x in xin]
         else:
-            pin = [torch.randint(0, 255, (L, C) + tail, generator=g, device=dev,
-                                 dtype=torch.int32).to(dt_) for _ in range(nbuf)]
-        pouts = [torch.empty((rs.max_out_len, C) + tail, dtype=dt_, device=dev) for _ in range(2)]
+            pin = [torch.randint(0, 255, ((C, L) if args.planar else (L, C)) + tail, generator=g,
+                                 device=dev, dtype=torch.int32).to(dt_) for _ in range(nbuf)]
+        oshape = (C, rs.max_out_len) if args.planar else (rs.max_out_len, C)
+        pouts = [torch.empty(oshape + tail, dtype=dt_, device=dev) for _ in range(2)]
 
     def run(k0, k):
         n_out = 0
         for i in range(k0, k0 + k):
             if args.pcm:
-                n_out += rs.process_pcm(pin[i % nbuf], out_format=fmt, out=pouts[i % 2]).shape[0]
+                n_out += rs.process_pcm(pin[i % nbuf], out_format=fmt, out=pouts[i % 2],
+                                        planar=args.planar).shape[1 if args.planar else 0]
             else:
                 n_out += rs.process(xin[i % nbuf], out=outs[i % 2]).shape[1]
         return n_out
@@ -224,7 +229,8 @@ def main():
             "config": {"workload": "CDSPResampler24 %g->%g, %d channels/GPU x %d-sample blocks, "
                                    "fp64, inputs and outputs resident in HBM" %
                                    (args.src, args.dst, C, L),
-                       "channels_per_gpu": C, "block": L, "io": args.pcm or "f64 planar",
+                       "channels_per_gpu": C, "block": L, "io": ((args.pcm + (" planar" if args.planar else " interleaved"))
+                                                   if args.pcm else "f64 planar"),
                        "out_msamples_per_s":
                            round(n_out * C * world / dt / 1e6, 3),
                        "chain": rs.describe().strip().split("\n")},

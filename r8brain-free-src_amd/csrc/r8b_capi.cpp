@@ -98,30 +98,43 @@ int batch_process_host(Batch* h, const double* in, long long in_stride, int l, d
 	return n;
 }
 
-// PCM boundary: ingest kernel -> staging rows -> the resampler -> staging rows -> egress kernel, all
-// on `stream`, nothing synchronises
+// PCM boundary.  Planar buffers are decoded by the first stage's loads and encoded by the last
+// stage's stores (Engine::process_planar); an interleaved side goes through a transposing kernel
+// and the staging rows.  Everything is enqueued on `stream`, nothing synchronises.
 int batch_process_pcm(Batch* h, const void* d_in, int in_fmt, int in_interleaved,
 	long long in_stride, int l, void* d_out, int out_fmt, int out_interleaved, long long out_stride,
 	void* stream)
 {
-	h->need_staging();
 	Engine& e = *h->eng;
-	if (l < 0 || l > h->in_cap) throw std::runtime_error("input length exceeds MaxInLen");
 	auto valid = [](int f) { return f >= kPcmF64 && f <= kPcmS32; };
 	if (!valid(in_fmt) || !valid(out_fmt)) throw std::runtime_error("unknown PCM sample format");
+	if (l < 0 || l > e.plan().max_in) throw std::runtime_error("input length exceeds MaxInLen");
 	if (l == 0) return 0;
+	// Src == Dst has no stage to fuse into: both sides staged
+	const bool pass = e.plan().stages.empty();
+	const bool stage_in = in_interleaved || pass, stage_out = out_interleaved || pass;
+	if (stage_in || stage_out) h->need_staging();
 	PcmLaunch P;
-	P.pcm = const_cast<void*>(d_in);
-	P.fmt = in_fmt;
-	P.interleaved = in_interleaved ? 1 : 0;
-	P.pcm_stride = in_stride;
-	P.planar = h->d_in;
-	P.planar_stride = h->in_cap;
 	P.nch = e.channels();
-	P.n = l;
-	launch_pcm_in(P, stream);
-	const int n = e.process(h->d_in, h->in_cap, l, h->d_out, h->out_cap, stream);
-	if (n > 0)
+	if (stage_in)
+	{
+		P.pcm = const_cast<void*>(d_in);
+		P.fmt = in_fmt;
+		P.interleaved = in_interleaved ? 1 : 0;
+		P.pcm_stride = in_stride;
+		P.planar = h->d_in;
+		P.planar_stride = h->in_cap;
+		P.n = l;
+		launch_pcm_in(P, stream);
+		d_in = h->d_in;
+		in_fmt = kPcmF64;
+		in_stride = h->in_cap;
+	}
+	void* const out = stage_out ? h->d_out : d_out;
+	const int n = pass ? e.process(static_cast<const double*>(d_in), in_stride, l, h->d_out,
+		h->out_cap, stream) : e.process_planar(d_in, in_fmt, in_stride, l, out,
+		stage_out ? (int) kPcmF64 : out_fmt, stage_out ? (long long) h->out_cap : out_stride, stream);
+	if (stage_out && n > 0)
 	{
 		P.pcm = d_out;
 		P.fmt = out_fmt;

@@ -648,6 +648,16 @@ R8B_HD void cx_whole_row(const ConvxLaunch& X, double* row, int tid)
 	for (int i = 0; i < FLENP; i++) row[i] = i < X.flen ? X.wtab[(long) i * X.out_step + t] : 0.0;
 }
 
+R8B_HD void cx_mac8(const double* row, const double* v, double& s0, double& s1)
+{
+#pragma unroll
+	for (int i = 0; i < 8; i += 2)
+	{
+		s0 += row[i] * v[i];
+		s1 += row[i + 1] * v[i + 1];
+	}
+}
+
 template<int FLEN>
 R8B_HD void cx_whole_compute(const ConvxLaunch& X, const double* y, const double* row, long long k,
 	int ch, int tid)
@@ -671,11 +681,17 @@ R8B_HD void cx_whole_compute(const ConvxLaunch& X, const double* y, const double
 		double v[FLEN];
 		R8B_LDS_WINDOW(FLEN, v, y + u);
 		double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-		for (int i = 0; i < FLEN; i += 2)
+		// taps in groups of eight, each behind the arrival of its own reads
+		R8B_LDS_ARRIVED(FLEN, v, 0);
+		cx_mac8(row, v, s0, s1);
+		R8B_LDS_ARRIVED(FLEN, v, 8);
+		cx_mac8(row + 8, v + 8, s0, s1);
+		R8B_LDS_ARRIVED(FLEN, v, 16);
+		cx_mac8(row + 16, v + 16, s0, s1);
+		if constexpr (FLEN > 24)
 		{
-			s0 += row[i] * v[i];
-			s1 += row[i + 1] * v[i + 1];
+			R8B_LDS_ARRIVED(FLEN, v, 24);
+			cx_mac8(row + 24, v + 24, s0, s1);
 		}
 		dst_store(X.wdst, ch, j, s0 + s1);
 	}

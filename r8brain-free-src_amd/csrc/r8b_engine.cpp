@@ -746,6 +746,22 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 	}
 }
 
+int Engine::process_planar(const void* d_in, int in_fmt, long long in_stride, int l, void* d_out,
+	int out_fmt, long long out_stride, void* stream)
+{
+	// the first stage decodes the caller's samples as it loads them, the last one encodes as it
+	// stores (src_load / dst_store): no staging copy, 2-4 bytes per sample at the HBM edge
+	struct Reset
+	{
+		Engine& e;
+		~Reset() { e.io_in_fmt_ = e.io_out_fmt_ = kPcmF64; }
+	} reset{*this};
+	io_in_fmt_ = in_fmt;
+	io_out_fmt_ = out_fmt;
+	return process(static_cast<const double*>(d_in), in_stride, l, static_cast<double*>(d_out),
+		out_stride, stream);
+}
+
 int Engine::process(const double* d_in, long long in_stride, int l, double* d_out,
 	long long out_stride, void* stream)
 {
@@ -760,6 +776,9 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 		TailLaunch T;
 		T.src.ring = d_in; T.src.ring_stride = 0; T.src.ring_mask = 0;
 		T.src.cur = d_in; T.src.cur_stride = in_stride; T.src.cur_base = 0;
+		T.src.cur_fmt = kPcmF64;
+		if (io_in_fmt_ != kPcmF64 || io_out_fmt_ != kPcmF64)
+			throw std::logic_error("pass-through of PCM buffers goes through the staging rows");
 		T.p0 = 0; T.p1 = l;
 		T.ring = d_out; T.ring_stride = out_stride; T.ring_mask = -1;
 		T.nch = nch_;
@@ -798,12 +817,14 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 			src.cur = d_in;
 			src.cur_stride = in_stride;
 			src.cur_base = m_prev;
+			src.cur_fmt = io_in_fmt_;
 		}
 		else
 		{
 			src.cur = nullptr;
 			src.cur_stride = 0;
 			src.cur_base = LLONG_MAX;
+			src.cur_fmt = kPcmF64;
 		}
 		DstView dst;
 		if (last + 1 == ns)
@@ -812,6 +833,7 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 			dst.stride = out_stride;
 			dst.mask = -1;
 			dst.off = -(fused ? wa : a);
+			dst.fmt = io_out_fmt_;
 		}
 		else
 		{
@@ -819,6 +841,7 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 			dst.stride = dev_[last + 1].ring_size;
 			dst.mask = dev_[last + 1].ring_size - 1;
 			dst.off = 0;
+			dst.fmt = kPcmF64;
 		}
 		const bool work = fused ? wb > wa : b > a;
 		if (s == 0) tail_done_ = false;
@@ -931,8 +954,8 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	L.blk_stride = g.in_len;
 	L.blk_offset = 0;
 	// aligned 16-byte loads of sample pairs need even positions on every side of the selection
-	L.vec_ok = (src.cur == nullptr || (((size_t) src.cur & 15) == 0 && (src.cur_stride & 1) == 0 &&
-		(src.cur_base & 1) == 0)) && (src.ring_stride & 1) == 0 && ((g.in_len / g.up) & 1) == 0 &&
+	L.vec_ok = src.cur_fmt == kPcmF64 && (src.cur == nullptr || (((size_t) src.cur & 15) == 0 &&
+		(src.cur_stride & 1) == 0 && (src.cur_base & 1) == 0)) && (src.ring_stride & 1) == 0 &&
 		((g.in_len / g.up) & 1) == 0 ? 1 : 0;
 	L.inplace = generic_conv_two_arrays(g) ? 0 : 1;
 	L.up_pow2 = g.up_pow2 ? 1 : 0;

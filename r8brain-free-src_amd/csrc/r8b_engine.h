@@ -30,6 +30,10 @@ public:
 	// returns output samples per channel produced by this call
 	int process(const double* d_in, long long in_stride, int l, double* d_out,
 		long long out_stride, void* stream);
+	// the same with PLANAR buffers of PCM samples (PcmFormat; strides in samples), converted by
+	// the first stage's loads and the last stage's stores; needs at least one stage (Src != Dst)
+	int process_planar(const void* d_in, int in_fmt, long long in_stride, int l, void* d_out,
+		int out_fmt, long long out_stride, void* stream);
 	void clear();
 	bool set_option(const std::string& name, int value);
 
@@ -96,6 +100,7 @@ private:
 	int device_;
 	std::vector<StageDev> dev_;
 	std::map<std::string, int> opt_;
+	int io_in_fmt_ = kPcmF64, io_out_fmt_ = kPcmF64; // formats of the current call's buffers
 	bool tail_done_ = false; // stage-0 history already written by the convolver kernel
 };
 

@@ -21,6 +21,7 @@
 #endif
 
 #include "r8b_launch.h"
+#include "r8b_pcm_codec.h"
 
 namespace r8bhip {
 
@@ -33,6 +34,19 @@ struct alignas(16) cd
 
 R8B_HD double src_load(const SrcView& s, int ch, long long pos)
 {
+	if (s.cur_fmt != kPcmF64)
+	{
+		// planar PCM caller buffer, decoded in place: element sizes differ from the ring's, so
+		// the select is a branch here
+		double v;
+		if (pos >= s.cur_base)
+			v = pcm_decode(reinterpret_cast<const unsigned char*>(s.cur) +
+				((long long) ch * s.cur_stride + (pos - s.cur_base)) * pcm_bytes(s.cur_fmt),
+				s.cur_fmt);
+		else
+			v = s.ring[(long long) ch * s.ring_stride + (pos & s.ring_mask)];
+		return pos < 0 ? 0.0 : v;
+	}
 	// one load through a selected address (no branches: a thread's loads stay in flight together)
 	const double* pr = s.ring + ((long long) ch * s.ring_stride + (pos & s.ring_mask));
 	const double* pc = s.cur + ((long long) ch * s.cur_stride + (pos - s.cur_base));
@@ -43,6 +57,12 @@ R8B_HD double src_load(const SrcView& s, int ch, long long pos)
 
 R8B_HD void dst_store(const DstView& d, int ch, long long q, double v)
 {
+	if (d.fmt != kPcmF64)
+	{
+		pcm_encode(reinterpret_cast<unsigned char*>(d.p) +
+			((long long) ch * d.stride + ((q + d.off) & d.mask)) * pcm_bytes(d.fmt), d.fmt, v);
+		return;
+	}
 	d.p[(long long) ch * d.stride + ((q + d.off) & d.mask)] = v;
 }
 

@@ -24,6 +24,25 @@
 		  "=v"(v[o + 5]), "=v"(v[o + 6]), "=v"(v[o + 7]) \
 		: "v"(a), "i"(8 * (o)), "i"(8 * (o) + 8), "i"(8 * (o) + 16), "i"(8 * (o) + 24), \
 		  "i"(8 * (o) + 32), "i"(8 * (o) + 40), "i"(8 * (o) + 48), "i"(8 * (o) + 56) : "memory")
+#ifndef R8B_STAGED_WAIT
+#define R8B_STAGED_WAIT 1
+#endif
+#if R8B_STAGED_WAIT
+// The reads are only issued here; R8B_LDS_ARRIVED(N, v, o) placed before the first use of
+// v[o..o+7] waits until those eight have returned (LDS returns in order), so the multiply-adds on
+// the first taps overlap the return of the later ones.
+#define R8B_LDS_WINDOW(N, v, p) \
+	{ \
+		const unsigned a_ = (unsigned) (unsigned long long) (p); \
+		R8B_LDS_READ8(v, 0, a_); R8B_LDS_READ8(v, 8, a_); R8B_LDS_READ8(v, 16, a_); \
+		if constexpr ((N) > 24) R8B_LDS_READ8(v, 24, a_); \
+	}
+#define R8B_LDS_ARRIVED(N, v, o) \
+	asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(v[o]), "+v"(v[(o) + 1]), "+v"(v[(o) + 2]), \
+		"+v"(v[(o) + 3]), "+v"(v[(o) + 4]), "+v"(v[(o) + 5]), "+v"(v[(o) + 6]), "+v"(v[(o) + 7]) \
+		: "n"((N) - 8 - (o) > 15 ? 15 : (N) - 8 - (o))) /* the counter has 4 bits */
+#else
+#define R8B_LDS_ARRIVED(N, v, o)
 #define R8B_LDS_WINDOW(N, v, p) \
 	{ \
 		const unsigned a_ = (unsigned) (unsigned long long) (p); \
@@ -38,6 +57,7 @@
 			"+v"(v[(N) - 6]), "+v"(v[(N) - 5]), "+v"(v[(N) - 4]), "+v"(v[(N) - 3]), \
 			"+v"(v[(N) - 2]), "+v"(v[(N) - 1])); \
 	}
+#endif
 #include "r8b_kernel_phases.h"
 #include "r8b_convx.h"
 #include "r8b_pcm.h"

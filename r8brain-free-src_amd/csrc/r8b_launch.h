@@ -9,6 +9,10 @@
 
 namespace r8bhip {
 
+// PCM sample formats a caller buffer may hold (r8b_pcm_codec.h, r8b_pcm.h); values are part of the C ABI
+// (include/r8bsrc.h, enum r8b_pcm_format)
+enum PcmFormat { kPcmF64 = 0, kPcmF32 = 1, kPcmS16 = 2, kPcmS24 = 3, kPcmS32 = 4 };
+
 // Where a stage reads its input stream x[pos] for channel ch:
 //   pos <  0          -> 0.0 (the stream starts at 0)
 //   pos >= cur_base   -> cur[ch*cur_stride + pos - cur_base]     (this call's fresh samples)
@@ -21,6 +25,7 @@ struct SrcView
 	const double* cur;
 	long long cur_stride;
 	long long cur_base;
+	int cur_fmt; // PcmFormat of `cur` (planar; strides in samples); the ring is always fp64
 };
 
 // Where a stage writes output sample q of channel ch: p[ch*stride + ((q + off) & mask)].
@@ -31,6 +36,7 @@ struct DstView
 	long long stride;
 	long long mask;
 	long long off;
+	int fmt; // PcmFormat of the buffer (caller's planar PCM buffer at the last stage), else fp64
 };
 
 struct cd;
@@ -138,10 +144,6 @@ struct TailLaunch
 	long long ring_mask;
 	int nch;
 };
-
-// PCM sample formats of the ingest/egress kernels (r8b_pcm.h); values are part of the C ABI
-// (include/r8bsrc.h, enum r8b_pcm_format)
-enum PcmFormat { kPcmF64 = 0, kPcmF32 = 1, kPcmS16 = 2, kPcmS24 = 3, kPcmS32 = 4 };
 
 struct PcmLaunch
 {

@@ -10,73 +10,15 @@
 //   encode: v * 2^(bits-1), round to nearest even, saturate to [-2^(bits-1), 2^(bits-1)-1]
 //           (no dither); float32 by round-to-nearest conversion; NaN encodes as 0 in the integer
 //           formats
-// Phases are shared with the host emulation of tests/emul like every other kernel.
+// The sample codec itself lives in r8b_pcm_codec.h (the stage kernels use it too, for planar PCM
+// buffers read and written in place).  Phases are shared with the host emulation of tests/emul
+// like every other kernel.
 #ifndef R8B_PCM_H
 #define R8B_PCM_H
-
-#include <math.h>
 
 #include "r8b_kernel_phases.h"
 
 namespace r8bhip {
-
-R8B_HD int pcm_bytes(int fmt)
-{
-	switch (fmt)
-	{
-	case kPcmF64: return 8;
-	case kPcmF32: return 4;
-	case kPcmS16: return 2;
-	case kPcmS24: return 3;
-	case kPcmS32: return 4;
-	}
-	return 0;
-}
-
-R8B_HD double pcm_decode(const unsigned char* p, int fmt)
-{
-	switch (fmt)
-	{
-	case kPcmF64: return *reinterpret_cast<const double*>(p);
-	case kPcmF32: return (double) *reinterpret_cast<const float*>(p);
-	case kPcmS16: return (double) *reinterpret_cast<const short*>(p) * (1.0 / 32768.0);
-	case kPcmS24:
-	{
-		// packed little-endian, no alignment: three byte loads
-		int v = (int) p[0] | ((int) p[1] << 8) | ((int) (signed char) p[2] << 16);
-		return (double) v * (1.0 / 8388608.0);
-	}
-	case kPcmS32: return (double) *reinterpret_cast<const int*>(p) * (1.0 / 2147483648.0);
-	}
-	return 0.0;
-}
-
-R8B_HD double pcm_quantize(double v, double scale)
-{
-	double q = rint(v * scale); // round half to even in both the HIP and the host build
-	if (!(q >= -scale)) q = q != q ? 0.0 : -scale;
-	if (q > scale - 1.0) q = scale - 1.0;
-	return q;
-}
-
-R8B_HD void pcm_encode(unsigned char* p, int fmt, double v)
-{
-	switch (fmt)
-	{
-	case kPcmF64: *reinterpret_cast<double*>(p) = v; break;
-	case kPcmF32: *reinterpret_cast<float*>(p) = (float) v; break;
-	case kPcmS16: *reinterpret_cast<short*>(p) = (short) (int) pcm_quantize(v, 32768.0); break;
-	case kPcmS24:
-	{
-		const int q = (int) pcm_quantize(v, 8388608.0);
-		p[0] = (unsigned char) (q & 255);
-		p[1] = (unsigned char) ((q >> 8) & 255);
-		p[2] = (unsigned char) ((q >> 16) & 255);
-		break;
-	}
-	case kPcmS32: *reinterpret_cast<int*>(p) = (int) (long long) pcm_quantize(v, 2147483648.0); break;
-	}
-}
 
 // byte offset of (frame f, channel c) in the PCM buffer
 R8B_HD long long pcm_offset(const PcmLaunch& L, long long f, int c)

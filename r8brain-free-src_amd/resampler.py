@@ -149,15 +149,19 @@ class BatchResampler(_Base):
             raise RuntimeError(self._err())
         return n
 
-    def process_pcm(self, x, out_format=None, out=None):
-        """Interleaved PCM in, interleaved PCM out, both CUDA tensors.  x: [frames, nch] of
-        int16 / int32 / float32 / float64, or uint8 [frames, nch, 3] for packed 24-bit.  Returns
-        a view [n, nch(, 3)] of `out` (allocated [max_out_len, nch(, 3)] if not given) in
-        `out_format` (default: the input's).  Enqueues on torch's current stream."""
+    def process_pcm(self, x, out_format=None, out=None, planar=False):
+        """PCM in, PCM out, both CUDA tensors.  Interleaved (default): x is [frames, nch] of
+        int16 / int32 / float32 / float64, or uint8 [frames, nch, 3] for packed 24-bit; returns a
+        view [n, nch(, 3)] of `out` (allocated [max_out_len, nch(, 3)] if not given) in
+        `out_format` (default: the input's).  planar=True: x is [nch, frames(, 3)] and the result
+        [nch, n(, 3)]; the conversion then happens inside the first and last stage kernels, no
+        staging copy.  Enqueues on torch's current stream."""
         import torch
         fmt_of = {torch.float64: PCM_F64, torch.float32: PCM_F32, torch.int16: PCM_S16,
                   torch.int32: PCM_S32, torch.uint8: PCM_S24}
         dtype_of = {v: k for k, v in fmt_of.items()}
+        if planar:
+            return self._process_pcm_planar(x, fmt_of, dtype_of, out_format, out)
         assert x.is_cuda and x.is_contiguous() and x.shape[1] == self.nch
         in_format = fmt_of[x.dtype]
         assert (x.dim() == 3 and x.shape[2] == 3) if in_format == PCM_S24 else x.dim() == 2
@@ -173,6 +177,24 @@ class BatchResampler(_Base):
         n = self.process_pcm_ptr(x.data_ptr(), in_format, True, self.nch, x.shape[0],
                                  out.data_ptr(), out_format, True, self.nch, stream)
         return out[:n]
+
+    def _process_pcm_planar(self, x, fmt_of, dtype_of, out_format, out):
+        import torch
+        assert x.is_cuda and x.is_contiguous() and x.shape[0] == self.nch
+        in_format = fmt_of[x.dtype]
+        assert (x.dim() == 3 and x.shape[2] == 3) if in_format == PCM_S24 else x.dim() == 2
+        if out_format is None:
+            out_format = in_format
+        tail = (3,) if out_format == PCM_S24 else ()
+        cap = max(self.max_out_len, 1)
+        if out is None:
+            out = torch.empty((self.nch, cap) + tail, dtype=dtype_of[out_format], device=x.device)
+        assert out.is_cuda and out.is_contiguous() and out.dtype == dtype_of[out_format]
+        assert out.shape[0] == self.nch and out.shape[1] >= self.max_out_len
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        n = self.process_pcm_ptr(x.data_ptr(), in_format, False, x.shape[1], x.shape[1],
+                                 out.data_ptr(), out_format, False, out.shape[1], stream)
+        return out[:, :n]
 
     def process_host(self, x):
         """x: float64 numpy [nch, l]; synchronous; returns numpy [nch, n]."""

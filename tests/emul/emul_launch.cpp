@@ -17,6 +17,7 @@
 #define R8B_HD inline
 // the GPU reads the tap window with inline-asm LDS loads; here it is a plain copy
 #define R8B_LDS_WINDOW(N, v, p) { for (int i_ = 0; i_ < (N); i_++) (v)[i_] = (p)[i_]; }
+#define R8B_LDS_ARRIVED(N, v, o)
 #include "r8b_kernel_phases.h"
 #include "r8b_convx.h"
 #include "r8b_pcm.h"

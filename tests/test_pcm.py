@@ -114,6 +114,23 @@ def test_pcm_emulated(emul, fin, fout, nch, interleaved):
     run_emul(emul, fin, fout, nch, interleaved)
 
 
+# planar buffers are decoded / encoded inside the first / last stage kernel: one case per kernel
+# that can sit at either end of a chain
+EDGE_TOPOLOGIES = [(44100.0, 44101.0),     # fast convolver first, polynomial interpolator last
+                   (176400.0, 44100.0),    # half-band decimator first, 2x-decimating convolver last
+                   (44100.0, 2822400.0),   # half-band cascade last
+                   (48000.0, 32000.0),     # generic convolver first and last
+                   (44100.0, 705600.0),    # half-band up-samplers last
+                   (96000.0, 11025.0),     # half-band decimators, convolver, whole-step interpolator
+                   (48000.0, 48000.0)]     # pass-through (staged)
+
+
+@pytest.mark.parametrize("src,dst", EDGE_TOPOLOGIES)
+def test_pcm_planar_fused_edges_emulated(emul, src, dst):
+    run_emul(emul, r8b.PCM_S16, r8b.PCM_S24, 3, False, src, dst)
+    run_emul(emul, r8b.PCM_F32, r8b.PCM_S32, 2, False, src, dst)
+
+
 def test_pcm_rounding_and_saturation(emul):
     """Src == Dst passes samples through: the codec alone.  Half-way cases round to even, values
     beyond full scale saturate, NaN encodes as 0."""
@@ -148,6 +165,25 @@ def test_pcm_gpu(fin, fout, nch):
         got = values_of(y.cpu().numpy(), fout)
         assert got.shape[0] == want.shape[1]
         assert np.array_equal(got, np_encode(want.T, fout)), (fin, fout, nch, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,dst", EDGE_TOPOLOGIES)
+def test_pcm_planar_fused_edges_gpu(src, dst):
+    import torch
+    nch, frames, chunk = 3, 3000, 1000
+    store, vals = make_pcm(r8b.PCM_S16, frames, nch, 23)
+    x = np_decode(vals, r8b.PCM_S16)
+    a = r8b.BatchResampler(src, dst, chunk, 2.0, 136.45, nch=nch)
+    b = r8b.BatchResampler(src, dst, chunk, 2.0, 136.45, nch=nch)
+    for i in range(0, frames, chunk):
+        want = b.process_host(np.ascontiguousarray(x[i:i + chunk].T))
+        t = torch.from_numpy(np.ascontiguousarray(store[i:i + chunk].T)).cuda()  # [nch, l]
+        y = a.process_pcm(t, out_format=r8b.PCM_S24, planar=True)
+        torch.cuda.synchronize()
+        got = unpack24(y.cpu().numpy())
+        assert got.shape == want.shape
+        assert np.array_equal(got, np_encode(want, r8b.PCM_S24)), (src, dst, i)
 
 
 @pytest.mark.gpu
