@@ -34,6 +34,7 @@ struct alignas(16) cd
 
 R8B_HD double src_load(const SrcView& s, int ch, long long pos)
 {
+#ifndef R8B_NO_PCM_FUSE // defined by the fp64-only build of r8b_kernels.hip
 	if (s.cur_fmt != kPcmF64)
 	{
 		// planar PCM caller buffer, decoded in place: element sizes differ from the ring's, so
@@ -47,6 +48,7 @@ R8B_HD double src_load(const SrcView& s, int ch, long long pos)
 			v = s.ring[(long long) ch * s.ring_stride + (pos & s.ring_mask)];
 		return pos < 0 ? 0.0 : v;
 	}
+#endif
 	// one load through a selected address (no branches: a thread's loads stay in flight together)
 	const double* pr = s.ring + ((long long) ch * s.ring_stride + (pos & s.ring_mask));
 	const double* pc = s.cur + ((long long) ch * s.cur_stride + (pos - s.cur_base));
@@ -57,12 +59,14 @@ R8B_HD double src_load(const SrcView& s, int ch, long long pos)
 
 R8B_HD void dst_store(const DstView& d, int ch, long long q, double v)
 {
+#ifndef R8B_NO_PCM_FUSE
 	if (d.fmt != kPcmF64)
 	{
 		pcm_encode(reinterpret_cast<unsigned char*>(d.p) +
 			((long long) ch * d.stride + ((q + d.off) & d.mask)) * pcm_bytes(d.fmt), d.fmt, v);
 		return;
 	}
+#endif
 	d.p[(long long) ch * d.stride + ((q + d.off) & d.mask)] = v;
 }
 

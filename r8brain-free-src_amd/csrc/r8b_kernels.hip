@@ -11,6 +11,19 @@
 #include <stdexcept>
 #include <string>
 
+// This file is compiled twice (Makefile).  As is: fp64 caller buffers only, the stage kernels carry
+// no format test at all.  With R8B_PCM_VARIANT: src_load / dst_store also decode / encode planar PCM
+// caller buffers in place (r8b_pcm_codec.h; the test costs the fp64 path 1-8 % when compiled in,
+// hence the twin).  The fp64 object exports the launchers the engine calls and forwards to the
+// *_pcm twins when a view carries a PCM format; helpers and the transposing PCM kernels live in
+// the fp64 object only.
+#ifdef R8B_PCM_VARIANT
+#define R8B_LAUNCH(name) name##_pcm
+#else
+#define R8B_LAUNCH(name) name##_f64
+#define R8B_NO_PCM_FUSE
+#endif
+
 #define R8B_HD __device__ __forceinline__
 // 8 consecutive doubles from LDS as 8 separate ds_read_b64 (the compiler would pair them into
 // ds_read2_b64, half the LDS rate); completion is awaited by the wait statement naming the
@@ -232,6 +245,7 @@ __global__ void k_tail(const TailLaunch L)
 }
 
 // ------------------------------------------------------------------ PCM ingest / egress (r8b_pcm.h)
+#ifndef R8B_PCM_VARIANT
 __global__ __launch_bounds__(256) void k_pcm_in(const PcmLaunch L)
 {
 	__shared__ double tile[kPcmTile * kPcmPitch];
@@ -261,6 +275,7 @@ __global__ __launch_bounds__(256) void k_pcm_out(const PcmLaunch L)
 	__syncthreads();
 	pcm_out_scatter(L, tile, f0, c0, threadIdx.x, 256);
 }
+#endif
 
 // ------------------------------------------------------------------ fast path (r8b_convx.h)
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory,
@@ -419,7 +434,7 @@ void set_lds_attrs()
 
 } // namespace
 
-void launch_conv(const ConvLaunch& L, void* stream)
+void R8B_LAUNCH(launch_conv)(const ConvLaunch& L, void* stream)
 {
 	set_lds_attrs();
 	const size_t lds = (size_t) (L.inplace ? L.n_in : L.n_in + L.n_out) * sizeof(double);
@@ -428,7 +443,7 @@ void launch_conv(const ConvLaunch& L, void* stream)
 	check(hipGetLastError(), "launch k_conv");
 }
 
-void launch_whole(const WholeLaunch& L, void* stream)
+void R8B_LAUNCH(launch_whole)(const WholeLaunch& L, void* stream)
 {
 	set_lds_attrs();
 	const long long n = L.b - L.a;
@@ -438,7 +453,7 @@ void launch_whole(const WholeLaunch& L, void* stream)
 	check(hipGetLastError(), "launch k_whole");
 }
 
-void launch_poly(const PolyLaunch& L, void* stream)
+void R8B_LAUNCH(launch_poly)(const PolyLaunch& L, void* stream)
 {
 	const long long n = L.b - L.a;
 	if (L.span_max > 0)
@@ -456,7 +471,7 @@ void launch_poly(const PolyLaunch& L, void* stream)
 	check(hipGetLastError(), "launch k_poly");
 }
 
-void launch_hbup(const HBLaunch& L, void* stream)
+void R8B_LAUNCH(launch_hbup)(const HBLaunch& L, void* stream)
 {
 	const long long n = (L.b + 1) / 2 - L.a / 2;
 	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
@@ -465,7 +480,7 @@ void launch_hbup(const HBLaunch& L, void* stream)
 	check(hipGetLastError(), "launch k_hbup");
 }
 
-void launch_hbdown(const HBLaunch& L, void* stream)
+void R8B_LAUNCH(launch_hbdown)(const HBLaunch& L, void* stream)
 {
 	const long long n = L.b - L.a;
 	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
@@ -474,7 +489,7 @@ void launch_hbdown(const HBLaunch& L, void* stream)
 	check(hipGetLastError(), "launch k_hbdown");
 }
 
-void launch_convx(const ConvxLaunch& X, int mode, void* stream)
+void R8B_LAUNCH(launch_convx)(const ConvxLaunch& X, int mode, void* stream)
 {
 	int logn = 0;
 	while ((2 << logn) < X.c.n_in) logn++;
@@ -506,7 +521,7 @@ void launch_convx(const ConvxLaunch& X, int mode, void* stream)
 	throw std::runtime_error("launch_convx: geometry not instantiated");
 }
 
-void launch_hbcascade(const HBCascadeLaunch& L, void* stream)
+void R8B_LAUNCH(launch_hbcascade)(const HBCascadeLaunch& L, void* stream)
 {
 	const long long n = L.b - L.a;
 	if (n <= 0) return;
@@ -516,13 +531,50 @@ void launch_hbcascade(const HBCascadeLaunch& L, void* stream)
 	check(hipGetLastError(), "launch k_hbcascade");
 }
 
-void launch_tail(const TailLaunch& L, void* stream)
+void R8B_LAUNCH(launch_tail)(const TailLaunch& L, void* stream)
 {
 	const long long n = L.p1 - L.p0;
 	if (n <= 0) return;
 	hipLaunchKernelGGL(k_tail, dim3((unsigned) ((n + 255) / 256), (unsigned) L.nch), dim3(256), 0,
 		(hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_tail");
+}
+
+#ifndef R8B_PCM_VARIANT
+// ------------------------------------------------------------------ format dispatch
+void launch_conv_pcm(const ConvLaunch& L, void* stream);
+void launch_whole_pcm(const WholeLaunch& L, void* stream);
+void launch_poly_pcm(const PolyLaunch& L, void* stream);
+void launch_hbup_pcm(const HBLaunch& L, void* stream);
+void launch_hbdown_pcm(const HBLaunch& L, void* stream);
+void launch_convx_pcm(const ConvxLaunch& X, int mode, void* stream);
+void launch_hbcascade_pcm(const HBCascadeLaunch& L, void* stream);
+void launch_tail_pcm(const TailLaunch& L, void* stream);
+
+#define R8B_DISPATCH(name, T) \
+	void name(const T& L, void* stream) \
+	{ \
+		if ((L.src.cur_fmt | L.dst.fmt) != kPcmF64) name##_pcm(L, stream); \
+		else name##_f64(L, stream); \
+	}
+R8B_DISPATCH(launch_conv, ConvLaunch)
+R8B_DISPATCH(launch_whole, WholeLaunch)
+R8B_DISPATCH(launch_poly, PolyLaunch)
+R8B_DISPATCH(launch_hbup, HBLaunch)
+R8B_DISPATCH(launch_hbdown, HBLaunch)
+R8B_DISPATCH(launch_hbcascade, HBCascadeLaunch)
+#undef R8B_DISPATCH
+
+void launch_convx(const ConvxLaunch& X, int mode, void* stream)
+{
+	if ((X.c.src.cur_fmt | X.c.dst.fmt | X.wdst.fmt) != kPcmF64) launch_convx_pcm(X, mode, stream);
+	else launch_convx_f64(X, mode, stream);
+}
+
+void launch_tail(const TailLaunch& L, void* stream)
+{
+	if (L.src.cur_fmt != kPcmF64) launch_tail_pcm(L, stream);
+	else launch_tail_f64(L, stream);
 }
 
 static void launch_pcm(const PcmLaunch& L, bool in, void* stream)
@@ -621,5 +673,6 @@ float dev_event_elapsed_ms(void* start, void* stop)
 	check(hipEventElapsedTime(&ms, (hipEvent_t) start, (hipEvent_t) stop), "hipEventElapsedTime");
 	return ms;
 }
+#endif // !R8B_PCM_VARIANT
 
 } // namespace r8bhip
