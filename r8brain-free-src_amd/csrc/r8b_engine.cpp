@@ -254,6 +254,57 @@ std::vector<double> spectral_constants_down(const std::vector<double>& H,
 	return out;
 }
 
+// Constants of the wave-per-block kernel's spectral stage (r8b_convw.h cw_spectral): backward bin
+// k = ca(k) Z[k mod N] + cb(k) conj(Z[-k mod N]); every case of the per-slot table `sc`
+// (spectral_constants) reduces to this form.  Layout: entry ((16s + 4i + s3) * 2 + {0: ca, 1: cb})
+// * 64 + lane for the bin lane (a, j1') owns at (s, i, s3): k = (a + 16s) + M2 ((4 j1' + i) + 16 s3).
+std::vector<double> spectral_constants_wave(const std::vector<double>& sc, int n_in, int up)
+{
+	const int N = n_in / 2, N2 = N * up, M2 = N2 / 64;
+	const int slots = N / 2 + 1;
+	int logn = 0;
+	while ((1 << logn) < N) logn++;
+	auto slot_of = [&](int kf)
+	{
+		if (kf >= N / 2) return N / 2;
+		int s = 0;
+		for (int b = 0; b < logn - 1; b++)
+			if (kf & (1 << b)) s |= 1 << (logn - 2 - b);
+		return s;
+	};
+	auto get = [&](int c, int kf, double* o)
+	{
+		const size_t at = ((size_t) c * slots + slot_of(kf)) * 2;
+		o[0] = sc[at];
+		o[1] = sc[at + 1];
+	};
+	std::vector<double> out((size_t) N2 * 2 * 2, 0.0);
+	for (int lane = 0; lane < 64; lane++)
+		for (int s = 0; s < M2 / 16; s++)
+			for (int i = 0; i < 4; i++)
+				for (int s3 = 0; s3 < 4; s3++)
+				{
+					const int k = ((lane >> 2) + 16 * s) + M2 * ((4 * (lane & 3) + i) + 16 * s3);
+					int ca, cb, kf;
+					if (up == 1)
+					{
+						if (k <= N / 2) { kf = k; ca = 0; cb = 1; }
+						else { kf = N - k; ca = 3; cb = 2; }
+					}
+					else
+					{
+						if (k <= N / 2) { kf = k; ca = 0; cb = 1; }
+						else if (k <= N) { kf = N - k; ca = 5; cb = 4; }
+						else if (k < N + N / 2) { kf = k - N; ca = 6; cb = 7; }
+						else { kf = 2 * N - k; ca = 3; cb = 2; }
+					}
+					const size_t e = (size_t) (16 * s + 4 * i + s3) * 2;
+					get(ca, kf, &out[((e + 0) * 64 + lane) * 2]);
+					get(cb, kf, &out[((e + 1) * 64 + lane) * 2]);
+				}
+	return out;
+}
+
 // LDS of the fast path: one padded complex array of n elements (r8b_convx.h, convx_lds_doubles)
 static size_t convx_work_bytes(int n) { return (size_t) 2 * (n + (n >> 4)) * sizeof(double); }
 
@@ -313,6 +364,10 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["fuse"] = 1;      // ... with the whole-step interpolator behind it fused in
 	opt_["fuse_hb"] = 1;   // runs of half-band up-samplers as one kernel
 	opt_["poly_tiled"] = 1; // polynomial interpolator: 16 channels share each coefficient fetch
+	// 1024/2048-point fast convolvers as one wavefront per block (r8b_convw.h): measured slower
+	// (cfg2 0.48 vs 0.30 ms: two resident waves per SIMD cannot hide the table fetches), kept as
+	// an option
+	opt_["wave_conv"] = 0;
 	opt_["fold_tail"] = 1; // fast convolver at stage 0 keeps the input history itself
 	// fused interpolator on the matrix cores (when a block holds 16 output groups): measured equal
 	// to the vector-ALU form on cfg2 (0.357 vs 0.362 ms: 10x fewer LDS reads, 13 % more FFT
@@ -352,6 +407,12 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 					spectral_constants(H, tw, g.bl2, g.n_in, g.up);
 				d.spec = (cd*) dev_alloc(sc.size() * sizeof(double));
 				dev_upload(d.spec, sc.data(), sc.size() * sizeof(double));
+				if (convw_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
+				{
+					const std::vector<double> sw = spectral_constants_wave(sc, g.n_in, g.up);
+					d.wspec = (cd*) dev_alloc(sw.size() * sizeof(double));
+					dev_upload(d.wspec, sw.data(), sw.size() * sizeof(double));
+				}
 			}
 		}
 		else if (sp.desc.kind == kFrac)
@@ -448,6 +509,7 @@ Engine::~Engine()
 		dev_free(d.H);
 		dev_free(d.tw);
 		dev_free(d.spec);
+		dev_free(d.wspec);
 		dev_free(d.table);
 		dev_free(d.wtab);
 		dev_free(d.mf_atab);
@@ -519,9 +581,11 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 		switch (sp.desc.kind)
 		{
 		case kConv:
-			*kernel = fuse_with_next(stage) ? "k_convx_whole" :
+			*kernel = fuse_with_next(stage) ?
+				(use_wave(sp.cg) && !opt_.at("mfma_interp") ? "k_convw_whole" : "k_convx_whole") :
 				((opt_.at("fast_conv") || !generic_conv_fits(sp.cg)) && convx_geometry_ok(
-				sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2) ? "k_convx" : "k_conv");
+				sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2) ?
+				(use_wave(sp.cg) ? "k_convw" : "k_convx") : "k_conv");
 			break;
 		case kFrac: *kernel = sp.whole ? "k_whole" : "k_poly"; break;
 		case kHBUp: *kernel = group_len(stage) > 1 ? "k_hbcascade" : "k_hbup"; break;
@@ -682,7 +746,8 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		{
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
-			launch_convx(X, 0, stream);
+			if (use_wave(g)) launch_convw(X, 0, stream);
+			else launch_convx(X, 0, stream);
 			if (L.tail_ring != nullptr) tail_done_ = true;
 		}
 		else
@@ -934,6 +999,11 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 	launch_hbcascade(L, stream);
 }
 
+bool Engine::use_wave(const ConvGeom& g) const
+{
+	return opt_.at("wave_conv") && convw_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2);
+}
+
 bool Engine::fuse_with_next(size_t s) const
 {
 	if (!opt_.at("fuse") || !opt_.at("fast_conv") || s + 1 >= plan_.stages.size()) return false;
@@ -966,7 +1036,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 		throw std::runtime_error("transform plan too deep");
 	for (int i = 0; i < L.n_fwd; i++) L.fwd_radix[i] = d.fwd_radix[(size_t) i];
 	for (int i = 0; i < L.n_inv; i++) L.inv_radix[i] = d.inv_radix[(size_t) i];
-	L.H = d.H; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec;
+	L.H = d.H; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.wspec = d.wspec;
 	L.nch = nch_;
 	L.threads = opt_.at("conv_threads");
 	L.src = src;
@@ -1066,7 +1136,8 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			B.u_lo = (int) (jlo * In / Out - w.fll - t0);
 			B.pad = 0;
 		}
-		launch_convx(X, 1, stream);
+		if (use_wave(c.cg)) launch_convw(X, 1, stream);
+		else launch_convx(X, 1, stream);
 		if (X.c.tail_ring != nullptr) tail_done_ = true;
 		X.c.tail_ring = nullptr; // once per call
 	}

@@ -64,6 +64,7 @@ private:
 		double* H = nullptr;
 		cd* tw = nullptr;
 		cd* spec = nullptr; // fast-path spectral constants
+		cd* wspec = nullptr; // the same for the wave-per-block kernel (per backward bin)
 		int tw_len = 0;
 		double* table = nullptr;
 		double* wtab = nullptr; // whole-step bank, transposed per residue class (fused kernel)
@@ -85,6 +86,7 @@ private:
 	void plan_transforms();
 	void ensure_ring(size_t s);
 	bool fuse_with_next(size_t s) const;
+	bool use_wave(const ConvGeom& g) const;
 	void prepare_mfma(size_t s);
 	int group_len(size_t s) const;
 	void launch_cascade(size_t s, int glen, long long fa, long long fb, const SrcView& src,

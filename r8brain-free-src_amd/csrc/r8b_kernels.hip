@@ -73,6 +73,9 @@
 #endif
 #include "r8b_kernel_phases.h"
 #include "r8b_convx.h"
+// nothing is scheduled across this point (no instruction is emitted)
+#define R8B_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#include "r8b_convw.h"
 #include "r8b_pcm.h"
 
 namespace r8bhip {
@@ -401,6 +404,69 @@ __global__ __launch_bounds__(kConvxThreads, (LOGN + (UPLOG > 0 ? UPLOG : 0) >= 1
 	convx_body<LOGN, UPLOG, MODE, FLENP>(ex, X, reinterpret_cast<double*>(smem), X.c.k0 + blk, (int) ch);
 }
 
+// ------------------------------------------------------------------ fast path, one wave per block
+template<int LOGN, int UPLOG>
+struct WaveExec
+{
+	ConvwState<LOGN, UPLOG> st;
+	// the steps of a block exchange data between the lanes of ONE wave through LDS: the LDS queue
+	// of a wave is in order, so only the compiler has to be kept from moving accesses across
+	template<class F>
+	__device__ __forceinline__ void step(F f)
+	{
+		f((int) threadIdx.x, st);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+};
+
+template<int LOGN, int UPLOG, int MODE, int FLENP>
+#ifndef R8B_CONVW_WAVES
+#define R8B_CONVW_WAVES 2
+#endif
+__global__ __launch_bounds__(kWaveLanes) __attribute__((amdgpu_waves_per_eu(R8B_CONVW_WAVES)))
+void k_convw(const ConvxLaunch X)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	// XCD-aware mapping as in k_convx
+	const unsigned w = blockIdx.x, nblk = (unsigned) X.c.nblk, nch = (unsigned) X.c.nch;
+	unsigned blk, ch;
+	if ((nch & 7u) == 0)
+	{
+		const unsigned i = w >> 3;
+		blk = i % nblk;
+		ch = ((i / nblk) << 3) + (w & 7u);
+	}
+	else
+	{
+		blk = w % nblk;
+		ch = w / nblk;
+	}
+	blk = (unsigned) __builtin_amdgcn_readfirstlane((int) blk);
+	ch = (unsigned) __builtin_amdgcn_readfirstlane((int) ch);
+	WaveExec<LOGN, UPLOG> ex;
+	convw_body<LOGN, UPLOG, MODE, FLENP>(ex, X, reinterpret_cast<double*>(smem), X.c.k0 + blk, (int) ch);
+}
+
+template<int LOGN, int UPLOG, int MODE, int FLENP>
+void launch_convw_t(const ConvxLaunch& X, hipStream_t stream)
+{
+	static bool attr_done = false;
+	auto kern = k_convw<LOGN, UPLOG, MODE, FLENP>;
+	const size_t lds = (size_t) convw_lds_need(convw_plane_doubles<LOGN, UPLOG>(), X.c.in_len) *
+		sizeof(double);
+	if (!attr_done)
+	{
+		check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+			hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(k_convw)");
+		attr_done = true;
+	}
+	hipLaunchKernelGGL(kern, dim3((unsigned) X.c.nblk * (unsigned) X.c.nch), dim3(kWaveLanes), lds,
+		stream, X);
+	check(hipGetLastError(), "launch k_convw");
+}
+
 template<int LOGN, int UPLOG, int MODE, int FLENP>
 void launch_convx_t(const ConvxLaunch& X, hipStream_t stream)
 {
@@ -521,6 +587,25 @@ void R8B_LAUNCH(launch_convx)(const ConvxLaunch& X, int mode, void* stream)
 	throw std::runtime_error("launch_convx: geometry not instantiated");
 }
 
+void R8B_LAUNCH(launch_convw)(const ConvxLaunch& X, int mode, void* stream)
+{
+	int logn = 0;
+	while ((2 << logn) < X.c.n_in) logn++;
+	const int up = X.c.up;
+	const bool wide = X.flen > 24;
+#define R8B_CONVW_DISPATCH(LN, UL) \
+	if (logn == LN && up == (1 << UL)) \
+	{ \
+		if (mode == 0) launch_convw_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
+		else if (wide) launch_convw_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
+		else launch_convw_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
+		return; \
+	}
+	R8B_CONVW_GEOMS(R8B_CONVW_DISPATCH)
+#undef R8B_CONVW_DISPATCH
+	throw std::runtime_error("launch_convw: geometry not instantiated");
+}
+
 void R8B_LAUNCH(launch_hbcascade)(const HBCascadeLaunch& L, void* stream)
 {
 	const long long n = L.b - L.a;
@@ -548,6 +633,7 @@ void launch_poly_pcm(const PolyLaunch& L, void* stream);
 void launch_hbup_pcm(const HBLaunch& L, void* stream);
 void launch_hbdown_pcm(const HBLaunch& L, void* stream);
 void launch_convx_pcm(const ConvxLaunch& X, int mode, void* stream);
+void launch_convw_pcm(const ConvxLaunch& X, int mode, void* stream);
 void launch_hbcascade_pcm(const HBCascadeLaunch& L, void* stream);
 void launch_tail_pcm(const TailLaunch& L, void* stream);
 
@@ -569,6 +655,12 @@ void launch_convx(const ConvxLaunch& X, int mode, void* stream)
 {
 	if ((X.c.src.cur_fmt | X.c.dst.fmt | X.wdst.fmt) != kPcmF64) launch_convx_pcm(X, mode, stream);
 	else launch_convx_f64(X, mode, stream);
+}
+
+void launch_convw(const ConvxLaunch& X, int mode, void* stream)
+{
+	if ((X.c.src.cur_fmt | X.c.dst.fmt | X.wdst.fmt) != kPcmF64) launch_convw_pcm(X, mode, stream);
+	else launch_convw_f64(X, mode, stream);
 }
 
 void launch_tail(const TailLaunch& L, void* stream)

@@ -67,6 +67,7 @@ struct ConvLaunch
 	const double* H; // bl2/2+1 reals: zero-phase kernel spectrum / bl2
 	const cd* tw;    // tw_len complex: exp(-2 pi i e / tw_len)
 	const cd* spec;  // fast path only: per-slot spectral-stage constants (r8b_convx.h)
+	const cd* wspec; // wave-per-block form: (ca, cb) per backward bin, [slot][lane] (r8b_convw.h)
 	int tw_len;
 	// work: blocks [k0, k0+nblk) x channels [0, nch); outputs clipped to [a, b)
 	long long k0;
@@ -217,6 +218,14 @@ inline bool convx_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow
 	return false;
 }
 
+// wave-per-block form of the fast path (r8b_convw.h): 1024- or 2048-point transforms, no decimation
+inline bool convw_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
+{
+	if (!convx_geometry_ok(n_in, n_out, up, down, up_pow2) || down != 1) return false;
+	return (n_in == 2048 || n_in == 4096) && (n_out == 2048 || n_out == 4096);
+}
+#define R8B_CONVW_GEOMS(M) M(10, 0) M(10, 1) M(11, 0)
+
 // launchers (asynchronous on `stream`, a hipStream_t)
 void launch_conv(const ConvLaunch& L, void* stream);
 void launch_whole(const WholeLaunch& L, void* stream);
@@ -230,6 +239,8 @@ void launch_pcm_out(const PcmLaunch& L, void* stream); // planar fp64 -> PCM
 // mode 0: convolver output to X.c.dst; mode 1 / 2: fused interpolator output to X.wdst (FIR on
 // the vector ALU / on the matrix cores)
 void launch_convx(const ConvxLaunch& X, int mode, void* stream);
+// the same work, one wavefront per block (modes 0 and 1; needs X.c.wspec)
+void launch_convw(const ConvxLaunch& X, int mode, void* stream);
 
 // memory helpers; all throw std::runtime_error with the HIP error text on failure
 void dev_select(int device);          // -1 keeps the current device

@@ -20,6 +20,7 @@
 #define R8B_LDS_ARRIVED(N, v, o)
 #include "r8b_kernel_phases.h"
 #include "r8b_convx.h"
+#include "r8b_convw.h"
 #include "r8b_pcm.h"
 
 namespace r8bhip {
@@ -225,6 +226,56 @@ void emul_convx_t(const ConvxLaunch& X)
 			EmulExec<LOGN, UPLOG> ex;
 			convx_body<LOGN, UPLOG, MODE, FLENP>(ex, X, base, X.c.k0 + bx, ch);
 		}
+}
+
+// wave-per-block form: a step runs on all 64 lanes before the next one starts
+template<int LOGN, int UPLOG>
+struct EmulWaveExec
+{
+	std::vector<ConvwState<LOGN, UPLOG>> st;
+	EmulWaveExec() : st((size_t) kWaveLanes) {}
+	template<class F>
+	void step(F f)
+	{
+		for (int l = 0; l < kWaveLanes; l++) f(l, st[(size_t) l]);
+	}
+};
+
+template<int LOGN, int UPLOG, int MODE, int FLENP>
+void emul_convw_t(const ConvxLaunch& X)
+{
+	std::vector<double> lds((size_t) convw_lds_need(convw_plane_doubles<LOGN, UPLOG>(), X.c.in_len) + 2);
+	double* base = lds.data();
+	if (((size_t) base & 15) != 0) base++;
+	for (int ch = 0; ch < X.c.nch; ch++)
+		for (int bx = 0; bx < X.c.nblk; bx++)
+		{
+			for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
+			EmulWaveExec<LOGN, UPLOG> ex;
+			for (auto& s : ex.st)
+				for (int i = 0; i < ConvwGeom<LOGN, UPLOG>::MX; i++)
+					s.vr[i] = s.vi[i] = std::numeric_limits<double>::quiet_NaN();
+			convw_body<LOGN, UPLOG, MODE, FLENP>(ex, X, base, X.c.k0 + bx, ch);
+		}
+}
+
+void launch_convw(const ConvxLaunch& X, int mode, void*)
+{
+	int logn = 0;
+	while ((2 << logn) < X.c.n_in) logn++;
+	const int up = X.c.up;
+	const bool wide = X.flen > 24;
+#define R8B_CONVW_DISPATCH(LN, UL) \
+	if (logn == LN && up == (1 << UL)) \
+	{ \
+		if (mode == 0) emul_convw_t<LN, UL, 0, 24>(X); \
+		else if (wide) emul_convw_t<LN, UL, 1, 32>(X); \
+		else emul_convw_t<LN, UL, 1, 24>(X); \
+		return; \
+	}
+	R8B_CONVW_GEOMS(R8B_CONVW_DISPATCH)
+#undef R8B_CONVW_DISPATCH
+	throw std::runtime_error("emul launch_convw: geometry not instantiated");
 }
 
 void launch_convx(const ConvxLaunch& X, int mode, void*)

@@ -92,6 +92,23 @@ def test_emulated_matrix_core_interpolator(emul, case):
     assert rms <= RMS_TOL and pk <= PEAK_TOL, (rms, pk)
 
 
+@pytest.mark.parametrize("fuse", [1, 0])
+@pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[1], STREAM_CASES[6], STREAM_CASES[13],
+                                  STREAM_CASES[18], (192000.0, 44100.0, 4096, 1000, 20000, 2.0, 180.15)])
+def test_emulated_wave_per_block_convolver(emul, case, fuse):
+    """option wave_conv: 1024/2048-point fast convolvers as one wavefront per block
+    (r8b_convw.h: in-register radix passes, lane transpositions through LDS)"""
+    src, dst, maxin, chunk, n, tb, att = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, lib=emul)
+    b.set_option("wave_conv", 1)
+    b.set_option("fuse", fuse)
+    b.set_option("timing", 1)
+    assert any(t[0].startswith("k_convw") for t in b.stage_timings())
+    b.set_option("timing", 0)
+    rms, pk = compare_stream(b, src, dst, maxin, chunk, n, tb, att, 2)
+    assert rms <= RMS_TOL and pk <= PEAK_TOL, (rms, pk)
+
+
 def test_unsupported_geometry_fails_loudly(emul):
     """A radix-3 convolver whose 32768-point block does not fit LDS: creation must fail with a
     message, not fall back to anything."""
