@@ -366,11 +366,59 @@ R8B_HD cd src_block_load2(const SrcBlock& b, int rel)
 // forward pass (thread b owns butterfly b: complex elements b + p*N/R, i.e. real samples
 // 2e, 2e+1 of the circular block).  Issued one block ahead, at the start of the long
 // interpolation phase of the previous block, so that HBM latency is off the critical path.
-template<int LOGN, int UPLOG>
+R8B_HD double src_block_load1(const SrcBlock& b, int rel)
+{
+	const double* pr = b.pr + ((b.b_lo + (unsigned) rel) & b.mask);
+	const double* pc = b.pc + rel;
+	const double v = *(rel >= b.c_rel ? pc : pr);
+	return rel < b.z_rel ? 0.0 : v;
+}
+
+// MODE 3, non-2^k up-sampling (3x): virtual sample t of the zero-stuffed stream is x[t / up] when
+// up divides t, else 0 (reference CDSPBlockConvolver.h:414-496, copyUpsample).  base_v = up * B +
+// bm is the block's virtual start; for the circular offset rel_v the source index is
+// B + floor((bm + rel_v) / up).
+R8B_HD double cx_stuffed_sample(const SrcBlock& sb, int up, int bm, int rel_v, int bias)
+{
+	// bias = up * kb keeps the dividend positive (rel_v >= -bl2)
+	const unsigned w = (unsigned) (bm + rel_v + bias);
+	const unsigned q = up == 3 ? w / 3u : w / (unsigned) up;
+	const bool hit = q * (unsigned) up == w;
+	const double v = src_block_load1(sb, hit ? (int) q - bias / up : 0);
+	return hit ? v : 0.0;
+}
+
+template<int LOGN, int UPLOG, int MODE = 0>
 R8B_HD void cx_prefetch(const ConvLaunch& L, ConvxState<LOGN, UPLOG>& st, long long k, int ch, int tid)
 {
 	typedef ConvxState<LOGN, UPLOG> St;
 	constexpr int R = St::RF, N = 1 << LOGN, nb = N / R, NIN = 2 * N;
+	if constexpr (MODE == 3)
+	{
+		if (!L.up_pow2)
+		{
+			const long long base_v = k * (long long) L.blk_stride + L.blk_offset;
+			const long long B = base_v / L.up;
+			const int bm = (int) (base_v - B * L.up);
+			const int bias = L.up * (NIN / L.up + 2);
+			const SrcBlock sb = src_block(L.src, ch, B);
+#pragma unroll
+			for (int f = 0; f < St::FF; f++)
+			{
+				const int b = tid + f * kConvxThreads;
+				if (b >= nb) continue;
+#pragma unroll
+				for (int p = 0; p < R; p++)
+				{
+					const int i = 2 * (b + p * nb);
+					st.pre[f][p].re = cx_stuffed_sample(sb, L.up, bm, i < L.in_len ? i : i - NIN, bias);
+					st.pre[f][p].im = cx_stuffed_sample(sb, L.up, bm,
+						i + 1 < L.in_len ? i + 1 : i + 1 - NIN, bias);
+				}
+			}
+			return;
+		}
+	}
 	const int iln = L.in_len / L.up;
 	const long long base = (k * (long long) L.blk_stride + L.blk_offset) / L.up;
 	const SrcBlock sb = src_block(L.src, ch, base);
@@ -657,11 +705,28 @@ R8B_HD void cx_final_store(const ConvLaunch& L, double* y, const ConvxState<LOGN
 // MODE 0: K7, write the block's valid outputs that fall into [a, b).  Decimating: output q sits at
 // virtual time q * down; the block's first one is (block start) / down - floor(fl2 / down), both
 // in_len and the block starts being multiples of down (reference CDSPBlockConvolver.h:150-165).
-template<int UPLOG>
+template<int UPLOG, int MODE = 0>
 R8B_HD void cx_store_conv(const ConvLaunch& L, const double* y, long long k, int ch, int tid)
 {
 	long long q0 = cx_block_t0(L, k);
 	int n = L.in_len;
+	if constexpr (MODE == 3)
+	{
+		if (!L.down_pow2 && L.down > 1)
+		{
+			// strided decimation (3x): output q sits at virtual time q * down (reference
+			// CDSPBlockConvolver.h:564-583); y[u] is virtual time t0 + u
+			const long long t0 = q0;
+			const long long qf = t0 <= 0 ? -((-t0) / L.down) : (t0 + L.down - 1) / L.down;
+			const int u0 = (int) (qf * L.down - t0);
+			for (int j = tid; u0 + j * L.down < n; j += kConvxThreads)
+			{
+				const long long q = qf + j;
+				if (q >= L.a && q < L.b) dst_store(L.dst, ch, q, y[u0 + j * L.down]);
+			}
+			return;
+		}
+	}
 	if constexpr (UPLOG < 0)
 	{
 		q0 = ((k * (long long) L.blk_stride + L.blk_offset) >> -UPLOG) - (L.fl2 >> -UPLOG);
@@ -855,7 +920,7 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 	cd* const buf = reinterpret_cast<cd*>(rbuf);
 	ex.phase([&](int tid, St& st)
 	{
-		cx_prefetch<LOGN, UPLOG>(L, st, k, ch, tid);
+		cx_prefetch<LOGN, UPLOG, MODE>(L, st, k, ch, tid);
 		if constexpr (St::FF == 1)
 		{
 			if (tid < (1 << LOGN) / St::RF)
@@ -878,7 +943,7 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 	ex.phase([&](int tid, St& st) { cx_final_compute<LOGN, UPLOG>(L, buf, st, tid); });
 	ex.phase([&](int tid, St& st)
 	{
-		cx_final_store<LOGN, UPLOG, MODE != 0>(L, rbuf, st, k, tid);
+		cx_final_store<LOGN, UPLOG, MODE == 1 || MODE == 2>(L, rbuf, st, k, tid);
 		if constexpr (MODE == 1) cx_whole_row<FLENP>(X, st.row, tid);
 		if constexpr (MODE == 2) ex.template mfma_prefetch<(FLENP > 24 ? 12 : 10)>(X);
 	});
@@ -901,7 +966,7 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 		ex.phase([&](int tid, St& st)
 		{
 			if constexpr (MODE == 1) cx_whole_compute<FLENP>(X, rbuf, st.row, k, ch, tid);
-			else cx_store_conv<UPLOG>(L, rbuf, k, ch, tid);
+			else cx_store_conv<UPLOG, MODE>(L, rbuf, k, ch, tid);
 		});
 	}
 }

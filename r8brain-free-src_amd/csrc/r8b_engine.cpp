@@ -388,7 +388,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 			if (g.n_in < 32 || g.n_out < 32)
 				throw std::runtime_error("block convolver transform too short");
 			// the generic kernel keeps both transforms' arrays in LDS, the fast path works in place
-			const bool fast_ok = convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2) &&
+			const bool m3 = convx_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
+			const bool fast_ok = (m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2)) &&
 				convx_work_bytes(std::max(g.n_in, g.n_out) / 2) <= 160 * 1024;
 			if (!generic_conv_fits(g) && !fast_ok)
 				throw std::runtime_error("low-pass filter too long for the LDS-resident "
@@ -400,11 +401,13 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 			d.tw_len = g.bl2;
 			d.tw = (cd*) dev_alloc(tw.size() * sizeof(double));
 			dev_upload(d.tw, tw.data(), tw.size() * sizeof(double));
-			if (convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
+			if (m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
 			{
-				const std::vector<double> sc = g.down > 1 ?
-					spectral_constants_down(H, tw, g.bl2, g.n_in, g.down) :
-					spectral_constants(H, tw, g.bl2, g.n_in, g.up);
+				// (3x zero stuffing / 3x strided decimation are 1:1 for the transforms)
+				const int eup = g.up_pow2 ? g.up : 1, edown = g.down_pow2 ? g.down : 1;
+				const std::vector<double> sc = edown > 1 ?
+					spectral_constants_down(H, tw, g.bl2, g.n_in, edown) :
+					spectral_constants(H, tw, g.bl2, g.n_in, eup);
 				d.spec = (cd*) dev_alloc(sc.size() * sizeof(double));
 				dev_upload(d.spec, sc.data(), sc.size() * sizeof(double));
 				if (convw_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
@@ -583,8 +586,9 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 		case kConv:
 			*kernel = fuse_with_next(stage) ?
 				(use_wave(sp.cg) && !opt_.at("mfma_interp") ? "k_convw_whole" : "k_convx_whole") :
-				((opt_.at("fast_conv") || !generic_conv_fits(sp.cg)) && convx_geometry_ok(
-				sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2) ?
+				((opt_.at("fast_conv") || !generic_conv_fits(sp.cg)) && (convx_mode3_ok(sp.cg.n_in,
+				sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2, sp.cg.down_pow2) ||
+				convx_geometry_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2)) ?
 				(use_wave(sp.cg) ? "k_convw" : "k_convx") : "k_conv");
 			break;
 		case kFrac: *kernel = sp.whole ? "k_whole" : "k_poly"; break;
@@ -741,12 +745,14 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		L.nblk = (int) (k1 - L.k0 + 1);
 		L.a = a; L.b = b;
 		L.dst = dst;
+		const bool m3 = convx_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
 		if ((opt_.at("fast_conv") || !generic_conv_fits(g)) &&
-			convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
+			(m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2)))
 		{
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
-			if (use_wave(g)) launch_convw(X, 0, stream);
+			if (m3) launch_convx(X, 3, stream);
+			else if (use_wave(g)) launch_convw(X, 0, stream);
 			else launch_convx(X, 0, stream);
 			if (L.tail_ring != nullptr) tail_done_ = true;
 		}

@@ -559,15 +559,17 @@ void R8B_LAUNCH(launch_convx)(const ConvxLaunch& X, int mode, void* stream)
 {
 	int logn = 0;
 	while ((2 << logn) < X.c.n_in) logn++;
-	const int up = X.c.up;
+	// mode 3: a 3x zero-stuffed input / 3x strided output is 1:1 as far as the transforms go
+	const int up = X.c.up_pow2 ? X.c.up : 1;
 	const bool wide = X.flen > 24;
 #define R8B_CONVX_DISPATCH_DOWN(LN, DL) \
 	if (logn == LN && X.c.down == (1 << DL)) \
 	{ \
-		launch_convx_t<LN, -DL, 0, 24>(X, (hipStream_t) stream); \
+		if (mode == 3) launch_convx_t<LN, -DL, 3, 24>(X, (hipStream_t) stream); \
+		else launch_convx_t<LN, -DL, 0, 24>(X, (hipStream_t) stream); \
 		return; \
 	}
-	if (X.c.down > 1)
+	if (X.c.down_pow2 && X.c.down > 1)
 	{
 		R8B_CONVX_GEOMS_DOWN(R8B_CONVX_DISPATCH_DOWN)
 	}
@@ -576,6 +578,7 @@ void R8B_LAUNCH(launch_convx)(const ConvxLaunch& X, int mode, void* stream)
 	if (logn == LN && up == (1 << UL)) \
 	{ \
 		if (mode == 0) launch_convx_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
+		else if (mode == 3) launch_convx_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
 		else if (mode == 2 && wide) launch_convx_t<LN, UL, 2, 32>(X, (hipStream_t) stream); \
 		else if (mode == 2) launch_convx_t<LN, UL, 2, 24>(X, (hipStream_t) stream); \
 		else if (wide) launch_convx_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \

@@ -218,6 +218,14 @@ inline bool convx_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow
 	return false;
 }
 
+// MODE 3 of the fast path: the same transforms behind a zero-stuffing load (3x up-sampling) and/or
+// in front of a strided store (3x decimation) -- ratios 3/1, 1/3, 2/3, 3/2
+inline bool convx_mode3_ok(int n_in, int n_out, int up, int down, bool up_pow2, bool down_pow2)
+{
+	if (!((!up_pow2 && up == 3) || (!down_pow2 && down == 3))) return false;
+	return convx_geometry_ok(n_in, n_out, up_pow2 ? up : 1, down_pow2 ? down : 1, true);
+}
+
 // wave-per-block form of the fast path (r8b_convw.h): 1024- or 2048-point transforms, no decimation
 inline bool convw_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
 {

@@ -282,15 +282,16 @@ void launch_convx(const ConvxLaunch& X, int mode, void*)
 {
 	int logn = 0;
 	while ((2 << logn) < X.c.n_in) logn++;
-	const int up = X.c.up;
+	const int up = X.c.up_pow2 ? X.c.up : 1;
 	const bool wide = X.flen > 24;
 #define R8B_CONVX_DISPATCH_DOWN(LN, DL) \
 	if (logn == LN && X.c.down == (1 << DL)) \
 	{ \
-		emul_convx_t<LN, -DL, 0, 24>(X); \
+		if (mode == 3) emul_convx_t<LN, -DL, 3, 24>(X); \
+		else emul_convx_t<LN, -DL, 0, 24>(X); \
 		return; \
 	}
-	if (X.c.down > 1)
+	if (X.c.down_pow2 && X.c.down > 1)
 	{
 		R8B_CONVX_GEOMS_DOWN(R8B_CONVX_DISPATCH_DOWN)
 	}
@@ -299,6 +300,7 @@ void launch_convx(const ConvxLaunch& X, int mode, void*)
 	if (logn == LN && up == (1 << UL)) \
 	{ \
 		if (mode == 0) emul_convx_t<LN, UL, 0, 24>(X); \
+		else if (mode == 3) emul_convx_t<LN, UL, 3, 24>(X); \
 		else if (mode == 2 && wide) emul_convx_t<LN, UL, 2, 32>(X); \
 		else if (mode == 2) emul_convx_t<LN, UL, 2, 24>(X); \
 		else if (wide) emul_convx_t<LN, UL, 1, 32>(X); \
