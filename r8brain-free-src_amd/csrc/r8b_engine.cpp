@@ -999,9 +999,13 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 	int tile = 1 << glen;
 	while (tile < 4096) tile <<= 1;
 	L.tile = tile;
-	L.buf = tile / 2 + 96; // largest intermediate stream of a tile (input of the last stage)
+	L.buf = tile / 2 + 96;  // largest intermediate stream of a tile (input of the last stage)
+	L.buf2 = tile / 4 + 96; // the one before it (the buffers alternate)
 	L.nch = nch_;
 	L.src = src; L.dst = dst;
+	// output q is even for the first of a pair: its element index is even when the offset is
+	L.pair_ok = dst.fmt == kPcmF64 && ((size_t) dst.p & 15) == 0 && (dst.stride & 1) == 0 &&
+		(dst.off & 1) == 0 ? 1 : 0;
 	launch_hbcascade(L, stream);
 }
 

@@ -693,6 +693,17 @@ R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, int s, const double* xin, long
 		const int o = qoff + 2 * i;
 		if (last)
 		{
+			if (L.pair_ok && o >= 0 && o + 1 < nout)
+			{
+				// the even/odd output pair as one 16-byte store (full 128-byte lines per wave
+				// instruction instead of two half-used ones)
+				cd v;
+				v.re = ev;
+				v.im = od;
+				*reinterpret_cast<cd*>(L.dst.p + ((long long) ch * L.dst.stride +
+					((q + L.dst.off) & L.dst.mask))) = v;
+				continue;
+			}
 			if (o >= 0 && o < nout) dst_store(L.dst, ch, q, ev);
 			if (o + 1 >= 0 && o + 1 < nout) dst_store(L.dst, ch, q + 1, od);
 		}

@@ -213,8 +213,10 @@ __global__ void k_hbdown(const HBLaunch L)
 __global__ void k_hbcascade(const HBCascadeLaunch L)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
-	double* const b0 = reinterpret_cast<double*>(smem);
-	double* const b1 = b0 + L.buf;
+	// two buffers, alternating; the last stage's input (tile/2 samples) lands in the big one, so
+	// the other never holds more than tile/4
+	double* const big = reinterpret_cast<double*>(smem);
+	double* const small = big + L.buf;
 	const int tid = threadIdx.x, nthr = blockDim.x;
 	const int ch = blockIdx.y;
 	const long long q0 = L.a + (long long) blockIdx.x * L.tile;
@@ -222,10 +224,10 @@ __global__ void k_hbcascade(const HBCascadeLaunch L)
 	if (q1 > L.b) q1 = L.b;
 	HBCRanges R;
 	hbc_ranges(L, q0, q1, R);
-	hbc_load(L, R, b0, ch, tid, nthr);
+	double* xin = ((L.nst - 1) & 1) ? small : big;
+	double* yout = ((L.nst - 1) & 1) ? big : small;
+	hbc_load(L, R, xin, ch, tid, nthr);
 	__syncthreads();
-	double* xin = b0;
-	double* yout = b1;
 	long long in_lo = R.in_lo;
 	for (int s = 0; s < L.nst; s++)
 	{
@@ -615,7 +617,7 @@ void R8B_LAUNCH(launch_hbcascade)(const HBCascadeLaunch& L, void* stream)
 	if (n <= 0) return;
 	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
 	hipLaunchKernelGGL(k_hbcascade, dim3(tiles, (unsigned) L.nch), dim3(256),
-		(size_t) 2 * L.buf * sizeof(double), (hipStream_t) stream, L);
+		(size_t) (L.buf + L.buf2) * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_hbcascade");
 }
 

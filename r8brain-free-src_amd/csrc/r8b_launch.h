@@ -130,7 +130,8 @@ struct HBCascadeLaunch
 	double taps[kMaxCascade][14];
 	long long a, b;                // outputs of the LAST stage to produce
 	int tile;                      // last-stage outputs per workgroup (multiple of 2^nst)
-	int buf;                       // doubles per LDS buffer (two buffers): tile/2 + slack
+	int buf, buf2;                 // doubles of the two LDS buffers: tile/2 + slack, tile/4 + slack
+	int pair_ok;                   // the destination admits aligned 16-byte stores of output pairs
 	int nch;
 	SrcView src;                   // input stream of the first stage
 	DstView dst;

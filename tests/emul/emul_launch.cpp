@@ -315,7 +315,7 @@ void launch_convx(const ConvxLaunch& X, int mode, void*)
 void launch_hbcascade(const HBCascadeLaunch& L, void*)
 {
 	const int nthr = 256;
-	std::vector<double> lds((size_t) 2 * L.buf);
+	std::vector<double> lds((size_t) (L.buf + L.buf2));
 	const long long n = L.b - L.a;
 	if (n <= 0) return;
 	const int tiles = (int) ((n + L.tile - 1) / L.tile);
@@ -328,14 +328,18 @@ void launch_hbcascade(const HBCascadeLaunch& L, void*)
 			if (q1 > L.b) q1 = L.b;
 			HBCRanges R;
 			hbc_ranges(L, q0, q1, R);
-			if (R.in_hi - R.in_lo > L.buf) throw std::runtime_error("emul: cascade LDS");
-			double* xin = lds.data();
-			double* yout = xin + L.buf;
+			// big / small buffer as in k_hbcascade; every stream must fit the one it lands in
+			double* const big = lds.data();
+			double* const small = big + L.buf;
+			double* xin = ((L.nst - 1) & 1) ? small : big;
+			double* yout = ((L.nst - 1) & 1) ? big : small;
+			if (R.in_hi - R.in_lo > (xin == big ? L.buf : L.buf2))
+				throw std::runtime_error("emul: cascade LDS");
 			for (int t = 0; t < nthr; t++) hbc_load(L, R, xin, ch, t, nthr);
 			long long in_lo = R.in_lo;
 			for (int s = 0; s < L.nst; s++)
 			{
-				if (s + 1 < L.nst && R.hi[s] - R.lo[s] > L.buf)
+				if (s + 1 < L.nst && R.hi[s] - R.lo[s] > (yout == big ? L.buf : L.buf2))
 					throw std::runtime_error("emul: cascade LDS");
 				for (int t = 0; t < nthr; t++)
 					hbc_stage(L, s, xin, in_lo, R.lo[s], R.hi[s], yout, s + 1 == L.nst, ch, t, nthr);

@@ -6,9 +6,12 @@ run() {
 run --src 96000 --dst 44100
 run --src 176400 --dst 44100
 run --src 96000 --dst 48000
-run --src 88200 --dst 44100 --opt fast_conv=0
 run --src 44100 --dst 44101
 run --src 44100 --dst 88200
 run --src 48000 --dst 32000
+run --src 48000 --dst 32000 --opt fast_conv=0
+run --src 32000 --dst 48000
+run --src 44100 --dst 132300
+run --src 96000 --dst 32000
 run --src 44100 --dst 2822400 --block 1024 --channels 64
 run --src 44100 --dst 2822400 --block 1024 --channels 1024
