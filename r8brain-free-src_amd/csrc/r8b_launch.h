@@ -197,16 +197,17 @@ struct ConvxLaunch
 // for the 2x-decimating convolver (log2 of the forward complex length, down shift)
 #define R8B_CONVX_GEOMS(M) M(8, 1) M(9, 0) M(9, 1) M(10, 0) M(10, 1) M(11, 0) M(11, 1) M(12, 0) \
 	M(12, 1) M(13, 0)
-#define R8B_CONVX_GEOMS_DOWN(M) M(8, 1) M(9, 1) M(10, 1) M(11, 1) M(12, 1) M(13, 1)
+#define R8B_CONVX_GEOMS_DOWN(M) M(8, 1) M(9, 1) M(10, 1) M(11, 1) M(12, 1) M(13, 1) \
+	M(10, 2) M(11, 2) M(12, 2) M(13, 2)
 
 inline bool convx_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
 {
-	if (!up_pow2 || (down != 1 && down != 2) || (up != 1 && up != 2)) return false;
-	if (down == 2 ? (up != 1 || n_out * 2 != n_in) : n_out != n_in * up) return false;
+	if (!up_pow2 || (down != 1 && down != 2 && down != 4) || (up != 1 && up != 2)) return false;
+	if (down > 1 ? (up != 1 || n_out * down != n_in) : n_out != n_in * up) return false;
 	int logn = 0;
 	while ((2 << logn) < n_in) logn++;
 	if ((2 << logn) != n_in) return false;
-	if (down == 2)
+	if (down > 1)
 	{
 #define R8B_CONVX_CHECK(LN, DL) if (logn == LN && down == (1 << DL)) return true;
 		R8B_CONVX_GEOMS_DOWN(R8B_CONVX_CHECK)
@@ -220,7 +221,7 @@ inline bool convx_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow
 }
 
 // MODE 3 of the fast path: the same transforms behind a zero-stuffing load (3x up-sampling) and/or
-// in front of a strided store (3x decimation) -- ratios 3/1, 1/3, 2/3, 3/2
+// in front of a strided store (3x decimation) -- ratios 3/1, 1/3, 2/3, 3/2, 3/4
 inline bool convx_mode3_ok(int n_in, int n_out, int up, int down, bool up_pow2, bool down_pow2)
 {
 	if (!((!up_pow2 && up == 3) || (!down_pow2 && down == 3))) return false;
