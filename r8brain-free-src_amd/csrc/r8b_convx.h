@@ -34,6 +34,12 @@
 namespace r8bhip {
 
 static const int kConvxThreads = 256;
+
+// compiler scheduling fence (no instruction is emitted): r8b_kernels.hip defines it as
+// __builtin_amdgcn_sched_barrier(0); elsewhere it is nothing
+#ifndef R8B_SCHED_FENCE
+#define R8B_SCHED_FENCE()
+#endif
 static const int kConvxRunPad = 32; // zeros behind the linear output run (see cx_final_store)
 
 // padded complex index: one spare slot after every 16
@@ -789,14 +795,18 @@ R8B_HD void cx_whole_compute(const ConvxLaunch& X, const double* y, const double
 		R8B_LDS_WINDOW(FLEN, v, y + u);
 		double s0 = 0.0, s1 = 0.0;
 		// taps in groups of eight, each behind the arrival of its own reads
+		// (the fences keep the scheduler from sinking the multiply-adds below the last wait)
 		R8B_LDS_ARRIVED(FLEN, v, 0);
 		cx_mac8(row, v, s0, s1);
+		R8B_SCHED_FENCE();
 		R8B_LDS_ARRIVED(FLEN, v, 8);
 		cx_mac8(row + 8, v + 8, s0, s1);
+		R8B_SCHED_FENCE();
 		R8B_LDS_ARRIVED(FLEN, v, 16);
 		cx_mac8(row + 16, v + 16, s0, s1);
 		if constexpr (FLEN > 24)
 		{
+			R8B_SCHED_FENCE();
 			R8B_LDS_ARRIVED(FLEN, v, 24);
 			cx_mac8(row + 24, v + 24, s0, s1);
 		}

@@ -72,9 +72,11 @@
 	}
 #endif
 #include "r8b_kernel_phases.h"
-#include "r8b_convx.h"
 // nothing is scheduled across this point (no instruction is emitted)
+#ifndef R8B_NO_SCHED_FENCE
 #define R8B_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#include "r8b_convx.h"
 #include "r8b_convw.h"
 #include "r8b_pcm.h"
 
