@@ -373,73 +373,82 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// to the vector-ALU form on cfg2 (0.357 vs 0.362 ms: 10x fewer LDS reads, 13 % more FFT
 	// blocks), so the simpler form stays the default
 	opt_["mfma_interp"] = 0;
-	dev_.resize(plan_.stages.size());
-	for (size_t s = 0; s < plan_.stages.size(); s++)
+	// a constructor that throws half way must not leak what it has already put on the device
+	try
 	{
-		const StagePlan& sp = plan_.stages[s];
-		StageDev& d = dev_[s];
-		const long long hist = sp.history();
-		d.ring_size = pow2_at_least(s == 0 ? hist : hist + plan_.stage_max_in[s]);
-		// rings are allocated on first use (ensure_ring): the ring between two fused stages is
-		// never touched and would be the largest allocation (cfg2: 512 MB)
-		if (sp.desc.kind == kConv)
+		dev_.resize(plan_.stages.size());
+		for (size_t s = 0; s < plan_.stages.size(); s++)
 		{
-			const ConvGeom& g = sp.cg;
-			if (g.n_in < 32 || g.n_out < 32)
-				throw std::runtime_error("block convolver transform too short");
-			// the generic kernel keeps both transforms' arrays in LDS, the fast path works in place
-			const bool m3 = convx_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
-			const bool fast_ok = (m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2)) &&
-				convx_work_bytes(std::max(g.n_in, g.n_out) / 2) <= 160 * 1024;
-			if (!generic_conv_fits(g) && !fast_ok)
-				throw std::runtime_error("low-pass filter too long for the LDS-resident "
-					"block convolver (transition band too narrow)");
-			const std::vector<double> H = kernel_spectrum(*sp.lp, g.bl2, 1.0 / g.bl2);
-			d.H = (double*) dev_alloc(H.size() * sizeof(double));
-			dev_upload(d.H, H.data(), H.size() * sizeof(double));
-			const std::vector<double> tw = make_twiddles(g.bl2);
-			d.tw_len = g.bl2;
-			d.tw = (cd*) dev_alloc(tw.size() * sizeof(double));
-			dev_upload(d.tw, tw.data(), tw.size() * sizeof(double));
-			if (m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
+			const StagePlan& sp = plan_.stages[s];
+			StageDev& d = dev_[s];
+			const long long hist = sp.history();
+			d.ring_size = pow2_at_least(s == 0 ? hist : hist + plan_.stage_max_in[s]);
+			// rings are allocated on first use (ensure_ring): the ring between two fused stages is
+			// never touched and would be the largest allocation (cfg2: 512 MB)
+			if (sp.desc.kind == kConv)
 			{
-				// (3x zero stuffing / 3x strided decimation are 1:1 for the transforms)
-				const int eup = g.up_pow2 ? g.up : 1, edown = g.down_pow2 ? g.down : 1;
-				const std::vector<double> sc = edown > 1 ?
-					spectral_constants_down(H, tw, g.bl2, g.n_in, edown) :
-					spectral_constants(H, tw, g.bl2, g.n_in, eup);
-				d.spec = (cd*) dev_alloc(sc.size() * sizeof(double));
-				dev_upload(d.spec, sc.data(), sc.size() * sizeof(double));
-				if (convw_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
+				const ConvGeom& g = sp.cg;
+				if (g.n_in < 32 || g.n_out < 32)
+					throw std::runtime_error("block convolver transform too short");
+				// the generic kernel keeps both transforms' arrays in LDS, the fast path works in place
+				const bool m3 = convx_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
+				const bool fast_ok = (m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2)) &&
+					convx_work_bytes(std::max(g.n_in, g.n_out) / 2) <= 160 * 1024;
+				if (!generic_conv_fits(g) && !fast_ok)
+					throw std::runtime_error("low-pass filter too long for the LDS-resident "
+						"block convolver (transition band too narrow)");
+				const std::vector<double> H = kernel_spectrum(*sp.lp, g.bl2, 1.0 / g.bl2);
+				d.H = (double*) dev_alloc(H.size() * sizeof(double));
+				dev_upload(d.H, H.data(), H.size() * sizeof(double));
+				const std::vector<double> tw = make_twiddles(g.bl2);
+				d.tw_len = g.bl2;
+				d.tw = (cd*) dev_alloc(tw.size() * sizeof(double));
+				dev_upload(d.tw, tw.data(), tw.size() * sizeof(double));
+				if (m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
 				{
-					const std::vector<double> sw = spectral_constants_wave(sc, g.n_in, g.up);
-					d.wspec = (cd*) dev_alloc(sw.size() * sizeof(double));
-					dev_upload(d.wspec, sw.data(), sw.size() * sizeof(double));
+					// (3x zero stuffing / 3x strided decimation are 1:1 for the transforms)
+					const int eup = g.up_pow2 ? g.up : 1, edown = g.down_pow2 ? g.down : 1;
+					const std::vector<double> sc = edown > 1 ?
+						spectral_constants_down(H, tw, g.bl2, g.n_in, edown) :
+						spectral_constants(H, tw, g.bl2, g.n_in, eup);
+					d.spec = (cd*) dev_alloc(sc.size() * sizeof(double));
+					dev_upload(d.spec, sc.data(), sc.size() * sizeof(double));
+					if (convw_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
+					{
+						const std::vector<double> sw = spectral_constants_wave(sc, g.n_in, g.up);
+						d.wspec = (cd*) dev_alloc(sw.size() * sizeof(double));
+						dev_upload(d.wspec, sw.data(), sw.size() * sizeof(double));
+					}
+				}
+			}
+			else if (sp.desc.kind == kFrac)
+			{
+				const std::vector<double>& t = sp.bank->table;
+				d.table = (double*) dev_alloc(t.size() * sizeof(double));
+				dev_upload(d.table, t.data(), t.size() * sizeof(double));
+				if (sp.whole)
+				{
+					std::vector<double> w((size_t) sp.flen * sp.out_step);
+					for (int r = 0; r < sp.out_step; r++)
+					{
+						const int ph = (int) (((long long) r * sp.in_step) % sp.out_step);
+						for (int i = 0; i < sp.flen; i++)
+							w[(size_t) i * sp.out_step + r] = t[(size_t) ph * sp.flen + i];
+					}
+					d.wtab = (double*) dev_alloc(w.size() * sizeof(double));
+					dev_upload(d.wtab, w.data(), w.size() * sizeof(double));
 				}
 			}
 		}
-		else if (sp.desc.kind == kFrac)
-		{
-			const std::vector<double>& t = sp.bank->table;
-			d.table = (double*) dev_alloc(t.size() * sizeof(double));
-			dev_upload(d.table, t.data(), t.size() * sizeof(double));
-			if (sp.whole)
-			{
-				std::vector<double> w((size_t) sp.flen * sp.out_step);
-				for (int r = 0; r < sp.out_step; r++)
-				{
-					const int ph = (int) (((long long) r * sp.in_step) % sp.out_step);
-					for (int i = 0; i < sp.flen; i++)
-						w[(size_t) i * sp.out_step + r] = t[(size_t) ph * sp.flen + i];
-				}
-				d.wtab = (double*) dev_alloc(w.size() * sizeof(double));
-				dev_upload(d.wtab, w.data(), w.size() * sizeof(double));
-			}
-		}
+		plan_transforms();
+		for (size_t s = 0; s + 1 < plan_.stages.size(); s++)
+			if (fuse_with_next(s)) prepare_mfma(s);
 	}
-	plan_transforms();
-	for (size_t s = 0; s + 1 < plan_.stages.size(); s++)
-		if (fuse_with_next(s)) prepare_mfma(s);
+	catch (...)
+	{
+		release();
+		throw;
+	}
 }
 
 // Geometry and A fragments of the matrix-core interpolator (r8b_convx.h, MODE 2) for the fused
@@ -497,7 +506,9 @@ void Engine::prepare_mfma(size_t s)
 	d.mf_ok = true;
 }
 
-Engine::~Engine()
+Engine::~Engine() { release(); }
+
+void Engine::release()
 {
 	for (StageDev& d : dev_)
 	{
@@ -517,6 +528,7 @@ Engine::~Engine()
 		dev_free(d.wtab);
 		dev_free(d.mf_atab);
 	}
+	dev_.clear();
 }
 
 void Engine::plan_transforms()

@@ -81,6 +81,7 @@ private:
 		long long t_in = 0, t_out = 0; // per-channel samples in/out over the timed launches
 	};
 	void* get_event(StageDev& d);
+	void release();
 	unsigned long long config_hash() const;
 
 	void plan_transforms();
