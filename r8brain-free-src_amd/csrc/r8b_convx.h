@@ -99,6 +99,9 @@ struct ConvxState
 	cd tw0[RF > 8 ? 6 : (RF > 4 ? 4 : 3)]; // first-pass twiddles: same for every block
 	cd pre[FF][RF];                        // inputs of the block's first-pass butterflies
 	cd sp[SP][NSP];
+	// spectral stage by output position (R8B_CX_SPEC_BY_POSITION): one backward input per slot
+	static constexpr int SO = DOWN ? 1 : (N2 + kConvxThreads - 1) / kConvxThreads;
+	cd so[SO];
 	double fr[FIN][RL], fi[FIN][RL];
 	double row[32];
 };
@@ -512,6 +515,60 @@ R8B_HD int cx_spec_bin(int slot)
 	return slot == N / 2 ? N / 2 : N;
 }
 
+// ---- spectral stage addressed by OUTPUT POSITION (up-sampling 1 or 2) -------------------------------
+// Every backward input is Z'[k'] = ca(k') Z[k' mod N] + cb(k') conj(Z[-k' mod N]) (all cases of
+// cx_spec_write() below reduce to this form).  With thread <-> position P of the backward array
+// (bin k' = bitrev(P)) every LDS access is conflict free: the write is position P itself, the first
+// read is forward position P >> UPLOG (pairs of lanes share it when UPLOG = 1), and the second read
+// -- the position of the NEGATED bin -- mirrors the first inside its power-of-two range:
+// negating k keeps its lowest set bit and inverts the bits above it; in the bit-reversed domain
+// that is "keep the highest set bit of p, invert the bits below": 3*2^m - 1 - p, m = floor(log2 p),
+// so 64 consecutive lanes read 64 consecutive positions in descending order.  (Addressed by forward
+// bin pair, as before, the reads and the four writes scatter bit-reversed: 2-4-way conflicts, half
+// of all bank-conflict cycles of the kernel.)  Constants: L.spec2[c * N2 + P], c = 0 (ca), 1 (cb).
+#ifndef R8B_CX_SPEC_BY_POSITION
+#define R8B_CX_SPEC_BY_POSITION 1
+#endif
+
+R8B_HD int cx_negpos(int p)
+{
+	if (p == 0) return 0;
+	const int m = 31 - __builtin_clz((unsigned) p);
+	return (3 << m) - 1 - p;
+}
+
+template<int LOGN, int UPLOG>
+R8B_HD void cx_spec2_compute(const ConvLaunch& L, const cd* buf, ConvxState<LOGN, UPLOG>& st, int tid)
+{
+	typedef ConvxState<LOGN, UPLOG> St;
+	constexpr int N2 = St::N2, SH = UPLOG > 0 ? UPLOG : 0;
+#pragma unroll
+	for (int s = 0; s < St::SO; s++)
+	{
+		const int P = tid + s * kConvxThreads;
+		if (P >= N2) continue;
+		const int pf = P >> SH;
+		const cd u = buf[cpad(pf)], v = buf[cpad(cx_negpos(pf))];
+		const cd ca = L.spec2[P], cb = L.spec2[N2 + P];
+		cd o;
+		o.re = ca.re * u.re - ca.im * u.im + cb.re * v.re + cb.im * v.im;
+		o.im = ca.re * u.im + ca.im * u.re + cb.im * v.re - cb.re * v.im;
+		st.so[s] = o;
+	}
+}
+
+template<int LOGN, int UPLOG>
+R8B_HD void cx_spec2_write(cd* buf, const ConvxState<LOGN, UPLOG>& st, int tid)
+{
+	typedef ConvxState<LOGN, UPLOG> St;
+#pragma unroll
+	for (int s = 0; s < St::SO; s++)
+	{
+		const int P = tid + s * kConvxThreads;
+		if (P < St::N2) buf[cpad(P)] = st.so[s];
+	}
+}
+
 // spectral stage, part 1: forward bins (kf, N-kf) -> registers
 template<int LOGN, int UPLOG>
 R8B_HD void cx_spec_read(const cd* buf, ConvxState<LOGN, UPLOG>& st, int tid)
@@ -688,6 +745,7 @@ R8B_HD void cx_final_store(const ConvLaunch& L, double* y, const ConvxState<LOGN
 	const int fl2 = UPLOG < 0 ? L.fl2 >> -UPLOG : L.fl2;
 	const int in_len = UPLOG < 0 ? L.in_len >> -UPLOG : L.in_len;
 	const int nzero = !ZERO_NEG || t0 >= 0 ? 0 : (-t0 > in_len ? in_len : (int) -t0);
+	const bool pair = (fl2 & 1) == 0;
 #pragma unroll
 	for (int f = 0; f < St::FIN; f++)
 	{
@@ -699,6 +757,16 @@ R8B_HD void cx_final_store(const ConvLaunch& L, double* y, const ConvxState<LOGN
 			const int e = b + p * q; // complex index: reals 2e, 2e+1 at circular positions c
 			const int u0 = (2 * e + fl2) & mask, u1 = (2 * e + 1 + fl2) & mask;
 			const double v0 = u0 < nzero ? 0.0 : st.fr[f][p], v1 = u1 < nzero ? 0.0 : st.fi[f][p];
+			if (pair && u0 + 1 < in_len)
+			{
+				// even filter half-length: the pair is one aligned 16-byte store (two 8-byte
+				// stores at a 16-byte lane stride conflict two ways)
+				cd v;
+				v.re = v0;
+				v.im = v1;
+				*reinterpret_cast<cd*>(y + u0) = v;
+				continue;
+			}
 			if (u0 < in_len) y[u0] = v0;
 			if (u1 < in_len) y[u1] = v1;
 		}
@@ -940,10 +1008,15 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 		cx_first_pass<LOGN, UPLOG>(L, buf, st, tid);
 	});
 	if constexpr (NPF > 1) cx_fwd_seq<LOGN, UPLOG, 1>(ex, L, buf);
-	ex.phase([&](int tid, St& st) { cx_spec_read<LOGN, UPLOG>(buf, st, tid); });
 	ex.phase([&](int tid, St& st)
 	{
-		cx_spec_write<LOGN, UPLOG>(L, buf, st, tid);
+		if constexpr (UPLOG >= 0 && R8B_CX_SPEC_BY_POSITION) cx_spec2_compute<LOGN, UPLOG>(L, buf, st, tid);
+		else cx_spec_read<LOGN, UPLOG>(buf, st, tid);
+	});
+	ex.phase([&](int tid, St& st)
+	{
+		if constexpr (UPLOG >= 0 && R8B_CX_SPEC_BY_POSITION) cx_spec2_write<LOGN, UPLOG>(buf, st, tid);
+		else cx_spec_write<LOGN, UPLOG>(L, buf, st, tid);
 		if constexpr (cx_inv_pair_local<LOGN, UPLOG>())
 			InvPass<LOGN2, 1>::prefetch(st.tw, L.tw, L.tw_len, tid);
 		else

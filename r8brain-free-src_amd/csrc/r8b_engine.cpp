@@ -258,9 +258,9 @@ std::vector<double> spectral_constants_down(const std::vector<double>& H,
 // k = ca(k) Z[k mod N] + cb(k) conj(Z[-k mod N]); every case of the per-slot table `sc`
 // (spectral_constants) reduces to this form.  Layout: entry ((16s + 4i + s3) * 2 + {0: ca, 1: cb})
 // * 64 + lane for the bin lane (a, j1') owns at (s, i, s3): k = (a + 16s) + M2 ((4 j1' + i) + 16 s3).
-std::vector<double> spectral_constants_wave(const std::vector<double>& sc, int n_in, int up)
+// (ca, cb) of backward bin k out of the per-slot table `sc` (spectral_constants, up 1 or 2)
+static void bin_constants(const std::vector<double>& sc, int N, int up, int k, double* ca, double* cb)
 {
-	const int N = n_in / 2, N2 = N * up, M2 = N2 / 64;
 	const int slots = N / 2 + 1;
 	int logn = 0;
 	while ((1 << logn) < N) logn++;
@@ -272,12 +272,45 @@ std::vector<double> spectral_constants_wave(const std::vector<double>& sc, int n
 			if (kf & (1 << b)) s |= 1 << (logn - 2 - b);
 		return s;
 	};
-	auto get = [&](int c, int kf, double* o)
+	int a, b, kf;
+	if (up == 1)
 	{
-		const size_t at = ((size_t) c * slots + slot_of(kf)) * 2;
-		o[0] = sc[at];
-		o[1] = sc[at + 1];
-	};
+		if (k <= N / 2) { kf = k; a = 0; b = 1; }
+		else { kf = N - k; a = 3; b = 2; }
+	}
+	else
+	{
+		if (k <= N / 2) { kf = k; a = 0; b = 1; }
+		else if (k <= N) { kf = N - k; a = 5; b = 4; }
+		else if (k < N + N / 2) { kf = k - N; a = 6; b = 7; }
+		else { kf = 2 * N - k; a = 3; b = 2; }
+	}
+	const size_t ia = ((size_t) a * slots + slot_of(kf)) * 2, ib = ((size_t) b * slots + slot_of(kf)) * 2;
+	ca[0] = sc[ia]; ca[1] = sc[ia + 1];
+	cb[0] = sc[ib]; cb[1] = sc[ib + 1];
+}
+
+// Constants of the fast path's spectral stage addressed by output position (r8b_convx.h
+// cx_spec2_compute): entry c * N2 + P holds ca (c = 0) / cb (c = 1) of bin bitrev(P).
+std::vector<double> spectral_constants_by_position(const std::vector<double>& sc, int n_in, int up)
+{
+	const int N = n_in / 2, N2 = N * up;
+	int logn2 = 0;
+	while ((1 << logn2) < N2) logn2++;
+	std::vector<double> out((size_t) N2 * 2 * 2, 0.0);
+	for (int P = 0; P < N2; P++)
+	{
+		int k = 0;
+		for (int b = 0; b < logn2; b++)
+			if (P & (1 << b)) k |= 1 << (logn2 - 1 - b);
+		bin_constants(sc, N, up, k, &out[(size_t) P * 2], &out[((size_t) N2 + P) * 2]);
+	}
+	return out;
+}
+
+std::vector<double> spectral_constants_wave(const std::vector<double>& sc, int n_in, int up)
+{
+	const int N = n_in / 2, N2 = N * up, M2 = N2 / 64;
 	std::vector<double> out((size_t) N2 * 2 * 2, 0.0);
 	for (int lane = 0; lane < 64; lane++)
 		for (int s = 0; s < M2 / 16; s++)
@@ -285,22 +318,9 @@ std::vector<double> spectral_constants_wave(const std::vector<double>& sc, int n
 				for (int s3 = 0; s3 < 4; s3++)
 				{
 					const int k = ((lane >> 2) + 16 * s) + M2 * ((4 * (lane & 3) + i) + 16 * s3);
-					int ca, cb, kf;
-					if (up == 1)
-					{
-						if (k <= N / 2) { kf = k; ca = 0; cb = 1; }
-						else { kf = N - k; ca = 3; cb = 2; }
-					}
-					else
-					{
-						if (k <= N / 2) { kf = k; ca = 0; cb = 1; }
-						else if (k <= N) { kf = N - k; ca = 5; cb = 4; }
-						else if (k < N + N / 2) { kf = k - N; ca = 6; cb = 7; }
-						else { kf = 2 * N - k; ca = 3; cb = 2; }
-					}
 					const size_t e = (size_t) (16 * s + 4 * i + s3) * 2;
-					get(ca, kf, &out[((e + 0) * 64 + lane) * 2]);
-					get(cb, kf, &out[((e + 1) * 64 + lane) * 2]);
+					bin_constants(sc, N, up, k, &out[((e + 0) * 64 + lane) * 2],
+						&out[((e + 1) * 64 + lane) * 2]);
 				}
 	return out;
 }
@@ -413,6 +433,12 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 						spectral_constants(H, tw, g.bl2, g.n_in, eup);
 					d.spec = (cd*) dev_alloc(sc.size() * sizeof(double));
 					dev_upload(d.spec, sc.data(), sc.size() * sizeof(double));
+					if (edown == 1)
+					{
+						const std::vector<double> s2 = spectral_constants_by_position(sc, g.n_in, eup);
+						d.spec2 = (cd*) dev_alloc(s2.size() * sizeof(double));
+						dev_upload(d.spec2, s2.data(), s2.size() * sizeof(double));
+					}
 					if (convw_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
 					{
 						const std::vector<double> sw = spectral_constants_wave(sc, g.n_in, g.up);
@@ -523,6 +549,7 @@ void Engine::release()
 		dev_free(d.H);
 		dev_free(d.tw);
 		dev_free(d.spec);
+		dev_free(d.spec2);
 		dev_free(d.wspec);
 		dev_free(d.table);
 		dev_free(d.wtab);
@@ -1058,7 +1085,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 		throw std::runtime_error("transform plan too deep");
 	for (int i = 0; i < L.n_fwd; i++) L.fwd_radix[i] = d.fwd_radix[(size_t) i];
 	for (int i = 0; i < L.n_inv; i++) L.inv_radix[i] = d.inv_radix[(size_t) i];
-	L.H = d.H; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.wspec = d.wspec;
+	L.H = d.H; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.spec2 = d.spec2; L.wspec = d.wspec;
 	L.nch = nch_;
 	L.threads = opt_.at("conv_threads");
 	L.src = src;

@@ -64,6 +64,7 @@ private:
 		double* H = nullptr;
 		cd* tw = nullptr;
 		cd* spec = nullptr; // fast-path spectral constants
+		cd* spec2 = nullptr; // the same per backward position (up 1 or 2)
 		cd* wspec = nullptr; // the same for the wave-per-block kernel (per backward bin)
 		int tw_len = 0;
 		double* table = nullptr;

@@ -67,6 +67,7 @@ struct ConvLaunch
 	const double* H; // bl2/2+1 reals: zero-phase kernel spectrum / bl2
 	const cd* tw;    // tw_len complex: exp(-2 pi i e / tw_len)
 	const cd* spec;  // fast path only: per-slot spectral-stage constants (r8b_convx.h)
+	const cd* spec2; // fast path, up 1 or 2: (ca, cb) per backward POSITION, [c * N2 + P]
 	const cd* wspec; // wave-per-block form: (ca, cb) per backward bin, [slot][lane] (r8b_convw.h)
 	int tw_len;
 	// work: blocks [k0, k0+nblk) x channels [0, nch); outputs clipped to [a, b)
