@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--block", type=int, default=16384, help="input samples per channel per step")
     ap.add_argument("--src", type=float, default=44100.0)
     ap.add_argument("--dst", type=float, default=96000.0)
+    ap.add_argument("--tb", type=float, default=2.0, help="transition band, percent (side runs)")
+    ap.add_argument("--atten", type=float, default=180.15, help="stop-band attenuation (side runs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value")
     ap.add_argument("--pcm", choices=["s16", "s24", "s32", "f32"], default=None,
@@ -147,7 +149,7 @@ def main():
     # channel_shard(channels*world, r, world)
     lo, hi = channel_shard(args.channels * world, rank, world)
     C, L = hi - lo, args.block
-    rs = r8b.BatchResampler(args.src, args.dst, L, 2.0, 180.15, nch=C, device=local_rank)
+    rs = r8b.BatchResampler(args.src, args.dst, L, args.tb, args.atten, nch=C, device=local_rank)
     for o in args.opt:
         k, v = o.split("=")
         rs.set_option(k, int(v))
