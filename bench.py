@@ -245,7 +245,8 @@ def main():
                          "path_frac": round(path_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                                             4)},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:
+            # (N = 1 only: the CPU leg is a per-box baseline, not part of the scaling runs)
             # sample channel for the error report: rerun channel 0 of a fresh stream on the GPU
             chk = r8b.BatchResampler(args.src, args.dst, L, 2.0, 180.15, nch=1,
                                      device=local_rank)

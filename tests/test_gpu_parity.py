@@ -258,3 +258,27 @@ def test_gpu_checkpoint_resume(src, dst):
     blob = checkpoint_roundtrip(lambda: r8b.BatchResampler(src, dst, 700, 2.0, 136.45, nch=3),
                                 src, dst)
     assert blob.size > 64
+
+
+@pytest.mark.gpu
+def test_bench_contract(tmp_path):
+    """bench.py prints ONE JSON line carrying the driver's contract fields plus `roofline` (live
+    HIP-event timing of the dominant kernel) -- a short run of the real script."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup",
+                          "2", "--no-cpu"], check=True, stdout=subprocess.PIPE, text=True).stdout
+    lines = [l for l in out.split("\n") if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["dtype"] == "f64"
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["achieved"] > 0
+    assert d["value"] > 0 and abs(d["value"] - 1024 * 16384 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
