@@ -379,6 +379,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["conv_threads"] = 256;
 	opt_["whole_tile"] = 1024;
 	opt_["hb_tile"] = 1024;
+	opt_["hbc_tile"] = 0; // last-stage outputs per workgroup of the half-band cascade (0: by batch)
 	opt_["timing"] = 0;
 	opt_["fast_conv"] = 1; // compile-time-sized convolver kernel when the geometry allows
 	opt_["fuse"] = 1;      // ... with the whole-step interpolator behind it fused in
@@ -1034,9 +1035,14 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 		for (int k = 0; k < sp.hb_n; k++) L.taps[g][k] = sp.hb_taps[k];
 	}
 	L.a = fa; L.b = fb;
-	// last-stage outputs per workgroup: a multiple of 2^glen, about 4096
+	// last-stage outputs per workgroup: a multiple of 2^glen.  A tile costs ~1.7 us of a CU
+	// whatever its size (six dependent phases), so large batches take 8192 (51 KB LDS, 3
+	// workgroups per CU: 0.19 vs 0.22 ms on cfg5 x 1024 channels) and small ones 4096, which
+	// keeps every CU busy
+	int want = opt_.at("hbc_tile");
+	if (want == 0) want = (fb - fa + 8191) / 8192 * (long long) nch_ >= 256 * 6 ? 8192 : 4096;
 	int tile = 1 << glen;
-	while (tile < 4096) tile <<= 1;
+	while (tile < want) tile <<= 1;
 	L.tile = tile;
 	L.buf = tile / 2 + 96;  // largest intermediate stream of a tile (input of the last stage)
 	L.buf2 = tile / 4 + 96; // the one before it (the buffers alternate)
