@@ -379,6 +379,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["conv_threads"] = 256;
 	opt_["whole_tile"] = 1024;
 	opt_["hb_tile"] = 1024;
+	opt_["hbd_span"] = 4096; // first-stage input samples per workgroup of the decimating cascade
 	opt_["hbc_tile"] = 0; // last-stage outputs per workgroup of the half-band cascade (0: by batch)
 	opt_["timing"] = 0;
 	opt_["fast_conv"] = 1; // compile-time-sized convolver kernel when the geometry allows
@@ -402,7 +403,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 		{
 			const StagePlan& sp = plan_.stages[s];
 			StageDev& d = dev_[s];
-			const long long hist = sp.history();
+			const long long hist = stage_history(s);
 			d.ring_size = pow2_at_least(s == 0 ? hist : hist + plan_.stage_max_in[s]);
 			// rings are allocated on first use (ensure_ring): the ring between two fused stages is
 			// never touched and would be the largest allocation (cfg2: 512 MB)
@@ -633,7 +634,7 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 			break;
 		case kFrac: *kernel = sp.whole ? "k_whole" : "k_poly"; break;
 		case kHBUp: *kernel = group_len(stage) > 1 ? "k_hbcascade" : "k_hbup"; break;
-		case kHBDown: *kernel = "k_hbdown"; break;
+		case kHBDown: *kernel = group_len(stage) > 1 ? "k_hbdcascade" : "k_hbdown"; break;
 		}
 	}
 	d.ms_sum = 0.0;
@@ -967,6 +968,7 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 				dev_event_record(e0, stream);
 			}
 			if (fused && sp.desc.kind == kConv) launch_fused(s, wa, wb, src, dst, stream);
+			else if (fused && sp.desc.kind == kHBDown) launch_dcascade(s, glen, wa, wb, src, dst, stream);
 			else if (fused) launch_cascade(s, glen, wa, wb, src, dst, stream);
 			else launch_stage(s, m_prev, a, b, ps, src, dst, stream);
 			if (timing)
@@ -987,7 +989,7 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 				TailLaunch T;
 				T.src = src;
 				T.p1 = sp.m;
-				T.p0 = sp.m - sp.history();
+				T.p0 = sp.m - stage_history(0);
 				if (T.p0 < 0) T.p0 = 0;
 				T.ring = dev_[0].ring_alt;
 				T.ring_stride = dev_[0].ring_size;
@@ -1006,14 +1008,72 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 int Engine::group_len(size_t s) const
 {
 	if (fuse_with_next(s)) return 2;
-	if (opt_.at("fuse_hb") && plan_.stages[s].desc.kind == kHBUp)
+	const StageKind kind = plan_.stages[s].desc.kind;
+	if (opt_.at("fuse_hb") && (kind == kHBUp || kind == kHBDown))
 	{
 		int n = 1;
-		while (s + n < plan_.stages.size() && plan_.stages[s + n].desc.kind == kHBUp &&
+		while (s + n < plan_.stages.size() && plan_.stages[s + n].desc.kind == kind &&
 			n < kMaxCascade) n++;
 		return n;
 	}
 	return 1;
+}
+
+// input samples a stage must keep from earlier calls.  A run of half-band decimators executed as
+// one kernel looks back over the accumulated filter spans of the whole run.
+long long Engine::stage_history(size_t s) const
+{
+	const StagePlan& sp = plan_.stages[s];
+	if (sp.desc.kind != kHBDown) return sp.history();
+	long long span = 0;
+	int g = 0;
+	while (s + g < plan_.stages.size() && plan_.stages[s + g].desc.kind == kHBDown && g < kMaxCascade)
+	{
+		const int T = plan_.stages[s + g].hb_n <= 4 ? 4 : (plan_.stages[s + g].hb_n <= 8 ? 8 : 14);
+		span += (long long) (2 * T - 1) << g;
+		g++;
+	}
+	return std::max<long long>(sp.history(), 2 * span + (2LL << g) + 64);
+}
+
+void Engine::launch_dcascade(size_t s, int glen, long long fa, long long fb, const SrcView& src,
+	const DstView& dst, void* stream)
+{
+	HBCascadeLaunch L;
+	L.nst = glen;
+	for (int g = 0; g < kMaxCascade; g++)
+	{
+		L.ntaps[g] = 0;
+		for (int k = 0; k < 14; k++) L.taps[g][k] = 0.0;
+	}
+	for (int g = 0; g < glen; g++)
+	{
+		const StagePlan& sp = plan_.stages[s + g];
+		if (sp.hb_n > 14) throw std::runtime_error("half-band filter too long");
+		L.ntaps[g] = sp.hb_n <= 4 ? 4 : (sp.hb_n <= 8 ? 8 : 14);
+		for (int k = 0; k < sp.hb_n; k++) L.taps[g][k] = sp.hb_taps[k];
+	}
+	L.a = fa; L.b = fb;
+	// last-stage outputs per workgroup: about 4096 first-stage input samples
+	int tile = std::max(32, opt_.at("hbd_span") >> glen);
+	L.tile = tile;
+	// LDS: stage inputs alternate between two buffers; size each for a full tile
+	long long lo = 0, hi = tile, even = 0, odd = 0;
+	for (int g = glen - 1; g >= 0; g--)
+	{
+		const int T = L.ntaps[g];
+		const long long ilo = 2 * lo - (2 * T - 1), ihi = 2 * (hi - 1) + (2 * T - 1) + 1;
+		lo = ilo;
+		hi = ihi;
+		long long& m = (g & 1) ? odd : even;
+		m = std::max(m, hi - lo);
+	}
+	L.buf = (int) even + 8;
+	L.buf2 = (int) odd + 8;
+	L.pair_ok = 0;
+	L.nch = nch_;
+	L.src = src; L.dst = dst;
+	launch_hbdcascade(L, stream);
 }
 
 void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, const SrcView& src,
@@ -1102,7 +1162,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 		const StagePlan& sp0 = plan_.stages[0];
 		L.tail_ring = dev_[0].ring_alt;
 		L.tail_p1 = sp0.m;
-		L.tail_p0 = sp0.m - sp0.history();
+		L.tail_p0 = sp0.m - stage_history(0);
 		if (L.tail_p0 < 0) L.tail_p0 = 0;
 	}
 }

@@ -93,6 +93,9 @@ private:
 	int group_len(size_t s) const;
 	void launch_cascade(size_t s, int glen, long long fa, long long fb, const SrcView& src,
 		const DstView& dst, void* stream);
+	void launch_dcascade(size_t s, int glen, long long fa, long long fb, const SrcView& src,
+		const DstView& dst, void* stream);
+	long long stage_history(size_t s) const;
 	void fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const;
 	void launch_fused(size_t s, long long wa, long long wb, const SrcView& src,
 		const DstView& dst, void* stream);

@@ -724,6 +724,65 @@ R8B_HD void hbc_stage(const HBCascadeLaunch& L, int s, const double* xin, long l
 	else hbc_stage_t<14>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
 }
 
+// ------------------------------------------------------------------------------------ decimating cascade
+//
+// A run of 2x half-band decimators (deep decimation chains, e.g. 2822400 -> 176400 of the
+// reference's bench/sacd.cpp) executed by one kernel.  Tile of last-stage outputs [q0, q1); stage s
+// produces [lo[s], hi[s]) from its input over [2 lo - (2T-1), 2 (hi-1) + (2T-1)]:
+//   y[n] = x[2n] + sum_k f[k] (x[2n+1+2k] + x[2n-1-2k])   (reference CDSPHBDownsampler.h:282-295)
+// Uses HBCascadeLaunch (taps zero-padded to 4 / 8 / 14 like the up-sampling cascade).
+
+R8B_HD void hbd_ranges(const HBCascadeLaunch& L, long long q0, long long q1, HBCRanges& R)
+{
+	long long lo = q0, hi = q1;
+	for (int s = L.nst - 1; s >= 0; s--)
+	{
+		R.lo[s] = lo;
+		R.hi[s] = hi;
+		const int T = L.ntaps[s];
+		const long long ilo = 2 * lo - (2 * T - 1), ihi = 2 * (hi - 1) + (2 * T - 1) + 1;
+		lo = ilo;
+		hi = ihi;
+	}
+	R.in_lo = lo;
+	R.in_hi = hi;
+}
+
+template<int TP>
+R8B_HD void hbd_stage_t(const HBCascadeLaunch& L, int s, const double* xin, long long in_lo,
+	long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr)
+{
+	double f[TP];
+#pragma unroll
+	for (int k = 0; k < TP; k++) f[k] = L.taps[s][k];
+	const int cnt = (int) (hi - lo);
+	const int xoff = (int) (2 * lo - in_lo); // index of x[2 lo] in xin
+	for (int i = tid; i < cnt; i += nthr)
+	{
+		const double* x = xin + xoff + 2 * i; // x[0] == stream x[2 (lo + i)]
+		double a0 = x[0], a1 = 0.0;
+#pragma unroll
+		for (int k = 0; k < TP; k += 2)
+		{
+			a0 += f[k] * (x[1 + 2 * k] + x[-1 - 2 * k]);
+			a1 += f[k + 1] * (x[3 + 2 * k] + x[-3 - 2 * k]);
+		}
+		// a stage's stream starts at position 0: earlier outputs do not exist for the next stage
+		const double v = lo + i < 0 ? 0.0 : a0 + a1;
+		if (last) dst_store(L.dst, ch, lo + i, v);
+		else yout[i] = v;
+	}
+}
+
+R8B_HD void hbd_stage(const HBCascadeLaunch& L, int s, const double* xin, long long in_lo,
+	long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr)
+{
+	const int T = L.ntaps[s];
+	if (T <= 4) hbd_stage_t<4>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
+	else if (T <= 8) hbd_stage_t<8>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
+	else hbd_stage_t<14>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
+}
+
 } // namespace r8bhip
 
 #endif

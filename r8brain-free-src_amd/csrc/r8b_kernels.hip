@@ -242,6 +242,33 @@ __global__ void k_hbcascade(const HBCascadeLaunch L)
 	}
 }
 
+// ------------------------------------------------------------------ decimating half-band cascade
+__global__ void k_hbdcascade(const HBCascadeLaunch L)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	// inputs of the even stages live in the first buffer, of the odd stages in the second
+	double* const even = reinterpret_cast<double*>(smem);
+	double* const odd = even + L.buf;
+	const int tid = threadIdx.x, nthr = blockDim.x;
+	const int ch = blockIdx.y;
+	const long long q0 = L.a + (long long) blockIdx.x * L.tile;
+	long long q1 = q0 + L.tile;
+	if (q1 > L.b) q1 = L.b;
+	HBCRanges R;
+	hbd_ranges(L, q0, q1, R);
+	const int len = (int) (R.in_hi - R.in_lo);
+	for (int i = tid; i < len; i += nthr) even[i] = src_load(L.src, ch, R.in_lo + i);
+	__syncthreads();
+	long long in_lo = R.in_lo;
+	for (int s = 0; s < L.nst; s++)
+	{
+		hbd_stage(L, s, (s & 1) ? odd : even, in_lo, R.lo[s], R.hi[s], (s & 1) ? even : odd,
+			s + 1 == L.nst, ch, tid, nthr);
+		__syncthreads();
+		in_lo = R.lo[s];
+	}
+}
+
 // ------------------------------------------------------------------ history tail of the caller's buffer
 __global__ void k_tail(const TailLaunch L)
 {
@@ -623,6 +650,17 @@ void R8B_LAUNCH(launch_hbcascade)(const HBCascadeLaunch& L, void* stream)
 	check(hipGetLastError(), "launch k_hbcascade");
 }
 
+void R8B_LAUNCH(launch_hbdcascade)(const HBCascadeLaunch& L, void* stream)
+{
+	set_lds_attrs();
+	const long long n = L.b - L.a;
+	if (n <= 0) return;
+	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
+	hipLaunchKernelGGL(k_hbdcascade, dim3(tiles, (unsigned) L.nch), dim3(256),
+		(size_t) (L.buf + L.buf2) * sizeof(double), (hipStream_t) stream, L);
+	check(hipGetLastError(), "launch k_hbdcascade");
+}
+
 void R8B_LAUNCH(launch_tail)(const TailLaunch& L, void* stream)
 {
 	const long long n = L.p1 - L.p0;
@@ -642,6 +680,7 @@ void launch_hbdown_pcm(const HBLaunch& L, void* stream);
 void launch_convx_pcm(const ConvxLaunch& X, int mode, void* stream);
 void launch_convw_pcm(const ConvxLaunch& X, int mode, void* stream);
 void launch_hbcascade_pcm(const HBCascadeLaunch& L, void* stream);
+void launch_hbdcascade_pcm(const HBCascadeLaunch& L, void* stream);
 void launch_tail_pcm(const TailLaunch& L, void* stream);
 
 #define R8B_DISPATCH(name, T) \
@@ -656,6 +695,7 @@ R8B_DISPATCH(launch_poly, PolyLaunch)
 R8B_DISPATCH(launch_hbup, HBLaunch)
 R8B_DISPATCH(launch_hbdown, HBLaunch)
 R8B_DISPATCH(launch_hbcascade, HBCascadeLaunch)
+R8B_DISPATCH(launch_hbdcascade, HBCascadeLaunch)
 #undef R8B_DISPATCH
 
 void launch_convx(const ConvxLaunch& X, int mode, void* stream)

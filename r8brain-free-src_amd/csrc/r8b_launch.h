@@ -244,6 +244,8 @@ void launch_poly(const PolyLaunch& L, void* stream);
 void launch_hbup(const HBLaunch& L, void* stream);
 void launch_hbdown(const HBLaunch& L, void* stream);
 void launch_hbcascade(const HBCascadeLaunch& L, void* stream);
+// a run of half-band decimators (same descriptor; buf / buf2 = even / odd stage inputs)
+void launch_hbdcascade(const HBCascadeLaunch& L, void* stream);
 void launch_tail(const TailLaunch& L, void* stream);
 void launch_pcm_in(const PcmLaunch& L, void* stream);  // PCM -> planar fp64
 void launch_pcm_out(const PcmLaunch& L, void* stream); // planar fp64 -> PCM

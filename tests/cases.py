@@ -41,6 +41,7 @@ STREAM_CASES = [
     (88200.0, 44100.0, 1024, 700, 12000, 2.0, 180.15),          # 2x decimating convolver alone
     (32000.0, 48000.0, 1024, 777, 20000, 2.0, 180.15),          # 3/2: zero stuffing + 2x decimating spectrum
     (96000.0, 32000.0, 2048, 2048, 30000, 2.0, 136.45),         # 1/3: strided decimation alone
+    (705600.0, 44100.0, 2048, 1333, 70000, 2.0, 136.45),        # three half-band decimators as one kernel
     (20.0, 21.0, 300, 300, 6000, 1.0, 49.0),                    # 8-tap interpolator rows (zero padding)
     (32000.0, 96000.0, 2048, 2048, 30000, 1.0, 180.15),         # 3x zero stuffing, 16384-point, in place
     (96000.0, 32000.0, 4096, 4096, 60000, 1.0, 180.15),         # strided 3x decimation, 16384-point

@@ -349,6 +349,39 @@ void launch_hbcascade(const HBCascadeLaunch& L, void*)
 		}
 }
 
+void launch_hbdcascade(const HBCascadeLaunch& L, void*)
+{
+	const int nthr = 256;
+	std::vector<double> lds((size_t) (L.buf + L.buf2));
+	const long long n = L.b - L.a;
+	if (n <= 0) return;
+	const int tiles = (int) ((n + L.tile - 1) / L.tile);
+	for (int ch = 0; ch < L.nch; ch++)
+		for (int bx = 0; bx < tiles; bx++)
+		{
+			for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
+			const long long q0 = L.a + (long long) bx * L.tile;
+			long long q1 = q0 + L.tile;
+			if (q1 > L.b) q1 = L.b;
+			HBCRanges R;
+			hbd_ranges(L, q0, q1, R);
+			double* const even = lds.data();
+			double* const odd = even + L.buf;
+			if (R.in_hi - R.in_lo > L.buf) throw std::runtime_error("emul: decimating cascade LDS");
+			for (long long i = 0; i < R.in_hi - R.in_lo; i++) even[i] = src_load(L.src, ch, R.in_lo + i);
+			long long in_lo = R.in_lo;
+			for (int s = 0; s < L.nst; s++)
+			{
+				if (s + 1 < L.nst && R.hi[s] - R.lo[s] > ((s & 1) ? L.buf : L.buf2))
+					throw std::runtime_error("emul: decimating cascade LDS");
+				for (int t = 0; t < nthr; t++)
+					hbd_stage(L, s, (s & 1) ? odd : even, in_lo, R.lo[s], R.hi[s],
+						(s & 1) ? even : odd, s + 1 == L.nst, ch, t, nthr);
+				in_lo = R.lo[s];
+			}
+		}
+}
+
 void launch_tail(const TailLaunch& L, void*)
 {
 	for (int ch = 0; ch < L.nch; ch++)

@@ -235,7 +235,8 @@ def test_cxx_frontend(torch, tmp_path):
 
 @pytest.mark.parametrize("opts", [{"mfma_interp": 1}, {"fuse": 0}, {"fuse": 0, "fast_conv": 0},
                                   {"fuse_hb": 0}, {"wave_conv": 1}, {"wave_conv": 1, "fuse": 0}])
-@pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[1], STREAM_CASES[2], STREAM_CASES[6]])
+@pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[1], STREAM_CASES[2], STREAM_CASES[4],
+                                  STREAM_CASES[6]])
 def test_hip_alternative_kernel_paths(torch, case, opts):
     """every kernel path behind the engine options (matrix-core interpolator, unfused fast
     convolver, generic kernels, unfused half-bands, one-wavefront-per-block convolver) produces
