@@ -330,59 +330,10 @@ R8B_HD cd src_load2(const SrcView& s, int ch, long long pos)
 	return r;
 }
 
-// All loads of a block are positions base + rel with a workgroup-uniform 64-bit base and a small
-// per-lane offset: the uniform part (row pointers, the fresh/history boundary, the stream start)
-// is folded once on the scalar unit, each load is left with 32-bit arithmetic.  (Through
-// src_load2 every load repeats ~70 instructions of 64-bit address and select arithmetic.)
-struct SrcBlock
-{
-	const double* pc; // where position `base` would sit in the caller's buffer
-	const double* pr; // the channel's ring row
-	unsigned b_lo, mask; // low half of base; ring mask (ring sizes are far below 2^32)
-	int c_rel;        // rel >= c_rel  <=>  position >= cur_base (fresh sample)
-	int z_rel;        // rel <  z_rel  <=>  position < 0 (reads as zero)
-};
-
-R8B_HD int clamp_rel(long long d)
-{
-	return d > 0x3fffffffLL ? 0x3fffffff : (d < -0x3fffffffLL ? -0x3fffffff : (int) d);
-}
-
-R8B_HD SrcBlock src_block(const SrcView& s, int ch, long long base)
-{
-	SrcBlock b;
-	b.pr = s.ring + (long long) ch * s.ring_stride;
-	b.pc = s.cur + ((long long) ch * s.cur_stride + (base - s.cur_base));
-	b.b_lo = (unsigned) base;
-	b.mask = (unsigned) s.ring_mask;
-	b.c_rel = clamp_rel(s.cur_base - base);
-	b.z_rel = clamp_rel(-base);
-	return b;
-}
-
-R8B_HD cd src_block_load2(const SrcBlock& b, int rel)
-{
-	const double* pr = b.pr + ((b.b_lo + (unsigned) rel) & b.mask);
-	const double* pc = b.pc + rel;
-	const cd v = *reinterpret_cast<const cd*>(rel >= b.c_rel ? pc : pr);
-	cd r;
-	r.re = rel < b.z_rel ? 0.0 : v.re;
-	r.im = rel < b.z_rel ? 0.0 : v.im;
-	return r;
-}
-
 // K1: the block's input goes from global memory straight into the registers of the first
 // forward pass (thread b owns butterfly b: complex elements b + p*N/R, i.e. real samples
 // 2e, 2e+1 of the circular block).  Issued one block ahead, at the start of the long
 // interpolation phase of the previous block, so that HBM latency is off the critical path.
-R8B_HD double src_block_load1(const SrcBlock& b, int rel)
-{
-	const double* pr = b.pr + ((b.b_lo + (unsigned) rel) & b.mask);
-	const double* pc = b.pc + rel;
-	const double v = *(rel >= b.c_rel ? pc : pr);
-	return rel < b.z_rel ? 0.0 : v;
-}
-
 // MODE 3, non-2^k up-sampling (3x): virtual sample t of the zero-stuffed stream is x[t / up] when
 // up divides t, else 0 (reference CDSPBlockConvolver.h:414-496, copyUpsample).  base_v = up * B +
 // bm is the block's virtual start; for the circular offset rel_v the source index is

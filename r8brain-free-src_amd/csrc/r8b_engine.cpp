@@ -379,7 +379,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["conv_threads"] = 256;
 	opt_["whole_tile"] = 1024;
 	opt_["hb_tile"] = 1024;
-	opt_["hbd_span"] = 4096; // first-stage input samples per workgroup of the decimating cascade
+	opt_["fuse_hbd"] = 2;    // runs of half-band decimators as one kernel: 0 never, 1 always, 2 by batch size
+	opt_["hbd_span"] = 2048; // first-stage input samples per workgroup of the decimating cascade
 	opt_["hbc_tile"] = 0; // last-stage outputs per workgroup of the half-band cascade (0: by batch)
 	opt_["timing"] = 0;
 	opt_["fast_conv"] = 1; // compile-time-sized convolver kernel when the geometry allows
@@ -1009,7 +1010,15 @@ int Engine::group_len(size_t s) const
 {
 	if (fuse_with_next(s)) return 2;
 	const StageKind kind = plan_.stages[s].desc.kind;
-	if (opt_.at("fuse_hb") && (kind == kHBUp || kind == kHBDown))
+	// Runs of decimators: one kernel saves two launches and the intermediate streams, but pays
+	// ~25 % of halo recomputation and holds 25 KB of LDS per workgroup; measured on sacd.cpp's
+	// 2822400 -> 176400 it wins on small batches (64 ch x 65536: 0.032 vs 0.037 ms) and loses on
+	// large ones (256 ch: 0.111 vs 0.099 ms).  The choice must not change between calls (the
+	// unfused stages keep their history in rings the fused kernel never writes): it is made from
+	// the object's constants.
+	const bool down_ok = opt_.at("fuse_hbd") == 1 || (opt_.at("fuse_hbd") == 2 &&
+		(long long) nch_ * plan_.stage_max_in[s] < (8LL << 20));
+	if (opt_.at("fuse_hb") && (kind == kHBUp || (kind == kHBDown && down_ok)))
 	{
 		int n = 1;
 		while (s + n < plan_.stages.size() && plan_.stages[s + n].desc.kind == kind &&
@@ -1071,6 +1080,7 @@ void Engine::launch_dcascade(size_t s, int glen, long long fa, long long fb, con
 	L.buf = (int) even + 8;
 	L.buf2 = (int) odd + 8;
 	L.pair_ok = 0;
+	L.in_end = plan_.stages[s].m;
 	L.nch = nch_;
 	L.src = src; L.dst = dst;
 	launch_hbdcascade(L, stream);
@@ -1108,6 +1118,7 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 	L.buf2 = tile / 4 + 96; // the one before it (the buffers alternate)
 	L.nch = nch_;
 	L.src = src; L.dst = dst;
+	L.in_end = plan_.stages[s].m;
 	// output q is even for the first of a pair: its element index is even when the offset is
 	L.pair_ok = dst.fmt == kPcmF64 && ((size_t) dst.p & 15) == 0 && (dst.stride & 1) == 0 &&
 		(dst.off & 1) == 0 ? 1 : 0;

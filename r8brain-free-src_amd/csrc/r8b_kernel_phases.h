@@ -70,6 +70,73 @@ R8B_HD void dst_store(const DstView& d, int ch, long long q, double v)
 	d.p[(long long) ch * d.stride + ((q + d.off) & d.mask)] = v;
 }
 
+// All loads of a block are positions base + rel with a workgroup-uniform 64-bit base and a small
+// per-lane offset: the uniform part (row pointers, the fresh/history boundary, the stream start)
+// is folded once on the scalar unit, each load is left with 32-bit arithmetic.  (Through
+// src_load every load repeats ~70 instructions of 64-bit address and select arithmetic.)
+struct SrcBlock
+{
+	const double* pc; // where position `base` would sit in the caller's buffer
+	const double* pr; // the channel's ring row
+	unsigned b_lo, mask; // low half of base; ring mask (ring sizes are far below 2^32)
+	int c_rel;        // rel >= c_rel  <=>  position >= cur_base (fresh sample)
+	int z_rel;        // rel <  z_rel  <=>  position < 0 (reads as zero)
+#ifndef R8B_NO_PCM_FUSE
+	// PCM-aware build: single-sample loads of a PCM caller buffer go through src_load()
+	const SrcView* sv;
+	int ch;
+	long long base;
+#endif
+};
+
+R8B_HD int clamp_rel(long long d)
+{
+	return d > 0x3fffffffLL ? 0x3fffffff : (d < -0x3fffffffLL ? -0x3fffffff : (int) d);
+}
+
+R8B_HD SrcBlock src_block(const SrcView& s, int ch, long long base)
+{
+	SrcBlock b;
+	b.pr = s.ring + (long long) ch * s.ring_stride;
+	b.b_lo = (unsigned) base;
+	b.mask = (unsigned) s.ring_mask;
+	// cur_base is LLONG_MAX when the stage has no caller buffer, and base may be negative (first
+	// tile of a stream): nothing here may overflow or form a wild pointer
+	const bool far = s.cur_base > base + 0x3fffffffLL;
+	b.c_rel = far ? 0x3fffffff : clamp_rel(s.cur_base - base);
+	b.pc = far ? s.ring : s.cur + ((long long) ch * s.cur_stride + (base - s.cur_base));
+	b.z_rel = clamp_rel(-base);
+#ifndef R8B_NO_PCM_FUSE
+	b.sv = &s;
+	b.ch = ch;
+	b.base = base;
+#endif
+	return b;
+}
+
+R8B_HD cd src_block_load2(const SrcBlock& b, int rel)
+{
+	const double* pr = b.pr + ((b.b_lo + (unsigned) rel) & b.mask);
+	const double* pc = b.pc + rel;
+	const cd v = *reinterpret_cast<const cd*>(rel >= b.c_rel ? pc : pr);
+	cd r;
+	r.re = rel < b.z_rel ? 0.0 : v.re;
+	r.im = rel < b.z_rel ? 0.0 : v.im;
+	return r;
+}
+
+R8B_HD double src_block_load1(const SrcBlock& b, int rel)
+{
+#ifndef R8B_NO_PCM_FUSE
+	if (b.sv->cur_fmt != kPcmF64) return src_load(*b.sv, b.ch, b.base + rel);
+#endif
+	const double* pr = b.pr + ((b.b_lo + (unsigned) rel) & b.mask);
+	const double* pc = b.pc + rel;
+	const double v = *(rel >= b.c_rel ? pc : pr);
+	return rel < b.z_rel ? 0.0 : v;
+}
+
+
 // ------------------------------------------------------------------------------------ small DFTs
 
 // (r,i) *= w16^E with w16 = exp(-2 pi i / 16); CONJ selects exp(+...)
@@ -657,7 +724,9 @@ R8B_HD void hbc_load(const HBCascadeLaunch& L, const HBCRanges& R, double* buf, 
 	int nthr)
 {
 	const int len = (int) (R.in_hi - R.in_lo);
-	for (int i = tid; i < len; i += nthr) buf[i] = src_load(L.src, ch, R.in_lo + i);
+	const SrcBlock sb = src_block(L.src, ch, R.in_lo);
+	const int end = clamp_rel(L.in_end - R.in_lo);
+	for (int i = tid; i < len; i += nthr) buf[i] = i < end ? src_block_load1(sb, i) : 0.0;
 }
 
 // one stage: input x[] (LDS, xin[0] = stream position in_lo) -> outputs [lo, hi) either into LDS

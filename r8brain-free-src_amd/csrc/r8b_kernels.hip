@@ -189,7 +189,10 @@ __global__ void k_hbup(const HBLaunch L)
 	if (n1 > ne) n1 = ne;
 	const long long lo = n0 - (T - 1);
 	const int len = (int) (n1 - n0) + 2 * T - 1;
-	for (int i = tid; i < len; i += nthr) xs[i] = src_load(L.src, ch, lo + i);
+	{
+		const SrcBlock sb = src_block(L.src, ch, lo);
+		for (int i = tid; i < len; i += nthr) xs[i] = src_block_load1(sb, i);
+	}
 	__syncthreads();
 	hbup_compute(L, xs, n0, n1, ch, tid, nthr);
 }
@@ -206,7 +209,10 @@ __global__ void k_hbdown(const HBLaunch L)
 	if (n1 > L.b) n1 = L.b;
 	const long long lo = 2 * n0 - (2 * T - 1);
 	const int len = (int) (2 * (n1 - n0 - 1) + 1) + 2 * (2 * T - 1);
-	for (int i = tid; i < len; i += nthr) xs[i] = src_load(L.src, ch, lo + i);
+	{
+		const SrcBlock sb = src_block(L.src, ch, lo);
+		for (int i = tid; i < len; i += nthr) xs[i] = src_block_load1(sb, i);
+	}
 	__syncthreads();
 	hbdown_compute(L, xs, n0, n1, ch, tid, nthr);
 }
@@ -257,7 +263,11 @@ __global__ void k_hbdcascade(const HBCascadeLaunch L)
 	HBCRanges R;
 	hbd_ranges(L, q0, q1, R);
 	const int len = (int) (R.in_hi - R.in_lo);
-	for (int i = tid; i < len; i += nthr) even[i] = src_load(L.src, ch, R.in_lo + i);
+	{
+		const SrcBlock sb = src_block(L.src, ch, R.in_lo);
+		const int end = clamp_rel(L.in_end - R.in_lo);
+		for (int i = tid; i < len; i += nthr) even[i] = i < end ? src_block_load1(sb, i) : 0.0;
+	}
 	__syncthreads();
 	long long in_lo = R.in_lo;
 	for (int s = 0; s < L.nst; s++)

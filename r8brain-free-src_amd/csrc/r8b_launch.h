@@ -133,6 +133,8 @@ struct HBCascadeLaunch
 	int tile;                      // last-stage outputs per workgroup (multiple of 2^nst)
 	int buf, buf2;                 // doubles of the two LDS buffers: tile/2 + slack, tile/4 + slack
 	int pair_ok;                   // the destination admits aligned 16-byte stores of output pairs
+	long long in_end;              // input positions >= in_end have not arrived: the zero-padded
+	                               // taps reach past the real filter, those loads must not happen
 	int nch;
 	SrcView src;                   // input stream of the first stage
 	DstView dst;

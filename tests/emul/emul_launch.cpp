@@ -368,7 +368,8 @@ void launch_hbdcascade(const HBCascadeLaunch& L, void*)
 			double* const even = lds.data();
 			double* const odd = even + L.buf;
 			if (R.in_hi - R.in_lo > L.buf) throw std::runtime_error("emul: decimating cascade LDS");
-			for (long long i = 0; i < R.in_hi - R.in_lo; i++) even[i] = src_load(L.src, ch, R.in_lo + i);
+			for (long long i = 0; i < R.in_hi - R.in_lo; i++)
+				even[i] = R.in_lo + i < L.in_end ? src_load(L.src, ch, R.in_lo + i) : 0.0;
 			long long in_lo = R.in_lo;
 			for (int s = 0; s < L.nst; s++)
 			{

@@ -283,3 +283,33 @@ def test_bench_contract(tmp_path):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["achieved"] > 0
     assert d["value"] > 0 and abs(d["value"] - 1024 * 16384 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
+
+
+@pytest.mark.gpu
+def test_gpu_deep_decimation_full_size(torch):
+    """sacd.cpp's second pass at a large block (256 channels x 65536 samples, 2822400 -> 176400: a run
+    of half-band decimators as one kernel, then the convolver): exact-size device buffers (reads past
+    the end of the caller's buffer would fault), channel 0 against the oracle, all channels
+    against the unfused kernels."""
+    nch, L = 256, 65536
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    a = r8b.BatchResampler(2822400.0, 176400.0, L, 2.0, 180.15, nch=nch)
+    a.set_option("fuse_hbd", 1)  # (by default a batch this large keeps the first stages unfused)
+    b = r8b.BatchResampler(2822400.0, 176400.0, L, 2.0, 180.15, nch=nch)
+    b.set_option("fuse_hb", 0)
+    o = O.OracleResampler(2822400.0, 176400.0, L, 2.0, 180.15)
+    for _ in range(3):
+        x = torch.rand((nch, L), generator=g, dtype=torch.float64, device="cuda") * 2.0 - 1.0
+        ya = a.process(x).clone()
+        yb = b.process(x).clone()
+        torch.cuda.synchronize()
+        assert ya.shape == yb.shape
+        if ya.shape[1]:
+            dd = (ya - yb).abs().max().item()  # same filters, different summation order
+            assert dd <= 1e-14, dd
+        yo = o.process(x[0].cpu().numpy())
+        assert len(yo) == ya.shape[1]
+        if len(yo):
+            d = ya[0].cpu().numpy() - yo
+            assert rms(d) <= RMS_TOL and peak(d) <= PEAK_TOL
