@@ -581,16 +581,19 @@ R8B_HD double poly_one(const PolyLaunch& L, int ch, long long i)
 // Tiled form: a workgroup takes kPolyTC channels x kPolyTO consecutive outputs.  All channels
 // follow the same position schedule, so the interpolated taps c0 + c1 x + c2 x^2 (reference
 // CDSPFracInterpolator.h:1088-1150) depend on the output index only: they are evaluated once per
-// output into LDS (cf[o * flen + t], plus the x-row offset of output o) and shared by the 16
+// output into LDS (cf[t * kPolyTO + o], plus the x-row offset of output o) and shared by the 16
 // channels; each channel's input span is staged in LDS (row pitch odd against bank conflicts).
-static const int kPolyTC = 16; // channels per workgroup (lanes 0..15 of each 16-lane group)
+// In the compute phase thread (o, g) pulls output o's taps into registers once and walks channels
+// g, g+4, ...: one LDS read per multiply-add, and a wave stores 64 consecutive outputs of one
+// channel (lanes = channels, as before, wrote 64 scattered 8-byte words per store).
+static const int kPolyTC = 16; // channels per workgroup
 static const int kPolyTO = 64; // outputs per workgroup
 
 R8B_HD int poly_pitch(int span) { return span | 1; }
 
 R8B_HD int poly_lds_doubles(int span_max, int flen)
 {
-	return (span_max | 1) * kPolyTC + kPolyTO * flen + kPolyTO;
+	return (span_max | 1) * kPolyTC + kPolyTO * flen + 3 * kPolyTO;
 }
 
 // input span [lo, lo + len) needed by outputs i0 .. i1-1 of this call
@@ -608,52 +611,87 @@ R8B_HD void poly_tile_load(const PolyLaunch& L, double* xs, int pitch, long long
 	int tid, int nthr)
 {
 	for (int c = 0; c < kPolyTC && ch0 + c < L.nch; c++)
-		for (int i = tid; i < len; i += nthr) xs[c * pitch + i] = src_load(L.src, ch0 + c, lo + i);
+	{
+		const SrcBlock sb = src_block(L.src, ch0 + c, lo);
+		for (int i = tid; i < len; i += nthr) xs[c * pitch + i] = src_block_load1(sb, i);
+	}
 }
 
-R8B_HD void poly_tile_coefs(const PolyLaunch& L, double* cf, double* xoff, long long lo, long long i0,
-	long long i1, int tid, int nthr)
+// per output: x-row offset, bank entry and its fractional argument (xoff[o], xoff[64 + o],
+// xoff[128 + o]) -- the position arithmetic (an fp64 division among it) once per output, not once
+// per tap
+R8B_HD void poly_tile_pos(const PolyLaunch& L, double* xoff, long long lo, long long i0, long long i1,
+	int tid, int nthr)
 {
 	const int nout = (int) (i1 - i0);
-	for (int idx = tid; idx < nout * L.flen; idx += nthr)
+	for (int o = tid; o < nout; o += nthr)
 	{
-		const int o = idx / L.flen, t = idx - o * L.flen;
 		long long rpos;
 		double fpos;
 		poly_position(L, i0 + o, &rpos, &fpos);
-		double x, x2;
+		double x;
 		int fti;
 		{
 #pragma clang fp contract(off)
 			x = fpos * L.fracs;
 			fti = (int) x;
 			x -= fti;
+		}
+		xoff[o] = (double) (rpos - L.fll - lo);
+		xoff[kPolyTO + o] = (double) fti;
+		xoff[2 * kPolyTO + o] = x;
+	}
+}
+
+R8B_HD void poly_tile_coefs(const PolyLaunch& L, double* cf, const double* xoff, long long i0,
+	long long i1, int tid, int nthr)
+{
+	const int nout = (int) (i1 - i0);
+	for (int idx = tid; idx < nout * L.flen; idx += nthr)
+	{
+		const int o = idx / L.flen, t = idx - o * L.flen;
+		const int fti = (int) xoff[kPolyTO + o];
+		const double x = xoff[2 * kPolyTO + o];
+		double x2;
+		{
+#pragma clang fp contract(off)
 			x2 = x * x;
 		}
 		const double* c = L.table + ((long) fti * L.flen + t) * 3;
-		cf[idx] = c[0] + c[1] * x + c[2] * x2;
-		if (t == 0) xoff[o] = (double) (rpos - L.fll - lo);
+		cf[t * kPolyTO + o] = c[0] + c[1] * x + c[2] * x2;
+	}
+}
+
+template<int FLENP>
+R8B_HD void poly_tile_compute_t(const PolyLaunch& L, const double* xs, int pitch, const double* cf,
+	const double* xoff, long long i0, long long i1, int ch0, int tid, int nthr)
+{
+	const int o = tid % kPolyTO, g = tid / kPolyTO, ng = nthr / kPolyTO;
+	if (i0 + o >= i1) return;
+	double row[FLENP];
+#pragma unroll
+	for (int t = 0; t < FLENP; t++) row[t] = t < L.flen ? cf[t * kPolyTO + o] : 0.0;
+	const int xo = (int) xoff[o];
+	for (int c = g; c < kPolyTC && ch0 + c < L.nch; c += ng)
+	{
+		const double* xv = xs + c * pitch + xo;
+		double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+		for (int t = 0; t < FLENP; t += 2)
+		{
+			// (taps beyond flen are zero; their x slots are not read)
+			s0 += row[t] * (t < L.flen ? xv[t] : 0.0);
+			s1 += row[t + 1] * (t + 1 < L.flen ? xv[t + 1] : 0.0);
+		}
+		dst_store(L.dst, ch0 + c, L.a + i0 + o, s0 + s1);
 	}
 }
 
 R8B_HD void poly_tile_compute(const PolyLaunch& L, const double* xs, int pitch, const double* cf,
 	const double* xoff, long long i0, long long i1, int ch0, int tid, int nthr)
 {
-	const int c = tid % kPolyTC;
-	if (ch0 + c >= L.nch) return;
-	for (long long i = i0 + tid / kPolyTC; i < i1; i += nthr / kPolyTC)
-	{
-		const int o = (int) (i - i0);
-		const double* k = cf + o * L.flen;
-		const double* xv = xs + c * pitch + (int) xoff[o];
-		double s0 = 0.0, s1 = 0.0;
-		for (int t = 0; t < L.flen; t += 2)
-		{
-			s0 += k[t] * xv[t];
-			s1 += k[t + 1] * xv[t + 1];
-		}
-		dst_store(L.dst, ch0 + c, L.a + i, s0 + s1);
-	}
+	if (L.flen <= 24) poly_tile_compute_t<24>(L, xs, pitch, cf, xoff, i0, i1, ch0, tid, nthr);
+	else poly_tile_compute_t<32>(L, xs, pitch, cf, xoff, i0, i1, ch0, tid, nthr);
 }
 
 // ------------------------------------------------------------------------------------ half-band

@@ -170,7 +170,9 @@ __global__ void k_poly_tiled(const PolyLaunch L)
 	double* const cf = xs + pitch * kPolyTC;
 	double* const xoff = cf + kPolyTO * L.flen;
 	poly_tile_load(L, xs, pitch, lo, len, ch0, tid, nthr);
-	poly_tile_coefs(L, cf, xoff, lo, i0, i1, tid, nthr);
+	poly_tile_pos(L, xoff, lo, i0, i1, tid, nthr);
+	__syncthreads();
+	poly_tile_coefs(L, cf, xoff, i0, i1, tid, nthr);
 	__syncthreads();
 	poly_tile_compute(L, xs, pitch, cf, xoff, i0, i1, ch0, tid, nthr);
 }
@@ -567,7 +569,7 @@ void R8B_LAUNCH(launch_poly)(const PolyLaunch& L, void* stream)
 	{
 		// x rows (poly_pitch) + interpolated taps + row offsets: poly_lds_doubles()
 		const size_t lds = ((size_t) (L.span_max | 1) * kPolyTC + (size_t) kPolyTO * L.flen +
-			kPolyTO) * sizeof(double);
+			3 * kPolyTO) * sizeof(double);
 		hipLaunchKernelGGL(k_poly_tiled, dim3((unsigned) ((n + kPolyTO - 1) / kPolyTO),
 			(unsigned) ((L.nch + kPolyTC - 1) / kPolyTC)), dim3(256), lds, (hipStream_t) stream, L);
 		check(hipGetLastError(), "launch k_poly_tiled");

@@ -103,7 +103,8 @@ void launch_poly(const PolyLaunch& L, void*)
 				if (len > L.span_max) throw std::runtime_error("emul: poly tile span overflows LDS");
 				for (int t = 0; t < nthr; t++)
 					poly_tile_load(L, xs.data(), pitch, lo, len, by * kPolyTC, t, nthr);
-				for (int t = 0; t < nthr; t++) poly_tile_coefs(L, cf, xoff, lo, i0, i1, t, nthr);
+				for (int t = 0; t < nthr; t++) poly_tile_pos(L, xoff, lo, i0, i1, t, nthr);
+				for (int t = 0; t < nthr; t++) poly_tile_coefs(L, cf, xoff, i0, i1, t, nthr);
 				for (int t = 0; t < nthr; t++)
 					poly_tile_compute(L, xs.data(), pitch, cf, xoff, i0, i1, by * kPolyTC, t, nthr);
 			}
