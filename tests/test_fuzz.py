@@ -1,0 +1,175 @@
+"""Differential fuzz of the whole host side (designer, topology, schedule, ring/history logic) and
+of every kernel's index arithmetic: random rates, transition bands, attenuations, MaxInLen and call
+lengths through the engine under the host emulation (tests/emul, test infrastructure) against the
+compiled reference (oracle/_ref), or the numpy restatement when that library is absent.  Seeded:
+the case list is the same on every run."""
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import r8b_oracle as O
+from cases import RMS_TOL, PEAK_TOL
+from conftest import ROOT
+
+r8b = importlib.import_module("r8brain-free-src_amd")
+
+RATES = [8000.0, 11025.0, 16000.0, 22050.0, 32000.0, 44100.0, 48000.0, 64000.0, 88200.0, 96000.0,
+         176400.0, 192000.0, 352800.0, 384000.0]
+
+
+def _cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        kind = rng.integers(0, 4)
+        if kind == 0:      # table rates
+            src, dst = rng.choice(RATES, 2, replace=False)
+        elif kind == 1:    # arbitrary integers (whole stepping with odd steps, or none)
+            src, dst = float(rng.integers(8000, 200000)), float(rng.integers(8000, 200000))
+        elif kind == 2:    # small-integer ratios as in zerotest
+            src, dst = 20.0, float(rng.integers(21, 640))
+            if rng.integers(0, 2):
+                src, dst = dst, src
+        else:              # non-integer rates
+            src, dst = float(rng.uniform(8000, 100000)), float(rng.uniform(8000, 100000))
+        if src == dst:
+            continue
+        tb = float(np.round(rng.uniform(0.7, 6.0), 2))
+        att = float(np.round(rng.uniform(60.0, 200.0), 2))
+        maxin = int(rng.integers(16, 3000))
+        out.append((float(src), float(dst), maxin, tb, att, int(rng.integers(0, 1 << 30))))
+    return out
+
+
+@pytest.fixture(scope="module")
+def emul():
+    d = os.path.join(ROOT, "tests", "emul")
+    subprocess.run(["make"], cwd=d, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return r8b.bind(os.path.join(d, "_build", "libr8bsrc_emul.so"))
+
+
+@pytest.fixture(scope="module")
+def reference():
+    import refwrap as R
+    return R if R.available() else None
+
+
+@pytest.mark.parametrize("case", _cases(60, 20260924))
+def test_fuzz_emulated_engine_vs_reference(emul, reference, case):
+    src, dst, maxin, tb, att, seed = case
+    try:
+        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, lib=emul)
+    except RuntimeError as e:
+        # the one documented unsupported corner (radix-3 convolver with a 32768-point block)
+        assert "too long" in str(e), e
+        pytest.skip("unsupported geometry: " + str(e))
+    if reference is not None:
+        refs = [reference.RefResampler(src, dst, maxin, tb, att) for _ in range(2)]
+    else:
+        refs = [O.OracleResampler(src, dst, maxin, tb, att) for _ in range(2)]
+    rng = np.random.default_rng(seed)
+    # enough input to get past the start-up latency (deep decimation chains: > 100 000 samples)
+    # and produce a few hundred outputs, in ragged calls
+    total = int(min(400000, max(6000, b.getInputRequiredForOutput(300) + 4 * maxin)))
+    x = np.stack([O.splitmix_uniform(seed % 1000 + c, total) for c in range(2)])
+    pos, sq, cnt, pk = 0, 0.0, 0, 0.0
+    while pos < total:
+        l = int(min(total - pos, rng.integers(1, maxin + 1)))
+        y = b.process_host(x[:, pos:pos + l])
+        for c in range(2):
+            yr = refs[c].process(x[c, pos:pos + l])
+            assert len(yr) == y.shape[1], (case, pos, l, len(yr), y.shape)
+            if len(yr):
+                d = y[c] - yr
+                sq += float(np.sum(d * d))
+                pk = max(pk, float(np.abs(d).max()))
+                cnt += len(yr)
+        pos += l
+    assert cnt > 0, case
+    rms = (sq / cnt) ** 0.5
+    assert rms <= RMS_TOL and pk <= PEAK_TOL, (case, rms, pk)
+
+
+OPTION_SETS = [{"fuse": 0}, {"fast_conv": 0, "fuse": 0}, {"wave_conv": 1}, {"wave_conv": 1, "fuse": 0},
+               {"mfma_interp": 1}, {"fuse_hb": 0}, {"fuse_hbd": 1}, {"fuse_hbd": 0},
+               {"poly_tiled": 0}, {"fold_tail": 0}, {"conv_radix": 4, "fast_conv": 0, "fuse": 0},
+               {"hbc_tile": 1024}, {"hbd_span": 512, "fuse_hbd": 1}]
+
+
+@pytest.mark.parametrize("idx", range(52))
+def test_fuzz_kernel_options_vs_reference(emul, reference, idx):
+    """the same differential check with the alternative kernel paths switched on at random"""
+    case = _cases(52, 77)[idx]
+    opts = OPTION_SETS[idx % len(OPTION_SETS)]
+    src, dst, maxin, tb, att, seed = case
+    try:
+        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, lib=emul)
+    except RuntimeError as e:
+        assert "too long" in str(e), e
+        pytest.skip("unsupported geometry: " + str(e))
+    for k, v in opts.items():
+        b.set_option(k, v)
+    if reference is not None:
+        refs = [reference.RefResampler(src, dst, maxin, tb, att) for _ in range(2)]
+    else:
+        refs = [O.OracleResampler(src, dst, maxin, tb, att) for _ in range(2)]
+    rng = np.random.default_rng(seed)
+    total = int(min(400000, max(6000, b.getInputRequiredForOutput(300) + 4 * maxin)))
+    x = np.stack([O.splitmix_uniform(seed % 1000 + c, total) for c in range(2)])
+    pos, sq, cnt, pk = 0, 0.0, 0, 0.0
+    while pos < total:
+        l = int(min(total - pos, rng.integers(1, maxin + 1)))
+        y = b.process_host(x[:, pos:pos + l])
+        for c in range(2):
+            yr = refs[c].process(x[c, pos:pos + l])
+            assert len(yr) == y.shape[1], (case, opts, pos, l, len(yr), y.shape)
+            if len(yr):
+                d = y[c] - yr
+                sq += float(np.sum(d * d))
+                pk = max(pk, float(np.abs(d).max()))
+                cnt += len(yr)
+        pos += l
+    rms = (sq / max(cnt, 1)) ** 0.5
+    assert cnt > 0 and rms <= RMS_TOL and pk <= PEAK_TOL, (case, opts, rms, pk)
+
+
+def _gpu_cases():
+    return [c for c in _cases(120, 555) if c[2] >= 400][:24]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _gpu_cases())
+def test_fuzz_gpu_vs_reference(reference, case):
+    """the differential check on the real HIP path (fewer, larger-MaxInLen cases: every call is a
+    host round trip here)"""
+    src, dst, maxin, tb, att, seed = case
+    try:
+        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=3)
+    except RuntimeError as e:
+        assert "too long" in str(e), e
+        pytest.skip("unsupported geometry: " + str(e))
+    if reference is not None:
+        refs = [reference.RefResampler(src, dst, maxin, tb, att) for _ in range(3)]
+    else:
+        refs = [O.OracleResampler(src, dst, maxin, tb, att) for _ in range(3)]
+    rng = np.random.default_rng(seed)
+    total = int(min(400000, max(6000, b.getInputRequiredForOutput(300) + 4 * maxin)))
+    x = np.stack([O.splitmix_uniform(seed % 1000 + c, total) for c in range(3)])
+    pos, sq, cnt, pk = 0, 0.0, 0, 0.0
+    while pos < total:
+        l = int(min(total - pos, rng.integers(maxin // 2, maxin + 1)))
+        y = b.process_host(x[:, pos:pos + l])
+        for c in range(3):
+            yr = refs[c].process(x[c, pos:pos + l])
+            assert len(yr) == y.shape[1], (case, pos, l, len(yr), y.shape)
+            if len(yr):
+                d = y[c] - yr
+                sq += float(np.sum(d * d))
+                pk = max(pk, float(np.abs(d).max()))
+                cnt += len(yr)
+        pos += l
+    rms = (sq / max(cnt, 1)) ** 0.5
+    assert cnt > 0 and rms <= RMS_TOL and pk <= PEAK_TOL, (case, rms, pk)
