@@ -173,3 +173,31 @@ def test_fuzz_gpu_vs_reference(reference, case):
         pos += l
     rms = (sq / max(cnt, 1)) ** 0.5
     assert cnt > 0 and rms <= RMS_TOL and pk <= PEAK_TOL, (case, rms, pk)
+
+
+@pytest.mark.parametrize("cfg", [(44100.0, 96000.0, 1024, 2.0, 180.15), (44100.0, 44101.0, 700, 2.0, 136.45),
+                                 (2822400.0, 176400.0, 4096, 2.0, 180.15), (48000.0, 32000.0, 333, 2.0, 109.56),
+                                 (96000.0, 11025.0, 2048, 3.0, 160.0)])
+def test_soak_long_streams_emulated(emul, reference, cfg):
+    """thousands of ragged calls, millions of samples: ring wrap-arounds, the polynomial
+    interpolator's counter re-base (every 1000 outputs), split launches -- still the reference's
+    stream call by call"""
+    if reference is None:
+        pytest.skip("needs the compiled reference (the numpy restatement is too slow for this)")
+    src, dst, maxin, tb, att = cfg
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=1, lib=emul)
+    r = reference.RefResampler(src, dst, maxin, tb, att)
+    rng = np.random.default_rng(5)
+    sq, pk, cnt = 0.0, 0.0, 0
+    for i in range(2000):
+        l = int(rng.integers(1, maxin + 1))
+        x = O.splitmix_uniform(i + 1, l)
+        y = b.process_host(x[None, :])[0]
+        yr = r.process(x)
+        assert len(y) == len(yr), (cfg, i, len(y), len(yr))
+        if len(y):
+            d = y - yr
+            sq += float(np.sum(d * d))
+            pk = max(pk, float(np.abs(d).max()))
+            cnt += len(y)
+    assert cnt > 100000 and (sq / cnt) ** 0.5 <= RMS_TOL and pk <= PEAK_TOL, (cfg, cnt, sq, pk)
