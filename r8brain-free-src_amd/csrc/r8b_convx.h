@@ -780,14 +780,13 @@ R8B_HD void cx_whole_row(const ConvxLaunch& X, double* row, int tid)
 	for (int i = 0; i < FLENP; i++) row[i] = i < X.flen ? X.wtab[(long) i * X.out_step + t] : 0.0;
 }
 
-R8B_HD void cx_mac8(const double* row, const double* v, double& s0, double& s1)
+#ifndef R8B_CX_ACCS
+#define R8B_CX_ACCS 2 // independent accumulators of the tap sum (4 or 8: measured no faster)
+#endif
+R8B_HD void cx_mac8(const double* row, const double* v, double* s)
 {
 #pragma unroll
-	for (int i = 0; i < 8; i += 2)
-	{
-		s0 += row[i] * v[i];
-		s1 += row[i + 1] * v[i + 1];
-	}
+	for (int i = 0; i < 8; i++) s[i % R8B_CX_ACCS] += row[i] * v[i];
 }
 
 template<int FLEN>
@@ -812,24 +811,27 @@ R8B_HD void cx_whole_compute(const ConvxLaunch& X, const double* y, const double
 	{
 		double v[FLEN];
 		R8B_LDS_WINDOW(FLEN, v, y + u);
-		double s0 = 0.0, s1 = 0.0;
+		double s[R8B_CX_ACCS] = {};
 		// taps in groups of eight, each behind the arrival of its own reads
 		// (the fences keep the scheduler from sinking the multiply-adds below the last wait)
 		R8B_LDS_ARRIVED(FLEN, v, 0);
-		cx_mac8(row, v, s0, s1);
+		cx_mac8(row, v, s);
 		R8B_SCHED_FENCE();
 		R8B_LDS_ARRIVED(FLEN, v, 8);
-		cx_mac8(row + 8, v + 8, s0, s1);
+		cx_mac8(row + 8, v + 8, s);
 		R8B_SCHED_FENCE();
 		R8B_LDS_ARRIVED(FLEN, v, 16);
-		cx_mac8(row + 16, v + 16, s0, s1);
+		cx_mac8(row + 16, v + 16, s);
 		if constexpr (FLEN > 24)
 		{
 			R8B_SCHED_FENCE();
 			R8B_LDS_ARRIVED(FLEN, v, 24);
-			cx_mac8(row + 24, v + 24, s0, s1);
+			cx_mac8(row + 24, v + 24, s);
 		}
-		dst_store(X.wdst, ch, j, s0 + s1);
+		double sum = s[0];
+#pragma unroll
+		for (int i = 1; i < R8B_CX_ACCS; i++) sum += s[i];
+		dst_store(X.wdst, ch, j, sum);
 	}
 }
 
