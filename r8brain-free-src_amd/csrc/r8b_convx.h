@@ -43,11 +43,17 @@ static const int kConvxThreads = 256;
 static const int kConvxRunPad = 32; // zeros behind the linear output run (see cx_final_store)
 
 // padded complex index: one spare slot after every 16
-R8B_HD int cpad(int e) { return e + (e >> 4); }
+#ifndef R8B_CX_PADSHIFT
+#define R8B_CX_PADSHIFT 4
+#endif
+R8B_HD int cpad(int e) { return e + (e >> R8B_CX_PADSHIFT); }
 // padded index of real sample i when the reals are viewed as packed complex pairs
 R8B_HD int rpad(int i) { return i + ((i >> 5) << 1); }
 
-constexpr int convx_lds_doubles(int logn2) { return 2 * ((1 << logn2) + ((1 << logn2) >> 4)); }
+constexpr int convx_lds_doubles(int logn2)
+{
+	return 2 * ((1 << logn2) + ((1 << logn2) >> R8B_CX_PADSHIFT));
+}
 // LDS doubles a workgroup needs: the padded work array, which the linear output run aliases once the
 // last backward pass sits in registers
 inline int convx_lds_need(int logn2, int in_len, int /*mode*/)
