@@ -313,3 +313,17 @@ def test_gpu_deep_decimation_full_size(torch):
         if len(yo):
             d = ya[0].cpu().numpy() - yo
             assert rms(d) <= RMS_TOL and peak(d) <= PEAK_TOL
+
+
+@pytest.mark.gpu
+def test_cxx_batch_device(tmp_path):
+    """the batch C ABI from a plain C++/HIP host program with its own device buffers and stream
+    (tests/cxx_batch.cpp): rows equal the single-stream entry bitwise, across a checkpoint"""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "cxx_batch")
+    libdir = os.path.dirname(r8b.lib_path())
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cxx_batch.cpp"),
+                    "-L" + libdir, "-lr8bsrc_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.returncode, out.stdout)
