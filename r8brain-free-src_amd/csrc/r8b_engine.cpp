@@ -325,6 +325,39 @@ std::vector<double> spectral_constants_wave(const std::vector<double>& sc, int n
 	return out;
 }
 
+std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n_out)
+{
+	const int N = n_in, N2 = n_out, up = N2 / N;
+	int ln = 0;
+	while ((1 << ln) < N) ln++;
+	auto Hf = [&](int m) -> long double { return H[(size_t) (m <= N2 / 2 ? m : N2 - m)]; };
+	auto rev = [](int v, int bits)
+	{
+		int r = 0;
+		for (int b = 0; b < bits; b++)
+			if (v & (1 << b)) r |= 1 << (bits - 1 - b);
+		return r;
+	};
+	std::vector<double> out((size_t) 8 * 256 * 2, 0.0);
+	for (int t = 0; t < 256; t++)
+		for (int c = 0; c < 8; c++)
+		{
+			double* o = &out[((size_t) c * 256 + t) * 2];
+			if (up == 2)
+			{
+				const int k = rev(8 * t + c, ln);
+				o[0] = (double) (Hf(k) + Hf(k + N));
+				o[1] = (double) (Hf(k) - Hf(k + N));
+			}
+			else
+			{
+				o[0] = (double) Hf(rev(16 * t + 2 * c, ln));
+				o[1] = (double) Hf(rev(16 * t + 2 * c + 1, ln));
+			}
+		}
+	return out;
+}
+
 // LDS of the fast path: one padded complex array of n elements (r8b_convx.h, convx_lds_doubles)
 static size_t convx_work_bytes(int n) { return (size_t) 2 * (n + (n >> 4)) * sizeof(double); }
 
@@ -391,6 +424,15 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// (cfg2 0.48 vs 0.30 ms: two resident waves per SIMD cannot hide the table fetches), kept as
 	// an option
 	opt_["wave_conv"] = 0;
+	// two channels per workgroup as one complex transform (r8b_convp.h) where the geometry allows
+	opt_["pair_conv"] = 1;
+	// ... with the fused whole-step interpolator on the matrix cores when it up-samples (In <= Out)
+	opt_["pair_mfma"] = 0;
+	// ... or on the vector ALU with two adjacent phases per thread (half the LDS reads per output)
+	opt_["pair_two"] = 1;
+	// persistent pair kernel: workgroups per launch (two per CU of the MI355X; 0: one per block)
+	opt_["pair_loop"] = 0;
+	opt_["pair_stage"] = 1; // ... staging the next block's samples in LDS by LDS-DMA
 	opt_["fold_tail"] = 1; // fast convolver at stage 0 keeps the input history itself
 	// fused interpolator on the matrix cores (when a block holds 16 output groups): measured equal
 	// to the vector-ALU form on cfg2 (0.357 vs 0.362 ms: 10x fewer LDS reads, 13 % more FFT
@@ -442,6 +484,12 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 						d.spec2 = (cd*) dev_alloc(s2.size() * sizeof(double));
 						dev_upload(d.spec2, s2.data(), s2.size() * sizeof(double));
 					}
+					if (convp_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
+					{
+						const std::vector<double> hp = pair_constants(H, g.n_in, g.n_out);
+						d.hp = (cd*) dev_alloc(hp.size() * sizeof(double));
+						dev_upload(d.hp, hp.data(), hp.size() * sizeof(double));
+					}
 					if (convw_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
 					{
 						const std::vector<double> sw = spectral_constants_wave(sc, g.n_in, g.up);
@@ -471,7 +519,11 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 		}
 		plan_transforms();
 		for (size_t s = 0; s + 1 < plan_.stages.size(); s++)
-			if (fuse_with_next(s)) prepare_mfma(s);
+			if (fuse_with_next(s))
+			{
+				prepare_mfma(s);
+				prepare_two_phase(s);
+			}
 	}
 	catch (...)
 	{
@@ -492,12 +544,6 @@ void Engine::prepare_mfma(size_t s)
 	auto r_of = [&](int ph) { return (int) ((long long) ph * In / Out); };
 	const int tiles = (Out + 15) / 16;
 	if (tiles > 16) return;
-	// first valid time of block k is k*16*In - fll - e, e chosen so that the block's first fresh
-	// input sample sits on an even input position (16-byte loads)
-	const int align = 2 * up;
-	const int boff = (c.cg.fl2 - w.fll) / align * align;
-	if (boff < 0) return;
-	const int e = c.cg.fl2 - w.fll - boff;
 	int span = 0;
 	for (int p = 0; p < tiles; p++)
 	{
@@ -507,15 +553,13 @@ void Engine::prepare_mfma(size_t s)
 	// the kernel unrolls a fixed number of K steps: 10 (<= 24 taps) or 12 (<= 32 taps)
 	const int ksteps = w.flen > 24 ? 12 : 10;
 	if ((span + 3) / 4 > ksteps) return;
-	// everything a block reads must lie inside its valid run (+8 zero-extension doubles)
-	const int max_index = r_of(16 * (tiles - 1)) + e + In * 15 + 3 + 4 * (ksteps - 1);
-	if (max_index >= c.cg.in_len + 8 || 16 * In > c.cg.in_len) return;
-	if (w.fll + e + 15 * In + r_of(Out - 1) + w.fl2 + 1 > c.cg.in_len) return;
+	// the banded table: tile p, K step st, lane -> T[row(ph)][4 st + (lane >> 4) - (r_ph - r_(16 p))],
+	// ph = 16 p + (lane & 15)
 	std::vector<double> at((size_t) tiles * ksteps * 64, 0.0);
 	const std::vector<double>& T = w.bank->table;
 	for (int p = 0; p < tiles; p++)
 	{
-		d.mf_boff[p] = r_of(16 * p) + e;
+		d.mf_r16[p] = r_of(16 * p);
 		for (int st = 0; st < ksteps; st++)
 			for (int lane = 0; lane < 64; lane++)
 			{
@@ -531,8 +575,123 @@ void Engine::prepare_mfma(size_t s)
 	dev_upload(d.mf_atab, at.data(), at.size() * sizeof(double));
 	d.mf_ksteps = ksteps;
 	d.mf_tiles = tiles;
+	d.mf_tab_ok = true;
+	// one-channel kernel (r8b_convx.h MODE 2): a block must hold exactly 16 output groups.  First
+	// valid time of block k is k*16*In - fll - e, e chosen so that the block's first fresh input
+	// sample sits on an even input position (16-byte loads)
+	const int align = 2 * up;
+	const int boff = (c.cg.fl2 - w.fll) / align * align;
+	if (boff < 0) return;
+	const int e = c.cg.fl2 - w.fll - boff;
+	// everything a block reads must lie inside its valid run (+8 zero-extension doubles)
+	const int max_index = r_of(16 * (tiles - 1)) + e + In * 15 + 3 + 4 * (ksteps - 1);
+	if (max_index >= c.cg.in_len + 8 || 16 * In > c.cg.in_len) return;
+	if (w.fll + e + 15 * In + r_of(Out - 1) + w.fl2 + 1 > c.cg.in_len) return;
+	for (int p = 0; p < tiles; p++) d.mf_boff[p] = r_of(16 * p) + e;
 	d.mf_e = e;
 	d.mf_ok = true;
+}
+
+// Pair kernel with the interpolator on the matrix cores (r8b_convp.h MODE 2): blocks keep the
+// ragged output ranges of the vector form; needs the banded table, at most kConvpSets phase tiles per
+// wave and room in LDS for the rows cut by a block's range.
+bool Engine::use_pair_mfma(size_t s, int* run_off) const
+{
+	const StagePlan& c = plan_.stages[s];
+	const StagePlan& w = plan_.stages[s + 1];
+	const StageDev& dw = dev_[s + 1];
+	if (!opt_.at("pair_mfma") || !use_pair(c.cg) || !dw.mf_tab_ok) return false;
+	const int tiles = dw.mf_tiles;
+	for (int wv = 0; wv < 4; wv++)
+		if (((wv + 1) * tiles + 3) / 4 - wv * tiles / 4 > 3) return false;
+	// the first group of a block may start up to In slots before the run, the last one end that far
+	// behind it
+	const int off = (w.in_step + 16 + 15) / 16 * 16;
+	if (off + c.cg.in_len + w.in_step + 4 * dw.mf_ksteps + 16 > c.cg.n_out) return false;
+	if (run_off) *run_off = off;
+	return true;
+}
+
+// Tables of the pair kernel's two-phases-per-thread interpolator (r8b_convp.h MODE 4) for the fused
+// pair (convolver s, whole-step interpolator s+1); needs In <= Out and at most 24 taps.
+void Engine::prepare_two_phase(size_t s)
+{
+	const StagePlan& w = plan_.stages[s + 1];
+	StageDev& d = dev_[s + 1];
+	const int In = w.in_step, Out = w.out_step;
+	if (In > Out || w.flen > 24 || Out < 2) return;
+	const int NP = (Out + 1) / 2;           // phase pairs
+	const int nsg = (NP + 15) / 16;         // 16-lane LDS service groups per set
+	const int nsets = 16 / nsg;             // a workgroup has 16 service groups
+	if (nsets < 1) return;
+	auto r_of = [&](int ph) { return (int) ((long long) ph * In / Out); };
+	// deal the phase pairs to service groups such that the window starts inside a group fall into
+	// different 16-byte bank groups (start mod 16) wherever the counts allow
+	std::vector<std::vector<int>> grp((size_t) nsg);
+	std::vector<std::vector<int>> cls(16);
+	for (int q = 0; q < NP; q++) cls[(size_t) (r_of(2 * q) & 15)].push_back(q);
+	for (int r = 0; r < 16; r++)
+		for (int q : cls[(size_t) r])
+		{
+			int best = -1;
+			bool best_clash = true;
+			for (int g = 0; g < nsg; g++)
+			{
+				if (grp[(size_t) g].size() >= 16) continue;
+				bool clash = false;
+				for (int o : grp[(size_t) g]) clash = clash || (r_of(2 * o) & 15) == r;
+				if (best < 0 || (best_clash && !clash) ||
+					(best_clash == clash && grp[(size_t) g].size() < grp[(size_t) best].size()))
+				{
+					best = g;
+					best_clash = clash;
+				}
+			}
+			if (best < 0) return;
+			grp[(size_t) best].push_back(q);
+		}
+	// lanes LDS serves together for 16-byte reads (MI355X_MICROARCH.md, LDS): within each half of a
+	// wave the quads {0, 3, 5, 6} and {1, 2, 4, 7}
+	std::vector<int> pt(256, -1);
+	std::vector<double> ct((size_t) 50 * 256, 0.0);
+	const std::vector<double>& T = w.bank->table;
+	for (int t = 0; t < 256; t++)
+	{
+		const int wave = t >> 6, lane = t & 63, half = lane >> 5, quad = (lane & 31) >> 2;
+		static const int cls_of[8] = { 0, 1, 1, 0, 1, 0, 0, 1 }, rank_of[8] = { 0, 0, 1, 1, 2, 2, 3, 3 };
+		const int sg = 4 * wave + 2 * half + cls_of[quad];
+		const int pos = 4 * rank_of[quad] + (lane & 3);
+		const int set = sg / nsg, g = sg % nsg;
+		if (set >= nsets || pos >= (int) grp[(size_t) g].size()) continue;
+		const int q = grp[(size_t) g][(size_t) pos];
+		pt[(size_t) t] = q | (set << 16);
+		const int p0 = 2 * q, p1 = 2 * q + 1;
+		const int row0 = (int) (((long long) p0 * In) % Out);
+		for (int i = 0; i < w.flen; i++) ct[(size_t) i * 256 + t] = T[(size_t) row0 * w.flen + i];
+		if (p1 < Out)
+		{
+			const int row1 = (int) (((long long) p1 * In) % Out), dl = r_of(p1) - r_of(p0);
+			for (int i = 0; i < w.flen; i++)
+				ct[(size_t) (25 + i + dl) * 256 + t] = T[(size_t) row1 * w.flen + i];
+		}
+	}
+	d.ptab = (int*) dev_alloc(pt.size() * sizeof(int));
+	dev_upload(d.ptab, pt.data(), pt.size() * sizeof(int));
+	d.ctab = (double*) dev_alloc(ct.size() * sizeof(double));
+	dev_upload(d.ctab, ct.data(), ct.size() * sizeof(double));
+	d.nsets = nsets;
+}
+
+bool Engine::use_pair_two(size_t s, int* run_off) const
+{
+	const StagePlan& c = plan_.stages[s];
+	const StagePlan& w = plan_.stages[s + 1];
+	const StageDev& dw = dev_[s + 1];
+	if (!opt_.at("pair_two") || !use_pair(c.cg) || dw.ptab == nullptr) return false;
+	const int off = (w.in_step + 16 + 15) / 16 * 16;
+	if (off + c.cg.in_len + w.in_step + 32 + 16 > c.cg.n_out) return false;
+	if (run_off) *run_off = off;
+	return true;
 }
 
 Engine::~Engine() { release(); }
@@ -554,9 +713,12 @@ void Engine::release()
 		dev_free(d.spec);
 		dev_free(d.spec2);
 		dev_free(d.wspec);
+		dev_free(d.hp);
 		dev_free(d.table);
 		dev_free(d.wtab);
 		dev_free(d.mf_atab);
+		dev_free(d.ptab);
+		dev_free(d.ctab);
 	}
 	dev_.clear();
 }
@@ -627,7 +789,8 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 		{
 		case kConv:
 			*kernel = fuse_with_next(stage) ?
-				(use_wave(sp.cg) && !opt_.at("mfma_interp") ? "k_convw_whole" : "k_convx_whole") :
+				(use_pair(sp.cg) && !opt_.at("mfma_interp") ? "k_convp_whole" :
+				(use_wave(sp.cg) && !opt_.at("mfma_interp") ? "k_convw_whole" : "k_convx_whole")) :
 				((opt_.at("fast_conv") || !generic_conv_fits(sp.cg)) && (convx_mode3_ok(sp.cg.n_in,
 				sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2, sp.cg.down_pow2) ||
 				convx_geometry_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2)) ?
@@ -791,9 +954,12 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		if ((opt_.at("fast_conv") || !generic_conv_fits(g)) &&
 			(m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2)))
 		{
-			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0;
+			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0; X.run_off = 0;
+			X.ptab = nullptr; X.ctab = nullptr; X.nsets = 0; X.persist = opt_.at("pair_loop");
+			X.stage_off = opt_.at("pair_stage") && X.persist > 0 ? 48 * 1024 : 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
 			if (m3) launch_convx(X, 3, stream);
+			else if (use_pair(g)) launch_convp(X, 0, stream);
 			else if (use_wave(g)) launch_convw(X, 0, stream);
 			else launch_convx(X, 0, stream);
 			if (L.tail_ring != nullptr) tail_done_ = true;
@@ -1125,6 +1291,12 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 	launch_hbcascade(L, stream);
 }
 
+bool Engine::use_pair(const ConvGeom& g) const
+{
+	return opt_.at("pair_conv") && !opt_.at("wave_conv") &&
+		convp_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2);
+}
+
 bool Engine::use_wave(const ConvGeom& g) const
 {
 	return opt_.at("wave_conv") && convw_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2);
@@ -1162,7 +1334,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 		throw std::runtime_error("transform plan too deep");
 	for (int i = 0; i < L.n_fwd; i++) L.fwd_radix[i] = d.fwd_radix[(size_t) i];
 	for (int i = 0; i < L.n_inv; i++) L.inv_radix[i] = d.inv_radix[(size_t) i];
-	L.H = d.H; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.spec2 = d.spec2; L.wspec = d.wspec;
+	L.H = d.H; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.spec2 = d.spec2; L.wspec = d.wspec; L.hp = d.hp;
 	L.nch = nch_;
 	L.threads = opt_.at("conv_threads");
 	L.src = src;
@@ -1221,6 +1393,19 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 		}
 		return;
 	}
+	int run_off = 0;
+	const bool pair_mf = use_pair_mfma(s, &run_off);
+	const bool pair_two = !pair_mf && use_pair_two(s, &run_off);
+	X.run_off = run_off;
+	X.ptab = dw.ptab; X.ctab = dw.ctab; X.nsets = dw.nsets;
+	X.persist = opt_.at("pair_loop");
+	// staging area at 48 KB: behind the run in every mode (checked), 32 KB long
+	X.stage_off = opt_.at("pair_stage") && X.persist > 0 && run_off + in_len + 32 <= 3072 ? 48 * 1024 : 0;
+	if (pair_mf)
+	{
+		X.mf_atab = dw.mf_atab; X.mf_ksteps = dw.mf_ksteps; X.mf_tiles = dw.mf_tiles;
+		for (int i = 0; i < 16; i++) X.mf_boff[i] = dw.mf_r16[i];
+	}
 	// Blocks start S virtual samples apart with S = in_len - (interpolator taps, rounded up to
 	// the up factor): the valid ranges [k*S - fl2, k*S - fl2 + in_len) of consecutive blocks
 	// overlap by at least flen-1 convolver outputs, so each interpolator tap window lies inside
@@ -1262,7 +1447,24 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			B.u_lo = (int) (jlo * In / Out - w.fll - t0);
 			B.pad = 0;
 		}
-		if (use_wave(c.cg)) launch_convw(X, 1, stream);
+		if (pair_mf || pair_two)
+		{
+			for (int i = 0; i < X.c.nblk; i++)
+			{
+				SpanInfo& B = X.blk[i];
+				B.pad = 0;
+				if (B.jhi <= B.jlo) continue;
+				const long long t0 = (k0 + i) * S - fl2c;
+				const long long g0 = B.jlo / Out, glast = (B.jhi - 1) / Out;
+				B.ph_lo = (int) (glast - g0);
+				// mode 2: column tiles of 8 groups; mode 4: the phase the block's last group ends before
+				B.pad = pair_mf ? (int) (glast - g0 + 8) / 8 : (int) (B.jhi - glast * Out);
+				B.u_lo = (int) (In * g0 - w.fll - t0) + run_off;
+			}
+			launch_convp(X, pair_mf ? 2 : 4, stream);
+		}
+		else if (use_pair(c.cg)) launch_convp(X, 1, stream);
+		else if (use_wave(c.cg)) launch_convw(X, 1, stream);
 		else launch_convx(X, 1, stream);
 		if (X.c.tail_ring != nullptr) tail_done_ = true;
 		X.c.tail_ring = nullptr; // once per call

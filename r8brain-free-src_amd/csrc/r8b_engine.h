@@ -66,6 +66,7 @@ private:
 		cd* spec = nullptr; // fast-path spectral constants
 		cd* spec2 = nullptr; // the same per backward position (up 1 or 2)
 		cd* wspec = nullptr; // the same for the wave-per-block kernel (per backward bin)
+		cd* hp = nullptr;    // pair kernel: kernel constants of the middle pass (r8b_convp.h)
 		int tw_len = 0;
 		double* table = nullptr;
 		double* wtab = nullptr; // whole-step bank, transposed per residue class (fused kernel)
@@ -74,6 +75,13 @@ private:
 		int mf_ksteps = 0, mf_tiles = 0, mf_e = 0;
 		int mf_boff[16] = {};
 		bool mf_ok = false;
+		// the table alone (block independent): what the pair kernel's mode 2 needs
+		bool mf_tab_ok = false;
+		int mf_r16[16] = {}; // floor(16 p in_step / out_step)
+		// pair kernel, two adjacent phases per thread (mode 4): thread table and 25-tap row pairs
+		int* ptab = nullptr;
+		double* ctab = nullptr;
+		int nsets = 0;
 		std::vector<int> fwd_radix, inv_radix;
 		std::vector<std::pair<void*, void*>> pending; // (start, stop) events not yet read
 		std::vector<void*> free_events;
@@ -89,6 +97,10 @@ private:
 	void ensure_ring(size_t s);
 	bool fuse_with_next(size_t s) const;
 	bool use_wave(const ConvGeom& g) const;
+	bool use_pair(const ConvGeom& g) const;
+	bool use_pair_mfma(size_t s, int* run_off) const;
+	bool use_pair_two(size_t s, int* run_off) const;
+	void prepare_two_phase(size_t s);
 	void prepare_mfma(size_t s);
 	int group_len(size_t s) const;
 	void launch_cascade(size_t s, int glen, long long fa, long long fb, const SrcView& src,
@@ -122,6 +134,11 @@ std::vector<double> kernel_spectrum(const LpFilter& f, int bl2, double scale);
 // spectrum (kernel_spectrum), tw the exp(-2 pi i e / bl2) table.
 std::vector<double> spectral_constants(const std::vector<double>& H, const std::vector<double>& tw,
 	int bl2, int n_in, int up);
+// kernel constants of the pair kernel's middle pass (r8b_convp.h): 8 x 256 pairs, entry c * 256 + t;
+// 2x up (n_out = 2 n_in): (H[k] + H[k+N], H[k] - H[k+N]) for forward position 8 t + c, bin k =
+// bitrev(position), N = n_in; 1:1: H of backward positions 16 t + 2 c and 16 t + 2 c + 1.  H is the
+// scaled kernel spectrum (bl2/2 + 1 reals), mirrored for bins above bl2/2.
+std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n_out);
 // radices (each in {2,4,8,16}, <= max_radix) whose product is N, largest first
 std::vector<int> plan_radices(int N, int max_radix);
 

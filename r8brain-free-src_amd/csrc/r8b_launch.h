@@ -69,6 +69,7 @@ struct ConvLaunch
 	const cd* spec;  // fast path only: per-slot spectral-stage constants (r8b_convx.h)
 	const cd* spec2; // fast path, up 1 or 2: (ca, cb) per backward POSITION, [c * N2 + P]
 	const cd* wspec; // wave-per-block form: (ca, cb) per backward bin, [slot][lane] (r8b_convw.h)
+	const cd* hp;    // pair form (r8b_convp.h): kernel constants of the middle pass, [c * 256 + thread]
 	int tw_len;
 	// work: blocks [k0, k0+nblk) x channels [0, nch); outputs clipped to [a, b)
 	long long k0;
@@ -194,6 +195,22 @@ struct ConvxLaunch
 	const double* mf_atab;
 	int mf_ksteps, mf_tiles;
 	int mf_boff[16];
+	// pair form, mode 2 (r8b_convp.h): the run of (A, B) pairs starts at LDS slot run_off; mf_boff[p]
+	// is floor(16 p in_step / out_step); per block blk[].u_lo = run slot of the window of phase 0 of
+	// the block's first output group, .ph_lo = groups - 1, .pad = column tiles (8 groups x 2 channels;
+	// mode 4: the phase the block's last group ends before, 1 .. out_step; 0: the block has no output)
+	int run_off;
+	// pair form, mode 4 (two adjacent phases per thread, r8b_convp.h): per thread its phase pair and
+	// group set (ptab[t] = q | set << 16, -1: idle), the two 25-tap rows ctab[i * 256 + t], the sets
+	const int* ptab;
+	const double* ctab;
+	int nsets;
+	// pair form: workgroups of the persistent launch (each walks a contiguous range of the pair-major
+	// item list); 0: one workgroup per item
+	int persist;
+	// persistent form: byte offset of the LDS staging area the next block's samples are DMAed into
+	// (32 KB; the launch allocates LDS up to stage_off + 32 KB), 0: no staging (plain loads)
+	int stage_off;
 };
 
 // geometries the fast path is instantiated for: (log2 of the forward complex length, up shift), and
@@ -239,6 +256,15 @@ inline bool convw_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow
 }
 #define R8B_CONVW_GEOMS(M) M(10, 0) M(10, 1) M(11, 0)
 
+// pair form of the fast path (r8b_convp.h): two channels per workgroup as one complex transform;
+// 2048-point blocks up-sampled 2x and 4096-point blocks 1:1 (4096-point backward transform)
+inline bool convp_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
+{
+	if (!up_pow2 || down != 1) return false;
+	return (n_in == 2048 && n_out == 4096 && up == 2) || (n_in == 4096 && n_out == 4096 && up == 1);
+}
+#define R8B_CONVP_GEOMS(M) M(11, 1) M(12, 0)
+
 // launchers (asynchronous on `stream`, a hipStream_t)
 void launch_conv(const ConvLaunch& L, void* stream);
 void launch_whole(const WholeLaunch& L, void* stream);
@@ -254,6 +280,8 @@ void launch_pcm_out(const PcmLaunch& L, void* stream); // planar fp64 -> PCM
 // mode 0: convolver output to X.c.dst; mode 1 / 2: fused interpolator output to X.wdst (FIR on
 // the vector ALU / on the matrix cores)
 void launch_convx(const ConvxLaunch& X, int mode, void* stream);
+// the same work in pair form (modes 0, 1 and 2; needs X.c.hp)
+void launch_convp(const ConvxLaunch& X, int mode, void* stream);
 // the same work, one wavefront per block (modes 0 and 1; needs X.c.wspec)
 void launch_convw(const ConvxLaunch& X, int mode, void* stream);
 

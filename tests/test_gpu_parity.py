@@ -89,8 +89,11 @@ def test_hip_single_stage_matches_reference_stage(torch, refwrap, stage):
         y = hb.process_host(np.stack([x[i:i + chunk]] * 2))
         assert y.shape[1] == len(yr)
         if len(yr):
-            assert np.array_equal(y[0], y[1])
-            assert rms(y[0] - yr) <= RMS_TOL and peak(y[0] - yr) <= PEAK_TOL
+            # (the pair kernel carries channel 0 in the real and channel 1 in the imaginary part of one
+            # complex transform: equal inputs give equal outputs to rounding, not bit for bit)
+            assert peak(y[0] - y[1]) <= 4e-15
+            for c in range(2):
+                assert rms(y[c] - yr) <= RMS_TOL and peak(y[c] - yr) <= PEAK_TOL
 
 
 def test_hip_chunk_invariance_is_bitwise(torch):
