@@ -81,6 +81,7 @@ struct ConvpState
 	cd hp[8];
 	double row[32];
 	double rows2[2 * 25]; // mode 4: the two rows of the thread's phase pair
+	int pt;               // ... and its entry of X.ptab
 };
 
 constexpr int convp_lds_bytes(int logn2) { return (1 << logn2) * 16; }
@@ -156,83 +157,39 @@ R8B_HD void pdit_regs(const cd* buf, int n, int b, const cd* twr, double* vr, do
 
 // K1: thread t owns the radix-E1 butterfly over elements t + 256 p of the first pass; element i of the
 // circular block is sample i of channel A (real part) and of channel B (imaginary part).  A wave
-// reads 64 consecutive samples of each channel per load.  The samples wait in registers: the
-// persistent form of the kernel issues these loads one block ahead (r8b_kernels.hip k_convp_loop).
+// reads 64 consecutive samples of each channel per load.
 template<int LN, int UL>
 R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, int chA, int chB, int tid)
 {
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int R = G::E1, q = G::N / R;
-	const int iln = L.in_len / L.up;
-	const long long base = (k * (long long) L.blk_stride + L.blk_offset) / L.up;
+	const int iln = L.in_len >> UL; // (L.up == 1 << UL)
+	const long long base = (k * (long long) L.blk_stride + L.blk_offset) >> UL; // (>= 0, even)
+	// most blocks of a call lie entirely inside the caller's buffer: one uniform row pointer per channel
+	// and a 32-bit offset per load (the general form selects ring / buffer / zero per sample: ~12
+	// vector instructions per load)
+	if (L.src.cur_fmt == kPcmF64 && base - (G::N - iln) >= L.src.cur_base && base - (G::N - iln) >= 0)
+	{
+		const double* const pa = L.src.cur + ((long long) chA * L.src.cur_stride + (base - L.src.cur_base));
+		const double* const pb = L.src.cur + ((long long) chB * L.src.cur_stride + (base - L.src.cur_base));
+#pragma unroll
+		for (int p = 0; p < R; p++)
+		{
+			const int i = tid + p * q;
+			const int rel = i < iln ? i : i - G::N;
+			st.pr[p] = pa[rel];
+			st.pi[p] = pb[rel];
+		}
+		return;
+	}
 	const SrcBlock sa = src_block(L.src, chA, base), sb = src_block(L.src, chB, base);
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
 		const int i = tid + p * q;
 		const int rel = i < iln ? i : i - G::N;
-#if defined(R8B_P_SKIP) && (R8B_P_SKIP & 1)
-		st.pr[p] = 1e-3 * (rel & 255) + (double) sa.b_lo * 1e-9;
-		st.pi[p] = 1e-3 * (rel & 127) + (double) sb.b_lo * 1e-9;
-#else
 		st.pr[p] = src_block_load1(sa, rel);
 		st.pi[p] = src_block_load1(sb, rel);
-#endif
-	}
-}
-
-// ---- the persistent form stages the NEXT block's samples in LDS by LDS-DMA (no registers) -----------
-// Staging area: 2048 (E1 = 8) or 4096 (E1 = 16) doubles of channel A, then as many of channel B, behind
-// the run (slots the interpolation phase does not touch; the launch allocates 16 KB beyond the
-// transform array for it).  One DMA operation moves two consecutive samples (16 bytes) per lane: op
-// o = pair (o mod N/2) of channel A (o < N/2) or B, landing at byte 16 o of the area -- a wave's 64 ops
-// are 64 consecutive 16-byte words, as LDS-DMA requires.
-template<int LN, int UL>
-struct ConvpStage
-{
-	typedef ConvpGeom<LN, UL> G;
-	static constexpr int OPS = G::N, PER_THREAD = OPS / kConvpThreads; // ops per block, per thread
-};
-
-// can block k be staged?  needs 16-byte loads of sample pairs everywhere (L.vec_ok) and no position
-// before the start of the stream (those read as zero, which a DMA cannot produce)
-template<int LN, int UL>
-R8B_HD bool cp_can_stage(const ConvLaunch& L, long long k)
-{
-	typedef ConvpGeom<LN, UL> G;
-	const int iln = L.in_len / L.up;
-	const long long base = (k * (long long) L.blk_stride + L.blk_offset) / L.up;
-	return G::E1 == 8 && L.vec_ok && L.src.cur_fmt == kPcmF64 && base - (G::N - iln) >= 0;
-}
-
-// global address of the sample pair DMA op (r, tid) of block k fetches
-template<int LN, int UL>
-R8B_HD const double* cp_stage_src(const ConvLaunch& L, long long k, int chA, int chB, int r, int tid)
-{
-	typedef ConvpGeom<LN, UL> G;
-	const int o = tid + kConvpThreads * r;
-	const int ch = o < G::N / 2 ? chA : chB;
-	const int i = 2 * (o & (G::N / 2 - 1));
-	const int iln = L.in_len / L.up;
-	const long long base = (k * (long long) L.blk_stride + L.blk_offset) / L.up;
-	const int rel = i < iln ? i : i - G::N;
-	const long long pos = base + rel;
-	const double* pr = L.src.ring + ((long long) ch * L.src.ring_stride + (pos & L.src.ring_mask));
-	const double* pc = L.src.cur + ((long long) ch * L.src.cur_stride + (pos - L.src.cur_base));
-	return pos >= L.src.cur_base ? pc : pr;
-}
-
-// first forward pass from the staging area
-template<int LN, int UL>
-R8B_HD void cp_unstage(const double* stage, ConvpState<LN, UL>& st, int tid)
-{
-	typedef ConvpGeom<LN, UL> G;
-	constexpr int R = G::E1, q = G::N / R;
-#pragma unroll
-	for (int p = 0; p < R; p++)
-	{
-		st.pr[p] = stage[tid + p * q];
-		st.pi[p] = stage[G::N + tid + p * q];
 	}
 }
 
@@ -295,12 +252,7 @@ R8B_HD void cp_hp_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int tid)
 #pragma unroll
 	for (int c = 0; c < 8; c++)
 	{
-#if defined(R8B_P_SKIP) && (R8B_P_SKIP & 8)
-		st.hp[c].re = 1e-3 * (c + 1) + 1e-9 * tid;
-		st.hp[c].im = 1e-3 * (c + 2) - 1e-9 * tid;
-#else
 		st.hp[c] = L.hp[c * kConvpThreads + tid];
-#endif
 	}
 }
 
@@ -395,6 +347,24 @@ R8B_HD void cp_final_store(const ConvLaunch& L, cd* y, const ConvpState<LN, UL>&
 	// a stage's stream starts at t = 0: earlier outputs do not exist for the interpolator
 	// (reference CDSPFracInterpolator.h:834-859)
 	const int nzero = t0 >= 0 ? 0 : (-t0 > L.in_len ? L.in_len : (int) -t0);
+	const int in_len = L.in_len, u0 = (tid + L.fl2) & mask;
+	if (nzero == 0)
+	{
+		// (every block but the first ones of a stream)
+#pragma unroll
+		for (int p = 0; p < 16; p++)
+		{
+			const int u = (u0 + kConvpThreads * p) & mask;
+			if (u < in_len)
+			{
+				cd v;
+				v.re = st.vr[p];
+				v.im = st.vi[p];
+				y[u] = v;
+			}
+		}
+	}
+	else
 #pragma unroll
 	for (int p = 0; p < 16; p++)
 	{
@@ -428,11 +398,7 @@ R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 	{
 		const int u = (tid + kConvpThreads * p + L.fl2) & mask;
 		const long long q = t0 + u;
-#if defined(R8B_P_SKIP) && (R8B_P_SKIP & 2)
-		if (st.vr[p] == 1.2345e300)
-#else
 		if (u < L.in_len && q >= L.a && q < L.b)
-#endif
 		{
 			dst_store(L.dst, chA, q, st.vr[p]);
 			if (bvalid) dst_store(L.dst, chB, q, st.vi[p]);
@@ -482,56 +448,6 @@ R8B_HD void cp_whole_compute(const ConvxLaunch& X, const cd* y, const double* ro
 	}
 }
 
-// MODE 2: K8 on the matrix cores, both channels of the pair at once.  Output j = Out g + ph (group g,
-// phase ph) reads y[In g + r_ph - fll + i], r_ph = floor(ph In / Out).  A tile is D[16 x 16] =
-// A[16 x K] B[K x 16] (v_mfma_f64_16x16x4_f64, K steps of 4) with
-//   rows    m = 2 gl + c : channel c of group g0 + 8 ct + gl (column tile ct = 8 groups x 2 channels),
-//           A[m][kk] = y_c[In g + r_(16 pt) - fll + kk]: one 8-byte LDS read per lane and K step;
-//   columns n : phase 16 pt + n, B[kk][n] = T[row(ph)][kk - (r_ph - r_(16 pt))], zero outside the taps
-//           (the banded table X.mf_atab, block independent: a wave keeps the tiles of its <= 3 phase
-//           tiles in registers);
-// so a lane's four results are one channel's outputs at 16 consecutive phases per 16-lane group: a
-// store instruction writes four 128-byte runs.  Blocks keep their own (ragged) output ranges: groups
-// cut by the block's range [jlo, jhi) are computed whole and masked at the store; every LDS slot a
-// masked or zero-weighted product reads holds a finite value (the whole array was written by the
-// transform passes).  Versus the vector form: no polyphase row in registers, 1/7 of the LDS reads,
-// and the multiply-adds run on the matrix pipe next to the other workgroup's transform passes.
-// Operand layout (cdna_hip_programming.md section 3): lane l supplies A[l&15][l>>4] and
-// B[l>>4][l&15]; D register i of lane l is row (l>>4) + 4 i, column l&15.
-static const int kConvpSets = 3; // phase tiles a wave can hold
-
-// phase tiles of wave w: [w * tiles / 4, ...) -- at most kConvpSets (checked by the host)
-R8B_HD int cp_mfma_first_tile(const ConvxLaunch& X, int wave) { return wave * X.mf_tiles / 4; }
-
-// index (in doubles) of lane's A operand of K step 0: run slot of (group, K column lane >> 4), channel
-// lane & 1
-R8B_HD int cp_mfma_a_index(const ConvxLaunch& X, const SpanInfo& B, int pt, int ct, int lane)
-{
-	int gl = 8 * ct + ((lane & 15) >> 1);
-	gl = gl > B.ph_lo ? B.ph_lo : gl; // rows beyond the block's last group repeat it (masked anyway)
-	return 2 * (B.u_lo + X.in_step * gl + X.mf_boff[pt] + (lane >> 4)) + (lane & 1);
-}
-
-R8B_HD void cp_mfma_store(const ConvxLaunch& X, const SpanInfo& B, int pt, int ct, int lane, int chA,
-	int chB, bool bvalid, const double* d)
-{
-	const int ph = 16 * pt + (lane & 15);
-	if (ph >= X.out_step) return;
-	const long long jg = B.jlo - B.jlo_mod + ph;
-#pragma unroll
-	for (int i = 0; i < 4; i++)
-	{
-		const int m = (lane >> 4) + 4 * i;
-		const long long j = jg + (long long) X.out_step * (8 * ct + (m >> 1));
-#if defined(R8B_P_SKIP) && (R8B_P_SKIP & 2)
-		if (d[i] == 1.2345e300)
-#else
-		if (j >= B.jlo && j < B.jhi && ((m & 1) == 0 || bvalid))
-#endif
-			dst_store(X.wdst, (m & 1) ? chB : chA, j, d[i]);
-	}
-}
-
 // MODE 4: K8 on the vector ALU, two ADJACENT phases per thread.  With In <= Out the tap windows of
 // phases 2q and 2q+1 start 0 or 1 samples apart, so 25 (A, B) pairs read from LDS feed four outputs
 // (two phases x two channels): half the LDS reads per output of the one-phase form, and with
@@ -544,25 +460,27 @@ R8B_HD void cp_mfma_store(const ConvxLaunch& X, const SpanInfo& B, int pt, int c
 // computed whole and masked at the store (slots outside the run hold finite transform data).
 static const int kConvpTaps2 = 25;
 
-R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int tid)
+R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int* pt, int tid)
 {
+	*pt = X.ptab[tid];
+	// X.ctab holds the 50 values of a thread as 25 pairs, pair i of thread t at [(i * 256 + t) * 2]: a
+	// wave reads 64 consecutive 16-byte entries per load
+	const cd* ct = reinterpret_cast<const cd*>(X.ctab) + tid;
 #pragma unroll
-	for (int i = 0; i < 2 * kConvpTaps2; i++)
+	for (int i = 0; i < kConvpTaps2; i++)
 	{
-#if defined(R8B_P_SKIP) && (R8B_P_SKIP & 8)
-		rows[i] = 1e-2 * (i + 1) + 1e-9 * tid;
-#else
-		rows[i] = X.ctab[i * kConvpThreads + tid];
-#endif
+		const cd v = ct[i * kConvpThreads];
+		rows[2 * i] = v.re;
+		rows[2 * i + 1] = v.im;
 	}
 }
 
-R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* rows, long long k,
-	int chA, int chB, bool bvalid, int tid)
+R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* rows, int pt, long long k,
+	int chA, int chB, bool bvalid)
 {
-	const int pt = X.ptab[tid];
+	// pt: phase pair q (bits 0-7), group set (8-11), window start floor(2 q In / Out) (12-)
 	if (pt < 0) return;
-	const int q = pt & 0xffff, set = pt >> 16;
+	const int q = pt & 0xff, set = (pt >> 8) & 15, rq = pt >> 12;
 	// (block constants into registers once: the kernel arguments live in memory)
 	const SpanInfo& Bm = X.blk[k - X.c.k0];
 	const int hi_mod = Bm.pad, gmax = Bm.ph_lo, lo_mod = Bm.jlo_mod, u_lo = Bm.u_lo;
@@ -572,7 +490,9 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* r
 	// group 0 starts at the block's first output (phase lo_mod), the last group ends before phase hi_mod
 	const bool f0 = 2 * q >= lo_mod, f1 = 2 * q + 1 >= lo_mod && 2 * q + 1 < out_step;
 	const bool l0 = 2 * q < hi_mod, l1 = 2 * q + 1 < hi_mod && 2 * q + 1 < out_step;
-	const int rq = (int) ((unsigned) (2 * q * in_step) / (unsigned) out_step);
+	const bool linear = X.wdst.mask == -1 && X.wdst.fmt == kPcmF64;
+	double* const pa = X.wdst.p + ((long long) chA * X.wdst.stride + (jg + X.wdst.off));
+	double* const pb = X.wdst.p + ((long long) chB * X.wdst.stride + (jg + X.wdst.off));
 	for (int gl = set; gl <= gmax; gl += nsets)
 	{
 		const cd* w = y + (u_lo + in_step * gl + rq);
@@ -603,9 +523,25 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* r
 				b1[t & 1] += rows[kConvpTaps2 + t] * v[c & 1][i].im;
 			}
 		}
-		const long long j = jg + (long long) out_step * gl;
 		const bool v0 = (gl > 0 || f0) && (gl < gmax || l0);
 		const bool v1 = (gl > 0 ? 2 * q + 1 < out_step : f1) && (gl < gmax || l1);
+		if (linear)
+		{
+			// caller's buffer: row pointers once, a 32-bit index per output
+			const int o = out_step * gl;
+			if (v0)
+			{
+				pa[o] = a0[0] + a0[1];
+				if (bvalid) pb[o] = b0[0] + b0[1];
+			}
+			if (v1)
+			{
+				pa[o + 1] = a1[0] + a1[1];
+				if (bvalid) pb[o + 1] = b1[0] + b1[1];
+			}
+			continue;
+		}
+		const long long j = jg + (long long) out_step * gl;
 		if (v0)
 		{
 			dst_store(X.wdst, chA, j, a0[0] + a0[1]);
@@ -630,13 +566,8 @@ struct ConvpItem
 	bool bvalid;
 };
 
-// LOOP: the persistent form.  `staged`: the samples of `cur` wait in the LDS staging area (else they
-// are loaded here, like in the one-block form).  If has_next and the next item can be staged, its
-// DMA is issued behind the last barrier of the transforms, so that it flies during the
-// interpolation; returns whether that happened.  `stage` = the staging area (LOOP only).
-template<int LN, int UL, int MODE, int FLENP, bool LOOP, class Exec>
-R8B_HD bool convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, double* stage, const ConvpItem& cur,
-	bool staged, const ConvpItem& nxt, bool has_next)
+template<int LN, int UL, int MODE, int FLENP, class Exec>
+R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem& cur)
 {
 	typedef ConvpGeom<LN, UL> G;
 	typedef ConvpState<LN, UL> St;
@@ -644,13 +575,9 @@ R8B_HD bool convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, double* stage, c
 	const long long k = cur.k;
 	const int chA = cur.chA, chB = cur.chB;
 	const bool bvalid = cur.bvalid;
-	if constexpr (MODE == 2) ex.template mfma_pair_prefetch<(FLENP > 24 ? 12 : 10)>(X);
-	// (the first pass writes wave 3's part of the array, which the staging area overlaps: every thread
-	// has its samples in registers before any thread writes)
-	if (LOOP && staged) ex.phase([&](int tid, St& st) { cp_unstage<LN, UL>(stage, st, tid); });
 	ex.phase([&](int tid, St& st)
 	{
-		if (!(LOOP && staged)) cp_load<LN, UL>(L, st, k, chA, chB, tid);
+		cp_load<LN, UL>(L, st, k, chA, chB, tid);
 		cp_first<LN, UL>(L, buf, st, tid);
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, tid);
 		else cp_hp_prefetch<LN, UL>(L, st, tid);
@@ -700,51 +627,25 @@ R8B_HD bool convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, double* stage, c
 			}
 		});
 	}
-	bool next_staged = false;
-	auto prefetch_next = [&]()
-	{
-		if constexpr (LOOP)
-		{
-			if (has_next && stage != nullptr && cp_can_stage<LN, UL>(L, nxt.k))
-			{
-				ex.stage_issue(L, stage, nxt);
-				next_staged = true;
-			}
-		}
-	};
 	if constexpr (MODE == 0)
 	{
-		if constexpr (LOOP)
+		ex.each([&](int tid, St& st)
 		{
-			// (the staging area overlaps the array the last pass reads)
-			ex.phase([&](int tid, St& st) { cp_back2<LN, UL>(buf, st, tid); });
-			prefetch_next();
-		}
-		else ex.each([&](int tid, St& st) { cp_back2<LN, UL>(buf, st, tid); });
-		ex.each([&](int tid, St& st) { cp_store_conv<LN, UL>(L, st, k, chA, chB, bvalid, tid); });
-	}
-	else if constexpr (MODE == 2)
-	{
-		constexpr int KS = FLENP > 24 ? 12 : 10;
-		ex.phase([&](int tid, St& st) { cp_back2<LN, UL>(buf, st, tid); });
-		ex.phase([&](int tid, St& st) { cp_final_store<LN, UL>(L, buf + X.run_off, st, k, tid); });
-		prefetch_next();
-#if !defined(R8B_P_SKIP) || !(R8B_P_SKIP & 4)
-		ex.template mfma_pair_interp<KS>(X, buf, k, chA, chB, bvalid);
-#endif
+			cp_back2<LN, UL>(buf, st, tid);
+			cp_store_conv<LN, UL>(L, st, k, chA, chB, bvalid, tid);
+		});
 	}
 	else if constexpr (MODE == 4)
 	{
 		ex.phase([&](int tid, St& st)
 		{
 			cp_back2<LN, UL>(buf, st, tid);
-			cp_rows2_fetch(X, st.rows2, tid);
+			cp_rows2_fetch(X, st.rows2, &st.pt, tid);
 		});
 		ex.phase([&](int tid, St& st) { cp_final_store<LN, UL>(L, buf + X.run_off, st, k, tid); });
-		prefetch_next();
 		ex.each([&](int tid, St& st)
 		{
-			cp_whole2_compute(X, buf, st.rows2, k, chA, chB, bvalid, tid);
+			cp_whole2_compute(X, buf, st.rows2, st.pt, k, chA, chB, bvalid);
 		});
 	}
 	else
@@ -755,13 +656,11 @@ R8B_HD bool convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, double* stage, c
 			cx_whole_row<FLENP>(X, st.row, tid);
 		});
 		ex.phase([&](int tid, St& st) { cp_final_store<LN, UL>(L, buf, st, k, tid); });
-		prefetch_next();
 		ex.each([&](int tid, St& st)
 		{
 			cp_whole_compute<FLENP>(X, buf, st.row, k, chA, chB, bvalid, tid);
 		});
 	}
-	return next_staged;
 }
 
 // item i of a launch, pair major: blocks of one channel pair are consecutive (a persistent
@@ -775,6 +674,12 @@ R8B_HD ConvpItem convp_item(const ConvLaunch& L, long long i)
 	it.bvalid = it.chA + 1 < L.nch;
 	it.chB = it.bvalid ? it.chA + 1 : it.chA;
 	return it;
+}
+
+// floor(i / d) for i * d < 2^32 by a multiplication: magic = floor(2^32 / d) + 1 (set by the launcher)
+R8B_HD unsigned convp_div(unsigned i, unsigned magic)
+{
+	return (unsigned) (((unsigned long long) i * magic) >> 32);
 }
 
 } // namespace r8bhip

@@ -120,18 +120,6 @@ struct ConvxState
 template<int R>
 R8B_HD void tw_fetch(cd* twr, const cd* tw, int tw_len, int n, int j)
 {
-#if defined(R8B_P_SKIP) && (R8B_P_SKIP & 8)
-	// timing study only: no table fetch
-	{
-		const int nb = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
-		for (int i = 0; i < nb; i++)
-		{
-			twr[i].re = 1.0 - 1e-9 * (j + i);
-			twr[i].im = 1e-5 * (j + i + n);
-		}
-		return;
-	}
-#endif
 	const int ts = tw_len / n * j;
 	twr[0] = tw[ts];
 	if constexpr (R >= 4)

@@ -426,13 +426,9 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["wave_conv"] = 0;
 	// two channels per workgroup as one complex transform (r8b_convp.h) where the geometry allows
 	opt_["pair_conv"] = 1;
-	// ... with the fused whole-step interpolator on the matrix cores when it up-samples (In <= Out)
-	opt_["pair_mfma"] = 0;
-	// ... or on the vector ALU with two adjacent phases per thread (half the LDS reads per output)
+	// ... with two adjacent phases per thread in the fused interpolator when it up-samples (In <= Out:
+	// half the LDS reads per output, nearly all lanes busy)
 	opt_["pair_two"] = 1;
-	// persistent pair kernel: workgroups per launch (two per CU of the MI355X; 0: one per block)
-	opt_["pair_loop"] = 0;
-	opt_["pair_stage"] = 1; // ... staging the next block's samples in LDS by LDS-DMA
 	opt_["fold_tail"] = 1; // fast convolver at stage 0 keeps the input history itself
 	// fused interpolator on the matrix cores (when a block holds 16 output groups): measured equal
 	// to the vector-ALU form on cfg2 (0.357 vs 0.362 ms: 10x fewer LDS reads, 13 % more FFT
@@ -544,6 +540,12 @@ void Engine::prepare_mfma(size_t s)
 	auto r_of = [&](int ph) { return (int) ((long long) ph * In / Out); };
 	const int tiles = (Out + 15) / 16;
 	if (tiles > 16) return;
+	// first valid time of block k is k*16*In - fll - e, e chosen so that the block's first fresh
+	// input sample sits on an even input position (16-byte loads)
+	const int align = 2 * up;
+	const int boff = (c.cg.fl2 - w.fll) / align * align;
+	if (boff < 0) return;
+	const int e = c.cg.fl2 - w.fll - boff;
 	int span = 0;
 	for (int p = 0; p < tiles; p++)
 	{
@@ -553,13 +555,15 @@ void Engine::prepare_mfma(size_t s)
 	// the kernel unrolls a fixed number of K steps: 10 (<= 24 taps) or 12 (<= 32 taps)
 	const int ksteps = w.flen > 24 ? 12 : 10;
 	if ((span + 3) / 4 > ksteps) return;
-	// the banded table: tile p, K step st, lane -> T[row(ph)][4 st + (lane >> 4) - (r_ph - r_(16 p))],
-	// ph = 16 p + (lane & 15)
+	// everything a block reads must lie inside its valid run (+8 zero-extension doubles)
+	const int max_index = r_of(16 * (tiles - 1)) + e + In * 15 + 3 + 4 * (ksteps - 1);
+	if (max_index >= c.cg.in_len + 8 || 16 * In > c.cg.in_len) return;
+	if (w.fll + e + 15 * In + r_of(Out - 1) + w.fl2 + 1 > c.cg.in_len) return;
 	std::vector<double> at((size_t) tiles * ksteps * 64, 0.0);
 	const std::vector<double>& T = w.bank->table;
 	for (int p = 0; p < tiles; p++)
 	{
-		d.mf_r16[p] = r_of(16 * p);
+		d.mf_boff[p] = r_of(16 * p) + e;
 		for (int st = 0; st < ksteps; st++)
 			for (int lane = 0; lane < 64; lane++)
 			{
@@ -575,41 +579,8 @@ void Engine::prepare_mfma(size_t s)
 	dev_upload(d.mf_atab, at.data(), at.size() * sizeof(double));
 	d.mf_ksteps = ksteps;
 	d.mf_tiles = tiles;
-	d.mf_tab_ok = true;
-	// one-channel kernel (r8b_convx.h MODE 2): a block must hold exactly 16 output groups.  First
-	// valid time of block k is k*16*In - fll - e, e chosen so that the block's first fresh input
-	// sample sits on an even input position (16-byte loads)
-	const int align = 2 * up;
-	const int boff = (c.cg.fl2 - w.fll) / align * align;
-	if (boff < 0) return;
-	const int e = c.cg.fl2 - w.fll - boff;
-	// everything a block reads must lie inside its valid run (+8 zero-extension doubles)
-	const int max_index = r_of(16 * (tiles - 1)) + e + In * 15 + 3 + 4 * (ksteps - 1);
-	if (max_index >= c.cg.in_len + 8 || 16 * In > c.cg.in_len) return;
-	if (w.fll + e + 15 * In + r_of(Out - 1) + w.fl2 + 1 > c.cg.in_len) return;
-	for (int p = 0; p < tiles; p++) d.mf_boff[p] = r_of(16 * p) + e;
 	d.mf_e = e;
 	d.mf_ok = true;
-}
-
-// Pair kernel with the interpolator on the matrix cores (r8b_convp.h MODE 2): blocks keep the
-// ragged output ranges of the vector form; needs the banded table, at most kConvpSets phase tiles per
-// wave and room in LDS for the rows cut by a block's range.
-bool Engine::use_pair_mfma(size_t s, int* run_off) const
-{
-	const StagePlan& c = plan_.stages[s];
-	const StagePlan& w = plan_.stages[s + 1];
-	const StageDev& dw = dev_[s + 1];
-	if (!opt_.at("pair_mfma") || !use_pair(c.cg) || !dw.mf_tab_ok) return false;
-	const int tiles = dw.mf_tiles;
-	for (int wv = 0; wv < 4; wv++)
-		if (((wv + 1) * tiles + 3) / 4 - wv * tiles / 4 > 3) return false;
-	// the first group of a block may start up to In slots before the run, the last one end that far
-	// behind it
-	const int off = (w.in_step + 16 + 15) / 16 * 16;
-	if (off + c.cg.in_len + w.in_step + 4 * dw.mf_ksteps + 16 > c.cg.n_out) return false;
-	if (run_off) *run_off = off;
-	return true;
 }
 
 // Tables of the pair kernel's two-phases-per-thread interpolator (r8b_convp.h MODE 4) for the fused
@@ -619,7 +590,7 @@ void Engine::prepare_two_phase(size_t s)
 	const StagePlan& w = plan_.stages[s + 1];
 	StageDev& d = dev_[s + 1];
 	const int In = w.in_step, Out = w.out_step;
-	if (In > Out || w.flen > 24 || Out < 2) return;
+	if (In > Out || w.flen > 24 || Out < 2 || Out > 510) return;
 	const int NP = (Out + 1) / 2;           // phase pairs
 	const int nsg = (NP + 15) / 16;         // 16-lane LDS service groups per set
 	const int nsets = 16 / nsg;             // a workgroup has 16 service groups
@@ -664,15 +635,17 @@ void Engine::prepare_two_phase(size_t s)
 		const int set = sg / nsg, g = sg % nsg;
 		if (set >= nsets || pos >= (int) grp[(size_t) g].size()) continue;
 		const int q = grp[(size_t) g][(size_t) pos];
-		pt[(size_t) t] = q | (set << 16);
+		pt[(size_t) t] = q | (set << 8) | (r_of(2 * q) << 12);
 		const int p0 = 2 * q, p1 = 2 * q + 1;
 		const int row0 = (int) (((long long) p0 * In) % Out);
-		for (int i = 0; i < w.flen; i++) ct[(size_t) i * 256 + t] = T[(size_t) row0 * w.flen + i];
+		// value v (0..49: the 25 taps of phase p0, then of p1 shifted by its window offset) of thread t
+		// sits in pair v / 2: ct[((v / 2) * 256 + t) * 2 + v % 2]
+		auto put = [&](int v, double x) { ct[((size_t) (v / 2) * 256 + t) * 2 + (v & 1)] = x; };
+		for (int i = 0; i < w.flen; i++) put(i, T[(size_t) row0 * w.flen + i]);
 		if (p1 < Out)
 		{
 			const int row1 = (int) (((long long) p1 * In) % Out), dl = r_of(p1) - r_of(p0);
-			for (int i = 0; i < w.flen; i++)
-				ct[(size_t) (25 + i + dl) * 256 + t] = T[(size_t) row1 * w.flen + i];
+			for (int i = 0; i < w.flen; i++) put(25 + i + dl, T[(size_t) row1 * w.flen + i]);
 		}
 	}
 	d.ptab = (int*) dev_alloc(pt.size() * sizeof(int));
@@ -955,8 +928,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			(m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2)))
 		{
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0; X.run_off = 0;
-			X.ptab = nullptr; X.ctab = nullptr; X.nsets = 0; X.persist = opt_.at("pair_loop");
-			X.stage_off = opt_.at("pair_stage") && X.persist > 0 ? 48 * 1024 : 0;
+			X.ptab = nullptr; X.ctab = nullptr; X.nsets = 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
 			if (m3) launch_convx(X, 3, stream);
 			else if (use_pair(g)) launch_convp(X, 0, stream);
@@ -1394,18 +1366,9 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 		return;
 	}
 	int run_off = 0;
-	const bool pair_mf = use_pair_mfma(s, &run_off);
-	const bool pair_two = !pair_mf && use_pair_two(s, &run_off);
+	const bool pair_two = use_pair_two(s, &run_off);
 	X.run_off = run_off;
 	X.ptab = dw.ptab; X.ctab = dw.ctab; X.nsets = dw.nsets;
-	X.persist = opt_.at("pair_loop");
-	// staging area at 48 KB: behind the run in every mode (checked), 32 KB long
-	X.stage_off = opt_.at("pair_stage") && X.persist > 0 && run_off + in_len + 32 <= 3072 ? 48 * 1024 : 0;
-	if (pair_mf)
-	{
-		X.mf_atab = dw.mf_atab; X.mf_ksteps = dw.mf_ksteps; X.mf_tiles = dw.mf_tiles;
-		for (int i = 0; i < 16; i++) X.mf_boff[i] = dw.mf_r16[i];
-	}
 	// Blocks start S virtual samples apart with S = in_len - (interpolator taps, rounded up to
 	// the up factor): the valid ranges [k*S - fl2, k*S - fl2 + in_len) of consecutive blocks
 	// overlap by at least flen-1 convolver outputs, so each interpolator tap window lies inside
@@ -1447,7 +1410,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			B.u_lo = (int) (jlo * In / Out - w.fll - t0);
 			B.pad = 0;
 		}
-		if (pair_mf || pair_two)
+		if (pair_two)
 		{
 			for (int i = 0; i < X.c.nblk; i++)
 			{
@@ -1457,11 +1420,10 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 				const long long t0 = (k0 + i) * S - fl2c;
 				const long long g0 = B.jlo / Out, glast = (B.jhi - 1) / Out;
 				B.ph_lo = (int) (glast - g0);
-				// mode 2: column tiles of 8 groups; mode 4: the phase the block's last group ends before
-				B.pad = pair_mf ? (int) (glast - g0 + 8) / 8 : (int) (B.jhi - glast * Out);
+				B.pad = (int) (B.jhi - glast * Out); // the phase the block's last group ends before
 				B.u_lo = (int) (In * g0 - w.fll - t0) + run_off;
 			}
-			launch_convp(X, pair_mf ? 2 : 4, stream);
+			launch_convp(X, 4, stream);
 		}
 		else if (use_pair(c.cg)) launch_convp(X, 1, stream);
 		else if (use_wave(c.cg)) launch_convw(X, 1, stream);

@@ -75,9 +75,6 @@ private:
 		int mf_ksteps = 0, mf_tiles = 0, mf_e = 0;
 		int mf_boff[16] = {};
 		bool mf_ok = false;
-		// the table alone (block independent): what the pair kernel's mode 2 needs
-		bool mf_tab_ok = false;
-		int mf_r16[16] = {}; // floor(16 p in_step / out_step)
 		// pair kernel, two adjacent phases per thread (mode 4): thread table and 25-tap row pairs
 		int* ptab = nullptr;
 		double* ctab = nullptr;
@@ -98,7 +95,6 @@ private:
 	bool fuse_with_next(size_t s) const;
 	bool use_wave(const ConvGeom& g) const;
 	bool use_pair(const ConvGeom& g) const;
-	bool use_pair_mfma(size_t s, int* run_off) const;
 	bool use_pair_two(size_t s, int* run_off) const;
 	void prepare_two_phase(size_t s);
 	void prepare_mfma(size_t s);

@@ -495,99 +495,10 @@ void k_convw(const ConvxLaunch X)
 
 
 // ------------------------------------------------------------------ fast path, pair form (r8b_convp.h)
-#ifdef R8B_P_TRACE
-// timing study only (tools/variant.sh -DR8B_P_TRACE): per workgroup and wave, the shader clock when the
-// wave reaches each barrier and when it leaves it
-__device__ unsigned long long g_ptrace[4096 * 4 * 32];
-#endif
 template<int LN, int UL>
 struct GpuExecP
 {
 	ConvpState<LN, UL> st;
-#ifdef R8B_P_TRACE
-	int tn = 0;
-	__device__ __forceinline__ void stamp()
-	{
-		if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && tn < 32)
-			g_ptrace[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 32 + tn] = __builtin_amdgcn_s_memtime();
-		tn++;
-	}
-#endif
-	// MODE 2: the banded table tiles (B operands) of this wave's phase tiles, fetched at kernel start
-	double mf_b[kConvpSets][12];
-	template<int KS>
-	__device__ __forceinline__ void mfma_pair_prefetch(const ConvxLaunch& X)
-	{
-		const int wave = (int) threadIdx.x >> 6, lane = (int) threadIdx.x & 63;
-		const int pt0 = __builtin_amdgcn_readfirstlane(cp_mfma_first_tile(X, wave));
-#pragma unroll
-		for (int q = 0; q < kConvpSets; q++)
-		{
-			const int pt = pt0 + q < X.mf_tiles ? pt0 + q : X.mf_tiles - 1;
-			const double* bt = X.mf_atab + (long) pt * KS * 64 + lane;
-#pragma unroll
-			for (int s = 0; s < KS; s++) mf_b[q][s] = bt[s * 64];
-		}
-	}
-	template<int KS>
-	__device__ __forceinline__ void mfma_pair_interp(const ConvxLaunch& X, const cd* y, long long k,
-		int chA, int chB, bool bvalid)
-	{
-		typedef double d4 __attribute__((ext_vector_type(4)));
-		const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
-		const int lane = (int) threadIdx.x & 63;
-		const SpanInfo& B = X.blk[k - X.c.k0];
-		const int nct = B.pad;
-		if (nct == 0) return;
-		const int U = X.mf_tiles * nct, ulo = wave * U / 4, uhi = (wave + 1) * U / 4;
-		const int pt0 = cp_mfma_first_tile(X, wave);
-		const double* yd = reinterpret_cast<const double*>(y);
-#pragma unroll
-		for (int q = 0; q < kConvpSets; q++)
-		{
-			const int pt = pt0 + q;
-			int clo = ulo - pt * nct, chi = uhi - pt * nct;
-			clo = clo < 0 ? 0 : clo;
-			chi = chi > nct ? nct : chi;
-			for (int ct = clo; ct < chi; ct++)
-			{
-				const double* ap = yd + cp_mfma_a_index(X, B, pt, ct, lane);
-				double a[KS];
-#pragma unroll
-				for (int s = 0; s < KS; s++) a[s] = ap[8 * s];
-				d4 acc = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-				for (int s = 0; s < KS; s++)
-					acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], mf_b[q][s], acc, 0, 0, 0);
-				const double d[4] = { acc[0], acc[1], acc[2], acc[3] };
-				cp_mfma_store(X, B, pt, ct, lane, chA, chB, bvalid, d);
-			}
-		}
-	}
-	// LDS-DMA of the next block's samples into the staging area (r8b_convp.h): 16 bytes per lane and
-	// operation, global address per lane, LDS address = wave-uniform base + 16 * lane
-	__device__ __forceinline__ void stage_issue(const ConvLaunch& L, double* stage, const ConvpItem& nxt)
-	{
-		typedef __attribute__((address_space(3))) void lds_void;
-		const int wave = __builtin_amdgcn_readfirstlane((int) threadIdx.x >> 6);
-#pragma unroll
-		for (int r = 0; r < ConvpStage<LN, UL>::PER_THREAD; r++)
-		{
-			const double* src = cp_stage_src<LN, UL>(L, nxt.k, nxt.chA, nxt.chB, r, tid);
-			double* dst = stage + 2 * (64 * wave + kConvpThreads * r);
-			__builtin_amdgcn_global_load_lds(src, (lds_void*) dst, 16, 0, 0);
-		}
-	}
-	// the thread index the phases see.  The persistent kernel passes it through an empty asm at the top
-	// of every iteration: otherwise every address and table index derived from it is loop invariant,
-	// gets hoisted and kept in registers across the whole loop (hundreds of values: spills)
-	int tid = (int) threadIdx.x;
-	__device__ __forceinline__ void fresh_tid()
-	{
-		int t = (int) threadIdx.x;
-		asm volatile("" : "+v"(t));
-		tid = t;
-	}
 	// steps that exchange data between the lanes of ONE wave only (r8b_convp.h: forward passes 1..,
 	// middle pass, first backward pass): LDS serves a wave's accesses in issue order, so between the
 	// steps only the compiler must be kept from reordering them; a workgroup barrier ends the sequence
@@ -600,32 +511,20 @@ struct GpuExecP
 	template<class F0, class... F>
 	__device__ __forceinline__ void wave_steps(F0 f0, F... f)
 	{
-		f0(tid, st);
-		((wave_sync(), f(tid, st)), ...);
-#ifdef R8B_P_TRACE
-		stamp();
-#endif
+		f0((int) threadIdx.x, st);
+		((wave_sync(), f((int) threadIdx.x, st)), ...);
 		lds_barrier();
-#ifdef R8B_P_TRACE
-		stamp();
-#endif
 	}
 	template<class F>
 	__device__ __forceinline__ void each(F f) // no barrier
 	{
-		f(tid, st);
+		f((int) threadIdx.x, st);
 	}
 	template<class F>
 	__device__ __forceinline__ void phase(F f)
 	{
-		f(tid, st);
-#ifdef R8B_P_TRACE
-		stamp();
-#endif
+		f((int) threadIdx.x, st);
 		lds_barrier();
-#ifdef R8B_P_TRACE
-		stamp();
-#endif
 	}
 };
 
@@ -637,106 +536,46 @@ __global__ __launch_bounds__(kConvpThreads, 2) void k_convp(const ConvxLaunch X)
 	// XCD-aware mapping as in k_convx, over channel PAIRS
 	const unsigned w = blockIdx.x, nblk = (unsigned) X.c.nblk, npair = ((unsigned) X.c.nch + 1u) >> 1;
 	unsigned blk, pr;
-	if ((npair & 7u) == 0)
+	if (nblk == 1)
 	{
-		const unsigned i = w >> 3;
-		blk = i % nblk;
-		pr = ((i / nblk) << 3) + (w & 7u);
+		blk = 0;
+		pr = w;
+	}
+	else if ((npair & 7u) == 0)
+	{
+		const unsigned i = w >> 3, qd = convp_div(i, X.nblk_magic);
+		blk = i - qd * nblk;
+		pr = (qd << 3) + (w & 7u);
 	}
 	else
 	{
-		blk = w % nblk;
-		pr = w / nblk;
+		pr = convp_div(w, X.nblk_magic);
+		blk = w - pr * nblk;
 	}
 	blk = (unsigned) __builtin_amdgcn_readfirstlane((int) blk);
 	pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
 	const int chA = (int) (2u * pr);
 	const bool bvalid = chA + 1 < X.c.nch;
 	GpuExecP<LN, UL> ex;
-#ifdef R8B_P_TRACE
-	ex.stamp();
-#endif
 	ConvpItem cur;
 	cur.k = X.c.k0 + blk;
 	cur.chA = chA;
 	cur.chB = bvalid ? chA + 1 : chA;
 	cur.bvalid = bvalid;
-	convp_body<LN, UL, MODE, FLENP, false>(ex, X, reinterpret_cast<cd*>(smem), nullptr, cur, false, cur, false);
-#ifdef R8B_P_TRACE
-	ex.stamp();
-#endif
-}
-
-// Persistent form: gridDim.x workgroups (two per CU), each walks a contiguous range of the
-// pair-major item list.  The next item's samples are DMAed into an LDS staging area while the
-// current one is interpolated, the current one's output stores drain while the next one is
-// transformed, and no workgroup start-up or wind-down sits between two blocks.
-template<int LN, int UL, int MODE, int FLENP>
-__global__ __launch_bounds__(kConvpThreads, 2) void k_convp_loop(const ConvxLaunch X)
-{
-	extern __shared__ __align__(16) unsigned char smem[];
-	const long long items = (long long) X.c.nblk * (((long long) X.c.nch + 1) >> 1);
-	const long long g = blockIdx.x, G = gridDim.x;
-	long long i = g * items / G;
-	const long long i1 = (g + 1) * items / G;
-	if (i >= i1) return;
-	GpuExecP<LN, UL> ex;
-#ifndef R8B_P_STAGGER
-#define R8B_P_STAGGER 1
-#endif
-#if R8B_P_STAGGER
-	// All workgroups start together and do identical work: left alone they stay in step, every CU's two
-	// workgroups in the same phase (both on the vector ALU, or both waiting for memory) and the whole
-	// chip bursting at HBM and at the same table lines at once.  Start the second workgroup of a CU
-	// half an item late and spread the CUs over a quarter of an item.
-	{
-		const unsigned half = gridDim.x >> 1;
-		unsigned ticks = (blockIdx.x >= half ? R8B_P_STAGGER * 220u : 0u) + ((blockIdx.x >> 3) & 15u) * R8B_P_STAGGER * 7u;
-		for (; ticks > 0; ticks--) __builtin_amdgcn_s_sleep(1); // 64 cycles each
-	}
-#endif
-	double* const stage = X.stage_off > 0 ? reinterpret_cast<double*>(smem + X.stage_off) : nullptr;
-	ConvpItem cur = convp_item(X.c, i);
-	bool staged = false;
-	for (; i < i1; i++)
-	{
-		ex.fresh_tid();
-		const bool has_next = i + 1 < i1;
-		const ConvpItem nxt = convp_item(X.c, has_next ? i + 1 : i);
-		staged = convp_body<LN, UL, MODE, FLENP, true>(ex, X, reinterpret_cast<cd*>(smem), stage, cur,
-			staged, nxt, has_next);
-		cur = nxt;
-		// the staged samples have landed (and this item's stores are acknowledged) ...
-		if (staged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		// ... and the run (or the last pass's array) is dead only when every wave is through with it
-		lds_barrier();
-	}
+	convp_body<LN, UL, MODE, FLENP>(ex, X, reinterpret_cast<cd*>(smem), cur);
 }
 
 template<int LN, int UL, int MODE, int FLENP>
-void launch_convp_t(const ConvxLaunch& X, hipStream_t stream)
+void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 {
+	ConvxLaunch X = X0;
+	// (nblk = 1: floor(2^32 / 1) + 1 does not fit; 0 makes convp_div return 0, handled by the kernel)
+	X.nblk_magic = X.c.nblk > 1 ? (unsigned) (0x100000000ull / (unsigned) X.c.nblk) + 1u : 0u;
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
-#ifdef R8B_P_LDSPAD
-	const size_t lds = (size_t) convp_lds_bytes(LN + UL) + R8B_P_LDSPAD; // occupancy study only
-#else
 	const size_t lds = (size_t) convp_lds_bytes(LN + UL);
-#endif
 	check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
 		hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(k_convp)");
 	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
-	if (X.persist > 0)
-	{
-		auto loop = k_convp_loop<LN, UL, MODE, FLENP>;
-		check(hipFuncSetAttribute(reinterpret_cast<const void*>(loop),
-			hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(k_convp_loop)");
-		const unsigned items = (unsigned) X.c.nblk * npair;
-		const size_t lds_loop = X.stage_off > 0 ? (size_t) X.stage_off + 32 * 1024 : lds;
-		hipLaunchKernelGGL(loop, dim3(items < (unsigned) X.persist ? items : (unsigned) X.persist),
-			dim3(kConvpThreads), lds_loop, stream, X);
-		check(hipGetLastError(), "launch k_convp_loop");
-		return;
-	}
 	hipLaunchKernelGGL(kern, dim3((unsigned) X.c.nblk * npair), dim3(kConvpThreads), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
 }
@@ -912,8 +751,6 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 	{ \
 		if (mode == 0) launch_convp_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
 		else if (mode == 4) launch_convp_t<LN, UL, 4, 24>(X, (hipStream_t) stream); \
-		else if (mode == 2 && wide) launch_convp_t<LN, UL, 2, 32>(X, (hipStream_t) stream); \
-		else if (mode == 2) launch_convp_t<LN, UL, 2, 24>(X, (hipStream_t) stream); \
 		else if (wide) launch_convp_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
 		else launch_convp_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
 		return; \
@@ -952,13 +789,6 @@ void R8B_LAUNCH(launch_tail)(const TailLaunch& L, void* stream)
 		(hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_tail");
 }
-
-#if defined(R8B_P_TRACE) && !defined(R8B_PCM_VARIANT)
-extern "C" __attribute__((visibility("default"))) int r8b_ptrace_dump(unsigned long long* host, int n)
-{
-	return (int) hipMemcpyFromSymbol(host, HIP_SYMBOL(g_ptrace), (size_t) n * sizeof(unsigned long long));
-}
-#endif
 
 #ifndef R8B_PCM_VARIANT
 // ------------------------------------------------------------------ format dispatch

@@ -195,22 +195,17 @@ struct ConvxLaunch
 	const double* mf_atab;
 	int mf_ksteps, mf_tiles;
 	int mf_boff[16];
-	// pair form, mode 2 (r8b_convp.h): the run of (A, B) pairs starts at LDS slot run_off; mf_boff[p]
-	// is floor(16 p in_step / out_step); per block blk[].u_lo = run slot of the window of phase 0 of
-	// the block's first output group, .ph_lo = groups - 1, .pad = column tiles (8 groups x 2 channels;
-	// mode 4: the phase the block's last group ends before, 1 .. out_step; 0: the block has no output)
+	// pair form, mode 4 (two adjacent phases per thread, r8b_convp.h): the run of (A, B) pairs starts
+	// at LDS slot run_off; per block blk[].u_lo = run slot of the window of phase 0 of the block's first
+	// output group, .ph_lo = groups - 1, .pad = the phase the block's last group ends before (1 ..
+	// out_step; 0: the block has no output); per thread its phase pair, group set and window start
+	// (ptab[t] = q | set << 8 | floor(2 q in_step / out_step) << 12, -1: idle), the two 25-tap rows as
+	// 25 pairs (ctab[(i * 256 + t) * 2]), the number of group sets
 	int run_off;
-	// pair form, mode 4 (two adjacent phases per thread, r8b_convp.h): per thread its phase pair and
-	// group set (ptab[t] = q | set << 16, -1: idle), the two 25-tap rows ctab[i * 256 + t], the sets
 	const int* ptab;
 	const double* ctab;
 	int nsets;
-	// pair form: workgroups of the persistent launch (each walks a contiguous range of the pair-major
-	// item list); 0: one workgroup per item
-	int persist;
-	// persistent form: byte offset of the LDS staging area the next block's samples are DMAed into
-	// (32 KB; the launch allocates LDS up to stage_off + 32 KB), 0: no staging (plain loads)
-	int stage_off;
+	unsigned nblk_magic; // floor(2^32 / c.nblk) + 1 (filled in by the launcher; r8b_convp.h convp_div)
 };
 
 // geometries the fast path is instantiated for: (log2 of the forward complex length, up shift), and
@@ -280,7 +275,7 @@ void launch_pcm_out(const PcmLaunch& L, void* stream); // planar fp64 -> PCM
 // mode 0: convolver output to X.c.dst; mode 1 / 2: fused interpolator output to X.wdst (FIR on
 // the vector ALU / on the matrix cores)
 void launch_convx(const ConvxLaunch& X, int mode, void* stream);
-// the same work in pair form (modes 0, 1 and 2; needs X.c.hp)
+// the same work in pair form (modes 0, 1 and 4; needs X.c.hp)
 void launch_convp(const ConvxLaunch& X, int mode, void* stream);
 // the same work, one wavefront per block (modes 0 and 1; needs X.c.wspec)
 void launch_convw(const ConvxLaunch& X, int mode, void* stream);

@@ -268,75 +268,6 @@ struct EmulExecP
 {
 	std::vector<ConvpState<LN, UL>> st;
 	EmulExecP() : st((size_t) kConvpThreads) {}
-	// LDS-DMA model: every lane's 16 bytes land at wave base + 16 * lane of the staging area
-	void stage_issue(const ConvLaunch& L, double* stage, const ConvpItem& nxt)
-	{
-		for (int tid = 0; tid < kConvpThreads; tid++)
-			for (int r = 0; r < ConvpStage<LN, UL>::PER_THREAD; r++)
-			{
-				const double* src = cp_stage_src<LN, UL>(L, nxt.k, nxt.chA, nxt.chB, r, tid);
-				if (((size_t) src & 15) != 0) throw std::runtime_error("emul: unaligned DMA source");
-				double* dst = stage + 2 * (64 * (tid >> 6) + kConvpThreads * r) + 2 * (tid & 63);
-				dst[0] = src[0];
-				dst[1] = src[1];
-			}
-	}
-	// MODE 2 with a software model of v_mfma_f64_16x16x4_f64 (operand layout as in EmulExec)
-	template<int KS>
-	void mfma_pair_prefetch(const ConvxLaunch&) {}
-	template<int KS>
-	void mfma_pair_interp(const ConvxLaunch& X, const cd* y, long long k, int chA, int chB, bool bvalid)
-	{
-		if (X.mf_ksteps != KS) throw std::runtime_error("emul: K steps mismatch");
-		const SpanInfo& B = X.blk[k - X.c.k0];
-		const int nct = B.pad;
-		if (nct == 0) return;
-		const double* yd = reinterpret_cast<const double*>(y);
-		const int U = X.mf_tiles * nct;
-		std::vector<int> seen((size_t) U, 0);
-		for (int wave = 0; wave < kConvpThreads / 64; wave++)
-		{
-			const int ulo = wave * U / 4, uhi = (wave + 1) * U / 4;
-			const int pt0 = cp_mfma_first_tile(X, wave);
-			for (int q = 0; q < kConvpSets; q++)
-			{
-				const int pt = pt0 + q;
-				int clo = ulo - pt * nct, chi = uhi - pt * nct;
-				clo = clo < 0 ? 0 : clo;
-				chi = chi > nct ? nct : chi;
-				for (int ct = clo; ct < chi; ct++)
-				{
-					if (pt >= X.mf_tiles) throw std::runtime_error("emul: phase tile out of range");
-					seen[(size_t) (pt * nct + ct)]++;
-					double D[16][16] = {};
-					for (int s = 0; s < KS; s++)
-					{
-						double A[16][4], Bm[4][16];
-						for (int lane = 0; lane < 64; lane++)
-						{
-							const int ai = cp_mfma_a_index(X, B, pt, ct, lane) + 8 * s;
-							if (ai < 0 || ai >= 2 * (1 << (LN + UL)))
-								throw std::runtime_error("emul: MFMA operand outside LDS");
-							A[lane & 15][lane >> 4] = yd[ai];
-							Bm[lane >> 4][lane & 15] = X.mf_atab[((long) pt * KS + s) * 64 + lane];
-						}
-						for (int m = 0; m < 16; m++)
-							for (int n = 0; n < 16; n++)
-								for (int c = 0; c < 4; c++) D[m][n] += A[m][c] * Bm[c][n];
-					}
-					for (int lane = 0; lane < 64; lane++)
-					{
-						double d[4];
-						for (int i = 0; i < 4; i++) d[i] = D[(lane >> 4) + 4 * i][lane & 15];
-						cp_mfma_store(X, B, pt, ct, lane, chA, chB, bvalid, d);
-					}
-				}
-			}
-		}
-		// every (phase tile, column tile) unit exactly once
-		for (int v : seen)
-			if (v != 1) throw std::runtime_error("emul: MFMA unit coverage");
-	}
 	template<class F>
 	void phase(F f)
 	{
@@ -371,59 +302,18 @@ void emul_convp_t(const ConvxLaunch& X)
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
 	const long long items = (long long) X.c.nblk * ((X.c.nch + 1) / 2);
-	auto poison = [&](EmulExecP<LN, UL>& ex)
-	{
-		for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
-		for (auto& s : ex.st)
-			for (int i = 0; i < 16; i++) s.vr[i] = s.vi[i] = std::numeric_limits<double>::quiet_NaN();
-	};
-	if (X.persist > 0)
-	{
-		// the persistent form (k_convp_loop): workgroup g walks items [g items / G, (g+1) items / G)
-		std::vector<double> big((size_t) (X.stage_off + 32 * 1024) / sizeof(double) + 2);
-		double* lbase = X.stage_off > 0 ? big.data() : base;
-		if (((size_t) lbase & 15) != 0) lbase++;
-		double* const stage = X.stage_off > 0 ? lbase + X.stage_off / sizeof(double) : nullptr;
-		const long long G = std::min<long long>(items, X.persist);
-		for (long long g = 0; g < G; g++)
-		{
-			long long i = g * items / G;
-			const long long i1 = (g + 1) * items / G;
-			if (i >= i1) continue;
-			EmulExecP<LN, UL> ex;
-			ConvpItem cur = convp_item(X.c, i);
-			bool staged = false;
-			for (; i < i1; i++)
-			{
-				// poison everything but the staging area
-				for (auto& s : ex.st)
-					for (int j = 0; j < 16; j++)
-						s.vr[j] = s.vi[j] = s.pr[j] = s.pi[j] = std::numeric_limits<double>::quiet_NaN();
-				const size_t keep0 = stage ? (size_t) (stage - lbase) : 0, keep1 = keep0 + 4096;
-				const size_t total = stage ? keep1 : (size_t) convp_lds_bytes(LN + UL) / sizeof(double);
-				for (size_t j = 0; j < total; j++)
-					if (!(staged && j >= keep0 && j < keep1)) lbase[j] = std::numeric_limits<double>::quiet_NaN();
-				const bool has_next = i + 1 < i1;
-				const ConvpItem nxt = convp_item(X.c, has_next ? i + 1 : i);
-				staged = convp_body<LN, UL, MODE, FLENP, true>(ex, X, reinterpret_cast<cd*>(lbase), stage, cur,
-					staged, nxt, has_next);
-				cur = nxt;
-			}
-		}
-		return;
-	}
 	for (long long i = 0; i < items; i++)
 	{
 		EmulExecP<LN, UL> ex;
-		poison(ex);
-		const ConvpItem cur = convp_item(X.c, i);
-		convp_body<LN, UL, MODE, FLENP, false>(ex, X, reinterpret_cast<cd*>(base), nullptr, cur, false, cur, false);
+		for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
+		for (auto& s : ex.st)
+			for (int j = 0; j < 16; j++) s.vr[j] = s.vi[j] = std::numeric_limits<double>::quiet_NaN();
+		convp_body<LN, UL, MODE, FLENP>(ex, X, reinterpret_cast<cd*>(base), convp_item(X.c, i));
 	}
 }
 
 void launch_convp(const ConvxLaunch& X, int mode, void*)
 {
-	if (getenv("R8B_EMUL_TRACE")) fprintf(stderr, "emul launch_convp mode %d nblk %d\n", mode, X.c.nblk);
 	int ln = 0;
 	while ((1 << ln) < X.c.n_in) ln++;
 	const bool wide = X.flen > 24;
@@ -432,8 +322,6 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 	{ \
 		if (mode == 0) emul_convp_t<LN, UL, 0, 24>(X); \
 		else if (mode == 4) emul_convp_t<LN, UL, 4, 24>(X); \
-		else if (mode == 2 && wide) emul_convp_t<LN, UL, 2, 32>(X); \
-		else if (mode == 2) emul_convp_t<LN, UL, 2, 24>(X); \
 		else if (wide) emul_convp_t<LN, UL, 1, 32>(X); \
 		else emul_convp_t<LN, UL, 1, 24>(X); \
 		return; \
