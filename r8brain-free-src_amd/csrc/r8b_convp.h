@@ -86,6 +86,20 @@ struct ConvpState
 
 constexpr int convp_lds_bytes(int logn2) { return (1 << logn2) * 16; }
 
+// Twiddle base powers of a pass, pre-gathered per thread by the host (pair_twiddles() in
+// r8b_engine.cpp): entry (slot * 6 + c) * 256 + t = w_n^(j(t) m_c), m = {1, 2, 3, 4, 8, 12}; a wave
+// reads 64 consecutive 16-byte entries per load (the strided reads of the shared exp() table touch
+// up to 64 cache lines per load).  Slots: 0 first pass, 1 / 2 forward passes 1 / 2, 3 / 4 backward
+// passes with sub-lengths 256 / 4096.
+template<int R>
+R8B_HD void ptw_fetch(cd* twr, const cd* ptw, int slot, int tid)
+{
+	constexpr int NB = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
+	const cd* p = ptw + (slot * 6 * kConvpThreads + tid);
+#pragma unroll
+	for (int c = 0; c < NB; c++) twr[c] = p[c * kConvpThreads];
+}
+
 // ---- passes over the swizzled array ---------------------------------------------------------------
 
 template<int LN, int UL, int R, bool TW>
@@ -200,7 +214,7 @@ R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st,
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int R = G::E1, q = G::N / R;
 	cd loc[6];
-	tw_fetch<R>(loc, L.tw, L.tw_len, G::N, tid);
+	ptw_fetch<R>(loc, L.ptw, 0, tid);
 	double vr[R], vi[R];
 #pragma unroll
 	for (int p = 0; p < R; p++)
@@ -236,7 +250,7 @@ struct ConvpPre
 	static constexpr int n = G::N >> (I * G::EB1);
 	static R8B_HD void prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int tid)
 	{
-		tw_fetch<G::E1>(st.tw, L.tw, L.tw_len, n, tid & (n / G::E1 - 1));
+		ptw_fetch<G::E1>(st.tw, L.ptw, I, tid);
 	}
 	static R8B_HD void run(cd* buf, const ConvpState<LN, UL>& st, int tid)
 	{
@@ -493,6 +507,7 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* r
 	const bool linear = X.wdst.mask == -1 && X.wdst.fmt == kPcmF64;
 	double* const pa = X.wdst.p + ((long long) chA * X.wdst.stride + (jg + X.wdst.off));
 	double* const pb = X.wdst.p + ((long long) chB * X.wdst.stride + (jg + X.wdst.off));
+	const bool pair16 = (((size_t) pa | (size_t) pb) & 15) == 0 && (out_step & 1) == 0;
 	for (int gl = set; gl <= gmax; gl += nsets)
 	{
 		const cd* w = y + (u_lo + in_step * gl + rq);
@@ -527,8 +542,21 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* r
 		const bool v1 = (gl > 0 ? 2 * q + 1 < out_step : f1) && (gl < gmax || l1);
 		if (linear)
 		{
-			// caller's buffer: row pointers once, a 32-bit index per output
+			// caller's buffer: row pointers once, a 32-bit index per output; the two phases of a
+			// channel as one 16-byte store when the pair is aligned (the same for every thread: pairs
+			// start at even output indices of a group)
 			const int o = out_step * gl;
+			if (v0 && v1 && pair16)
+			{
+				cd va, vb;
+				va.re = a0[0] + a0[1];
+				va.im = a1[0] + a1[1];
+				vb.re = b0[0] + b0[1];
+				vb.im = b1[0] + b1[1];
+				*reinterpret_cast<cd*>(pa + o) = va;
+				if (bvalid) *reinterpret_cast<cd*>(pb + o) = vb;
+				continue;
+			}
 			if (v0)
 			{
 				pa[o] = a0[0] + a0[1];
@@ -600,13 +628,13 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	auto s_midc = [&](int tid, St& st)
 	{
 		cp_middle_compute<LN, UL>(buf, st, tid);
-		tw_fetch<16>(st.tw, L.tw, L.tw_len, 256, tid & 15);
+		ptw_fetch<16>(st.tw, L.ptw, 3, tid);
 	};
 	auto s_midw = [&](int tid, St& st) { cp_middle_write<LN, UL>(buf, st, tid); };
 	auto s_b1 = [&](int tid, St& st)
 	{
 		cp_back1<LN, UL>(buf, st, tid);
-		tw_fetch<16>(st.tw, L.tw, L.tw_len, 4096, tid);
+		ptw_fetch<16>(st.tw, L.ptw, 4, tid);
 	};
 	static_assert(G::NPRE == 2 || G::NPRE == 3, "pair kernel: two or three forward passes before the middle");
 	if constexpr (G::NPRE == 3) ex.wave_steps(s_pre1, s_pre2, s_midc, s_midw, s_b1);

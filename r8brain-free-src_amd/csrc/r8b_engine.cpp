@@ -358,6 +358,29 @@ std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n
 	return out;
 }
 
+std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int n_in)
+{
+	std::vector<double> out((size_t) 5 * 6 * 256 * 2, 0.0);
+	static const int mult[6] = { 1, 2, 3, 4, 8, 12 };
+	// (sub-length, j mask) per slot; forward passes have radix n_in / 256
+	const int e1 = n_in / 256;
+	int n[5] = { n_in, n_in / e1, n_in / e1 / e1, 256, 4096 };
+	int jm[5] = { 255, n[1] / e1 - 1, n[2] / e1 - 1, 15, 255 };
+	for (int slot = 0; slot < 5; slot++)
+	{
+		if (n[slot] < 2 || jm[slot] < 0) continue;
+		for (int t = 0; t < 256; t++)
+			for (int c = 0; c < 6; c++)
+			{
+				const long long e = (long long) (tw_len / n[slot]) * (t & jm[slot]) * mult[c];
+				const size_t o = (((size_t) slot * 6 + c) * 256 + t) * 2, i = (size_t) (e % tw_len) * 2;
+				out[o] = tw[i];
+				out[o + 1] = tw[i + 1];
+			}
+	}
+	return out;
+}
+
 // LDS of the fast path: one padded complex array of n elements (r8b_convx.h, convx_lds_doubles)
 static size_t convx_work_bytes(int n) { return (size_t) 2 * (n + (n >> 4)) * sizeof(double); }
 
@@ -485,6 +508,9 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 						const std::vector<double> hp = pair_constants(H, g.n_in, g.n_out);
 						d.hp = (cd*) dev_alloc(hp.size() * sizeof(double));
 						dev_upload(d.hp, hp.data(), hp.size() * sizeof(double));
+						const std::vector<double> pt = pair_twiddles(tw, g.bl2, g.n_in);
+						d.ptw = (cd*) dev_alloc(pt.size() * sizeof(double));
+						dev_upload(d.ptw, pt.data(), pt.size() * sizeof(double));
 					}
 					if (convw_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
 					{
@@ -687,6 +713,7 @@ void Engine::release()
 		dev_free(d.spec2);
 		dev_free(d.wspec);
 		dev_free(d.hp);
+		dev_free(d.ptw);
 		dev_free(d.table);
 		dev_free(d.wtab);
 		dev_free(d.mf_atab);
@@ -1306,7 +1333,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 		throw std::runtime_error("transform plan too deep");
 	for (int i = 0; i < L.n_fwd; i++) L.fwd_radix[i] = d.fwd_radix[(size_t) i];
 	for (int i = 0; i < L.n_inv; i++) L.inv_radix[i] = d.inv_radix[(size_t) i];
-	L.H = d.H; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.spec2 = d.spec2; L.wspec = d.wspec; L.hp = d.hp;
+	L.H = d.H; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.spec2 = d.spec2; L.wspec = d.wspec; L.hp = d.hp; L.ptw = d.ptw;
 	L.nch = nch_;
 	L.threads = opt_.at("conv_threads");
 	L.src = src;

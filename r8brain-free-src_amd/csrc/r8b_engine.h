@@ -67,6 +67,7 @@ private:
 		cd* spec2 = nullptr; // the same per backward position (up 1 or 2)
 		cd* wspec = nullptr; // the same for the wave-per-block kernel (per backward bin)
 		cd* hp = nullptr;    // pair kernel: kernel constants of the middle pass (r8b_convp.h)
+		cd* ptw = nullptr;   // pair kernel: twiddle base powers per pass and thread
 		int tw_len = 0;
 		double* table = nullptr;
 		double* wtab = nullptr; // whole-step bank, transposed per residue class (fused kernel)
@@ -135,6 +136,9 @@ std::vector<double> spectral_constants(const std::vector<double>& H, const std::
 // bitrev(position), N = n_in; 1:1: H of backward positions 16 t + 2 c and 16 t + 2 c + 1.  H is the
 // scaled kernel spectrum (bl2/2 + 1 reals), mirrored for bins above bl2/2.
 std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n_out);
+// twiddle base powers of the pair kernel's passes per thread (r8b_convp.h ptw_fetch): 5 slots x 6 x 256
+// complex; tw = exp(-2 pi i e / tw_len) table (interleaved), n_in = forward length (2048 or 4096)
+std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int n_in);
 // radices (each in {2,4,8,16}, <= max_radix) whose product is N, largest first
 std::vector<int> plan_radices(int N, int max_radix);
 
