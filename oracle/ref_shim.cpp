@@ -292,4 +292,65 @@ REFX_API double refx_bench(double src, double dst, int L, double tb, double atte
 	return mx;
 }
 
+// Batch checker for the full-size parity tests: one reference resampler per channel walks `calls`
+// process() calls of lens[k] samples (rows of x, xstride doubles apart, calls back to back) on
+// `nthreads` threads and compares each call's output with the same call's segment of y (rows ystride
+// apart, calls back to back; counts[k] = the count the device path returned for call k).  Per
+// channel: sum of squared differences and peak difference.  Returns 0, or 1 + k for the first call
+// whose output count differs from counts[k] (in any channel).
+REFX_API int refx_batch_check(double src, double dst, int maxin, double tb, double atten, int nch,
+	int calls, const int* lens, const double* x, long long xstride, const double* y, long long ystride,
+	const int* counts, int nthreads, double* sqerr, double* peak, long long* total)
+{
+	if (nthreads < 1) nthreads = 1;
+	if (nthreads > nch) nthreads = nch;
+	std::vector<int> bad((size_t) nthreads, 0);
+	std::vector<std::thread> th;
+	long long tot = 0;
+	for (int k = 0; k < calls; k++) tot += counts[k];
+	for (int t = 0; t < nthreads; t++)
+	{
+		th.emplace_back([&, t]()
+		{
+			const int c0 = (int) ((long long) nch * t / nthreads);
+			const int c1 = (int) ((long long) nch * (t + 1) / nthreads);
+			for (int c = c0; c < c1; c++)
+			{
+				CDSPResampler rs(src, dst, maxin, tb, atten, fprLinearPhase);
+				const double* xi = x + (long long) c * xstride;
+				const double* yi = y + (long long) c * ystride;
+				double sq = 0.0, pk = 0.0;
+				for (int k = 0; k < calls; k++)
+				{
+					double* op;
+					// (process() may write into its input buffer's working copy only: pass a copy)
+					std::vector<double> in(xi, xi + lens[k]);
+					const int n = rs.process(in.data(), lens[k], op);
+					if (n != counts[k])
+					{
+						if (bad[(size_t) t] == 0) bad[(size_t) t] = 1 + k;
+						break;
+					}
+					for (int i = 0; i < n; i++)
+					{
+						const double d = yi[i] - op[i];
+						sq += d * d;
+						const double a = d < 0 ? -d : d;
+						if (a > pk) pk = a;
+					}
+					xi += lens[k];
+					yi += n;
+				}
+				sqerr[c] = sq;
+				peak[c] = pk;
+			}
+		});
+	}
+	for (auto& v : th) v.join();
+	if (total != nullptr) *total = tot;
+	for (int t = 0; t < nthreads; t++)
+		if (bad[(size_t) t] != 0) return bad[(size_t) t];
+	return 0;
+}
+
 REFX_API const char* refx_version() { return R8B_VERSION; }

@@ -71,6 +71,10 @@ def _bind(lib):
     lib.refx_bench.restype = C.c_double
     lib.refx_bench.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_longlong)]
+    lib.refx_batch_check.restype = C.c_int
+    lib.refx_batch_check.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
+                                     C.c_int, _ip, _dp, C.c_longlong, _dp, C.c_longlong, _ip, C.c_int,
+                                     _dp, _dp, C.POINTER(C.c_longlong)]
     lib.refx_version.restype = C.c_char_p
     return lib
 
@@ -260,6 +264,32 @@ def bench(src, dst, L, nch, warm, calls, nthreads, tb=2.0, atten=180.15):
     secs = l.refx_bench(src, dst, L, tb, atten, nch, warm, calls, nthreads, outs)
     return dict(seconds=secs, in_samples=nch * L * calls, out_samples=outs.value,
                 threads=min(nthreads, nch), flags=flags)
+
+
+def batch_check(src, dst, maxin, lens, x, y, counts, tb=2.0, atten=180.15, nthreads=None):
+    """One reference resampler per row of x (nch x sum(lens), C order) walks the calls of lens[k]
+    samples on nthreads threads; y (nch x >= sum(counts)) holds the outputs of the path under test,
+    calls back to back.  Returns (rms per channel, peak per channel); raises if a call's output
+    count differs from counts[k]."""
+    import os
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    counts = np.ascontiguousarray(counts, dtype=np.int32)
+    nch = x.shape[0]
+    assert x.shape[1] >= int(lens.sum()) and y.shape[0] == nch and y.shape[1] >= int(counts.sum())
+    if nthreads is None:
+        nthreads = max(1, min(64, len(os.sched_getaffinity(0))))
+    sq = np.zeros(nch)
+    pk = np.zeros(nch)
+    tot = C.c_longlong()
+    rc = lib().refx_batch_check(src, dst, maxin, tb, atten, nch, len(lens), lens.ctypes.data_as(_ip), x.ctypes.data_as(_dp), x.shape[1],
+                                y.ctypes.data_as(_dp), y.shape[1], counts.ctypes.data_as(_ip),
+                                nthreads, sq.ctypes.data_as(_dp), pk.ctypes.data_as(_dp), tot)
+    if rc != 0:
+        raise AssertionError("output count of call %d differs from the reference's" % (rc - 1))
+    n = max(int(tot.value), 1)
+    return np.sqrt(sq / n), pk
 
 
 def splitmix_uniform(seed, n):

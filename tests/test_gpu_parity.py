@@ -176,46 +176,96 @@ def test_hip_device_tensor_entry_and_strides(torch):
         assert bool((out[:, n:] == -7.0).all())  # nothing written past the returned count
 
 
-@pytest.mark.parametrize("cfg", [(44100.0, 96000.0, 1024, 16384), (96000.0, 44100.0, 1024, 16384),
-                                 (44100.0, 2822400.0, 64, 1024)])
+FULL_CFGS = [(44100.0, 96000.0, 1024, 16384), (96000.0, 44100.0, 1024, 16384),
+             (44100.0, 2822400.0, 64, 1024)]
+
+
+@pytest.mark.parametrize("cfg", FULL_CFGS)
+def test_hip_full_size_all_channels_vs_reference(torch, refwrap, cfg):
+    """BASELINE.json configs 2, 3 and 5 at their full batch sizes: every channel its own
+    splitmix64 stream (seed 1 + channel), three calls, EVERY channel compared with the compiled
+    reference (one CDSPResampler24 per channel, run multi-threaded by oracle/ref_shim.cpp) --
+    like the reference's bench/r8bfreesrc.cpp:118-126 loop, but checking the samples."""
+    src, dst, nch, L = cfg
+    calls = 3
+    x = make_input(nch, L * calls, 1)
+    b = r8b.BatchResampler(src, dst, L, 2.0, 180.15, nch=nch, device=0)
+    xd = torch.from_numpy(x).cuda()
+    outs, counts = [], []
+    for i in range(calls):
+        y = b.process(xd[:, i * L:(i + 1) * L].contiguous())
+        counts.append(y.shape[1])
+        outs.append(y.clone())
+    y = torch.cat(outs, dim=1).cpu().numpy()
+    assert sum(counts) > 0
+    r, p = refwrap.batch_check(src, dst, L, [L] * calls, x, y, counts)
+    assert r.max() <= RMS_TOL and p.max() <= PEAK_TOL, (r.max(), p.max(), int(r.argmax()))
+
+
+@pytest.mark.parametrize("cfg", FULL_CFGS)
 def test_hip_full_size_properties(torch, cfg):
-    """BASELINE.json batch sizes: properties that need no oracle run at that size.
-      * channels are independent and share one schedule: identical input rows -> bitwise
-        identical output rows; spot channels match the oracle;
+    """size-independent properties at the BASELINE.json batch sizes:
       * linearity: R(a*x + b*z) == a*R(x) + b*R(z) to rounding;
       * a constant stream resamples to the same constant after the transient (DC gain 1 up to the
         filters' own imaging residue: <= 3e-13 through the convolver+interpolator, ~7e-10 through
-        the five half-band stages -- the oracle shows the same numbers)."""
+        the five half-band stages -- the oracle shows the same numbers);
+      * a channel does not depend on what its neighbours carry beyond rounding: the pair kernel packs
+        channels 2c and 2c+1 into one complex transform, so a loud neighbour leaves a residue of the
+        order of 1e-16 of ITS amplitude in the quiet channel (measured and bounded here)."""
     src, dst, nch, L = cfg
     calls = 3
     b = r8b.BatchResampler(src, dst, L, 2.0, 180.15, nch=nch, device=0)
-    base = make_input(4, L * calls, 101)
-    idx = np.arange(nch) % 4
-    x = torch.from_numpy(base).cuda()[torch.from_numpy(idx).cuda()]
-    outs = []
-    for i in range(calls):
-        y = b.process(x[:, i * L:(i + 1) * L].contiguous())
-        outs.append(y.clone())
-    y = torch.cat(outs, dim=1)
+    x = make_input(nch, L * calls, 101)
+    xd = torch.from_numpy(x).cuda()
+    y = torch.cat([b.process(xd[:, i * L:(i + 1) * L].contiguous()).clone() for i in range(calls)],
+                  dim=1).cpu().numpy()
     assert y.shape[1] > 0
-    for c in range(4, nch):
-        assert bool((y[c] == y[c % 4]).all())
-    for c in (0, 3):
-        o = O.OracleResampler(src, dst, L, 2.0, 180.15)
-        yo = np.concatenate([o.process(base[c, i * L:(i + 1) * L]) for i in range(calls)])
-        d = y[c].cpu().numpy() - yo
-        assert rms(d) <= RMS_TOL and peak(d) <= PEAK_TOL
     # linearity on two channels
     b2 = r8b.BatchResampler(src, dst, L, 2.0, 180.15, nch=1, device=0)
-    mix = 0.75 * base[0] - 0.5 * base[1]
+    mix = 0.75 * x[0] - 0.5 * x[1]
     ym = np.concatenate([b2.process_host(mix[None, i * L:(i + 1) * L])[0] for i in range(calls)])
-    yl = 0.75 * y[0].cpu().numpy() - 0.5 * y[1].cpu().numpy()
+    yl = 0.75 * y[0] - 0.5 * y[1]
     assert peak(ym - yl) <= 1e-13
     # DC gain
     b2.clear()
     yc = np.concatenate([b2.process_host(np.full((1, L), 0.5))[0] for _ in range(calls + 2)])
     tail = yc[len(yc) // 2:]
     assert len(tail) > 100 and peak(tail - 0.5) <= (5e-9 if dst > 1e6 else 2e-12)
+    # neighbour independence: channel 0 next to silence vs next to full-scale noise
+    b3 = r8b.BatchResampler(src, dst, L, 2.0, 180.15, nch=2, device=0)
+    quiet = np.stack([x[0], np.zeros_like(x[0])])
+    loud = np.stack([x[0], x[1]])
+    yq = np.concatenate([b3.process_host(quiet[:, i * L:(i + 1) * L]) for i in range(calls)], axis=1)
+    b3.clear()
+    yn = np.concatenate([b3.process_host(loud[:, i * L:(i + 1) * L]) for i in range(calls)], axis=1)
+    assert peak(yq[0] - yn[0]) <= 4e-15
+    assert peak(yq[1]) <= 4e-15  # a silent channel beside a loud one: residue only
+
+
+def test_hip_soak_ragged_calls_vs_reference(torch, refwrap):
+    """2400 ragged process() calls of one stream per channel on the real kernels (position wrap,
+    ring masks, block schedule over a long run), every call's count and samples against the
+    compiled reference"""
+    src, dst, maxin, nch = 44100.0, 96000.0, 2048, 3
+    rng = np.random.default_rng(2024)
+    lens = rng.integers(1, maxin + 1, size=2400).astype(np.int32)
+    lens[::7] = maxin
+    lens[3::11] = 1
+    n = int(lens.sum())
+    x = make_input(nch, n, 31)
+    b = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=nch, device=0)
+    xd = torch.from_numpy(x).cuda()
+    out = torch.empty((nch, b.max_out_len), dtype=torch.float64, device="cuda")
+    ys, counts, pos = [], [], 0
+    for l in lens:
+        yv = b.process(xd[:, pos:pos + int(l)].contiguous(), out=out)
+        counts.append(yv.shape[1])
+        if yv.shape[1]:
+            ys.append(yv.clone())
+        pos += int(l)
+    y = torch.cat(ys, dim=1).cpu().numpy()
+    r, p = refwrap.batch_check(src, dst, maxin, lens, x, y, counts)
+    assert r.max() <= RMS_TOL and p.max() <= PEAK_TOL, (r.max(), p.max())
 
 
 def test_cxx_frontend(torch, tmp_path):
