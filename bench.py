@@ -34,8 +34,12 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 def channel_shard(total_channels, rank, world):
     """Contiguous channel block [lo, hi) owned by `rank` (r8brain-free-src_amd/sharding.py)."""
-    lo = total_channels * rank // world
-    hi = total_channels * (rank + 1) // world
+    # whole channel PAIRS per rank: the pair kernel packs channels 2c and 2c+1 into one complex
+    # transform, so a shard boundary between them would change which channels share a transform (and
+    # with it the last bits of their samples); with pairs kept together sharded == unsharded bit for bit
+    pairs = (total_channels + 1) // 2
+    lo = min(2 * (pairs * rank // world), total_channels)
+    hi = min(2 * (pairs * (rank + 1) // world), total_channels)
     return lo, hi
 
 
@@ -192,6 +196,11 @@ def main():
     ap.add_argument("--tb", type=float, default=2.0, help="transition band, percent (side runs)")
     ap.add_argument("--atten", type=float, default=180.15, help="stop-band attenuation (side runs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--e2e", action="store_true",
+                    help="side measurement (SURVEY.md 8e): the whole batch lives on rank 0; every step "
+                         "scatters the channel shards over xGMI (one grouped send per peer), resamples "
+                         "them on all ranks and gathers the outputs back, double buffered; reports the "
+                         "end-to-end rate next to the kernel-only one")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value")
     ap.add_argument("--pcm", choices=["s16", "s24", "s32", "f32"], default=None,
                     help="side measurement: interleaved PCM in/out through the ingest/egress "
@@ -273,6 +282,37 @@ def main():
                 n_out += rs.process(xin[i % nbuf], out=outs[i % 2]).shape[1]
         return n_out
 
+    e2e = None
+    if args.e2e:
+        # the batch at rest on rank 0; shards travel every step (RootPipeline: scatter of step i+1 and
+        # gather of step i-1 on a side stream while step i is resampled)
+        total = args.channels * world
+        sh = r8b.ShardedBatchResampler(
+            lambda nch: r8b.BatchResampler(args.src, args.dst, L, args.tb, args.atten, nch=nch,
+                                           device=local_rank), total)
+        pipe = r8b.RootPipeline(sh, L, root=0, device=dev)
+        if rank == 0:
+            full = [torch.from_numpy(np.stack([splitmix_uniform(1 + c, L * nbuf)[i * L:(i + 1) * L]
+                                               for c in range(total)])).to(dev) for i in range(nbuf)]
+        else:
+            full = [None] * nbuf
+        pipe.run([full[i % nbuf] for i in range(args.warmup)])
+        barrier()
+        t0 = time.perf_counter()
+        got = pipe.run([full[i % nbuf] for i in range(args.steps)])
+        barrier()
+        dte = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dte], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dte = float(t.item())
+        e2e = {"ms_per_step": round(dte / args.steps * 1e3, 4),
+               "value": round(total * L * args.steps / dte / 1e6, 3), "unit": "Msamples/s",
+               "what": "scatter (root -> shards) + resample + gather (-> root) per step, double "
+                       "buffered, batch resident on rank 0",
+               "out_samples_per_step": int(got[-1].shape[1]) if rank == 0 and got else None}
+        del got
+
     run(0, args.warmup)
     barrier()
     t0 = time.perf_counter()
@@ -327,6 +367,9 @@ def main():
                          "path_frac": round(path_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                                             4)},
         }
+        if e2e is not None:
+            # (kernel-only = the line's own `value`: shards at rest; end-to-end beside it)
+            res["e2e"] = e2e
         if not args.no_cpu and world == 1:
             # (N = 1 only: the CPU leg is a per-box baseline, not part of the scaling runs)
             # error report: channel 0 of the timed batch's own stream (first three blocks), rerun

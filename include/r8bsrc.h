@@ -80,6 +80,10 @@ R8BSRC_DECL CR8BBatch r8b_batch_create(double SrcSampleRate, double DstSampleRat
 R8BSRC_DECL void r8b_batch_delete(CR8BBatch b);
 R8BSRC_DECL void r8b_batch_clear(CR8BBatch b);
 R8BSRC_DECL int r8b_batch_channels(CR8BBatch b);
+/* ordinal of the HIP device the object lives on (device = -1 at creation: the device that was
+   current then).  Every entry point runs on that device and leaves the caller's current device as
+   it found it. */
+R8BSRC_DECL int r8b_batch_device(CR8BBatch b);
 
 /* CDSPResampler::getMaxOutLen(0) for the MaxInLen given at creation (CDSPResampler.h:502-519):
  * the minimum per-channel capacity of the output buffer. */

@@ -9,7 +9,18 @@ CDSPResampler24, DLLResampler (see resampler.py) and `load()` (the ctypes handle
 libr8bsrc_hip.so).  Everything computes on the GPU through the C ABI of include/r8bsrc.h.
 """
 from ._capi import load, lib_path, bind, PROTOTYPES  # noqa: F401
-from .sharding import channel_shard, scatter_channels, gather_channels, ShardedBatchResampler  # noqa: F401
 from .resampler import (BatchResampler, CDSPResampler, CDSPResampler16, CDSPResampler16IR,  # noqa: F401
                         CDSPResampler24, DLLResampler, fprLinearPhase,
                         PCM_F64, PCM_F32, PCM_S16, PCM_S24, PCM_S32)
+
+
+_SHARDING = ("channel_shard", "scatter_channels", "gather_channels", "ShardedBatchResampler",
+             "RootPipeline")
+
+
+def __getattr__(name):
+    # the multi-GPU helpers need torch.distributed; the numpy-only host API must import without it
+    if name in _SHARDING:
+        from . import sharding
+        return getattr(sharding, name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))

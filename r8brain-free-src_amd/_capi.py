@@ -25,6 +25,7 @@ PROTOTYPES = [
     ("r8b_batch_delete", None, [C.c_void_p]),
     ("r8b_batch_clear", None, [C.c_void_p]),
     ("r8b_batch_channels", C.c_int, [C.c_void_p]),
+    ("r8b_batch_device", C.c_int, [C.c_void_p]),
     ("r8b_batch_max_out_len", C.c_int, [C.c_void_p]),
     ("r8b_batch_inlen", C.c_int, [C.c_void_p, C.c_int]),
     ("r8b_batch_inlen_before_outpos", C.c_int, [C.c_void_p, C.c_int]),
@@ -92,5 +93,16 @@ def load():
             raise RuntimeError("%s not found: build it with `make -C %s` (or "
                                "__graft_entry__.build()); there is no CPU fallback" %
                                (p, os.path.join(_HERE, "csrc")))
+        # A process that also uses PyTorch-ROCm must let torch load ITS HIP runtime first: the torch
+        # wheel bundles its own libamdhip64, and if this library pulls in the system one before, torch
+        # finds no device afterwards (measured on the GPU box: torch.cuda.is_available() turns False).
+        # Loaded after torch, libr8bsrc_hip.so resolves against the runtime already in the process.
+        # Hosts without torch are unaffected; C / C++ hosts link the system runtime as usual.
+        import sys
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         _lib = bind(p)
     return _lib

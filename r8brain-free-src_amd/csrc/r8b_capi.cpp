@@ -180,6 +180,8 @@ R8BSRC_DECL CR8BBatch r8b_batch_create_stage(int kind, double a, double b, doubl
 {
 	try
 	{
+		if (kind < 0 || kind > 3) throw std::runtime_error("stage kind must be 0 (convolver), 1 "
+			"(interpolator), 2 (half-band up) or 3 (half-band down)");
 		StageDesc sd;
 		sd.kind = (StageKind) kind;
 		sd.a = a; sd.b = b; sd.c = c; sd.d = d; sd.i0 = i0; sd.i1 = i1;
@@ -203,6 +205,8 @@ R8BSRC_DECL void r8b_batch_clear(CR8BBatch b)
 }
 
 R8BSRC_DECL int r8b_batch_channels(CR8BBatch b) { return ((Batch*) b)->eng->channels(); }
+
+R8BSRC_DECL int r8b_batch_device(CR8BBatch b) { return ((Batch*) b)->eng->device(); }
 
 R8BSRC_DECL int r8b_batch_max_out_len(CR8BBatch b) { return ((Batch*) b)->eng->plan().max_out_len; }
 

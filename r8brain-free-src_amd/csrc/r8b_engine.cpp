@@ -423,13 +423,13 @@ static long long pow2_at_least(long long v)
 }
 
 Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int device)
-	: nch_(nch), device_(device)
+	: nch_(nch), device_(dev_resolve(device))
 {
 	if (nch < 1) throw std::runtime_error("channel count must be >= 1");
 	if (nch > 65535) throw std::runtime_error("channel count must be <= 65535 per batch object "
 		"(grid y dimension); split larger batches");
 	if (maxin < 1) throw std::runtime_error("MaxInLen must be >= 1");
-	dev_select(device);
+	DevGuard guard(device_);
 	plan_.init(descs, maxin);
 	opt_["conv_radix"] = 8;
 	opt_["conv_threads"] = 256;
@@ -697,6 +697,8 @@ Engine::~Engine() { release(); }
 
 void Engine::release()
 {
+	if (dev_.empty()) return;
+	DevGuard guard(device_);
 	for (StageDev& d : dev_)
 	{
 		for (auto& pr : d.pending)
@@ -740,6 +742,15 @@ bool Engine::set_option(const std::string& name, int value)
 {
 	auto it = opt_.find(name);
 	if (it == opt_.end()) return false;
+	// Options that choose between fused and unfused kernels decide where a stage's history lives
+	// (unfused stages keep it in rings the fused kernels never write): once a stream has started they
+	// may only change after clear().
+	static const char* const structural[] = { "fuse", "fuse_hb", "fuse_hbd", "fold_tail", "fast_conv",
+		"mfma_interp", "wave_conv", "pair_conv", "pair_two" };
+	bool started = false;
+	for (const StagePlan& sp : plan_.stages) started = started || sp.m != 0;
+	for (const char* n : structural)
+		if (started && name == n && it->second != value) return false;
 	it->second = value;
 	plan_transforms();
 	return true;
@@ -848,13 +859,28 @@ unsigned long long Engine::config_hash() const
 	return h;
 }
 
+// does stage s ever own an input ring?  (the ring between the two stages of a fused pair / inside
+// a fused run is never touched)
+bool Engine::stage_owns_ring(size_t s) const
+{
+	size_t g = 0;
+	while (g < plan_.stages.size())
+	{
+		if (g == s) return true;
+		g += (size_t) group_len(g);
+	}
+	return false;
+}
+
 size_t Engine::state_size() const
 {
+	// the same before and after the first process() call: every ring a stage will ever own counts,
+	// allocated yet or not (save_state allocates the missing ones, their content is all zero)
 	size_t n = sizeof(StateHeader);
-	for (const StageDev& d : dev_)
+	for (size_t s = 0; s < dev_.size(); s++)
 	{
 		n += sizeof(StageState);
-		if (d.ring != nullptr) n += (size_t) d.ring_size * (size_t) nch_ * sizeof(double);
+		if (stage_owns_ring(s)) n += (size_t) dev_[s].ring_size * (size_t) nch_ * sizeof(double);
 	}
 	return n;
 }
@@ -863,7 +889,9 @@ size_t Engine::save_state(void* buf, size_t cap, void* stream)
 {
 	const size_t need = state_size();
 	if (cap < need) throw std::runtime_error("state buffer too small");
-	dev_select(device_);
+	DevGuard guard(device_);
+	for (size_t s = 0; s < dev_.size(); s++)
+		if (stage_owns_ring(s)) ensure_ring(s);
 	dev_sync(stream);
 	unsigned char* p = static_cast<unsigned char*>(buf);
 	StateHeader h;
@@ -882,10 +910,10 @@ size_t Engine::save_state(void* buf, size_t cap, void* stream)
 		st.rpos = sp.poly.rpos; st.pos_frac = sp.poly.pos_frac; st.pos_shift = sp.poly.pos_shift;
 		st.in_counter = sp.poly.in_counter; st.in_pos_int = sp.poly.in_pos_int;
 		st.ring_size = d.ring_size;
-		st.has_ring = d.ring != nullptr ? 1 : 0;
+		st.has_ring = stage_owns_ring(s) ? 1 : 0;
 		std::memcpy(p, &st, sizeof(st));
 		p += sizeof(st);
-		if (d.ring != nullptr)
+		if (st.has_ring)
 		{
 			const size_t bytes = (size_t) d.ring_size * (size_t) nch_ * sizeof(double);
 			dev_download(p, d.ring, bytes, stream);
@@ -906,27 +934,47 @@ void Engine::load_state(const void* buf, size_t size, void* stream)
 	if (std::memcmp(h.magic, "R8BHIPS1", 8) != 0) throw std::runtime_error("not a state blob");
 	if (h.config != config_hash() || h.nstages != (long long) dev_.size() || h.nch != nch_)
 		throw std::runtime_error("state blob was saved by a differently configured resampler");
-	dev_select(device_);
-	dev_sync(stream);
+	// pass 1: the whole blob against this object, nothing touched yet (a truncated or foreign blob
+	// must not leave a half-restored stream behind)
+	if (size != state_size()) throw std::runtime_error("state blob has the wrong size");
+	std::vector<StageState> sts(dev_.size());
+	std::vector<const unsigned char*> rings(dev_.size(), nullptr);
 	for (size_t s = 0; s < dev_.size(); s++)
 	{
-		StagePlan& sp = plan_.stages[s];
-		StageDev& d = dev_[s];
-		StageState st;
+		const StageDev& d = dev_[s];
+		StageState& st = sts[s];
 		if ((size_t) (end - p) < sizeof(st)) throw std::runtime_error("state blob truncated");
 		std::memcpy(&st, p, sizeof(st));
 		p += sizeof(st);
 		if (st.ring_size != d.ring_size) throw std::runtime_error("state blob ring size mismatch");
-		sp.m = st.m; sp.done = st.done;
-		sp.poly.rpos = st.rpos; sp.poly.pos_frac = st.pos_frac; sp.poly.pos_shift = st.pos_shift;
-		sp.poly.in_counter = (int) st.in_counter; sp.poly.in_pos_int = (int) st.in_pos_int;
+		if ((st.has_ring != 0) != stage_owns_ring(s))
+			throw std::runtime_error("state blob ring layout mismatch");
+		if (st.m < 0 || st.done < 0 || st.in_counter < 0 || st.in_pos_int < 0 ||
+			st.in_counter > INT_MAX || st.in_pos_int > INT_MAX || !(st.pos_frac >= 0.0 && st.pos_frac < 1.0))
+			throw std::runtime_error("state blob holds impossible counters");
 		if (st.has_ring)
 		{
 			const size_t bytes = (size_t) d.ring_size * (size_t) nch_ * sizeof(double);
 			if ((size_t) (end - p) < bytes) throw std::runtime_error("state blob truncated");
-			ensure_ring(s);
-			dev_upload(d.ring, p, bytes);
+			rings[s] = p;
 			p += bytes;
+		}
+	}
+	if (p != end) throw std::runtime_error("state blob has trailing bytes");
+	// pass 2: commit
+	DevGuard guard(device_);
+	dev_sync(stream);
+	for (size_t s = 0; s < dev_.size(); s++)
+	{
+		StagePlan& sp = plan_.stages[s];
+		const StageState& st = sts[s];
+		sp.m = st.m; sp.done = st.done;
+		sp.poly.rpos = st.rpos; sp.poly.pos_frac = st.pos_frac; sp.poly.pos_shift = st.pos_shift;
+		sp.poly.in_counter = (int) st.in_counter; sp.poly.in_pos_int = (int) st.in_pos_int;
+		if (rings[s] != nullptr)
+		{
+			ensure_ring(s);
+			dev_upload(dev_[s].ring, rings[s], (size_t) dev_[s].ring_size * (size_t) nch_ * sizeof(double));
 		}
 	}
 }
@@ -1045,7 +1093,28 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 {
 	if (l < 0 || l > plan_.max_in) throw std::runtime_error("input length exceeds MaxInLen");
 	if (l == 0) return 0;
-	dev_select(device_);
+	// raw device pointers from a foreign host: refuse what would read or write outside the rows
+	if (d_in == nullptr || d_out == nullptr) throw std::runtime_error("null device pointer");
+	if (nch_ > 1 && (in_stride < l || in_stride < 0))
+		throw std::runtime_error("in_stride is smaller than the number of input samples per row");
+	{
+		// what this call will return (the plan is advanced only by the stage loop below)
+		ChainPlan probe = plan_;
+		int n = l;
+		for (StagePlan& sp : probe.stages)
+		{
+			long long a, b;
+			sp.step(n, &a, &b, nullptr);
+			n = (int) (b - a);
+		}
+		if (plan_.stages.empty()) n = l;
+		if (nch_ > 1 && out_stride < n)
+			throw std::runtime_error("out_stride is smaller than the number of output samples of "
+				"this call (" + std::to_string(n) + "): rows would overlap");
+	}
+	if ((io_in_fmt_ == kPcmF64 && ((size_t) d_in & 7) != 0) || (io_out_fmt_ == kPcmF64 && ((size_t) d_out & 7) != 0))
+		throw std::runtime_error("fp64 buffers must be 8-byte aligned");
+	DevGuard guard(device_);
 	const size_t ns = plan_.stages.size();
 	if (ns == 0)
 	{

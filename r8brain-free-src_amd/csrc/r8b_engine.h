@@ -46,7 +46,8 @@ public:
 	// and the contents of every history ring, as one host blob.  load_state() accepts only a blob
 	// saved by an object of the same configuration (rates, filter parameters, MaxInLen, channel
 	// count, engine options); a stream resumed from it continues bit-identically.  Both wait for
-	// `stream`, the stream the process() calls were enqueued on.
+	// `stream`, the stream the process() calls were enqueued on.  state_size() is a constant of the
+	// object; load_state() checks the whole blob before it changes anything.
 	size_t state_size() const;
 	size_t save_state(void* buf, size_t cap, void* stream);
 	void load_state(const void* buf, size_t size, void* stream);
@@ -90,6 +91,7 @@ private:
 	void* get_event(StageDev& d);
 	void release();
 	unsigned long long config_hash() const;
+	bool stage_owns_ring(size_t s) const;
 
 	void plan_transforms();
 	void ensure_ring(size_t s);

@@ -8,8 +8,11 @@
 // and stay L2 resident.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+#include <set>
 #include <stdexcept>
 #include <string>
+#include <utility>
 
 // This file is compiled twice (Makefile).  As is: fp64 caller buffers only, the stage kernels carry
 // no format test at all.  With R8B_PCM_VARIANT: src_load / dst_store also decode / encode planar PCM
@@ -89,6 +92,20 @@ void check(hipError_t e, const char* what)
 {
 	if (e != hipSuccess)
 		throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// Opt-in to more than 64 KB of dynamic LDS.  Function attributes are per DEVICE, so the memo is keyed
+// by (function, device ordinal): a process that drives several GPUs opts in on each of them.
+void lds_opt_in(const void* fn, const char* what)
+{
+	static std::mutex mu;
+	static std::set<std::pair<const void*, int>> done;
+	int dev = 0;
+	check(hipGetDevice(&dev), "hipGetDevice");
+	std::lock_guard<std::mutex> lock(mu);
+	if (done.count(std::make_pair(fn, dev))) return;
+	check(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), what);
+	done.insert(std::make_pair(fn, dev));
 }
 
 // ------------------------------------------------------------------ overlap-save block convolver
@@ -573,8 +590,7 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	X.nblk_magic = X.c.nblk > 1 ? (unsigned) (0x100000000ull / (unsigned) X.c.nblk) + 1u : 0u;
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	const size_t lds = (size_t) convp_lds_bytes(LN + UL);
-	check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-		hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(k_convp)");
+	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
 	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
 	hipLaunchKernelGGL(kern, dim3((unsigned) X.c.nblk * npair), dim3(kConvpThreads), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
@@ -583,16 +599,10 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 template<int LOGN, int UPLOG, int MODE, int FLENP>
 void launch_convw_t(const ConvxLaunch& X, hipStream_t stream)
 {
-	static bool attr_done = false;
 	auto kern = k_convw<LOGN, UPLOG, MODE, FLENP>;
 	const size_t lds = (size_t) convw_lds_need(convw_plane_doubles<LOGN, UPLOG>(), X.c.in_len) *
 		sizeof(double);
-	if (!attr_done)
-	{
-		check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-			hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(k_convw)");
-		attr_done = true;
-	}
+	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convw)");
 	hipLaunchKernelGGL(kern, dim3((unsigned) X.c.nblk * (unsigned) X.c.nch), dim3(kWaveLanes), lds,
 		stream, X);
 	check(hipGetLastError(), "launch k_convw");
@@ -601,32 +611,20 @@ void launch_convw_t(const ConvxLaunch& X, hipStream_t stream)
 template<int LOGN, int UPLOG, int MODE, int FLENP>
 void launch_convx_t(const ConvxLaunch& X, hipStream_t stream)
 {
-	static bool attr_done = false;
 	auto kern = k_convx<LOGN, UPLOG, MODE, FLENP>;
 	// work array; the linear output run (in_len + kConvxRunPad doubles) aliases its start
 	const size_t lds = (size_t) convx_lds_need(UPLOG > 0 ? LOGN + UPLOG : LOGN, X.c.in_len, MODE) * sizeof(double);
-	if (!attr_done)
-	{
-		check(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-			hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), "hipFuncSetAttribute(k_convx)");
-		attr_done = true;
-	}
+	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convx)");
 	hipLaunchKernelGGL(kern, dim3((unsigned) X.c.nblk * (unsigned) X.c.nch), dim3(kConvxThreads),
 		lds, stream, X);
 	check(hipGetLastError(), "launch k_convx");
 }
 
-bool g_attr_done = false;
-
 void set_lds_attrs()
 {
-	if (g_attr_done) return;
-	const int big = 160 * 1024;
-	check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv),
-		hipFuncAttributeMaxDynamicSharedMemorySize, big), "hipFuncSetAttribute(k_conv)");
-	check(hipFuncSetAttribute(reinterpret_cast<const void*>(k_whole),
-		hipFuncAttributeMaxDynamicSharedMemorySize, big), "hipFuncSetAttribute(k_whole)");
-	g_attr_done = true;
+	lds_opt_in(reinterpret_cast<const void*>(k_conv), "hipFuncSetAttribute(k_conv)");
+	lds_opt_in(reinterpret_cast<const void*>(k_whole), "hipFuncSetAttribute(k_whole)");
+	lds_opt_in(reinterpret_cast<const void*>(k_hbdcascade), "hipFuncSetAttribute(k_hbdcascade)");
 }
 
 } // namespace
@@ -858,14 +856,21 @@ void launch_pcm_out(const PcmLaunch& L, void* stream) { launch_pcm(L, false, str
 
 // ------------------------------------------------------------------ memory helpers
 
-void dev_select(int device)
+int dev_resolve(int device)
 {
-	if (device >= 0) check(hipSetDevice(device), "hipSetDevice");
-	else
-	{
-		int cur = 0;
-		check(hipGetDevice(&cur), "hipGetDevice (is a HIP device visible? there is no CPU fallback)");
-	}
+	int n = 0;
+	check(hipGetDeviceCount(&n), "hipGetDeviceCount (is a HIP device visible? there is no CPU fallback)");
+	if (device < 0) check(hipGetDevice(&device), "hipGetDevice");
+	if (device >= n) throw std::runtime_error("device ordinal out of range");
+	return device;
+}
+
+int dev_swap(int device)
+{
+	int cur = -1;
+	check(hipGetDevice(&cur), "hipGetDevice");
+	if (cur != device) check(hipSetDevice(device), "hipSetDevice");
+	return cur;
 }
 
 void* dev_alloc(size_t bytes)

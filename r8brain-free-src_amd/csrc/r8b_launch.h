@@ -282,7 +282,20 @@ void launch_convp(const ConvxLaunch& X, int mode, void* stream);
 void launch_convw(const ConvxLaunch& X, int mode, void* stream);
 
 // memory helpers; all throw std::runtime_error with the HIP error text on failure
-void dev_select(int device);          // -1 keeps the current device
+// Device selection.  dev_resolve: the ordinal an object created with `device` lives on (-1: the
+// thread's current device).  DevGuard makes `device` current for its lifetime and restores the
+// caller's device afterwards, so that an object on device 1 never changes what the calling thread
+// (or torch) considers current.
+int dev_resolve(int device);
+int dev_swap(int device);              // makes `device` current, returns the previous one
+struct DevGuard
+{
+	int prev;
+	explicit DevGuard(int device) : prev(dev_swap(device)) {}
+	~DevGuard() { if (prev >= 0) (void) dev_swap(prev); }
+	DevGuard(const DevGuard&) = delete;
+	DevGuard& operator=(const DevGuard&) = delete;
+};
 void* dev_alloc(size_t bytes);        // zero-initialised
 void dev_free(void* p);
 void dev_zero(void* p, size_t bytes, void* stream);

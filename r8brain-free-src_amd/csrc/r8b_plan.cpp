@@ -197,7 +197,7 @@ int StagePlan::history() const
 
 std::string StagePlan::describe() const
 {
-	char buf[256];
+	char buf[256] = "(unknown stage kind)";
 	switch (desc.kind)
 	{
 	case kConv:

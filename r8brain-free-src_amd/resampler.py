@@ -109,6 +109,9 @@ class BatchResampler(_Base):
         import torch
         assert x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.shape[0] == self.nch
         assert x.stride(1) == 1
+        dev = self._lib.r8b_batch_device(self._h)
+        if x.device.index != dev or (out is not None and out.device.index != dev):
+            raise ValueError("tensors on cuda:%s, the resampler lives on cuda:%d" % (x.device.index, dev))
         l = x.shape[1]
         if out is None:
             out = torch.empty((self.nch, max(self.max_out_len, 1)), dtype=torch.float64,

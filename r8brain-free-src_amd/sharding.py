@@ -14,55 +14,76 @@ import torch
 import torch.distributed as dist
 
 
+def _rank_world():
+    """(rank, world) of the default process group; (0, 1) when none is initialised (single GPU)."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def channel_shard(total_channels, rank, world):
     """[lo, hi) of the channels owned by `rank`."""
-    lo = total_channels * rank // world
-    hi = total_channels * (rank + 1) // world
+    # whole channel PAIRS per rank: the pair kernel packs channels 2c and 2c+1 into one complex
+    # transform, so a shard boundary between them would change which channels share a transform (and
+    # with it the last bits of their samples); with pairs kept together sharded == unsharded bit for bit
+    pairs = (total_channels + 1) // 2
+    lo = min(2 * (pairs * rank // world), total_channels)
+    hi = min(2 * (pairs * (rank + 1) // world), total_channels)
     return lo, hi
+
+
+def _run_p2p(ops):
+    """All point-to-point transfers of one scatter / gather as ONE group (dist.batch_isend_irecv: a
+    single ncclGroupStart/End on RCCL), so that every xGMI link carries its shard at the same time
+    instead of one transfer after the other."""
+    if not ops:
+        return
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
 
 
 def scatter_channels(x_full, total_channels, length, src=0, device=None, dtype=torch.float64):
     """x_full: [total_channels, length] on rank `src` (ignored elsewhere).  Returns this rank's
-    shard [hi-lo, length].  One send per peer, so on xGMI each point-to-point link carries exactly
-    one shard."""
-    rank, world = dist.get_rank(), dist.get_world_size()
+    shard [hi-lo, length].  One grouped send per peer: on xGMI each point-to-point link carries
+    exactly one shard and all links are busy together."""
+    rank, world = _rank_world()
     lo, hi = channel_shard(total_channels, rank, world)
     device = device if device is not None else (x_full.device if x_full is not None else "cpu")
     local = torch.empty((hi - lo, length), dtype=dtype, device=device)
+    ops = []
     if rank == src:
-        reqs = []
+        keep = []
         for r in range(world):
             a, b = channel_shard(total_channels, r, world)
             if r == src:
                 local.copy_(x_full[a:b, :length])
             elif b > a:
-                reqs.append(dist.isend(x_full[a:b, :length].contiguous(), dst=r))
-        for q in reqs:
-            q.wait()
+                keep.append(x_full[a:b, :length].contiguous())
+                ops.append(dist.P2POp(dist.isend, keep[-1], r))
     elif hi > lo:
-        dist.recv(local, src=src)
+        ops.append(dist.P2POp(dist.irecv, local, src))
+    _run_p2p(ops)
     return local
 
 
 def gather_channels(y_local, total_channels, dst=0):
     """Inverse of scatter_channels for the per-rank outputs [hi-lo, n] (same n on every rank: all
     ranks follow the same schedule).  Returns [total_channels, n] on `dst`, None elsewhere."""
-    rank, world = dist.get_rank(), dist.get_world_size()
+    rank, world = _rank_world()
     n = y_local.shape[1]
     if rank == dst:
         out = torch.empty((total_channels, n), dtype=y_local.dtype, device=y_local.device)
-        reqs = []
+        ops = []
         for r in range(world):
             a, b = channel_shard(total_channels, r, world)
             if r == dst:
                 out[a:b].copy_(y_local)
-            elif b > a:
-                reqs.append((dist.irecv(out[a:b], src=r), None))
-        for q, _ in reqs:
-            q.wait()
+            elif b > a and n > 0:
+                ops.append(dist.P2POp(dist.irecv, out[a:b], r))
+        _run_p2p(ops)
         return out
-    if y_local.shape[0] > 0:
-        dist.send(y_local.contiguous(), dst=dst)
+    if y_local.shape[0] > 0 and n > 0:
+        _run_p2p([dist.P2POp(dist.isend, y_local.contiguous(), dst)])
     return None
 
 
@@ -74,7 +95,7 @@ class ShardedBatchResampler:
     def __init__(self, factory, total_channels):
         """factory(nch) -> object with process(x_local) -> y_local (e.g. a BatchResampler)"""
         self.total = int(total_channels)
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.rank, self.world = _rank_world()
         self.lo, self.hi = channel_shard(self.total, self.rank, self.world)
         self.local = factory(self.hi - self.lo) if self.hi > self.lo else None
 
@@ -85,3 +106,68 @@ class ShardedBatchResampler:
         x = scatter_channels(x_full, self.total, length, src=root, device=device)
         y = self.local.process(x) if self.local is not None else x[:, :0]
         return gather_channels(y, self.total, dst=root)
+
+
+class RootPipeline:
+    """A batch that lives on ONE rank (SURVEY.md 8e "end-to-end"): per call scatter the channel shards,
+    resample them everywhere, gather the outputs back -- double buffered, so that the transfers of
+    call i+1 (out-bound) and call i-1 (in-bound) run on a side stream while call i is resampled.
+    On xGMI every peer link carries exactly one shard per direction and call (grouped sends).
+
+    `sharded`: a ShardedBatchResampler; `length`: samples per channel and call.  With CPU tensors
+    (gloo, the tests) there are no streams and the steps simply run in order."""
+
+    def __init__(self, sharded, length, root=0, device=None):
+        self.sh, self.length, self.root = sharded, int(length), root
+        self.device = torch.device(device if device is not None else "cpu")
+        self.cuda = self.device.type == "cuda"
+        self.side = torch.cuda.Stream(self.device) if self.cuda else None
+
+    def _on_side(self):
+        import contextlib
+        return torch.cuda.stream(self.side) if self.cuda else contextlib.nullcontext()
+
+    def run(self, batches):
+        """batches: list of [total_channels, length] tensors on the root (anything elsewhere; only
+        the length of the list matters there).  Returns the list of gathered outputs on the root
+        (None elsewhere).  Call i's scatter is issued before call i-1's gather, both on the side
+        stream; the resampling of call i-1 runs on the current stream in between."""
+        n = len(batches)
+        outs = [None] * n
+        shards = [None] * n
+        ready = [None] * n   # scatter of call i complete (event on the side stream)
+        done = [None] * n    # resampling of call i complete (event on the current stream)
+        rank = self.sh.rank
+
+        def scatter(i):
+            with self._on_side():
+                x = batches[i] if rank == self.root else None
+                shards[i] = scatter_channels(x, self.sh.total, self.length, src=self.root,
+                                             device=self.device)
+                if self.cuda:
+                    ready[i] = torch.cuda.Event()
+                    ready[i].record(self.side)
+
+        def gather(i, y):
+            with self._on_side():
+                if self.cuda:
+                    self.side.wait_event(done[i])
+                outs[i] = gather_channels(y, self.sh.total, dst=self.root)
+
+        if n:
+            scatter(0)
+        for i in range(n):
+            if i + 1 < n:
+                scatter(i + 1)
+            if self.cuda:
+                torch.cuda.current_stream(self.device).wait_event(ready[i])
+            x = shards[i]
+            y = self.sh.local.process(x) if self.sh.local is not None else x[:, :0]
+            if self.cuda:
+                y = y.clone()  # the resampler reuses its output buffer on the next call
+                done[i] = torch.cuda.Event()
+                done[i].record(torch.cuda.current_stream(self.device))
+            gather(i, y)
+        if self.cuda:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+        return outs

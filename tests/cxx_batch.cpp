@@ -72,9 +72,16 @@ int main()
 		double* ref;
 		const int n1 = r8b_process(one, in.data(), L, ref);
 		if (n1 != n) return 4;
+		// The pair kernel carries channels 2c and 2c+1 in the real and imaginary part of one complex
+		// transform; the single-stream object rides in the real part with a copy of itself beside it.
+		// So even rows (and the unpaired last one) equal the single-stream result bit for bit, odd rows
+		// to rounding (a few 1e-16 of full scale).
 		for (int ch = 0; ch < nch; ch++)
 			for (int i = 0; i < n; i++)
-				if (out[(size_t) (ch * out_stride + i)] != ref[i]) return 5;
+			{
+				const double d = out[(size_t) (ch * out_stride + i)] - ref[i];
+				if ((ch & 1) == 0 ? d != 0.0 : (d > 4e-15 || d < -4e-15)) return 5;
+			}
 		printf("call %d: %d samples x %d channels equal\n", c, n, nch);
 	}
 	r8b_delete(one);

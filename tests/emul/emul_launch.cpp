@@ -495,7 +495,8 @@ static void emul_pcm(const PcmLaunch& L, bool in)
 void launch_pcm_in(const PcmLaunch& L, void*) { emul_pcm(L, true); }
 void launch_pcm_out(const PcmLaunch& L, void*) { emul_pcm(L, false); }
 
-void dev_select(int) {}
+int dev_resolve(int device) { return device < 0 ? 0 : device; }
+int dev_swap(int) { return -1; }
 
 void* dev_alloc(size_t bytes)
 {

@@ -152,5 +152,65 @@ def test_emulated_checkpoint_rejects_other_configuration(emul):
                   r8b.BatchResampler(44100.0, 88200.0, 700, 2.0, 136.45, nch=3, lib=emul)):
         with pytest.raises(RuntimeError, match="differently configured|ring size"):
             other.load_state_dict(blob)
-    with pytest.raises(RuntimeError, match="truncated"):
+    with pytest.raises(RuntimeError, match="truncated|wrong size"):
         a.load_state_dict(blob[:100])
+
+
+# ---- hardening of the batch ABI (engine logic, exercised through the emulation library) ----------
+
+def test_emulated_state_blob_is_validated_before_anything_changes(emul):
+    x = make_input(2, 6000, 17)
+    b = r8b.BatchResampler(44100.0, 96000.0, 1024, 2.0, 180.15, nch=2, lib=emul)
+    size0 = emul.r8b_batch_state_size(b._h)
+    b.process_host(x[:, :1024])
+    b.process_host(x[:, 1024:2048])
+    assert emul.r8b_batch_state_size(b._h) == size0      # a constant of the object
+    blob = b.state_dict()
+    assert blob.size == size0
+    y_next = b.process_host(x[:, 2048:3072])
+    # a truncated blob and a blob with impossible counters are refused as a whole ...
+    c = r8b.BatchResampler(44100.0, 96000.0, 1024, 2.0, 180.15, nch=2, lib=emul)
+    c.process_host(x[:, :1024])
+    keep = c.state_dict()
+    with pytest.raises(RuntimeError):
+        c.load_state_dict(blob[:-8])
+    bad = blob.copy()
+    bad[32:40] = 255                                       # first stage counter m = -1
+    with pytest.raises(RuntimeError):
+        c.load_state_dict(bad)
+    assert np.array_equal(c.state_dict(), keep)            # ... and leave the object untouched
+    # the intact blob resumes bit-identically
+    c.load_state_dict(blob)
+    assert np.array_equal(c.process_host(x[:, 2048:3072]), y_next)
+
+
+def test_emulated_structural_options_are_frozen_while_a_stream_runs(emul):
+    x = make_input(1, 3000, 19)
+    b = r8b.BatchResampler(44100.0, 96000.0, 1024, 2.0, 180.15, nch=1, lib=emul)
+    b.set_option("fuse", 0)          # before the first sample: fine
+    b.set_option("fuse", 1)
+    b.process_host(x[:, :1024])
+    with pytest.raises(KeyError):
+        b.set_option("fuse", 0)      # would move the history to rings the fused kernel never wrote
+    b.set_option("fuse", 1)          # unchanged value: fine
+    b.set_option("timing", 0)        # non-structural: fine
+    b.clear()
+    b.set_option("fuse", 0)          # after clear(): fine again
+
+
+def test_emulated_process_rejects_overlapping_rows_and_null_pointers(emul):
+    import ctypes as C
+    b = r8b.BatchResampler(44100.0, 96000.0, 1024, 2.0, 180.15, nch=2, lib=emul)
+    x = np.zeros((2, 1024))
+    y = np.zeros((2, b.max_out_len))
+    ok = emul.r8b_batch_process(b._h, x.ctypes.data_as(C.c_void_p), 1024, 1024,
+                                y.ctypes.data_as(C.c_void_p), b.max_out_len, None)
+    assert ok >= 0
+    for args in [(None, 1024, 1024, y.ctypes.data_as(C.c_void_p), b.max_out_len),     # null input
+                 (x.ctypes.data_as(C.c_void_p), 1024, 1024, None, b.max_out_len),     # null output
+                 (x.ctypes.data_as(C.c_void_p), 1000, 1024, y.ctypes.data_as(C.c_void_p), b.max_out_len),
+                 (x.ctypes.data_as(C.c_void_p), 1024, 1024, y.ctypes.data_as(C.c_void_p), 100)]:
+        assert emul.r8b_batch_process(b._h, args[0], args[1], args[2], args[3], args[4], None) == -1
+        assert emul.r8b_last_error()
+    with pytest.raises(Exception):
+        r8b.BatchResampler(0, 0, 1024, nch=1, lib=emul, stage=(7, 0.0, 0.0, 0.0, 0.0, 0, 0))

@@ -371,7 +371,8 @@ def test_gpu_deep_decimation_full_size(torch):
 @pytest.mark.gpu
 def test_cxx_batch_device(tmp_path):
     """the batch C ABI from a plain C++/HIP host program with its own device buffers and stream
-    (tests/cxx_batch.cpp): rows equal the single-stream entry bitwise, across a checkpoint"""
+    (tests/cxx_batch.cpp): even rows equal the single-stream entry bitwise, odd rows (the imaginary
+    halves of the pair kernel's transforms) to rounding, across a checkpoint"""
     import subprocess
     from conftest import ROOT
     exe = str(tmp_path / "cxx_batch")
