@@ -805,7 +805,8 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 				((opt_.at("fast_conv") || !generic_conv_fits(sp.cg)) && (convx_mode3_ok(sp.cg.n_in,
 				sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2, sp.cg.down_pow2) ||
 				convx_geometry_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2)) ?
-				(use_wave(sp.cg) ? "k_convw" : "k_convx") : "k_conv");
+				(use_pair(sp.cg) && !convx_mode3_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down,
+				sp.cg.up_pow2, sp.cg.down_pow2) ? "k_convp" : (use_wave(sp.cg) ? "k_convw" : "k_convx")) : "k_conv");
 			break;
 		case kFrac: *kernel = sp.whole ? "k_whole" : "k_poly"; break;
 		case kHBUp: *kernel = group_len(stage) > 1 ? "k_hbcascade" : "k_hbup"; break;

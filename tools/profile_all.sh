@@ -1,0 +1,36 @@
+#!/bin/bash
+# tools/profile_all.sh <tag> : rocprofv3 kernel stats + hardware counters for every hot kernel
+# (BASELINE configs 2, 3, 5 and the side topologies), on the GPU box.  Writes under
+# gpurun_out/prof_<tag>/<name>/; tools/profile_collect.py copies the summaries into profiles/.
+tag=$1
+R=$PWD
+out=$R/gpurun_out/prof_$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+prof() {
+  name=$1; shift
+  mkdir -p $out/$name
+  # driver-style bench line (20 steps) and the long one, no profiler attached
+  (cd $R && timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu "$@" > $out/$name/bench_20.json 2>/dev/null)
+  (cd $R && timeout 300 python bench.py --steps 400 --warmup 40 --no-cpu "$@" > $out/$name/bench_400.json 2>/dev/null)
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name/stats -- python $R/bench.py --steps 50 --warmup 10 --no-cpu "$@" > $out/$name/stats.log 2>&1
+  i=0
+  for grp in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+             "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES" \
+             "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE"; do
+    i=$((i+1))
+    timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$name/p$i -- python $R/bench.py --steps 4 --warmup 2 --no-cpu "$@" > $out/$name/p$i.log 2>&1
+  done
+  (cd $R && python tools/pmc_summary.py $out/$name > $out/$name/pmc_summary.txt 2>&1)
+  # keep only the summaries (the raw traces are large)
+  find $out/$name -name "*_kernel_stats.csv" -exec cp {} $out/$name/kernel_stats.csv \;
+  rm -rf $out/$name/stats $out/$name/p1 $out/$name/p2 $out/$name/p3 $out/$name/p4 $out/$name/p5
+}
+prof cfg2
+prof cfg3 --config cfg3
+prof cfg5 --config cfg5
+prof cfg5x1024 --src 44100 --dst 2822400 --block 1024 --channels 1024
+prof poly --src 44100 --dst 44101
+prof hbdown --src 176400 --dst 44100
+prof up2 --src 44100 --dst 88200
+ls $out/*
