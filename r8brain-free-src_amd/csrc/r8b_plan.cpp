@@ -1,6 +1,7 @@
 // r8b_plan.cpp -- see r8b_plan.h.
 #include "r8b_plan.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 
@@ -23,30 +24,42 @@ StagePlan make_stage_plan(const StageDesc& d)
 		g.bl2 = 2 << f.block_len_bits;
 		const int ups = bit_occupancy(g.up) - 1;
 		g.up_pow2 = (1 << ups) == g.up;
-		if (g.up_pow2)
-		{
-			g.prev_len = (f.kernel_len - 1 + g.up - 1) / g.up;
-			g.in_len = g.bl2 - g.prev_len * g.up;
-			g.n_in = g.bl2 / g.up;
-		}
-		else
-		{
-			g.prev_len = f.kernel_len - 1;
-			g.in_len = g.bl2 - g.prev_len;
-			g.n_in = g.bl2;
-		}
-		g.latency = g.in_len + g.fl2;
 		const int dsh = bit_occupancy(g.down) - 1;
 		g.down_pow2 = ((1 << dsh) == g.down) && g.down > 1;
-		g.n_out = g.bl2;
-		if (g.down_pow2)
+		// block geometry for a circular block of bl2 virtual samples
+		auto shape = [&](int bl2)
 		{
-			const int ilc = g.in_len & (g.down - 1);
-			g.prev_len += ilc;
-			g.in_len -= ilc;
-			g.latency -= ilc;
-			g.n_out = g.bl2 / g.down;
-		}
+			g.bl2 = bl2;
+			if (g.up_pow2)
+			{
+				g.prev_len = (f.kernel_len - 1 + g.up - 1) / g.up;
+				g.in_len = g.bl2 - g.prev_len * g.up;
+				g.n_in = g.bl2 / g.up;
+			}
+			else
+			{
+				g.prev_len = f.kernel_len - 1;
+				g.in_len = g.bl2 - g.prev_len;
+				g.n_in = g.bl2;
+			}
+			g.n_out = g.bl2;
+			int ilc = 0;
+			if (g.down_pow2)
+			{
+				ilc = g.in_len & (g.down - 1);
+				g.prev_len += ilc;
+				g.in_len -= ilc;
+				g.n_out = g.bl2 / g.down;
+			}
+			return ilc;
+		};
+		const int ilc = shape(g.bl2);
+		(void) ilc;
+		g.latency = g.in_len + g.fl2; // reference: InputLen (after the divisibility adjustment) + filter latency
+		g.ref_bl2 = g.bl2; g.ref_in_len = g.in_len; g.ref_n_in = g.n_in; g.ref_n_out = g.n_out;
+		// transforms longer than 16384 points do not fit a workgroup's LDS: shorter blocks, same filter
+		while ((g.n_in > 16384 || g.n_out > 16384) && g.bl2 / 2 - (f.kernel_len - 1) - g.down >= 64)
+			shape(g.bl2 / 2);
 	}
 	else if (d.kind == kFrac)
 	{
@@ -183,7 +196,8 @@ int StagePlan::history() const
 		// before the stream end and reaches bl2-in_len further back
 		// (+ up to one interpolator filter length when the next stage is fused in and starts a
 		// little earlier than this stage's own next output)
-		return (cg.in_len + cg.bl2) / cg.up + 64;
+		// (re-blocked geometry: the outputs due still lag the input by the REFERENCE's latency)
+		return (std::max(cg.in_len, cg.ref_in_len + cg.fl2 - (cg.bl2 - cg.in_len > 0 ? 0 : 0)) + cg.bl2) / cg.up + 64;
 	case kFrac:
 		return 2 * flen + 4;
 	case kHBUp:
@@ -202,8 +216,8 @@ std::string StagePlan::describe() const
 	{
 	case kConv:
 		snprintf(buf, sizeof(buf), "BlockConvolver: flt_len=%d in_len=%d io=%d/%d fft=%d/%d "
-			"latency=%d nfreq=%.6g tb=%.6g gain=%.6g\n", lp->kernel_len, cg.in_len, cg.up,
-			cg.down, cg.n_in, cg.n_out, cg.latency, desc.a, desc.b, desc.d);
+			"latency=%d nfreq=%.6g tb=%.6g gain=%.6g\n", lp->kernel_len, cg.ref_in_len, cg.up,
+			cg.down, cg.ref_n_in, cg.ref_n_out, cg.latency, desc.a, desc.b, desc.d);
 		break;
 	case kFrac:
 		snprintf(buf, sizeof(buf), "FracInterpolator: %.10g->%.10g whole=%d step=%d/%d taps=%d "

@@ -34,6 +34,12 @@ struct ConvGeom
 	int latency = 0;    // samples (virtual rate, before decimation) the stage swallows
 	int n_in = 0;       // length of the forward real FFT
 	int n_out = 0;      // length of the inverse real FFT
+	// The reference's own block (describe(), latency and per-call counts follow it).  When its
+	// transforms exceed what one workgroup can hold in LDS (16384 points), the kernels run the SAME
+	// filter on shorter blocks bl2 / in_len (overlap-save is exact for any block longer than the
+	// filter, and a shorter block never needs input the reference's latency has not already waited
+	// for), anchored at multiples of the shorter in_len: still bitwise chunk invariant.
+	int ref_bl2 = 0, ref_in_len = 0, ref_n_in = 0, ref_n_out = 0;
 	bool up_pow2 = true;   // up-sampling by spectrum replication (else explicit zero stuffing)
 	bool down_pow2 = false; // decimation by spectrum truncation (else strided pick)
 };

@@ -48,6 +48,22 @@ STREAM_CASES = [
 ]
 
 
+# Filters too long for the reference's own block to fit LDS (32768-point blocks: transition band 0.5 %
+# at 180 dB with a radix-3 factor): the engine runs the same filter on 16384-point blocks.  Exact for
+# plain and strided decimation; where the reference decimates by TRUNCATING the block spectrum (2^k
+# down factors, reference CDSPBlockConvolver.h:329-344) the truncation residue depends on the block
+# length, so those two ratios agree to the filter's own stop-band level (-219 dB)
+# instead of 1e-15: tolerance stated per case.
+# (src, dst, maxin, chunk, n_in, tb, atten, rms_tol, peak_tol)
+REBLOCK_CASES = [
+    (48000.0, 32000.0, 4096, 3000, 90000, 0.5, 180.15, RMS_TOL, PEAK_TOL),    # 2/3
+    (44100.0, 132300.0, 2048, 1000, 50000, 0.5, 180.15, RMS_TOL, PEAK_TOL),   # 3/1
+    (96000.0, 32000.0, 4096, 4096, 120000, 0.5, 180.15, RMS_TOL, PEAK_TOL),   # 1/3
+    (32000.0, 48000.0, 2048, 2048, 60000, 0.5, 180.15, 1e-13, 5e-12),         # 3/2 (truncated spectrum)
+    (64000.0, 48000.0, 2048, 777, 70000, 0.5, 180.15, 1e-10, 5e-10),          # 3/4 (truncated spectrum)
+]
+
+
 def make_input(nch, n, seed0=1):
     return np.stack([O.splitmix_uniform(seed0 + c, n) for c in range(nch)])
 

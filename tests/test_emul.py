@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import STREAM_CASES, RMS_TOL, PEAK_TOL, compare_stream, make_input
+from cases import STREAM_CASES, REBLOCK_CASES, RMS_TOL, PEAK_TOL, compare_stream, make_input
 from conftest import ROOT
 
 r8b = importlib.import_module("r8brain-free-src_amd")
@@ -29,6 +29,26 @@ def test_emulated_engine_matches_oracle(emul, case):
     b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, lib=emul)
     rms, pk = compare_stream(b, src, dst, maxin, chunk, n, tb, att, 2)
     assert rms <= RMS_TOL and pk <= PEAK_TOL, (rms, pk)
+
+
+@pytest.mark.parametrize("case", REBLOCK_CASES)
+def test_emulated_long_filters_on_shorter_blocks(emul, refwrap, case):
+    """radix-3 convolvers whose reference block is 32768 points: same filter,
+    16384-point blocks; per-call counts equal the reference's, samples to the stated tolerance"""
+    src, dst, maxin, chunk, n, tb, att, rtol, ptol = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, lib=emul)
+    assert "fft=32768" in b.describe() or "/32768" in b.describe()   # describes the reference's block
+    x = make_input(2, n, 5)
+    lens, ys, counts, pos = [], [], [], 0
+    while pos < n:
+        l = min(chunk, n - pos)
+        y = b.process_host(x[:, pos:pos + l])
+        lens.append(l)
+        counts.append(y.shape[1])
+        ys.append(y)
+        pos += l
+    r, p = refwrap.batch_check(src, dst, maxin, lens, x, np.concatenate(ys, axis=1), counts, tb, att)
+    assert r.max() <= rtol and p.max() <= ptol, (r.max(), p.max())
 
 
 @pytest.mark.parametrize("radix,threads", [(2, 64), (4, 256), (16, 128)])
@@ -110,10 +130,13 @@ def test_emulated_wave_per_block_convolver(emul, case, fuse):
 
 
 def test_unsupported_geometry_fails_loudly(emul):
-    """A radix-3 convolver whose 32768-point block does not fit LDS: creation must fail with a
-    message, not fall back to anything."""
+    """Every filter the reference accepts (transition band >= 0.5 %, attenuation <= 218 dB) is
+    supported (tests above: the longest ones on shorter blocks); OUTSIDE the reference's parameter
+    range a filter that cannot fit a workgroup's LDS must fail at creation with a message, not fall
+    back to anything."""
+    r8b.BatchResampler(32000.0, 96000.0, 1024, 0.5, 218.0, nch=1, lib=emul)   # longest radix-3 case
     with pytest.raises(RuntimeError, match="too long"):
-        r8b.BatchResampler(32000.0, 96000.0, 1024, 0.5, 218.0, nch=1, lib=emul)
+        r8b.BatchResampler(64000.0, 48000.0, 1024, 0.2, 218.0, nch=1, lib=emul)
 
 
 CKPT_CASES = [(44100.0, 96000.0), (96000.0, 44100.0), (44100.0, 44101.0), (44100.0, 2822400.0),

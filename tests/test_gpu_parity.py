@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import STREAM_CASES, RMS_TOL, PEAK_TOL, compare_stream, make_input
+from cases import STREAM_CASES, REBLOCK_CASES, RMS_TOL, PEAK_TOL, compare_stream, make_input
 from conftest import rms, peak
 
 pytestmark = pytest.mark.gpu
@@ -240,6 +240,25 @@ def test_hip_full_size_properties(torch, cfg):
     yn = np.concatenate([b3.process_host(loud[:, i * L:(i + 1) * L]) for i in range(calls)], axis=1)
     assert peak(yq[0] - yn[0]) <= 4e-15
     assert peak(yq[1]) <= 4e-15  # a silent channel beside a loud one: residue only
+
+
+@pytest.mark.parametrize("case", REBLOCK_CASES)
+def test_hip_long_filters_on_shorter_blocks(torch, refwrap, case):
+    """transition band 0.5 % at 180 dB with a radix-3 factor (the reference's block is 32768 points):
+    r8b_batch_create succeeds, counts equal the reference's, samples to the stated tolerance"""
+    src, dst, maxin, chunk, n, tb, att, rtol, ptol = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, device=0)
+    x = make_input(2, n, 5)
+    lens, ys, counts, pos = [], [], [], 0
+    while pos < n:
+        l = min(chunk, n - pos)
+        y = b.process_host(x[:, pos:pos + l])
+        lens.append(l)
+        counts.append(y.shape[1])
+        ys.append(y)
+        pos += l
+    r, p = refwrap.batch_check(src, dst, maxin, lens, x, np.concatenate(ys, axis=1), counts, tb, att)
+    assert r.max() <= rtol and p.max() <= ptol, (r.max(), p.max())
 
 
 def test_hip_soak_ragged_calls_vs_reference(torch, refwrap):
