@@ -33,9 +33,8 @@ public:
 		const EDSPFilterPhaseResponse ReqPhase = fprLinearPhase)
 		: SrcRate(SrcSampleRate), DstRate(DstSampleRate), MaxInLen(aMaxInLen)
 	{
-		if (ReqPhase != fprLinearPhase)
-			throw std::runtime_error("r8b (hip): minimum-phase filters are not supported");
-		h = r8b_batch_create(SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand, ReqAtten, 1, -1);
+		h = r8b_batch_create_ex(SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand, ReqAtten,
+			(int) ReqPhase, 1, -1);
 		if (h == nullptr) throw std::runtime_error(r8b_last_error());
 		const int mo = r8b_batch_max_out_len(h);
 		OutBuf.resize((size_t) (mo > 0 ? mo : 1));

@@ -139,6 +139,13 @@ R8BSRC_DECL long long r8b_batch_state_size(CR8BBatch b);
 R8BSRC_DECL long long r8b_batch_state_save(CR8BBatch b, void* buf, long long cap, void* stream);
 R8BSRC_DECL int r8b_batch_state_load(CR8BBatch b, const void* buf, long long size, void* stream);
 
+/* The same with the phase response of the low-pass filters selectable (reference CDSPResampler.h:117-120,
+ * EDSPFilterPhaseResponse CDSPFIRFilter.h:28-45): ReqPhase 0 = fprLinearPhase, 1 = fprMinPhase.  A
+ * minimum-phase chain carries fractional latencies from stage to stage like the reference does; it runs
+ * on the generic (unfused) kernels. */
+R8BSRC_DECL CR8BBatch r8b_batch_create_ex(double SrcSampleRate, double DstSampleRate, int MaxInLen,
+	double ReqTransBand, double ReqAtten, int ReqPhase, int nch, int device);
+
 /* Single DSP stage as a batch object (the reference's CDSPProcessor boundary,
  * CDSPProcessor.h:64-127), used by the stage-level parity tests:
  *   kind 0: CDSPBlockConvolver(getLPFilter(a=ReqNormFreq, b=ReqTransBand, c=ReqAtten, linear,
@@ -181,6 +188,13 @@ R8BSRC_DECL const char* r8b_last_error(void);
  * CDSPFIRFilter::getBlockLenBits/getLatency (CDSPFIRFilter.h:139-164). */
 R8BSRC_DECL int r8b_design_lpfilter(double ReqNormFreq, double ReqTransBand, double ReqAtten,
 	double ReqGain, int* BlockLenBits, int* Latency, double* taps, int cap);
+
+/* The same with the phase response selectable (0 = fprLinearPhase, 1 = fprMinPhase; reference
+ * CDSPFIRFilter.h:28-45).  Minimum phase: causal taps h[0..KernelLen-1]; *Latency / *LatencyFrac =
+ * integer and fractional part of the group delay at DC (CDSPFIRFilter.h:476-484). */
+R8BSRC_DECL int r8b_design_lpfilter_ex(double ReqNormFreq, double ReqTransBand, double ReqAtten,
+	double ReqGain, int ReqPhase, int* BlockLenBits, int* Latency, double* LatencyFrac, double* taps,
+	int cap);
 
 /* Fractional-delay bank (CDSPFracDelayFilterBank): rows 0..FilterFracs, FilterLen*ElementSize
  * doubles each, natural (unshuffled) element order.  FilterFracs = -1 selects the default

@@ -121,6 +121,31 @@ REFX_API int refx_lpfilter(double normfreq, double tb, double atten, double gain
 	return n;
 }
 
+// the same with the phase response selectable (0 linear, 1 minimum phase); kernelblock = the filter's
+// spectrum block as the reference keeps it (CDSPRealFFT::forward of the normalised taps: [0] = DC,
+// [1] = Nyquist, then (re, im) pairs, Ooura's e^{+i} sign); *latfrac = getLatencyFrac()
+REFX_API int refx_lpfilter_ex(double normfreq, double tb, double atten, double gain, int phase,
+	int* kernellen, int* blocklenbits, int* latency, double* latfrac, double* kernelblock, int cap)
+{
+	CDSPFIRFilter& f = CDSPFIRFilterCache::getLPFilter(normfreq, tb, atten,
+		phase ? fprMinPhase : fprLinearPhase, gain);
+	*kernellen = f.getKernelLen();
+	*blocklenbits = f.getBlockLenBits();
+	*latency = f.getLatency();
+	*latfrac = f.getLatencyFrac();
+	const int n = 2 << f.getBlockLenBits();
+	if (kernelblock != nullptr)
+		memcpy(kernelblock, f.getKernelBlock(), (size_t) (n < cap ? n : cap) * sizeof(double));
+	f.unref();
+	return n;
+}
+
+// front-end object with the phase response selectable
+REFX_API void* refx_create_ex(double src, double dst, int maxin, double tb, double atten, int phase)
+{
+	return new CDSPResampler(src, dst, maxin, tb, atten, phase ? fprMinPhase : fprLinearPhase);
+}
+
 REFX_API int refx_fracbank(int fracs, int elsize, int interppoints, double atten,
 	int third, int* fltlen, int* nfracs, double* table, int cap)
 {
@@ -298,6 +323,8 @@ REFX_API double refx_bench(double src, double dst, int L, double tb, double atte
 // apart, calls back to back; counts[k] = the count the device path returned for call k).  Per
 // channel: sum of squared differences and peak difference.  Returns 0, or 1 + k for the first call
 // whose output count differs from counts[k] (in any channel).
+static int g_batch_phase = 0; // set by refx_batch_check_ex around the call (tests are single-threaded)
+
 REFX_API int refx_batch_check(double src, double dst, int maxin, double tb, double atten, int nch,
 	int calls, const int* lens, const double* x, long long xstride, const double* y, long long ystride,
 	const int* counts, int nthreads, double* sqerr, double* peak, long long* total)
@@ -316,7 +343,7 @@ REFX_API int refx_batch_check(double src, double dst, int maxin, double tb, doub
 			const int c1 = (int) ((long long) nch * (t + 1) / nthreads);
 			for (int c = c0; c < c1; c++)
 			{
-				CDSPResampler rs(src, dst, maxin, tb, atten, fprLinearPhase);
+				CDSPResampler rs(src, dst, maxin, tb, atten, g_batch_phase ? fprMinPhase : fprLinearPhase);
 				const double* xi = x + (long long) c * xstride;
 				const double* yi = y + (long long) c * ystride;
 				double sq = 0.0, pk = 0.0;
@@ -351,6 +378,17 @@ REFX_API int refx_batch_check(double src, double dst, int maxin, double tb, doub
 	for (int t = 0; t < nthreads; t++)
 		if (bad[(size_t) t] != 0) return bad[(size_t) t];
 	return 0;
+}
+
+REFX_API int refx_batch_check_ex(double src, double dst, int maxin, double tb, double atten, int phase,
+	int nch, int calls, const int* lens, const double* x, long long xstride, const double* y,
+	long long ystride, const int* counts, int nthreads, double* sqerr, double* peak, long long* total)
+{
+	g_batch_phase = phase;
+	const int rc = refx_batch_check(src, dst, maxin, tb, atten, nch, calls, lens, x, xstride, y, ystride,
+		counts, nthreads, sqerr, peak, total);
+	g_batch_phase = 0;
+	return rc;
 }
 
 REFX_API const char* refx_version() { return R8B_VERSION; }

@@ -75,6 +75,15 @@ def _bind(lib):
     lib.refx_batch_check.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
                                      C.c_int, _ip, _dp, C.c_longlong, _dp, C.c_longlong, _ip, C.c_int,
                                      _dp, _dp, C.POINTER(C.c_longlong)]
+    lib.refx_lpfilter_ex.restype = C.c_int
+    lib.refx_lpfilter_ex.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                     _ip, _ip, _ip, _dp, _dp, C.c_int]
+    lib.refx_create_ex.restype = C.c_void_p
+    lib.refx_create_ex.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int]
+    lib.refx_batch_check_ex.restype = C.c_int
+    lib.refx_batch_check_ex.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
+                                        C.c_int, C.c_int, _ip, _dp, C.c_longlong, _dp, C.c_longlong, _ip,
+                                        C.c_int, _dp, _dp, C.POINTER(C.c_longlong)]
     lib.refx_version.restype = C.c_char_p
     return lib
 
@@ -135,10 +144,11 @@ ATTEN = {"16": 136.45, "16IR": 109.56, "24": 180.15}
 
 
 class RefResampler:
-    """r8b::CDSPResampler(src, dst, maxin, tb, atten, fprLinearPhase)."""
+    """r8b::CDSPResampler(src, dst, maxin, tb, atten, fprLinearPhase or fprMinPhase)."""
 
-    def __init__(self, src, dst, maxin, tb=2.0, atten=180.15):
-        self.h = lib().refx_create(src, dst, maxin, tb, atten)
+    def __init__(self, src, dst, maxin, tb=2.0, atten=180.15, phase=0):
+        self.h = (lib().refx_create_ex(src, dst, maxin, tb, atten, int(phase)) if phase else
+                  lib().refx_create(src, dst, maxin, tb, atten))
         self.maxin = maxin
         self.maxout = lib().refx_maxoutlen(self.h) if src != dst else maxin
         self._buf = np.empty(self.maxout + 16, dtype=np.float64)
@@ -266,7 +276,23 @@ def bench(src, dst, L, nch, warm, calls, nthreads, tb=2.0, atten=180.15):
                 threads=min(nthreads, nch), flags=flags)
 
 
-def batch_check(src, dst, maxin, lens, x, y, counts, tb=2.0, atten=180.15, nthreads=None):
+def lpfilter_taps(normfreq, tb, atten, gain, phase=0):
+    """(taps, latency, latency fraction) of the reference's low-pass, recovered from its spectrum block
+    (phase 1: the minimum-phase filter, causal taps)"""
+    kl, bb, lat, lf = C.c_int(), C.c_int(), C.c_int(), C.c_double()
+    n = lib().refx_lpfilter_ex(normfreq, tb, atten, gain, phase, kl, bb, lat, lf, None, 0)
+    blk = np.zeros(n)
+    lib().refx_lpfilter_ex(normfreq, tb, atten, gain, phase, kl, bb, lat, lf, blk.ctypes.data_as(_dp), n)
+    # Ooura rdft: blk[2k] + i blk[2k+1] = sum_j a_j e^{+2 pi i jk/n}; blk[1] = Nyquist; includes 2/n
+    spec = np.zeros(n // 2 + 1, dtype=complex)
+    spec[0] = blk[0]
+    spec[-1] = blk[1]
+    spec[1:-1] = blk[2::2] - 1j * blk[3::2]
+    taps = np.fft.irfft(spec, n) * (n / 2.0)
+    return taps[:kl.value].copy(), lat.value, lf.value
+
+
+def batch_check(src, dst, maxin, lens, x, y, counts, tb=2.0, atten=180.15, nthreads=None, phase=0):
     """One reference resampler per row of x (nch x sum(lens), C order) walks the calls of lens[k]
     samples on nthreads threads; y (nch x >= sum(counts)) holds the outputs of the path under test,
     calls back to back.  Returns (rms per channel, peak per channel); raises if a call's output
@@ -283,7 +309,7 @@ def batch_check(src, dst, maxin, lens, x, y, counts, tb=2.0, atten=180.15, nthre
     sq = np.zeros(nch)
     pk = np.zeros(nch)
     tot = C.c_longlong()
-    rc = lib().refx_batch_check(src, dst, maxin, tb, atten, nch, len(lens), lens.ctypes.data_as(_ip), x.ctypes.data_as(_dp), x.shape[1],
+    rc = lib().refx_batch_check_ex(src, dst, maxin, tb, atten, phase, nch, len(lens), lens.ctypes.data_as(_ip), x.ctypes.data_as(_dp), x.shape[1],
                                 y.ctypes.data_as(_dp), y.shape[1], counts.ctypes.data_as(_ip),
                                 nthreads, sq.ctypes.data_as(_dp), pk.ctypes.data_as(_dp), tot)
     if rc != 0:

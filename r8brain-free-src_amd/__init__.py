@@ -10,7 +10,7 @@ libr8bsrc_hip.so).  Everything computes on the GPU through the C ABI of include/
 """
 from ._capi import load, lib_path, bind, PROTOTYPES  # noqa: F401
 from .resampler import (BatchResampler, CDSPResampler, CDSPResampler16, CDSPResampler16IR,  # noqa: F401
-                        CDSPResampler24, DLLResampler, fprLinearPhase,
+                        CDSPResampler24, DLLResampler, fprLinearPhase, fprMinPhase,
                         PCM_F64, PCM_F32, PCM_S16, PCM_S24, PCM_S32)
 
 

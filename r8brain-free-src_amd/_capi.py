@@ -22,6 +22,8 @@ PROTOTYPES = [
     ("r8b_process", C.c_int, [C.c_void_p, dp, C.c_int, C.POINTER(dp)]),
     ("r8b_batch_create", C.c_void_p, [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
                                       C.c_int, C.c_int]),
+    ("r8b_batch_create_ex", C.c_void_p, [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double,
+                                         C.c_int, C.c_int, C.c_int]),
     ("r8b_batch_delete", None, [C.c_void_p]),
     ("r8b_batch_clear", None, [C.c_void_p]),
     ("r8b_batch_channels", C.c_int, [C.c_void_p]),
@@ -51,6 +53,9 @@ PROTOTYPES = [
     ("r8b_last_error", C.c_char_p, []),
     ("r8b_design_lpfilter", C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, ip, ip, dp,
                                       C.c_int]),
+    ("r8b_design_lpfilter_ex", C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.c_int]),
     ("r8b_design_fracbank", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, ip, ip, dp,
                                       C.c_int]),
     ("r8b_design_hbfilter", C.c_int, [C.c_double, C.c_int, C.c_int, dp, dp]),

@@ -175,6 +175,26 @@ R8BSRC_DECL CR8BBatch r8b_batch_create(double SrcSampleRate, double DstSampleRat
 	}
 }
 
+R8BSRC_DECL CR8BBatch r8b_batch_create_ex(double SrcSampleRate, double DstSampleRate, int MaxInLen,
+	double ReqTransBand, double ReqAtten, int ReqPhase, int nch, int device)
+{
+	try
+	{
+		if (ReqPhase != kLinearPhase && ReqPhase != kMinPhase)
+			throw std::runtime_error("ReqPhase must be 0 (linear phase) or 1 (minimum phase)");
+		std::unique_ptr<Batch> b(new Batch());
+		b->eng.reset(new Engine(build_topology(SrcSampleRate, DstSampleRate, ReqTransBand,
+			ReqAtten, ReqPhase), MaxInLen, nch, device));
+		g_err.clear();
+		return b.release();
+	}
+	catch (const std::exception& e)
+	{
+		set_err("r8b_batch_create_ex", e);
+		return nullptr;
+	}
+}
+
 R8BSRC_DECL CR8BBatch r8b_batch_create_stage(int kind, double a, double b, double c, double d,
 	int i0, int i1, int MaxInLen, int nch, int device)
 {
@@ -405,6 +425,19 @@ R8BSRC_DECL int r8b_design_lpfilter(double ReqNormFreq, double ReqTransBand, dou
 	const LpFilter& f = design_lp(ReqNormFreq, ReqTransBand, ReqAtten, ReqGain);
 	if (BlockLenBits) *BlockLenBits = f.block_len_bits;
 	if (Latency) *Latency = f.fl2;
+	if (taps)
+		memcpy(taps, f.taps.data(), sizeof(double) * (size_t) (f.kernel_len < cap ? f.kernel_len : cap));
+	return f.kernel_len;
+}
+
+R8BSRC_DECL int r8b_design_lpfilter_ex(double ReqNormFreq, double ReqTransBand, double ReqAtten,
+	double ReqGain, int ReqPhase, int* BlockLenBits, int* Latency, double* LatencyFrac, double* taps,
+	int cap)
+{
+	const LpFilter& f = design_lp(ReqNormFreq, ReqTransBand, ReqAtten, ReqGain, ReqPhase != 0);
+	if (BlockLenBits) *BlockLenBits = f.block_len_bits;
+	if (Latency) *Latency = f.fl2;
+	if (LatencyFrac) *LatencyFrac = f.lat_frac;
 	if (taps)
 		memcpy(taps, f.taps.data(), sizeof(double) * (size_t) (f.kernel_len < cap ? f.kernel_len : cap));
 	return f.kernel_len;

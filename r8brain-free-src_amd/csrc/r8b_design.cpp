@@ -3,6 +3,7 @@
 #include "r8b_design.h"
 
 #include <cmath>
+#include <complex>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -153,12 +154,102 @@ std::mutex g_cache_mutex;
 
 } // namespace
 
-const LpFilter& design_lp(double norm_freq, double trans_band, double atten, double gain)
+namespace {
+
+// in-place complex FFT (iterative radix 2), sign = -1: forward
+template<class T>
+void fft_host(std::vector<std::complex<T>>& a, int sign)
 {
-	typedef std::tuple<double, double, double, double> Key;
+	const size_t n = a.size();
+	for (size_t i = 1, j = 0; i < n; i++)
+	{
+		size_t bit = n >> 1;
+		for (; j & bit; bit >>= 1) j ^= bit;
+		j ^= bit;
+		if (i < j) std::swap(a[i], a[j]);
+	}
+	const long double two_pi = 6.283185307179586476925286766559L;
+	for (size_t len = 2; len <= n; len <<= 1)
+	{
+		std::vector<std::complex<T>> w(len / 2);
+		for (size_t k = 0; k < len / 2; k++)
+			w[k] = std::complex<T>((T) cosl(two_pi * k / len), (T) (sign * sinl(two_pi * k / len)));
+		for (size_t i = 0; i < n; i += len)
+			for (size_t k = 0; k < len / 2; k++)
+			{
+				const std::complex<T> u = a[i + k], v = a[i + k + len / 2] * w[k];
+				a[i + k] = u + v;
+				a[i + k + len / 2] = u - v;
+			}
+	}
+}
+
+// Minimum-phase transform of a FIR kernel through the cepstrum (reference CDSPRealFFT.h:681-785,
+// LenMult = 16, DoFinalMul = false): log-magnitude spectrum -> cepstrum -> discrete Hilbert transform
+// (positive quefrencies kept, negative ones negated, 0 and N/2 cleared) -> phase -> spectrum with the
+// original magnitudes -> time domain, first kernel_len samples.  The scale of the result is left as
+// it comes (the caller normalises the DC gain).
+// Arithmetic: fp64 like the reference, on purpose.  The deep stop band of these kernels (-180 dB and
+// below) lies under the rounding noise of an fp64 transform of this length; log|H| there -- and with
+// it the phase the Hilbert transform derives -- is set by that noise floor, so a more accurate
+// transform gives a (truer but) different filter: in extended precision the 1/3-band kernel comes
+// out 0.011 samples earlier than the reference's.
+template<class T>
+std::vector<double> min_phase_transform_t(const std::vector<double>& kernel)
+{
+	typedef std::complex<T> C;
+	const int klen = (int) kernel.size();
+	const int bits = bit_occupancy((long long) klen * 16 - 1);
+	const size_t n = (size_t) 1 << bits, n2 = n / 2;
+	std::vector<C> a(n, C(0, 0));
+	for (int i = 0; i < klen; i++) a[(size_t) i] = C((T) kernel[(size_t) i], 0);
+	fft_host(a, -1);
+	std::vector<T> mag(n2 + 1);
+	const T x0 = a[0].real(), xn = a[n2].real();
+	for (size_t k = 0; k <= n2; k++) mag[k] = std::sqrt(a[k].real() * a[k].real() + a[k].imag() * a[k].imag());
+	mag[0] = std::abs(x0);
+	mag[n2] = std::abs(xn);
+	std::vector<C> l(n);
+	for (size_t k = 0; k <= n2; k++)
+	{
+		const T v = std::log(mag[k] + (T) 1e-300);
+		l[k] = C(v, 0);
+		if (k != 0 && k != n2) l[n - k] = C(v, 0);
+	}
+	fft_host(l, +1); // cepstrum * n
+	std::vector<C> d(n);
+	d[0] = d[n2] = C(0, 0);
+	for (size_t i = 1; i < n2; i++) d[i] = C(l[i].real() / (T) n, 0);
+	for (size_t i = n2 + 1; i < n; i++) d[i] = C(-l[i].real() / (T) n, 0);
+	fft_host(d, -1); // purely imaginary: the phase
+	std::vector<C> s(n);
+	s[0] = C(x0, 0);
+	s[n2] = C(xn, 0);
+	for (size_t k = 1; k < n2; k++)
+	{
+		const T ph = d[k].imag();
+		s[k] = C(std::cos(ph) * mag[k], std::sin(ph) * mag[k]);
+		s[n - k] = std::conj(s[k]);
+	}
+	fft_host(s, +1);
+	std::vector<double> out((size_t) klen);
+	for (int i = 0; i < klen; i++) out[(size_t) i] = (double) (s[(size_t) i].real() / (T) n);
+	return out;
+}
+
+std::vector<double> min_phase_transform(const std::vector<double>& kernel)
+{
+	return min_phase_transform_t<double>(kernel);
+}
+
+} // namespace
+
+const LpFilter& design_lp(double norm_freq, double trans_band, double atten, double gain, bool min_phase)
+{
+	typedef std::tuple<double, double, double, double, bool> Key;
 	static std::map<Key, LpFilter> cache;
 	std::lock_guard<std::mutex> lock(g_cache_mutex);
-	const Key key(norm_freq, trans_band, atten, gain);
+	const Key key(norm_freq, trans_band, atten, gain, min_phase);
 	auto it = cache.find(key);
 	if (it != cache.end()) return it->second;
 
@@ -195,6 +286,24 @@ const LpFilter& design_lp(double norm_freq, double trans_band, double atten, dou
 		const double v = r * win.next() / t;
 		c[t] = v;
 		c[-t] = v;
+	}
+	if (min_phase)
+	{
+		// reference CDSPFIRFilter.h:476-484, 520-528: transform the raw kernel, take the group delay at
+		// DC as the latency (integer part consumed by the convolver, fraction handed to the next stage),
+		// then normalise.  The reference estimates the delay by a finite difference of the phase at
+		// 1e-9 rad (r8bbase.h:876-920); d(phase)/d(omega) at 0 is sum(n h[n]) / sum(h[n]) exactly.
+		f.taps = min_phase_transform(f.taps);
+		long double sn = 0.0L, sh = 0.0L;
+		for (int i = 0; i < f.kernel_len; i++)
+		{
+			sn += (long double) i * f.taps[(size_t) i];
+			sh += f.taps[(size_t) i];
+		}
+		const double gd = (double) (sn / sh);
+		f.zero_phase = false;
+		f.fl2 = (int) gd;
+		f.lat_frac = gd - f.fl2;
 	}
 	double s = 0.0;
 	for (int i = 0; i < f.kernel_len; i++) s += f.taps[(size_t) i];
@@ -375,13 +484,14 @@ bool whole_stepping(double ssr, double dsr, int* in_step, int* out_step)
 	return true;
 }
 
-std::vector<StageDesc> build_topology(double src, double dst, double tb, double atten)
+std::vector<StageDesc> build_topology(double src, double dst, double tb, double atten, int phase)
 {
 	std::vector<StageDesc> st;
 	auto conv = [&](double nf, double tbv, double gain, int up, int down)
 	{
 		StageDesc d;
 		d.kind = kConv; d.a = nf; d.b = tbv; d.c = atten; d.d = gain; d.i0 = up; d.i1 = down;
+		d.phase = phase;
 		st.push_back(d);
 	};
 	auto frac = [&](double s, double dd, bool third)

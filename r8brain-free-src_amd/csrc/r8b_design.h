@@ -20,14 +20,25 @@ namespace r8bhip {
 
 struct LpFilter
 {
-	std::vector<double> taps; // h[-fl2..fl2] stored at [0..2*fl2], DC gain == gain
-	int fl2 = 0;              // one-sided length == latency in samples
-	int kernel_len = 0;       // 2*fl2+1
+	// linear phase: h[-fl2..fl2] stored at [0..2*fl2]; minimum phase: causal h[0..kernel_len-1].
+	// DC gain == gain either way.
+	std::vector<double> taps;
+	// Latency in samples (integer part).  Linear phase: the one-sided length.  Minimum phase: the integer
+	// part of the group delay at DC (reference CDSPFIRFilter.h:476-484); lat_frac holds the rest.
+	int fl2 = 0;
+	double lat_frac = 0.0;
+	bool zero_phase = true;
+	int kernel_len = 0;       // 2*fl2+1 for linear phase
 	int block_len_bits = 0;   // CDSPFIRFilter::getBlockLenBits()
 };
 
-// Kaiser-power-windowed sinc low-pass (zero phase).
-const LpFilter& design_lp(double norm_freq, double trans_band, double atten, double gain);
+// reference EDSPFilterPhaseResponse (CDSPFIRFilter.h:28-45)
+enum FilterPhase { kLinearPhase = 0, kMinPhase = 1 };
+
+// Kaiser-power-windowed sinc low-pass; min_phase: followed by the cepstral minimum-phase transform
+// (reference CDSPRealFFT.h:681-785 calcMinPhaseTransform, 16x oversampled).
+const LpFilter& design_lp(double norm_freq, double trans_band, double atten, double gain,
+	bool min_phase = false);
 
 struct FracBank
 {
@@ -64,10 +75,12 @@ struct StageDesc
 	// hbup/hbdown: a=atten i0=steep i1=third
 	double a = 0, b = 0, c = 0, d = 0;
 	int i0 = 0, i1 = 0;
+	int phase = kLinearPhase; // conv only
 };
 
-// Stage chain a CDSPResampler(src, dst, ., tb, atten, linear phase) is made of.
-std::vector<StageDesc> build_topology(double src, double dst, double tb, double atten);
+// Stage chain a CDSPResampler(src, dst, ., tb, atten, phase) is made of.
+std::vector<StageDesc> build_topology(double src, double dst, double tb, double atten,
+	int phase = kLinearPhase);
 
 } // namespace r8bhip
 

@@ -75,6 +75,26 @@ std::vector<double> kernel_spectrum(const LpFilter& f, int bl2, double scale)
 	return H;
 }
 
+std::vector<double> kernel_spectrum_complex(const LpFilter& f, int bl2, int align, double scale)
+{
+	const std::vector<double> tw = make_twiddles(bl2);
+	std::vector<double> H((size_t) (bl2 / 2 + 1) * 2);
+	const int K = (int) f.taps.size();
+	for (int m = 0; m <= bl2 / 2; m++)
+	{
+		long double re = 0.0L, im = 0.0L;
+		for (int n = 0; n < K; n++)
+		{
+			const long long e = ((long long) m * (n - align)) & (bl2 - 1);
+			re += (long double) f.taps[(size_t) n] * tw[(size_t) e * 2];
+			im += (long double) f.taps[(size_t) n] * tw[(size_t) e * 2 + 1];
+		}
+		H[(size_t) m * 2] = (double) (re * scale);
+		H[(size_t) m * 2 + 1] = (double) (im * scale);
+	}
+	return H;
+}
+
 std::vector<double> spectral_constants(const std::vector<double>& H, const std::vector<double>& tw,
 	int bl2, int n_in, int up)
 {
@@ -481,6 +501,21 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 				if (!generic_conv_fits(g) && !fast_ok)
 					throw std::runtime_error("low-pass filter too long for the LDS-resident "
 						"block convolver (transition band too narrow)");
+				if (g.complex_h)
+				{
+					// minimum phase (or an alignment moved by inherited latency): complex spectrum, generic
+					// kernel only
+					if (!generic_conv_fits(g))
+						throw std::runtime_error("minimum-phase filter too long for the generic block convolver");
+					const std::vector<double> hc = kernel_spectrum_complex(*sp.lp, g.bl2, g.fl2, 1.0 / g.bl2);
+					d.Hc = (cd*) dev_alloc(hc.size() * sizeof(double));
+					dev_upload(d.Hc, hc.data(), hc.size() * sizeof(double));
+					const std::vector<double> tw = make_twiddles(g.bl2);
+					d.tw_len = g.bl2;
+					d.tw = (cd*) dev_alloc(tw.size() * sizeof(double));
+					dev_upload(d.tw, tw.data(), tw.size() * sizeof(double));
+					continue;
+				}
 				const std::vector<double> H = kernel_spectrum(*sp.lp, g.bl2, 1.0 / g.bl2);
 				d.H = (double*) dev_alloc(H.size() * sizeof(double));
 				dev_upload(d.H, H.data(), H.size() * sizeof(double));
@@ -710,6 +745,7 @@ void Engine::release()
 		dev_free(d.ring);
 		dev_free(d.ring_alt);
 		dev_free(d.H);
+		dev_free(d.Hc);
 		dev_free(d.tw);
 		dev_free(d.spec);
 		dev_free(d.spec2);
@@ -802,6 +838,7 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 			*kernel = fuse_with_next(stage) ?
 				(use_pair(sp.cg) && !opt_.at("mfma_interp") ? "k_convp_whole" :
 				(use_wave(sp.cg) && !opt_.at("mfma_interp") ? "k_convw_whole" : "k_convx_whole")) :
+				sp.cg.complex_h ? "k_conv" :
 				((opt_.at("fast_conv") || !generic_conv_fits(sp.cg)) && (convx_mode3_ok(sp.cg.n_in,
 				sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2, sp.cg.down_pow2) ||
 				convx_geometry_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2)) ?
@@ -981,11 +1018,17 @@ void Engine::load_state(const void* buf, size_t size, void* stream)
 }
 
 void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
-	const PolyState& ps, const SrcView& src, const DstView& dst, void* stream)
+	const PolyState& ps, const SrcView& src, const DstView& dst_in, void* stream)
 {
 	const StagePlan& sp = plan_.stages[s];
 	const StageDev& d = dev_[s];
 	(void) m_prev;
+	DstView dst = dst_in;
+	// emitted sample q is sample q + out_skip of the stage's stream function (fractional-latency chains
+	// only): compute the shifted range, store it out_skip positions earlier
+	a += sp.out_skip;
+	b += sp.out_skip;
+	dst.off -= sp.out_skip;
 	switch (sp.desc.kind)
 	{
 	case kConv:
@@ -1000,7 +1043,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		L.a = a; L.b = b;
 		L.dst = dst;
 		const bool m3 = convx_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
-		if ((opt_.at("fast_conv") || !generic_conv_fits(g)) &&
+		if (!g.complex_h && (opt_.at("fast_conv") || !generic_conv_fits(g)) &&
 			(m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2)))
 		{
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0; X.run_off = 0;
@@ -1025,6 +1068,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			WholeLaunch L;
 			L.in_step = sp.in_step; L.out_step = sp.out_step; L.flen = sp.flen;
 			L.fl2 = sp.fl2; L.fll = sp.fll;
+			L.pos0 = sp.pos0;
 			L.table = d.table;
 			L.a = a; L.b = b;
 			L.tile = opt_.at("whole_tile");
@@ -1243,6 +1287,7 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 
 int Engine::group_len(size_t s) const
 {
+	if (latency_chain()) return 1;
 	if (fuse_with_next(s)) return 2;
 	const StageKind kind = plan_.stages[s].desc.kind;
 	// Runs of decimators: one kernel saves two launches and the intermediate streams, but pays
@@ -1371,8 +1416,17 @@ bool Engine::use_wave(const ConvGeom& g) const
 	return opt_.at("wave_conv") && convw_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2);
 }
 
+bool Engine::latency_chain() const
+{
+	for (const StagePlan& sp : plan_.stages)
+		if (sp.out_skip != 0 || sp.pos0 != 0 || sp.frac0 != 0.0 || (sp.desc.kind == kConv && sp.cg.complex_h))
+			return true;
+	return false;
+}
+
 bool Engine::fuse_with_next(size_t s) const
 {
+	if (latency_chain()) return false;
 	if (!opt_.at("fuse") || !opt_.at("fast_conv") || s + 1 >= plan_.stages.size()) return false;
 	const StagePlan& c = plan_.stages[s];
 	const StagePlan& w = plan_.stages[s + 1];
@@ -1403,7 +1457,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 		throw std::runtime_error("transform plan too deep");
 	for (int i = 0; i < L.n_fwd; i++) L.fwd_radix[i] = d.fwd_radix[(size_t) i];
 	for (int i = 0; i < L.n_inv; i++) L.inv_radix[i] = d.inv_radix[(size_t) i];
-	L.H = d.H; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.spec2 = d.spec2; L.wspec = d.wspec; L.hp = d.hp; L.ptw = d.ptw;
+	L.H = d.H; L.Hc = d.Hc; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.spec2 = d.spec2; L.wspec = d.wspec; L.hp = d.hp; L.ptw = d.ptw;
 	L.nch = nch_;
 	L.threads = opt_.at("conv_threads");
 	L.src = src;

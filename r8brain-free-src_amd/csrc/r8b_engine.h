@@ -63,6 +63,7 @@ private:
 		double* ring_alt = nullptr; // stage 0 only: second history ring (calls alternate)
 		long long ring_size = 0;
 		double* H = nullptr;
+		cd* Hc = nullptr;    // complex kernel spectrum (minimum phase; generic kernel only)
 		cd* tw = nullptr;
 		cd* spec = nullptr; // fast-path spectral constants
 		cd* spec2 = nullptr; // the same per backward position (up 1 or 2)
@@ -98,6 +99,7 @@ private:
 	bool fuse_with_next(size_t s) const;
 	bool use_wave(const ConvGeom& g) const;
 	bool use_pair(const ConvGeom& g) const;
+	bool latency_chain() const; // some stage carries fractional-latency state (minimum phase): no fusing
 	bool use_pair_two(size_t s, int* run_off) const;
 	void prepare_two_phase(size_t s);
 	void prepare_mfma(size_t s);
@@ -126,6 +128,9 @@ private:
 std::vector<double> make_twiddles(int len);
 // zero-phase kernel spectrum H[m] = sum_t h[t] cos(2 pi m t / bl2), m = 0..bl2/2, times `scale`
 std::vector<double> kernel_spectrum(const LpFilter& f, int bl2, double scale);
+// general form: H[m] = scale * sum_n taps[n] exp(-2 pi i m (n - align) / bl2), m = 0..bl2/2 (interleaved re, im);
+// align = ConvGeom::fl2
+std::vector<double> kernel_spectrum_complex(const LpFilter& f, int bl2, int align, double scale);
 // constants of the fast path's spectral stage (r8b_convx.h cx_spec_write) for a block convolver
 // with forward complex length N = n_in/2 and backward length N2 = N*up (up in {1,2}): per slot
 // s (bin kf = bitrev(s) for s < N/2, kf = N/2 for s == N/2) 4 (up 1) or 8 (up 2) complex values,

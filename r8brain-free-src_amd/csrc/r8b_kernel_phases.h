@@ -432,6 +432,15 @@ R8B_HD cd stuffed_bin(const cd* za, int m, int N, int logN, const cd* tw, int tw
 R8B_HD cd product_bin(const ConvLaunch& L, const cd* za, int m, int N, int logN, int N2)
 {
 	cd r = stuffed_bin(za, m, N, logN, L.tw, L.tw_len);
+	if (L.Hc != nullptr)
+	{
+		// complex kernel spectrum (minimum phase; reference CDSPRealFFT.h:186-274 multiplyBlocks)
+		const cd h = L.Hc[m];
+		cd o;
+		o.re = h.re * r.re - h.im * r.im;
+		o.im = (m == N2 && L.down_pow2 && L.down > 1) ? 0.0 : h.re * r.im + h.im * r.re;
+		return o;
+	}
 	const double h = L.H[m];
 	if (m == N2 && L.down_pow2 && L.down > 1)
 	{
@@ -508,8 +517,8 @@ R8B_HD void conv_store(const ConvLaunch& L, const double* y, long long k, int ch
 R8B_HD void whole_tile_span(const WholeLaunch& L, long long j0, long long j1, long long* lo,
 	int* len)
 {
-	const long long r0 = j0 * L.in_step / L.out_step - L.fll;
-	const long long r1 = (j1 - 1) * L.in_step / L.out_step + L.fl2;
+	const long long r0 = (j0 * L.in_step + L.pos0) / L.out_step - L.fll;
+	const long long r1 = ((j1 - 1) * L.in_step + L.pos0) / L.out_step + L.fl2;
 	*lo = r0;
 	*len = (int) (r1 - r0 + 1);
 }
@@ -525,7 +534,7 @@ R8B_HD void whole_compute(const WholeLaunch& L, const double* xs, long long lo, 
 {
 	for (long long j = j0 + tid; j < j1; j += nthr)
 	{
-		const long long p = j * L.in_step;
+		const long long p = j * L.in_step + L.pos0;
 		const long long r = p / L.out_step;
 		const int ph = (int) (p - r * L.out_step);
 		const double* row = L.table + (long) ph * L.flen;

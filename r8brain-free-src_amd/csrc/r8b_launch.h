@@ -65,6 +65,7 @@ struct ConvLaunch
 	int fwd_radix[kMaxPasses];
 	int inv_radix[kMaxPasses];
 	const double* H; // bl2/2+1 reals: zero-phase kernel spectrum / bl2
+	const cd* Hc;    // generic kernel only: bl2/2+1 complex when the spectrum is not real (minimum phase), else null
 	const cd* tw;    // tw_len complex: exp(-2 pi i e / tw_len)
 	const cd* spec;  // fast path only: per-slot spectral-stage constants (r8b_convx.h)
 	const cd* spec2; // fast path, up 1 or 2: (ca, cb) per backward POSITION, [c * N2 + P]
@@ -85,6 +86,7 @@ struct ConvLaunch
 struct WholeLaunch
 {
 	int in_step, out_step, flen, fl2, fll;
+	int pos0;            // output j sits at position j*in_step + pos0 (reference InitFracPosW; 0 for linear phase)
 	const double* table; // out_step rows x flen
 	long long a, b;      // outputs to produce
 	int tile;            // outputs per workgroup

@@ -7,7 +7,7 @@
 
 namespace r8bhip {
 
-StagePlan make_stage_plan(const StageDesc& d)
+StagePlan make_stage_plan(const StageDesc& d, double prev_lat)
 {
 	StagePlan s;
 	s.desc = d;
@@ -15,7 +15,7 @@ StagePlan make_stage_plan(const StageDesc& d)
 	{
 		// geometry, reference CDSPBlockConvolver.h:62-185 (linear phase, PrevLatency 0,
 		// DoConsumeLatency)
-		const LpFilter& f = design_lp(d.a, d.b, d.c, d.d);
+		const LpFilter& f = design_lp(d.a, d.b, d.c, d.d, d.phase == kMinPhase);
 		s.lp = &f;
 		ConvGeom& g = s.cg;
 		g.up = d.i0;
@@ -55,7 +55,19 @@ StagePlan make_stage_plan(const StageDesc& d)
 		};
 		const int ilc = shape(g.bl2);
 		(void) ilc;
-		g.latency = g.in_len + g.fl2; // reference: InputLen (after the divisibility adjustment) + filter latency
+		// reference CDSPBlockConvolver.h:94-101: the filter's own fractional latency plus what the
+		// previous stage left (at this stage's virtual rate); the integer part is consumed here -- for
+		// the kernels it only moves the alignment of outputs against inputs, exactly like the half
+		// length of a linear-phase filter does, so it is folded into fl2 -- the rest goes on
+		{
+			double lf = f.lat_frac + prev_lat * g.up;
+			const int extra = (int) lf;
+			lf -= extra;
+			g.fl2 = f.fl2 + extra;
+			g.complex_h = !f.zero_phase || extra != 0;
+			s.lat_frac = lf / g.down;
+		}
+		g.latency = g.in_len + g.fl2; // reference: InputLen (after the divisibility adjustment) + latency
 		g.ref_bl2 = g.bl2; g.ref_in_len = g.in_len; g.ref_n_in = g.n_in; g.ref_n_out = g.n_out;
 		// transforms longer than 16384 points do not fit a workgroup's LDS: shorter blocks, same filter
 		while ((g.n_in > 16384 || g.n_out > 16384) && g.bl2 / 2 - (f.kernel_len - 1) - g.down >= 64)
@@ -72,10 +84,28 @@ StagePlan make_stage_plan(const StageDesc& d)
 		s.flen = s.bank->filter_len;
 		s.fl2 = s.flen / 2;
 		s.fll = s.fl2 - 1;
+		// reference CDSPFracInterpolator.h:721-752.  (The integer part of prev_lat -- input samples the
+		// interpolator swallows -- is added to the PREVIOUS stage's out_skip by ChainPlan::init.)
+		const double ifp = prev_lat - (double) (long long) prev_lat;
+		if (s.whole)
+		{
+			const double spos = ifp * s.out_step;
+			s.pos0 = (int) spos;
+			s.lat_frac = (spos - s.pos0) / s.in_step;
+		}
+		else
+		{
+			s.frac0 = ifp;
+			s.lat_frac = 0.0;
+		}
 	}
 	else
 	{
 		s.hb_n = select_hb_filter(d.a, d.i0, d.i1 != 0, &s.hb_taps, &s.hb_att);
+		// reference CDSPHBUpsampler.h:610-612 / CDSPHBDownsampler.h:88-90
+		double lf = d.kind == kHBUp ? prev_lat * 2.0 : prev_lat * 0.5;
+		s.out_skip = (long long) lf;
+		s.lat_frac = lf - (double) s.out_skip;
 	}
 	s.clear();
 	return s;
@@ -86,6 +116,9 @@ void StagePlan::clear()
 	m = 0;
 	done = 0;
 	poly = PolyState();
+	// reference CDSPFracInterpolator.h:849-857
+	poly.pos_frac = frac0;
+	poly.pos_shift = whole || dsr == 0.0 ? 0.0 : frac0 * dsr / ssr;
 }
 
 long long StagePlan::total(long long mm) const
@@ -104,7 +137,8 @@ long long StagePlan::total(long long mm) const
 		// fl2 further input samples exist
 		const long long lim = mm - fl2 - 1;
 		if (lim < 0) return 0;
-		return ((lim + 1) * out_step - 1) / in_step + 1;
+		const long long num = (lim + 1) * out_step - 1 - pos0; // position of output j: j*In + pos0
+		return num < 0 ? 0 : num / in_step + 1;
 	}
 	case kHBUp:
 		return mm > hb_n ? 2 * (mm - hb_n) : 0;
@@ -149,7 +183,7 @@ void StagePlan::step(int l, long long* a, long long* b, PolyState* ps)
 		*b = done;
 		return;
 	}
-	const long long t = total(m);
+	const long long t = total(m) - out_skip;
 	if (t > done) done = t;
 	*b = done;
 }
@@ -175,14 +209,15 @@ int StagePlan::in_len_before_out_pos(int pos) const
 	switch (desc.kind)
 	{
 	case kConv: // reference CDSPBlockConvolver.h:192-196
-		return (int) ((cg.latency + (double) pos * cg.down) / cg.up + 0.0 * cg.down / cg.up);
+		return (int) ((cg.latency + (double) pos * cg.down) / cg.up + lat_frac * cg.down / cg.up);
 	case kFrac: // reference CDSPFracInterpolator.h:802-815
-		if (whole) return fl2 + (int) ((0 + (double) pos * in_step) / out_step);
-		return fl2 + (int) (0.0 + pos * ssr / dsr);
+		if (whole) return fl2 + (int) ((pos0 + (double) pos * in_step) / out_step +
+			lat_frac * in_step / out_step);
+		return fl2 + (int) (frac0 + pos * ssr / dsr);
 	case kHBUp: // reference CDSPHBUpsampler.h:632-635
-		return hb_n + (int) ((0 + 0.0 + pos) * 0.5);
+		return hb_n + (int) (((double) out_skip + lat_frac + pos) * 0.5);
 	case kHBDown: // reference CDSPHBDownsampler.h:100-103
-		return 2 * hb_n - 1 + (int) ((0 + 0.0 + pos) * 2.0);
+		return 2 * hb_n - 1 + (int) (((double) out_skip + lat_frac + pos) * 2.0);
 	}
 	return 0;
 }
@@ -242,9 +277,16 @@ void ChainPlan::init(const std::vector<StageDesc>& descs, int maxin)
 	stage_max_in.clear();
 	max_in = maxin;
 	int mo = maxin;
+	double prev_lat = 0.0; // the fractional latency handed from stage to stage (reference CDSPResampler.h:688)
 	for (const StageDesc& d : descs)
 	{
-		stages.push_back(make_stage_plan(d));
+		if (d.kind == kFrac && prev_lat >= 1.0 && !stages.empty())
+		{
+			// whole input samples an interpolator swallows: the previous stage simply never emits them
+			stages.back().out_skip += (long long) prev_lat;
+		}
+		stages.push_back(make_stage_plan(d, prev_lat));
+		prev_lat = stages.back().lat_frac;
 		stage_max_in.push_back(mo);
 		mo = stages.back().max_out_len(mo);
 	}

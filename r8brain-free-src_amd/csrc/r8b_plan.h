@@ -27,7 +27,8 @@ namespace r8bhip {
 struct ConvGeom
 {
 	int up = 1, down = 1;
-	int fl2 = 0;        // filter half length == filter latency
+	int fl2 = 0;        // alignment of outputs against inputs, virtual samples: output q*down uses inputs up to
+	                    // q*down + fl2 (linear phase: the filter's half length == its latency)
 	int bl2 = 0;        // BlockLen2: length of the circular block (virtual, upsampled rate)
 	int in_len = 0;     // InputLen: new virtual samples per block
 	int prev_len = 0;   // PrevInputLen (input-rate samples when up is 2^k, virtual otherwise)
@@ -40,6 +41,9 @@ struct ConvGeom
 	// filter, and a shorter block never needs input the reference's latency has not already waited
 	// for), anchored at multiples of the shorter in_len: still bitwise chunk invariant.
 	int ref_bl2 = 0, ref_in_len = 0, ref_n_in = 0, ref_n_out = 0;
+	// the kernel spectrum is complex: minimum-phase filter, or a linear-phase one whose alignment moved by
+	// whole samples of latency inherited from the previous stage (fl2 != the filter's half length)
+	bool complex_h = false;
 	bool up_pow2 = true;   // up-sampling by spectrum replication (else explicit zero stuffing)
 	bool down_pow2 = false; // decimation by spectrum truncation (else strided pick)
 };
@@ -73,6 +77,21 @@ struct StagePlan
 	int hb_n = 0;
 	double hb_att = 0;
 
+	// Fractional latency bookkeeping (reference: every stage takes the previous stage's left-over
+	// fractional latency `PrevLatency` and reports its own, CDSPResampler.h:688).  Linear-phase chains
+	// have all of this zero.
+	//   out_skip  output samples of the underlying stream function that are dropped at the start of
+	//             the stream (reference: LatencyLeft of the half-band stages, CDSPHBUpsampler.h:715-727;
+	//             plus the input samples a following interpolator swallows, CDSPFracInterpolator.h:866-877);
+	//             emitted sample q is underlying sample q + out_skip
+	//   pos0      whole-step interpolator: InitFracPosW (CDSPFracInterpolator.h:741-743)
+	//   frac0     polynomial interpolator: InitFracPos (:721-723)
+	//   lat_frac  what this stage hands to the next one
+	long long out_skip = 0;
+	int pos0 = 0;
+	double frac0 = 0.0;
+	double lat_frac = 0.0;
+
 	// stream counters
 	long long m = 0;     // input samples received so far
 	long long done = 0;  // output samples emitted so far
@@ -92,7 +111,8 @@ private:
 	long long total(long long mm) const;
 };
 
-StagePlan make_stage_plan(const StageDesc& d);
+// prev_lat: the fractional latency the previous stage left (0 for the first stage)
+StagePlan make_stage_plan(const StageDesc& d, double prev_lat = 0.0);
 
 struct ChainPlan
 {

@@ -16,6 +16,7 @@ import numpy as np
 from . import _capi
 
 fprLinearPhase = 0
+fprMinPhase = 1
 
 
 # r8b_pcm_format (include/r8bsrc.h)
@@ -39,7 +40,8 @@ class BatchResampler(_Base):
     """`nch` independent CDSPResampler streams sharing one schedule (C ABI part 2)."""
 
     def __init__(self, SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand=2.0,
-                 ReqAtten=206.91, nch=1, device=-1, lib=None, stage=None):
+                 ReqAtten=206.91, nch=1, device=-1, lib=None, stage=None, phase=0):
+        """phase: 0 = fprLinearPhase (the reference's default), 1 = fprMinPhase"""
         super().__init__(lib)
         self.nch = int(nch)
         self.MaxInLen = int(aMaxInLen)
@@ -47,6 +49,10 @@ class BatchResampler(_Base):
             kind, a, b, c, d, i0, i1 = stage
             self._h = self._lib.r8b_batch_create_stage(int(kind), a, b, c, d, int(i0), int(i1),
                                                        self.MaxInLen, self.nch, int(device))
+        elif phase:
+            self._h = self._lib.r8b_batch_create_ex(SrcSampleRate, DstSampleRate, self.MaxInLen,
+                                                    ReqTransBand, ReqAtten, int(phase), self.nch,
+                                                    int(device))
         else:
             self._h = self._lib.r8b_batch_create(SrcSampleRate, DstSampleRate, self.MaxInLen,
                                                  ReqTransBand, ReqAtten, self.nch, int(device))
@@ -218,11 +224,9 @@ class CDSPResampler(_Base):
 
     def __init__(self, SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand=2.0,
                  ReqAtten=206.91, ReqPhase=fprLinearPhase, lib=None, device=-1):
-        if ReqPhase != fprLinearPhase:
-            raise NotImplementedError("minimum-phase filters are out of scope (SURVEY.md 8f)")
         super().__init__(lib)
         self._b = BatchResampler(SrcSampleRate, DstSampleRate, aMaxInLen, ReqTransBand, ReqAtten,
-                                 nch=1, device=device, lib=self._lib)
+                                 nch=1, device=device, lib=self._lib, phase=int(ReqPhase))
         self.SrcSampleRate, self.DstSampleRate = SrcSampleRate, DstSampleRate
         self.MaxInLen = int(aMaxInLen)
 

@@ -64,6 +64,29 @@ REBLOCK_CASES = [
 ]
 
 
+# Minimum-phase chains (reference fprMinPhase).  Per-call counts must equal the reference's exactly.
+# Samples: the reference derives the filter by a cepstral transform whose result in the deep stop band
+# is set by the rounding noise of ITS fp64 FFT (CDSPRealFFT.h:681-785): two correct evaluations of the
+# same transform agree on the taps to ~1e-8 at 136 dB, ~1e-5 at 180 dB and ~2e-3 for the 1/3-band
+# filter at 180 dB (the reference's comes out 0.011 samples later), and the streams inherit that.
+# Tolerances below are 3x what was measured against oracle/_ref on this box.
+# (src, dst, maxin, chunk, n_in, tb, atten, rms_tol, peak_tol)
+MINPHASE_CASES = [
+    (44100.0, 88200.0, 2048, 2048, 20000, 2.0, 180.15, 6e-5, 3e-4),     # convolver alone
+    (44100.0, 96000.0, 2048, 1000, 20000, 2.0, 180.15, 6e-5, 3e-4),     # + whole-step interpolator (InitFracPosW)
+    (96000.0, 44100.0, 2048, 2048, 30000, 2.0, 180.15, 6e-6, 3e-5),     # 1:1 convolver + interpolator
+    (44100.0, 44101.0, 1024, 1000, 9000, 2.0, 180.15, 2e-5, 8e-5),      # polynomial bank (InitFracPos)
+    (44100.0, 176400.0, 1024, 1024, 8000, 2.0, 180.15, 6e-5, 3e-4),     # half-band up with inherited latency
+    (44100.0, 2822400.0, 512, 512, 3000, 2.0, 180.15, 6e-5, 3e-4),      # five of them
+    (176400.0, 44100.0, 4096, 3000, 40000, 2.0, 180.15, 3e-5, 1.2e-4),  # decimators + 2x-decimating convolver
+    (88200.0, 44100.0, 2048, 2048, 20000, 2.0, 180.15, 4e-5, 2e-4),     # 2x-decimating convolver
+    (44100.0, 192000.0, 1024, 1024, 8000, 2.0, 180.15, 6e-5, 3e-4),     # interpolator -> convolver -> half-band
+    (64000.0, 48000.0, 2048, 2048, 30000, 2.0, 180.15, 5e-5, 2.5e-4),   # 3/4
+    (48000.0, 32000.0, 2048, 2048, 30000, 2.0, 180.15, 1e-2, 4e-2),     # 2/3: the 1/3-band filter (see above)
+    (44100.0, 96000.0, 1024, 777, 12000, 2.0, 136.45, 3e-7, 2e-6),      # 16-bit preset: taps agree to 2e-8
+]
+
+
 def make_input(nch, n, seed0=1):
     return np.stack([O.splitmix_uniform(seed0 + c, n) for c in range(nch)])
 

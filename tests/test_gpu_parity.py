@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import STREAM_CASES, REBLOCK_CASES, RMS_TOL, PEAK_TOL, compare_stream, make_input
+from cases import (STREAM_CASES, REBLOCK_CASES, MINPHASE_CASES, RMS_TOL, PEAK_TOL, compare_stream,
+                   make_input)
 from conftest import rms, peak
 
 pytestmark = pytest.mark.gpu
@@ -259,6 +260,14 @@ def test_hip_long_filters_on_shorter_blocks(torch, refwrap, case):
         pos += l
     r, p = refwrap.batch_check(src, dst, maxin, lens, x, np.concatenate(ys, axis=1), counts, tb, att)
     assert r.max() <= rtol and p.max() <= ptol, (r.max(), p.max())
+
+
+@pytest.mark.parametrize("case", MINPHASE_CASES)
+def test_hip_minimum_phase_chains(torch, refwrap, case):
+    """fprMinPhase on the HIP path (generic kernels): counts equal the reference's, samples to the
+    stated tolerance (tests/cases.py)"""
+    from test_emul import run_minphase_case
+    run_minphase_case({"device": 0}, refwrap, case)
 
 
 def test_hip_soak_ragged_calls_vs_reference(torch, refwrap):
