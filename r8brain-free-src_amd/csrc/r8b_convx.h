@@ -917,32 +917,6 @@ R8B_HD void cx_inv_seq(Exec& ex, const ConvLaunch& L, cd* buf)
 	}
 }
 
-// MODE 2: K8 on the matrix cores.  Outputs j = OutStep*g + ph (group g, phase ph) read
-// y[InStep*g + r_ph - fll + i], r_ph = floor(ph*InStep/OutStep): for a tile of 16 phases x 16
-// groups this is D[16x16] = A[16xK] * B[Kx16] with B[c][n] = y[InStep*n + c0 + c] and the banded,
-// group-independent A[m][c] = T[ph0+m][c - (r_(ph0+m) - r_ph0)] (zero outside the 24 taps), K
-// <= 40.  v_mfma_f64_16x16x4_f64 runs it on the MFMA pipe next to the other workgroups' FFT
-// VALU work, and every convolver output is read from LDS ~2.5 times instead of 24.  A block
-// covers exactly 16 groups (blk_stride = 16*InStep); wave w takes phase tiles w, w+4, ...
-// Operand layout (cdna_hip_programming.md section 3): lane l supplies A[l&15][l>>4] and
-// B[l>>4][l&15]; D register i of lane l is row (l>>4) + 4*i, column l&15.
-R8B_HD int cx_mfma_b_index(const ConvxLaunch& X, int p, int lane)
-{
-	return X.mf_boff[p] + X.in_step * (lane & 15) + (lane >> 4);
-}
-
-R8B_HD void cx_mfma_store(const ConvxLaunch& X, long long k, int ch, int p, int lane, const double* d)
-{
-	const long long jb = (long long) X.out_step * (16 * k + (lane & 15));
-#pragma unroll
-	for (int i = 0; i < 4; i++)
-	{
-		const int ph = 16 * p + (lane >> 4) + 4 * i;
-		const long long j = jb + ph;
-		if (ph < X.out_step && j >= X.wa && j < X.wb) dst_store(X.wdst, ch, j, d[i]);
-	}
-}
-
 // One workgroup = one block of one channel.  (A persistent variant that walks several blocks and
 // prefetches the next block's input during the output phase was tried: the loop-carried state
 // pushes hipcc into heavy SGPR/VGPR spilling, 3x slower.  Latency hiding is left to the 3-4
@@ -985,11 +959,9 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 	ex.phase([&](int tid, St& st) { cx_final_compute<LOGN, UPLOG>(L, buf, st, tid); });
 	ex.phase([&](int tid, St& st)
 	{
-		cx_final_store<LOGN, UPLOG, MODE == 1 || MODE == 2>(L, rbuf, st, k, tid);
+		cx_final_store<LOGN, UPLOG, MODE == 1>(L, rbuf, st, k, tid);
 		if constexpr (MODE == 1) cx_whole_row<FLENP>(X, st.row, tid);
-		if constexpr (MODE == 2) ex.template mfma_prefetch<(FLENP > 24 ? 12 : 10)>(X);
 	});
-	// K steps: 10 cover 24 taps + the 14-sample phase spread of a tile, 12 cover 32 taps
 	// history for the next call (stage 0 only): the first block's workgroup copies the tail of
 	// the caller's buffer into the other history ring; issued before the output phase, the
 	// stores need no wait
@@ -1002,15 +974,11 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 					src_load(L.src, ch, i);
 		});
 	}
-	if constexpr (MODE == 2) ex.template mfma_interp<(FLENP > 24 ? 12 : 10)>(X, rbuf, k, ch);
-	else
+	ex.phase([&](int tid, St& st)
 	{
-		ex.phase([&](int tid, St& st)
-		{
-			if constexpr (MODE == 1) cx_whole_compute<FLENP>(X, rbuf, st.row, k, ch, tid);
-			else cx_store_conv<UPLOG, MODE>(L, rbuf, k, ch, tid);
-		});
-	}
+		if constexpr (MODE == 1) cx_whole_compute<FLENP>(X, rbuf, st.row, k, ch, tid);
+		else cx_store_conv<UPLOG, MODE>(L, rbuf, k, ch, tid);
+	});
 }
 
 } // namespace r8bhip

@@ -274,11 +274,8 @@ std::vector<double> spectral_constants_down(const std::vector<double>& H,
 	return out;
 }
 
-// Constants of the wave-per-block kernel's spectral stage (r8b_convw.h cw_spectral): backward bin
-// k = ca(k) Z[k mod N] + cb(k) conj(Z[-k mod N]); every case of the per-slot table `sc`
-// (spectral_constants) reduces to this form.  Layout: entry ((16s + 4i + s3) * 2 + {0: ca, 1: cb})
-// * 64 + lane for the bin lane (a, j1') owns at (s, i, s3): k = (a + 16s) + M2 ((4 j1' + i) + 16 s3).
-// (ca, cb) of backward bin k out of the per-slot table `sc` (spectral_constants, up 1 or 2)
+// Backward bin k = ca(k) Z[k mod N] + cb(k) conj(Z[-k mod N]): every case of the per-slot table `sc`
+// (spectral_constants, up 1 or 2) reduces to this form; (ca, cb) of bin k out of that table.
 static void bin_constants(const std::vector<double>& sc, int N, int up, int k, double* ca, double* cb)
 {
 	const int slots = N / 2 + 1;
@@ -325,23 +322,6 @@ std::vector<double> spectral_constants_by_position(const std::vector<double>& sc
 			if (P & (1 << b)) k |= 1 << (logn2 - 1 - b);
 		bin_constants(sc, N, up, k, &out[(size_t) P * 2], &out[((size_t) N2 + P) * 2]);
 	}
-	return out;
-}
-
-std::vector<double> spectral_constants_wave(const std::vector<double>& sc, int n_in, int up)
-{
-	const int N = n_in / 2, N2 = N * up, M2 = N2 / 64;
-	std::vector<double> out((size_t) N2 * 2 * 2, 0.0);
-	for (int lane = 0; lane < 64; lane++)
-		for (int s = 0; s < M2 / 16; s++)
-			for (int i = 0; i < 4; i++)
-				for (int s3 = 0; s3 < 4; s3++)
-				{
-					const int k = ((lane >> 2) + 16 * s) + M2 * ((4 * (lane & 3) + i) + 16 * s3);
-					const size_t e = (size_t) (16 * s + 4 * i + s3) * 2;
-					bin_constants(sc, N, up, k, &out[((e + 0) * 64 + lane) * 2],
-						&out[((e + 1) * 64 + lane) * 2]);
-				}
 	return out;
 }
 
@@ -463,20 +443,12 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["fuse"] = 1;      // ... with the whole-step interpolator behind it fused in
 	opt_["fuse_hb"] = 1;   // runs of half-band up-samplers as one kernel
 	opt_["poly_tiled"] = 1; // polynomial interpolator: 16 channels share each coefficient fetch
-	// 1024/2048-point fast convolvers as one wavefront per block (r8b_convw.h): measured slower
-	// (cfg2 0.48 vs 0.30 ms: two resident waves per SIMD cannot hide the table fetches), kept as
-	// an option
-	opt_["wave_conv"] = 0;
 	// two channels per workgroup as one complex transform (r8b_convp.h) where the geometry allows
 	opt_["pair_conv"] = 1;
 	// ... with two adjacent phases per thread in the fused interpolator when it up-samples (In <= Out:
 	// half the LDS reads per output, nearly all lanes busy)
 	opt_["pair_two"] = 1;
 	opt_["fold_tail"] = 1; // fast convolver at stage 0 keeps the input history itself
-	// fused interpolator on the matrix cores (when a block holds 16 output groups): measured equal
-	// to the vector-ALU form on cfg2 (0.357 vs 0.362 ms: 10x fewer LDS reads, 13 % more FFT
-	// blocks), so the simpler form stays the default
-	opt_["mfma_interp"] = 0;
 	// a constructor that throws half way must not leak what it has already put on the device
 	try
 	{
@@ -547,12 +519,6 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 						d.ptw = (cd*) dev_alloc(pt.size() * sizeof(double));
 						dev_upload(d.ptw, pt.data(), pt.size() * sizeof(double));
 					}
-					if (convw_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
-					{
-						const std::vector<double> sw = spectral_constants_wave(sc, g.n_in, g.up);
-						d.wspec = (cd*) dev_alloc(sw.size() * sizeof(double));
-						dev_upload(d.wspec, sw.data(), sw.size() * sizeof(double));
-					}
 				}
 			}
 			else if (sp.desc.kind == kFrac)
@@ -576,72 +542,13 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 		}
 		plan_transforms();
 		for (size_t s = 0; s + 1 < plan_.stages.size(); s++)
-			if (fuse_with_next(s))
-			{
-				prepare_mfma(s);
-				prepare_two_phase(s);
-			}
+			if (fuse_with_next(s)) prepare_two_phase(s);
 	}
 	catch (...)
 	{
 		release();
 		throw;
 	}
-}
-
-// Geometry and A fragments of the matrix-core interpolator (r8b_convx.h, MODE 2) for the fused
-// pair (convolver s, whole-step interpolator s+1); leaves mf_ok false when a block cannot hold 16
-// groups of outputs.
-void Engine::prepare_mfma(size_t s)
-{
-	const StagePlan& c = plan_.stages[s];
-	const StagePlan& w = plan_.stages[s + 1];
-	StageDev& d = dev_[s + 1];
-	const int In = w.in_step, Out = w.out_step, up = c.cg.up;
-	auto r_of = [&](int ph) { return (int) ((long long) ph * In / Out); };
-	const int tiles = (Out + 15) / 16;
-	if (tiles > 16) return;
-	// first valid time of block k is k*16*In - fll - e, e chosen so that the block's first fresh
-	// input sample sits on an even input position (16-byte loads)
-	const int align = 2 * up;
-	const int boff = (c.cg.fl2 - w.fll) / align * align;
-	if (boff < 0) return;
-	const int e = c.cg.fl2 - w.fll - boff;
-	int span = 0;
-	for (int p = 0; p < tiles; p++)
-	{
-		const int last = std::min(16 * p + 15, Out - 1);
-		span = std::max(span, r_of(last) - r_of(16 * p) + w.flen);
-	}
-	// the kernel unrolls a fixed number of K steps: 10 (<= 24 taps) or 12 (<= 32 taps)
-	const int ksteps = w.flen > 24 ? 12 : 10;
-	if ((span + 3) / 4 > ksteps) return;
-	// everything a block reads must lie inside its valid run (+8 zero-extension doubles)
-	const int max_index = r_of(16 * (tiles - 1)) + e + In * 15 + 3 + 4 * (ksteps - 1);
-	if (max_index >= c.cg.in_len + 8 || 16 * In > c.cg.in_len) return;
-	if (w.fll + e + 15 * In + r_of(Out - 1) + w.fl2 + 1 > c.cg.in_len) return;
-	std::vector<double> at((size_t) tiles * ksteps * 64, 0.0);
-	const std::vector<double>& T = w.bank->table;
-	for (int p = 0; p < tiles; p++)
-	{
-		d.mf_boff[p] = r_of(16 * p) + e;
-		for (int st = 0; st < ksteps; st++)
-			for (int lane = 0; lane < 64; lane++)
-			{
-				const int ph = 16 * p + (lane & 15), col = 4 * st + (lane >> 4);
-				if (ph >= Out) continue;
-				const int idx = col - (r_of(ph) - r_of(16 * p));
-				if (idx < 0 || idx >= w.flen) continue;
-				const int row = (int) (((long long) ph * In) % Out);
-				at[((size_t) p * ksteps + st) * 64 + lane] = T[(size_t) row * w.flen + idx];
-			}
-	}
-	d.mf_atab = (double*) dev_alloc(at.size() * sizeof(double));
-	dev_upload(d.mf_atab, at.data(), at.size() * sizeof(double));
-	d.mf_ksteps = ksteps;
-	d.mf_tiles = tiles;
-	d.mf_e = e;
-	d.mf_ok = true;
 }
 
 // Tables of the pair kernel's two-phases-per-thread interpolator (r8b_convp.h MODE 4) for the fused
@@ -749,12 +656,10 @@ void Engine::release()
 		dev_free(d.tw);
 		dev_free(d.spec);
 		dev_free(d.spec2);
-		dev_free(d.wspec);
 		dev_free(d.hp);
 		dev_free(d.ptw);
 		dev_free(d.table);
 		dev_free(d.wtab);
-		dev_free(d.mf_atab);
 		dev_free(d.ptab);
 		dev_free(d.ctab);
 	}
@@ -782,7 +687,7 @@ bool Engine::set_option(const std::string& name, int value)
 	// (unfused stages keep it in rings the fused kernels never write): once a stream has started they
 	// may only change after clear().
 	static const char* const structural[] = { "fuse", "fuse_hb", "fuse_hbd", "fold_tail", "fast_conv",
-		"mfma_interp", "wave_conv", "pair_conv", "pair_two" };
+		"pair_conv", "pair_two" };
 	bool started = false;
 	for (const StagePlan& sp : plan_.stages) started = started || sp.m != 0;
 	for (const char* n : structural)
@@ -836,14 +741,13 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 		{
 		case kConv:
 			*kernel = fuse_with_next(stage) ?
-				(use_pair(sp.cg) && !opt_.at("mfma_interp") ? "k_convp_whole" :
-				(use_wave(sp.cg) && !opt_.at("mfma_interp") ? "k_convw_whole" : "k_convx_whole")) :
+				(use_pair(sp.cg) ? "k_convp_whole" : "k_convx_whole") :
 				sp.cg.complex_h ? "k_conv" :
 				((opt_.at("fast_conv") || !generic_conv_fits(sp.cg)) && (convx_mode3_ok(sp.cg.n_in,
 				sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2, sp.cg.down_pow2) ||
 				convx_geometry_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2)) ?
 				(use_pair(sp.cg) && !convx_mode3_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down,
-				sp.cg.up_pow2, sp.cg.down_pow2) ? "k_convp" : (use_wave(sp.cg) ? "k_convw" : "k_convx")) : "k_conv");
+				sp.cg.up_pow2, sp.cg.down_pow2) ? "k_convp" : "k_convx") : "k_conv");
 			break;
 		case kFrac: *kernel = sp.whole ? "k_whole" : "k_poly"; break;
 		case kHBUp: *kernel = group_len(stage) > 1 ? "k_hbcascade" : "k_hbup"; break;
@@ -1051,7 +955,6 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
 			if (m3) launch_convx(X, 3, stream);
 			else if (use_pair(g)) launch_convp(X, 0, stream);
-			else if (use_wave(g)) launch_convw(X, 0, stream);
 			else launch_convx(X, 0, stream);
 			if (L.tail_ring != nullptr) tail_done_ = true;
 		}
@@ -1407,13 +1310,8 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 
 bool Engine::use_pair(const ConvGeom& g) const
 {
-	return opt_.at("pair_conv") && !opt_.at("wave_conv") &&
+	return opt_.at("pair_conv") &&
 		convp_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2);
-}
-
-bool Engine::use_wave(const ConvGeom& g) const
-{
-	return opt_.at("wave_conv") && convw_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2);
 }
 
 bool Engine::latency_chain() const
@@ -1457,7 +1355,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 		throw std::runtime_error("transform plan too deep");
 	for (int i = 0; i < L.n_fwd; i++) L.fwd_radix[i] = d.fwd_radix[(size_t) i];
 	for (int i = 0; i < L.n_inv; i++) L.inv_radix[i] = d.inv_radix[(size_t) i];
-	L.H = d.H; L.Hc = d.Hc; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.spec2 = d.spec2; L.wspec = d.wspec; L.hp = d.hp; L.ptw = d.ptw;
+	L.H = d.H; L.Hc = d.Hc; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.spec2 = d.spec2; L.hp = d.hp; L.ptw = d.ptw;
 	L.nch = nch_;
 	L.threads = opt_.at("conv_threads");
 	L.src = src;
@@ -1493,29 +1391,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	const int in_len = c.cg.in_len, fl2c = c.cg.fl2, up = c.cg.up;
 	const long long In = w.in_step, Out = w.out_step;
 	X.c.blk_offset = 0;
-	X.mf_atab = nullptr; X.mf_ksteps = 0; X.mf_tiles = 0;
-	for (int i = 0; i < 16; i++) X.mf_boff[i] = 0;
 	const StageDev& dw = dev_[s + 1];
-	if (opt_.at("mfma_interp") && dw.mf_ok)
-	{
-		// matrix-core interpolation: block k = output groups [16k, 16k+16), i.e. outputs
-		// [16*Out*k, 16*Out*(k+1)); its run starts at time 16*In*k - fll - e
-		X.c.blk_stride = (int) (16 * In);
-		X.c.blk_offset = fl2c - w.fll - dw.mf_e;
-		X.mf_atab = dw.mf_atab; X.mf_ksteps = dw.mf_ksteps; X.mf_tiles = dw.mf_tiles;
-		for (int i = 0; i < 16; i++) X.mf_boff[i] = dw.mf_boff[i];
-		const long long per = 16 * Out;
-		const long long kfirst = wa / per, klast = (wb - 1) / per;
-		for (long long k0 = kfirst; k0 <= klast; k0 += kConvxMaxBlocks)
-		{
-			X.c.k0 = k0;
-			X.c.nblk = (int) (std::min(klast, k0 + kConvxMaxBlocks - 1) - k0 + 1);
-			launch_convx(X, 2, stream);
-			if (X.c.tail_ring != nullptr) tail_done_ = true;
-			X.c.tail_ring = nullptr; // once per call
-		}
-		return;
-	}
 	int run_off = 0;
 	const bool pair_two = use_pair_two(s, &run_off);
 	X.run_off = run_off;
@@ -1577,7 +1453,6 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			launch_convp(X, 4, stream);
 		}
 		else if (use_pair(c.cg)) launch_convp(X, 1, stream);
-		else if (use_wave(c.cg)) launch_convw(X, 1, stream);
 		else launch_convx(X, 1, stream);
 		if (X.c.tail_ring != nullptr) tail_done_ = true;
 		X.c.tail_ring = nullptr; // once per call

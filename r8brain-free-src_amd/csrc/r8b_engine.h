@@ -67,17 +67,11 @@ private:
 		cd* tw = nullptr;
 		cd* spec = nullptr; // fast-path spectral constants
 		cd* spec2 = nullptr; // the same per backward position (up 1 or 2)
-		cd* wspec = nullptr; // the same for the wave-per-block kernel (per backward bin)
 		cd* hp = nullptr;    // pair kernel: kernel constants of the middle pass (r8b_convp.h)
 		cd* ptw = nullptr;   // pair kernel: twiddle base powers per pass and thread
 		int tw_len = 0;
 		double* table = nullptr;
 		double* wtab = nullptr; // whole-step bank, transposed per residue class (fused kernel)
-		// matrix-core interpolation (fused mode 2): banded A fragments and tile geometry
-		double* mf_atab = nullptr;
-		int mf_ksteps = 0, mf_tiles = 0, mf_e = 0;
-		int mf_boff[16] = {};
-		bool mf_ok = false;
 		// pair kernel, two adjacent phases per thread (mode 4): thread table and 25-tap row pairs
 		int* ptab = nullptr;
 		double* ctab = nullptr;
@@ -97,12 +91,10 @@ private:
 	void plan_transforms();
 	void ensure_ring(size_t s);
 	bool fuse_with_next(size_t s) const;
-	bool use_wave(const ConvGeom& g) const;
 	bool use_pair(const ConvGeom& g) const;
 	bool latency_chain() const; // some stage carries fractional-latency state (minimum phase): no fusing
 	bool use_pair_two(size_t s, int* run_off) const;
 	void prepare_two_phase(size_t s);
-	void prepare_mfma(size_t s);
 	int group_len(size_t s) const;
 	void launch_cascade(size_t s, int glen, long long fa, long long fb, const SrcView& src,
 		const DstView& dst, void* stream);

@@ -80,7 +80,6 @@
 #define R8B_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 #include "r8b_convx.h"
-#include "r8b_convw.h"
 #include "r8b_convp.h"
 #include "r8b_pcm.h"
 
@@ -357,49 +356,6 @@ struct GpuExec
 {
 	ConvxState<LOGN, UPLOG> st;
 	unsigned rot = 0; // per-workgroup rotation of the logical wave roles
-	// MODE 2 output phase: every wave runs its phase tiles on the matrix cores.  The A fragments
-	// (L2) of a tile are fetched one tile ahead -- the first tile's before the barrier that ends
-	// the last FFT phase (mfma_prefetch) -- so only LDS reads and MFMAs are on the critical path.
-	double mf_a[12];
-	template<int KS>
-	__device__ __forceinline__ void mfma_prefetch(const ConvxLaunch& X)
-	{
-		const int wave = (int) threadIdx.x >> 6, lane = (int) threadIdx.x & 63;
-		if (wave < X.mf_tiles)
-		{
-			const double* at = X.mf_atab + (long) wave * KS * 64 + lane;
-#pragma unroll
-			for (int s = 0; s < KS; s++) mf_a[s] = at[s * 64];
-		}
-	}
-	template<int KS>
-	__device__ __forceinline__ void mfma_interp(const ConvxLaunch& X, const double* y, long long k, int ch)
-	{
-		typedef double d4 __attribute__((ext_vector_type(4)));
-		const int wave = (int) threadIdx.x >> 6, lane = (int) threadIdx.x & 63;
-		for (int p = wave; p < X.mf_tiles; p += kConvxThreads / 64)
-		{
-			const double* bp = y + cx_mfma_b_index(X, p, lane);
-			double a[KS], b[KS];
-#pragma unroll
-			for (int s = 0; s < KS; s++) a[s] = mf_a[s];
-#pragma unroll
-			for (int s = 0; s < KS; s++) b[s] = bp[4 * s];
-			const int pn = p + kConvxThreads / 64;
-			if (pn < X.mf_tiles)
-			{
-				const double* at = X.mf_atab + (long) pn * KS * 64 + lane;
-#pragma unroll
-				for (int s = 0; s < KS; s++) mf_a[s] = at[s * 64];
-			}
-			d4 acc = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-			for (int s = 0; s < KS; s++)
-				acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
-			const double d[4] = { acc[0], acc[1], acc[2], acc[3] };
-			cx_mfma_store(X, k, ch, p, lane, d);
-		}
-	}
 	// two wave-local steps in one phase: the second reads LDS words written by other lanes of the
 	// SAME wave in the first; LDS serves a wave's accesses in issue order, so only the compiler
 	// must be kept from reordering them
@@ -464,52 +420,6 @@ __global__ __launch_bounds__(kConvxThreads, (LOGN + (UPLOG > 0 ? UPLOG : 0) >= 1
 	ex.rot = (blk + ch) & 3u;
 	convx_body<LOGN, UPLOG, MODE, FLENP>(ex, X, reinterpret_cast<double*>(smem), X.c.k0 + blk, (int) ch);
 }
-
-// ------------------------------------------------------------------ fast path, one wave per block
-template<int LOGN, int UPLOG>
-struct WaveExec
-{
-	ConvwState<LOGN, UPLOG> st;
-	// the steps of a block exchange data between the lanes of ONE wave through LDS: the LDS queue
-	// of a wave is in order, so only the compiler has to be kept from moving accesses across
-	template<class F>
-	__device__ __forceinline__ void step(F f)
-	{
-		f((int) threadIdx.x, st);
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-	}
-};
-
-template<int LOGN, int UPLOG, int MODE, int FLENP>
-#ifndef R8B_CONVW_WAVES
-#define R8B_CONVW_WAVES 2
-#endif
-__global__ __launch_bounds__(kWaveLanes) __attribute__((amdgpu_waves_per_eu(R8B_CONVW_WAVES)))
-void k_convw(const ConvxLaunch X)
-{
-	extern __shared__ __align__(16) unsigned char smem[];
-	// XCD-aware mapping as in k_convx
-	const unsigned w = blockIdx.x, nblk = (unsigned) X.c.nblk, nch = (unsigned) X.c.nch;
-	unsigned blk, ch;
-	if ((nch & 7u) == 0)
-	{
-		const unsigned i = w >> 3;
-		blk = i % nblk;
-		ch = ((i / nblk) << 3) + (w & 7u);
-	}
-	else
-	{
-		blk = w % nblk;
-		ch = w / nblk;
-	}
-	blk = (unsigned) __builtin_amdgcn_readfirstlane((int) blk);
-	ch = (unsigned) __builtin_amdgcn_readfirstlane((int) ch);
-	WaveExec<LOGN, UPLOG> ex;
-	convw_body<LOGN, UPLOG, MODE, FLENP>(ex, X, reinterpret_cast<double*>(smem), X.c.k0 + blk, (int) ch);
-}
-
 
 // ------------------------------------------------------------------ fast path, pair form (r8b_convp.h)
 template<int LN, int UL>
@@ -594,18 +504,6 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
 	hipLaunchKernelGGL(kern, dim3((unsigned) X.c.nblk * npair), dim3(kConvpThreads), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
-}
-
-template<int LOGN, int UPLOG, int MODE, int FLENP>
-void launch_convw_t(const ConvxLaunch& X, hipStream_t stream)
-{
-	auto kern = k_convw<LOGN, UPLOG, MODE, FLENP>;
-	const size_t lds = (size_t) convw_lds_need(convw_plane_doubles<LOGN, UPLOG>(), X.c.in_len) *
-		sizeof(double);
-	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convw)");
-	hipLaunchKernelGGL(kern, dim3((unsigned) X.c.nblk * (unsigned) X.c.nch), dim3(kWaveLanes), lds,
-		stream, X);
-	check(hipGetLastError(), "launch k_convw");
 }
 
 template<int LOGN, int UPLOG, int MODE, int FLENP>
@@ -708,8 +606,6 @@ void R8B_LAUNCH(launch_convx)(const ConvxLaunch& X, int mode, void* stream)
 	{ \
 		if (mode == 0) launch_convx_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
 		else if (mode == 3) launch_convx_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
-		else if (mode == 2 && wide) launch_convx_t<LN, UL, 2, 32>(X, (hipStream_t) stream); \
-		else if (mode == 2) launch_convx_t<LN, UL, 2, 24>(X, (hipStream_t) stream); \
 		else if (wide) launch_convx_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
 		else launch_convx_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
 		return; \
@@ -718,26 +614,6 @@ void R8B_LAUNCH(launch_convx)(const ConvxLaunch& X, int mode, void* stream)
 #undef R8B_CONVX_DISPATCH
 	throw std::runtime_error("launch_convx: geometry not instantiated");
 }
-
-void R8B_LAUNCH(launch_convw)(const ConvxLaunch& X, int mode, void* stream)
-{
-	int logn = 0;
-	while ((2 << logn) < X.c.n_in) logn++;
-	const int up = X.c.up;
-	const bool wide = X.flen > 24;
-#define R8B_CONVW_DISPATCH(LN, UL) \
-	if (logn == LN && up == (1 << UL)) \
-	{ \
-		if (mode == 0) launch_convw_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
-		else if (wide) launch_convw_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
-		else launch_convw_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
-		return; \
-	}
-	R8B_CONVW_GEOMS(R8B_CONVW_DISPATCH)
-#undef R8B_CONVW_DISPATCH
-	throw std::runtime_error("launch_convw: geometry not instantiated");
-}
-
 
 void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 {
@@ -796,7 +672,6 @@ void launch_poly_pcm(const PolyLaunch& L, void* stream);
 void launch_hbup_pcm(const HBLaunch& L, void* stream);
 void launch_hbdown_pcm(const HBLaunch& L, void* stream);
 void launch_convx_pcm(const ConvxLaunch& X, int mode, void* stream);
-void launch_convw_pcm(const ConvxLaunch& X, int mode, void* stream);
 void launch_convp_pcm(const ConvxLaunch& X, int mode, void* stream);
 void launch_hbcascade_pcm(const HBCascadeLaunch& L, void* stream);
 void launch_hbdcascade_pcm(const HBCascadeLaunch& L, void* stream);
@@ -821,12 +696,6 @@ void launch_convx(const ConvxLaunch& X, int mode, void* stream)
 {
 	if ((X.c.src.cur_fmt | X.c.dst.fmt | X.wdst.fmt) != kPcmF64) launch_convx_pcm(X, mode, stream);
 	else launch_convx_f64(X, mode, stream);
-}
-
-void launch_convw(const ConvxLaunch& X, int mode, void* stream)
-{
-	if ((X.c.src.cur_fmt | X.c.dst.fmt | X.wdst.fmt) != kPcmF64) launch_convw_pcm(X, mode, stream);
-	else launch_convw_f64(X, mode, stream);
 }
 
 void launch_convp(const ConvxLaunch& X, int mode, void* stream)

@@ -69,7 +69,6 @@ struct ConvLaunch
 	const cd* tw;    // tw_len complex: exp(-2 pi i e / tw_len)
 	const cd* spec;  // fast path only: per-slot spectral-stage constants (r8b_convx.h)
 	const cd* spec2; // fast path, up 1 or 2: (ca, cb) per backward POSITION, [c * N2 + P]
-	const cd* wspec; // wave-per-block form: (ca, cb) per backward bin, [slot][lane] (r8b_convw.h)
 	const cd* hp;    // pair form (r8b_convp.h): kernel constants of the middle pass, [c * 256 + thread]
 	const cd* ptw;   // pair form: twiddle base powers per pass and thread, [(slot * 6 + c) * 256 + thread]
 	int tw_len;
@@ -193,11 +192,6 @@ struct ConvxLaunch
 	long long wa, wb;    // interpolator outputs to produce
 	DstView wdst;
 	SpanInfo blk[kConvxMaxBlocks]; // per block c.k0 + i (mode 1)
-	// mode 2 (interpolation on the matrix cores, r8b_convx.h): A fragments [tile][step][64 lanes],
-	// K steps of 4, phase tiles, and per tile the run index of B[0][0]
-	const double* mf_atab;
-	int mf_ksteps, mf_tiles;
-	int mf_boff[16];
 	// pair form, mode 4 (two adjacent phases per thread, r8b_convp.h): the run of (A, B) pairs starts
 	// at LDS slot run_off; per block blk[].u_lo = run slot of the window of phase 0 of the block's first
 	// output group, .ph_lo = groups - 1, .pad = the phase the block's last group ends before (1 ..
@@ -246,14 +240,6 @@ inline bool convx_mode3_ok(int n_in, int n_out, int up, int down, bool up_pow2, 
 	return convx_geometry_ok(n_in, n_out, up_pow2 ? up : 1, down_pow2 ? down : 1, true);
 }
 
-// wave-per-block form of the fast path (r8b_convw.h): 1024- or 2048-point transforms, no decimation
-inline bool convw_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
-{
-	if (!convx_geometry_ok(n_in, n_out, up, down, up_pow2) || down != 1) return false;
-	return (n_in == 2048 || n_in == 4096) && (n_out == 2048 || n_out == 4096);
-}
-#define R8B_CONVW_GEOMS(M) M(10, 0) M(10, 1) M(11, 0)
-
 // pair form of the fast path (r8b_convp.h): two channels per workgroup as one complex transform;
 // 2048-point blocks up-sampled 2x and 4096-point blocks 1:1 (4096-point backward transform)
 inline bool convp_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
@@ -275,13 +261,10 @@ void launch_hbdcascade(const HBCascadeLaunch& L, void* stream);
 void launch_tail(const TailLaunch& L, void* stream);
 void launch_pcm_in(const PcmLaunch& L, void* stream);  // PCM -> planar fp64
 void launch_pcm_out(const PcmLaunch& L, void* stream); // planar fp64 -> PCM
-// mode 0: convolver output to X.c.dst; mode 1 / 2: fused interpolator output to X.wdst (FIR on
-// the vector ALU / on the matrix cores)
+// mode 0: convolver output to X.c.dst; mode 1: fused interpolator output to X.wdst; mode 3: radix-3 edges
 void launch_convx(const ConvxLaunch& X, int mode, void* stream);
 // the same work in pair form (modes 0, 1 and 4; needs X.c.hp)
 void launch_convp(const ConvxLaunch& X, int mode, void* stream);
-// the same work, one wavefront per block (modes 0 and 1; needs X.c.wspec)
-void launch_convw(const ConvxLaunch& X, int mode, void* stream);
 
 // memory helpers; all throw std::runtime_error with the HIP error text on failure
 // Device selection.  dev_resolve: the ordinal an object created with `device` lives on (-1: the

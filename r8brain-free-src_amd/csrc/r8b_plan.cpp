@@ -232,7 +232,7 @@ int StagePlan::history() const
 		// (+ up to one interpolator filter length when the next stage is fused in and starts a
 		// little earlier than this stage's own next output)
 		// (re-blocked geometry: the outputs due still lag the input by the REFERENCE's latency)
-		return (std::max(cg.in_len, cg.ref_in_len + cg.fl2 - (cg.bl2 - cg.in_len > 0 ? 0 : 0)) + cg.bl2) / cg.up + 64;
+		return (std::max(cg.in_len, cg.ref_in_len + cg.fl2) + cg.bl2) / cg.up + 64;
 	case kFrac:
 		return 2 * flen + 4;
 	case kHBUp:

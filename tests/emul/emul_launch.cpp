@@ -21,7 +21,6 @@
 #define R8B_LDS_ARRIVED(N, v, o)
 #include "r8b_kernel_phases.h"
 #include "r8b_convx.h"
-#include "r8b_convw.h"
 #include "r8b_convp.h"
 #include "r8b_pcm.h"
 
@@ -159,38 +158,6 @@ struct EmulExec
 {
 	std::vector<ConvxState<LOGN, UPLOG>> st;
 	EmulExec() : st((size_t) kConvxThreads) {}
-	// MODE 2 output phase with a software model of v_mfma_f64_16x16x4_f64: lane l supplies
-	// A[l&15][l>>4] and B[l>>4][l&15]; D register i of lane l is row (l>>4)+4i, column l&15
-	template<int KS>
-	void mfma_prefetch(const ConvxLaunch&) {}
-	template<int KS>
-	void mfma_interp(const ConvxLaunch& X, const double* y, long long k, int ch)
-	{
-		if (X.mf_ksteps != KS) throw std::runtime_error("emul: K steps mismatch");
-		for (int wave = 0; wave < kConvxThreads / 64; wave++)
-			for (int p = wave; p < X.mf_tiles; p += kConvxThreads / 64)
-			{
-				double D[16][16] = {};
-				for (int s = 0; s < X.mf_ksteps; s++)
-				{
-					double A[16][4], B[4][16];
-					for (int lane = 0; lane < 64; lane++)
-					{
-						A[lane & 15][lane >> 4] = X.mf_atab[((long) p * X.mf_ksteps + s) * 64 + lane];
-						B[lane >> 4][lane & 15] = y[cx_mfma_b_index(X, p, lane) + 4 * s];
-					}
-					for (int m = 0; m < 16; m++)
-						for (int n = 0; n < 16; n++)
-							for (int c = 0; c < 4; c++) D[m][n] += A[m][c] * B[c][n];
-				}
-				for (int lane = 0; lane < 64; lane++)
-				{
-					double d[4];
-					for (int i = 0; i < 4; i++) d[i] = D[(lane >> 4) + 4 * i][lane & 15];
-					cx_mfma_store(X, k, ch, p, lane, d);
-				}
-			}
-	}
 	template<class F>
 	void phase(F f)
 	{
@@ -228,37 +195,6 @@ void emul_convx_t(const ConvxLaunch& X)
 			for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
 			EmulExec<LOGN, UPLOG> ex;
 			convx_body<LOGN, UPLOG, MODE, FLENP>(ex, X, base, X.c.k0 + bx, ch);
-		}
-}
-
-// wave-per-block form: a step runs on all 64 lanes before the next one starts
-template<int LOGN, int UPLOG>
-struct EmulWaveExec
-{
-	std::vector<ConvwState<LOGN, UPLOG>> st;
-	EmulWaveExec() : st((size_t) kWaveLanes) {}
-	template<class F>
-	void step(F f)
-	{
-		for (int l = 0; l < kWaveLanes; l++) f(l, st[(size_t) l]);
-	}
-};
-
-template<int LOGN, int UPLOG, int MODE, int FLENP>
-void emul_convw_t(const ConvxLaunch& X)
-{
-	std::vector<double> lds((size_t) convw_lds_need(convw_plane_doubles<LOGN, UPLOG>(), X.c.in_len) + 2);
-	double* base = lds.data();
-	if (((size_t) base & 15) != 0) base++;
-	for (int ch = 0; ch < X.c.nch; ch++)
-		for (int bx = 0; bx < X.c.nblk; bx++)
-		{
-			for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
-			EmulWaveExec<LOGN, UPLOG> ex;
-			for (auto& s : ex.st)
-				for (int i = 0; i < ConvwGeom<LOGN, UPLOG>::MX; i++)
-					s.vr[i] = s.vi[i] = std::numeric_limits<double>::quiet_NaN();
-			convw_body<LOGN, UPLOG, MODE, FLENP>(ex, X, base, X.c.k0 + bx, ch);
 		}
 }
 
@@ -331,25 +267,6 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 	throw std::runtime_error("emul launch_convp: geometry not instantiated");
 }
 
-void launch_convw(const ConvxLaunch& X, int mode, void*)
-{
-	int logn = 0;
-	while ((2 << logn) < X.c.n_in) logn++;
-	const int up = X.c.up;
-	const bool wide = X.flen > 24;
-#define R8B_CONVW_DISPATCH(LN, UL) \
-	if (logn == LN && up == (1 << UL)) \
-	{ \
-		if (mode == 0) emul_convw_t<LN, UL, 0, 24>(X); \
-		else if (wide) emul_convw_t<LN, UL, 1, 32>(X); \
-		else emul_convw_t<LN, UL, 1, 24>(X); \
-		return; \
-	}
-	R8B_CONVW_GEOMS(R8B_CONVW_DISPATCH)
-#undef R8B_CONVW_DISPATCH
-	throw std::runtime_error("emul launch_convw: geometry not instantiated");
-}
-
 void launch_convx(const ConvxLaunch& X, int mode, void*)
 {
 	int logn = 0;
@@ -373,8 +290,6 @@ void launch_convx(const ConvxLaunch& X, int mode, void*)
 	{ \
 		if (mode == 0) emul_convx_t<LN, UL, 0, 24>(X); \
 		else if (mode == 3) emul_convx_t<LN, UL, 3, 24>(X); \
-		else if (mode == 2 && wide) emul_convx_t<LN, UL, 2, 32>(X); \
-		else if (mode == 2) emul_convx_t<LN, UL, 2, 24>(X); \
 		else if (wide) emul_convx_t<LN, UL, 1, 32>(X); \
 		else emul_convx_t<LN, UL, 1, 24>(X); \
 		return; \

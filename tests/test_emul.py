@@ -155,29 +155,20 @@ def test_emulated_dll_abi(emul):
     assert len(d.process(x[:1024])) == 0
 
 
-@pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[6], STREAM_CASES[15]])
-def test_emulated_matrix_core_interpolator(emul, case):
-    """option mfma_interp: the fused interpolator as 16x16x4 fp64 matrix tiles (software model of
-    the instruction in tests/emul) gives the same stream"""
+@pytest.mark.parametrize("opts", [{"pair_conv": 0}, {"pair_conv": 0, "fuse": 0}, {"pair_two": 0},
+                                  {"fuse": 0}])
+@pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[1], STREAM_CASES[6], STREAM_CASES[13]])
+def test_emulated_alternative_fast_paths(emul, case, opts):
+    """the forms behind the engine options: one-channel fast path (r8b_convx.h) instead of the pair
+    kernel (r8b_convp.h), one phase per thread instead of two, unfused"""
     src, dst, maxin, chunk, n, tb, att = case
     b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, lib=emul)
-    b.set_option("mfma_interp", 1)
-    rms, pk = compare_stream(b, src, dst, maxin, chunk, n, tb, att, 2)
-    assert rms <= RMS_TOL and pk <= PEAK_TOL, (rms, pk)
-
-
-@pytest.mark.parametrize("fuse", [1, 0])
-@pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[1], STREAM_CASES[6], STREAM_CASES[13],
-                                  STREAM_CASES[18], (192000.0, 44100.0, 4096, 1000, 20000, 2.0, 180.15)])
-def test_emulated_wave_per_block_convolver(emul, case, fuse):
-    """option wave_conv: 1024/2048-point fast convolvers as one wavefront per block
-    (r8b_convw.h: in-register radix passes, lane transpositions through LDS)"""
-    src, dst, maxin, chunk, n, tb, att = case
-    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, lib=emul)
-    b.set_option("wave_conv", 1)
-    b.set_option("fuse", fuse)
+    for k, v in opts.items():
+        b.set_option(k, v)
     b.set_option("timing", 1)
-    assert any(t[0].startswith("k_convw") for t in b.stage_timings())
+    names = [t[0] for t in b.stage_timings()]
+    if opts.get("pair_conv", 1) == 0:
+        assert not any(t.startswith("k_convp") for t in names), names
     b.set_option("timing", 0)
     rms, pk = compare_stream(b, src, dst, maxin, chunk, n, tb, att, 2)
     assert rms <= RMS_TOL and pk <= PEAK_TOL, (rms, pk)

@@ -93,8 +93,8 @@ def test_fuzz_emulated_engine_vs_reference(emul, reference, case):
     assert rms <= RMS_TOL and pk <= PEAK_TOL, (case, rms, pk)
 
 
-OPTION_SETS = [{"fuse": 0}, {"fast_conv": 0, "fuse": 0}, {"wave_conv": 1}, {"wave_conv": 1, "fuse": 0},
-               {"mfma_interp": 1}, {"fuse_hb": 0}, {"fuse_hbd": 1}, {"fuse_hbd": 0},
+OPTION_SETS = [{"fuse": 0}, {"fast_conv": 0, "fuse": 0}, {"pair_conv": 0}, {"pair_conv": 0, "fuse": 0},
+               {"pair_two": 0}, {"fuse_hb": 0}, {"fuse_hbd": 1}, {"fuse_hbd": 0},
                {"poly_tiled": 0}, {"fold_tail": 0}, {"conv_radix": 4, "fast_conv": 0, "fuse": 0},
                {"hbc_tile": 1024}, {"hbd_span": 512, "fuse_hbd": 1}]
 

@@ -314,14 +314,13 @@ def test_cxx_frontend(torch, tmp_path):
     assert len(vals) == len(yo) and rms(vals - yo) <= RMS_TOL and peak(vals - yo) <= PEAK_TOL
 
 
-@pytest.mark.parametrize("opts", [{"mfma_interp": 1}, {"fuse": 0}, {"fuse": 0, "fast_conv": 0},
-                                  {"fuse_hb": 0}, {"wave_conv": 1}, {"wave_conv": 1, "fuse": 0}])
+@pytest.mark.parametrize("opts", [{"pair_two": 0}, {"fuse": 0}, {"fuse": 0, "fast_conv": 0},
+                                  {"fuse_hb": 0}, {"pair_conv": 0}, {"pair_conv": 0, "fuse": 0}])
 @pytest.mark.parametrize("case", [STREAM_CASES[0], STREAM_CASES[1], STREAM_CASES[2], STREAM_CASES[4],
                                   STREAM_CASES[6]])
 def test_hip_alternative_kernel_paths(torch, case, opts):
-    """every kernel path behind the engine options (matrix-core interpolator, unfused fast
-    convolver, generic kernels, unfused half-bands, one-wavefront-per-block convolver) produces
-    the same stream"""
+    """every kernel path behind the engine options (one-phase pair interpolator, unfused fast
+    convolver, generic kernels, unfused half-bands, one-channel fast path) produces the same stream"""
     src, dst, maxin, chunk, n, tb, att = case
     b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, device=0)
     for k, v in opts.items():
