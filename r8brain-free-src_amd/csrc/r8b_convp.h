@@ -26,8 +26,13 @@
 // 4096-point backward transform), two workgroups per CU; the XOR swizzle pswz() makes every pass
 // conflict free for 16-byte accesses without pad slots.
 //
-// Geometries: 2048-point forward / 4096-point backward (2x up: BASELINE configs 2, 4, 5) and
-// 4096 / 4096 (1:1: config 3); everything else stays on r8b_convx.h.
+// Geometries: backward transforms of 256 ... 4096 points, 1:1 or 2x up-sampling (4096: BASELINE configs
+// 2-5).  A thread always owns 16 elements of the backward transform, so a block pair takes NT = N2 / 16
+// threads and a 256-thread workgroup carries SUB = 4096 / N2 consecutive blocks of its channel pair, each
+// in its own N2-element part of the 64 KB array (short filters: the per-workgroup fixed costs and the
+// barriers are shared by up to 16 blocks, and below 1024 points a block never leaves its wave).  The
+// interpolator at the end works workgroup-wide over the runs of all SUB blocks.  Everything else stays on
+// r8b_convx.h.
 //
 // Reference semantics reproduced: CDSPBlockConvolver.h:252-354, 512-593, 606-629;
 // CDSPRealFFT.h:289-385; CDSPFracInterpolator.h:991-1060.
@@ -50,25 +55,45 @@ template<int LN, int UL>
 struct ConvpGeom
 {
 	static constexpr int N = 1 << LN, LN2 = LN + UL, N2 = 1 << LN2;
-	static constexpr int E1 = N / kConvpThreads, E2 = N2 / kConvpThreads; // elements per thread
-	static constexpr int EB1 = LN - 8;
-	static_assert(E2 == 16 && (E1 == 8 || E1 == 16), "pair kernel: 4096-point backward transform only");
+	static_assert(N2 >= 256 && N2 <= 4096 && (UL == 0 || UL == 1), "pair kernel: 256 ... 4096-point backward transforms");
+	static constexpr int NT = N2 / 16;            // threads per block pair
+	static constexpr int SUB = kConvpThreads / NT; // block pairs per workgroup
+	static constexpr int E1 = N / NT, E2 = 16;    // elements per thread, forward / backward
+	static constexpr int EB1 = 4 - UL;
 	static constexpr int NPRE = (LN - 1) / EB1;   // forward passes before the middle one (radix E1)
 	static constexpr int MB = LN - NPRE * EB1;    // log2 radix of the forward butterflies in the middle pass
 	static constexpr int RM = 1 << MB, NBF = E1 / RM;
-	// Wave w (threads 64 w ...) owns forward positions [w N/4, (w+1) N/4) after the first pass and
-	// backward positions [w N2/4, (w+1) N2/4) up to the last pass: the passes in between never leave
-	// that range (their butterflies span at most 512 / 1024 consecutive elements), so they need no
-	// workgroup barrier -- provided the wave's forward data lives where its backward data will: forward
-	// position p sits at slot fslot(p) = (p / (N/4)) * (N2/4) + p mod (N/4)  (the identity when N2 = N).
-	static constexpr int FW = N / 4, BW = N2 / 4;
+	// last backward pass (sub-length N2; none when N2 = 256): radix R2, NB2 butterflies per thread
+	static constexpr int R2 = N2 / 256, NB2 = R2 > 1 ? 16 / R2 : 0;
+	static constexpr int NBASE2 = R2 >= 16 ? 6 : (R2 >= 8 ? 4 : (R2 >= 4 ? 3 : 1));
+	static constexpr int NTW = NB2 * NBASE2 > 6 ? NB2 * NBASE2 : 6;
+	// Wave w of a block pair (NW waves each) owns forward positions [w N/NW, (w+1) N/NW) after the first
+	// pass and backward positions [w N2/NW, (w+1) N2/NW) up to the last pass: the passes in between
+	// never leave that range (their butterflies span at most 64 E1 / 1024 consecutive elements), so they
+	// need no workgroup barrier -- provided the wave's forward data lives where its backward data will:
+	// forward position p sits at slot fslot(p) = (p / FW) * BW + p mod FW  (the identity when N2 = N or
+	// when a block pair fits one wave).
+	static constexpr int NW = NT >= 64 ? NT / 64 : 1;
+	static constexpr int FW = N / NW, BW = N2 / NW;
 };
+
+// position of a thread inside its workgroup: block pair `sub`, thread `lt` of that pair
+template<int LN, int UL> R8B_HD int convp_sub(int tid)
+{
+	if constexpr (ConvpGeom<LN, UL>::SUB == 1) return 0;
+	else return tid / ConvpGeom<LN, UL>::NT;
+}
+template<int LN, int UL> R8B_HD int convp_lt(int tid)
+{
+	if constexpr (ConvpGeom<LN, UL>::SUB == 1) return tid;
+	else return tid & (ConvpGeom<LN, UL>::NT - 1);
+}
 
 template<int LN, int UL>
 R8B_HD int fslot(int p)
 {
 	typedef ConvpGeom<LN, UL> G;
-	if constexpr (UL == 0) return pswz(p);
+	if constexpr (UL == 0 || G::NW == 1) return pswz(p);
 	else return pswz((p / G::FW) * G::BW + (p & (G::FW - 1)));
 }
 
@@ -77,27 +102,27 @@ struct ConvpState
 {
 	double vr[16], vi[16];
 	double pr[16], pi[16]; // the block's input samples (channel A, channel B) of the first pass
-	cd tw[6];
+	cd tw[ConvpGeom<LN, UL>::NTW];
 	cd hp[8];
 	double row[32];
 	double rows2[2 * 25]; // mode 4: the two rows of the thread's phase pair
 	int pt;               // ... and its entry of X.ptab
 };
 
-constexpr int convp_lds_bytes(int logn2) { return (1 << logn2) * 16; }
+constexpr int convp_lds_bytes() { return 4096 * 16; } // SUB arrays of N2 complex
 
 // Twiddle base powers of a pass, pre-gathered per thread by the host (pair_twiddles() in
-// r8b_engine.cpp): entry (slot * 6 + c) * 256 + t = w_n^(j(t) m_c), m = {1, 2, 3, 4, 8, 12}; a wave
-// reads 64 consecutive 16-byte entries per load (the strided reads of the shared exp() table touch
-// up to 64 cache lines per load).  Slots: 0 first pass, 1 / 2 forward passes 1 / 2, 3 / 4 backward
-// passes with sub-lengths 256 / 4096.
-template<int R>
-R8B_HD void ptw_fetch(cd* twr, const cd* ptw, int slot, int tid)
+// r8b_engine.cpp): entry (row * NT + t) = w_n^(j(t) m_c), row = 6 slot + c, m = {1, 2, 3, 4, 8, 12}; a
+// wave reads consecutive 16-byte entries per load (the strided reads of the shared exp() table touch up
+// to 64 cache lines per load).  Slots: 0 first pass, 1 / 2 forward passes 1 / 2, 3 backward pass with
+// sub-length 256, 4 + m butterfly m of the last backward pass (sub-length N2, j = t + NT m).
+template<int R, int NT>
+R8B_HD void ptw_fetch(cd* twr, const cd* ptw, int slot, int lt)
 {
 	constexpr int NB = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
-	const cd* p = ptw + (slot * 6 * kConvpThreads + tid);
+	const cd* p = ptw + (slot * 6 * NT + lt);
 #pragma unroll
-	for (int c = 0; c < NB; c++) twr[c] = p[c * kConvpThreads];
+	for (int c = 0; c < NB; c++) twr[c] = p[c * NT];
 }
 
 // ---- passes over the swizzled array ---------------------------------------------------------------
@@ -168,12 +193,13 @@ R8B_HD void pdit_regs(const cd* buf, int n, int b, const cd* twr, double* vr, do
 }
 
 // ---- phases -----------------------------------------------------------------------------------------
+// (buf = the block pair's own N2-element array, lt = the thread's index inside the pair, 0 .. NT-1)
 
-// K1: thread t owns the radix-E1 butterfly over elements t + 256 p of the first pass; element i of the
+// K1: thread lt owns the radix-E1 butterfly over elements lt + NT p of the first pass; element i of the
 // circular block is sample i of channel A (real part) and of channel B (imaginary part).  A wave
 // reads 64 consecutive samples of each channel per load.
 template<int LN, int UL>
-R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, int chA, int chB, int tid)
+R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, int chA, int chB, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int R = G::E1, q = G::N / R;
@@ -189,7 +215,7 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 #pragma unroll
 		for (int p = 0; p < R; p++)
 		{
-			const int i = tid + p * q;
+			const int i = lt + p * q;
 			const int rel = i < iln ? i : i - G::N;
 			st.pr[p] = pa[rel];
 			st.pi[p] = pb[rel];
@@ -200,7 +226,7 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
-		const int i = tid + p * q;
+		const int i = lt + p * q;
 		const int rel = i < iln ? i : i - G::N;
 		st.pr[p] = src_block_load1(sa, rel);
 		st.pi[p] = src_block_load1(sb, rel);
@@ -209,12 +235,12 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 
 // first forward pass, from the registers cp_load() filled
 template<int LN, int UL>
-R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st, int tid)
+R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int R = G::E1, q = G::N / R;
 	cd loc[6];
-	ptw_fetch<R>(loc, L.ptw, 0, tid);
+	ptw_fetch<R, G::NT>(loc, L.ptw, 0, lt);
 	double vr[R], vi[R];
 #pragma unroll
 	for (int p = 0; p < R; p++)
@@ -238,7 +264,7 @@ R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st,
 		cd v;
 		v.re = vr[p];
 		v.im = vi[p];
-		buf[fslot<LN, UL>(tid + p * q)] = v;
+		buf[fslot<LN, UL>(lt + p * q)] = v;
 	}
 }
 
@@ -248,39 +274,39 @@ struct ConvpPre
 {
 	typedef ConvpGeom<LN, UL> G;
 	static constexpr int n = G::N >> (I * G::EB1);
-	static R8B_HD void prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int tid)
+	static R8B_HD void prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 	{
-		ptw_fetch<G::E1>(st.tw, L.ptw, I, tid);
+		ptw_fetch<G::E1, G::NT>(st.tw, L.ptw, I, lt);
 	}
-	static R8B_HD void run(cd* buf, const ConvpState<LN, UL>& st, int tid)
+	static R8B_HD void run(cd* buf, const ConvpState<LN, UL>& st, int lt)
 	{
-		pdif<LN, UL, G::E1, true>(buf, n, tid, st.tw);
+		pdif<LN, UL, G::E1, true>(buf, n, lt, st.tw);
 	}
 };
 
-// kernel constants of the middle pass, hp[c * 256 + t] (a wave reads 64 consecutive 16-byte entries):
+// kernel constants of the middle pass, hp[c * NT + t] (a wave reads consecutive 16-byte entries):
 //   2x up: (Hs, Hd) of forward position 8 t + c;   1:1: H of backward positions 16 t + 2 c, + 1
 template<int LN, int UL>
-R8B_HD void cp_hp_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int tid)
+R8B_HD void cp_hp_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 {
 #pragma unroll
 	for (int c = 0; c < 8; c++)
 	{
-		st.hp[c] = L.hp[c * kConvpThreads + tid];
+		st.hp[c] = L.hp[c * ConvpGeom<LN, UL>::NT + lt];
 	}
 }
 
 // middle pass, compute part: results (the backward array's positions 16 t + p after the first
 // backward pass) stay in st.vr / st.vi
 template<int LN, int UL>
-R8B_HD void cp_middle_compute(const cd* buf, ConvpState<LN, UL>& st, int tid)
+R8B_HD void cp_middle_compute(const cd* buf, ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
 	double zr[G::E1], zi[G::E1];
 #pragma unroll
 	for (int c = 0; c < G::E1; c++)
 	{
-		const cd v = buf[fslot<LN, UL>(G::E1 * tid + c)];
+		const cd v = buf[fslot<LN, UL>(G::E1 * lt + c)];
 		zr[c] = v.re;
 		zi[c] = v.im;
 	}
@@ -315,7 +341,7 @@ R8B_HD void cp_middle_compute(const cd* buf, ConvpState<LN, UL>& st, int tid)
 }
 
 template<int LN, int UL>
-R8B_HD void cp_middle_write(cd* buf, const ConvpState<LN, UL>& st, int tid)
+R8B_HD void cp_middle_write(cd* buf, const ConvpState<LN, UL>& st, int lt)
 {
 #pragma unroll
 	for (int p = 0; p < 16; p++)
@@ -323,52 +349,102 @@ R8B_HD void cp_middle_write(cd* buf, const ConvpState<LN, UL>& st, int tid)
 		cd v;
 		v.re = st.vr[p];
 		v.im = st.vi[p];
-		buf[pswz(16 * tid + p)] = v;
+		buf[pswz(16 * lt + p)] = v;
 	}
 }
 
-// backward pass with sub-length 256 (radix 16, in place)
+// backward pass with sub-length 256 (radix 16); in place, or -- when it is the last one (N2 = 256: its
+// elements lt + 16 p are the thread's elements lt + NT p of the result) -- into st.vr / st.vi
 template<int LN, int UL>
-R8B_HD void cp_back1(cd* buf, const ConvpState<LN, UL>& st, int tid)
+R8B_HD void cp_back1(cd* buf, ConvpState<LN, UL>& st, int lt)
 {
-	double vr[16], vi[16];
-	pdit_regs<16, true>(buf, 256, tid, st.tw, vr, vi);
-	const int e0 = (tid >> 4) * 256 + (tid & 15);
-#pragma unroll
-	for (int p = 0; p < 16; p++)
+	if constexpr (ConvpGeom<LN, UL>::R2 == 1) pdit_regs<16, true>(buf, 256, lt, st.tw, st.vr, st.vi);
+	else
 	{
-		cd v;
-		v.re = vr[p];
-		v.im = vi[p];
-		buf[pswz(e0 + p * 16)] = v;
+		double vr[16], vi[16];
+		pdit_regs<16, true>(buf, 256, lt, st.tw, vr, vi);
+		const int e0 = (lt >> 4) * 256 + (lt & 15);
+#pragma unroll
+		for (int p = 0; p < 16; p++)
+		{
+			cd v;
+			v.re = vr[p];
+			v.im = vi[p];
+			buf[pswz(e0 + p * 16)] = v;
+		}
 	}
 }
 
-// last backward pass (sub-length 4096): element t + 256 p = (y_A, y_B) at circular time t + 256 p
+// twiddles of the last backward pass: NB2 butterflies per thread, NBASE2 base powers each
 template<int LN, int UL>
-R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int tid)
+R8B_HD void cp_back2_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 {
-	pdit_regs<16, true>(buf, 4096, tid, st.tw, st.vr, st.vi);
+	typedef ConvpGeom<LN, UL> G;
+#pragma unroll
+	for (int m = 0; m < G::NB2; m++) ptw_fetch<G::R2, G::NT>(st.tw + m * G::NBASE2, L.ptw, 4 + m, lt);
+}
+
+// last backward pass (sub-length N2, radix R2 = N2 / 256): the thread's elements lt + NT i, i = 0 .. 15,
+// = (y_A, y_B) at circular time lt + NT i; butterfly m works on i = m + NB2 p
+template<int LN, int UL>
+R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	if constexpr (G::R2 == 16) pdit_regs<16, true>(buf, G::N2, lt, st.tw, st.vr, st.vi);
+	else if constexpr (G::R2 > 1)
+	{
+		constexpr int R = G::R2, NB = G::NB2;
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+		{
+			const cd v = buf[pswz(lt + G::NT * i)];
+			st.vr[i] = v.re;
+			st.vi[i] = v.im;
+		}
+#pragma unroll
+		for (int m = 0; m < NB; m++)
+		{
+			double ar[R], ai[R];
+			ar[0] = st.vr[m];
+			ai[0] = st.vi[m];
+#pragma unroll
+			for (int p = 1; p < R; p++)
+			{
+				const cd w = tw_get(st.tw + m * G::NBASE2, bitrev_c<R>(p));
+				const double xr = st.vr[m + NB * p], xi = st.vi[m + NB * p];
+				ar[p] = xr * w.re + xi * w.im;
+				ai[p] = xi * w.re - xr * w.im;
+			}
+			dit_regs<R>(ar, ai);
+#pragma unroll
+			for (int p = 0; p < R; p++)
+			{
+				st.vr[m + NB * p] = ar[p];
+				st.vi[m + NB * p] = ai[p];
+			}
+		}
+	}
 }
 
 // MODE 1: the block's valid outputs as one linear run of (A, B) pairs, y[u] = outputs at time t0 + u
 template<int LN, int UL>
-R8B_HD void cp_final_store(const ConvLaunch& L, cd* y, const ConvpState<LN, UL>& st, long long k, int tid)
+R8B_HD void cp_final_store(const ConvLaunch& L, cd* y, const ConvpState<LN, UL>& st, long long k, int lt)
 {
-	// (y already points at the run: buf + run_off)
-	constexpr int mask = ConvpGeom<LN, UL>::N2 - 1;
+	// (y already points at the run: the pair's array + run_off)
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int mask = G::N2 - 1;
 	const long long t0 = cx_block_t0(L, k);
 	// a stage's stream starts at t = 0: earlier outputs do not exist for the interpolator
 	// (reference CDSPFracInterpolator.h:834-859)
 	const int nzero = t0 >= 0 ? 0 : (-t0 > L.in_len ? L.in_len : (int) -t0);
-	const int in_len = L.in_len, u0 = (tid + L.fl2) & mask;
+	const int in_len = L.in_len, u0 = (lt + L.fl2) & mask;
 	if (nzero == 0)
 	{
 		// (every block but the first ones of a stream)
 #pragma unroll
 		for (int p = 0; p < 16; p++)
 		{
-			const int u = (u0 + kConvpThreads * p) & mask;
+			const int u = (u0 + G::NT * p) & mask;
 			if (u < in_len)
 			{
 				cd v;
@@ -382,7 +458,7 @@ R8B_HD void cp_final_store(const ConvLaunch& L, cd* y, const ConvpState<LN, UL>&
 #pragma unroll
 	for (int p = 0; p < 16; p++)
 	{
-		const int u = (tid + kConvpThreads * p + L.fl2) & mask;
+		const int u = (lt + G::NT * p + L.fl2) & mask;
 		if (u < L.in_len)
 		{
 			cd v;
@@ -392,25 +468,26 @@ R8B_HD void cp_final_store(const ConvLaunch& L, cd* y, const ConvpState<LN, UL>&
 		}
 	}
 	// zero extension read (times zero taps) by the padded polyphase rows
-	if (tid < kConvxRunPad)
+	for (int i = lt; i < kConvxRunPad; i += G::NT)
 	{
 		cd z;
 		z.re = z.im = 0.0;
-		y[L.in_len + tid] = z;
+		y[L.in_len + i] = z;
 	}
 }
 
 // MODE 0: K7 straight from the registers
 template<int LN, int UL>
 R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int chA,
-	int chB, bool bvalid, int tid)
+	int chB, bool bvalid, int lt)
 {
-	constexpr int mask = ConvpGeom<LN, UL>::N2 - 1;
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int mask = G::N2 - 1;
 	const long long t0 = cx_block_t0(L, k);
 #pragma unroll
 	for (int p = 0; p < 16; p++)
 	{
-		const int u = (tid + kConvpThreads * p + L.fl2) & mask;
+		const int u = (lt + G::NT * p + L.fl2) & mask;
 		const long long q = t0 + u;
 		if (u < L.in_len && q >= L.a && q < L.b)
 		{
@@ -585,11 +662,13 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* r
 
 // ---- the kernel body ---------------------------------------------------------------------------------
 
-// one unit of work: block k of the channel pair (chA, chB); bvalid: chB is a real channel (an odd
-// channel count leaves the last one without a partner: its block rides alone, chB = chA)
+// one workgroup's work: blocks k0 .. k0 + nvalid - 1 (nvalid <= SUB) of the channel pair (chA, chB);
+// bvalid: chB is a real channel (an odd channel count leaves the last one without a partner: its block
+// rides alone, chB = chA)
 struct ConvpItem
 {
 	long long k;
+	int nvalid;
 	int chA, chB;
 	bool bvalid;
 };
@@ -600,48 +679,72 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	typedef ConvpGeom<LN, UL> G;
 	typedef ConvpState<LN, UL> St;
 	const ConvLaunch& L = X.c;
-	const long long k = cur.k;
 	const int chA = cur.chA, chB = cur.chB;
 	const bool bvalid = cur.bvalid;
+	// a thread's block pair: its own part of the array; slots past the launch's last block redo that block
+	// (they take part in every barrier) and store nothing
+	auto sub_of = [&](int tid) { return convp_sub<LN, UL>(tid); };
+	auto lt_of = [&](int tid) { return convp_lt<LN, UL>(tid); };
+	auto buf_of = [&](int tid) { return buf + sub_of(tid) * G::N2; };
+	auto k_of = [&](int tid)
+	{
+		if constexpr (G::SUB == 1) return cur.k;
+		else
+		{
+			const int sb = sub_of(tid);
+			return cur.k + (sb < cur.nvalid ? sb : cur.nvalid - 1);
+		}
+	};
+	auto live = [&](int tid)
+	{
+		if constexpr (G::SUB == 1) return true;
+		else return sub_of(tid) < cur.nvalid;
+	};
 	ex.phase([&](int tid, St& st)
 	{
-		cp_load<LN, UL>(L, st, k, chA, chB, tid);
-		cp_first<LN, UL>(L, buf, st, tid);
-		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, tid);
-		else cp_hp_prefetch<LN, UL>(L, st, tid);
+		const int lt = lt_of(tid);
+		cp_load<LN, UL>(L, st, k_of(tid), chA, chB, lt);
+		cp_first<LN, UL>(L, buf_of(tid), st, lt);
+		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
+		else cp_hp_prefetch<LN, UL>(L, st, lt);
 	});
 	// forward passes 1 .., the middle pass and the first backward pass stay inside each wave's own range
 	// of the array (ConvpGeom): wave-level ordering points instead of workgroup barriers between them
 	auto s_pre1 = [&](int tid, St& st)
 	{
-		ConvpPre<LN, UL, 1>::run(buf, st, tid);
-		if constexpr (G::NPRE > 2) ConvpPre<LN, UL, 2>::prefetch(L, st, tid);
-		else cp_hp_prefetch<LN, UL>(L, st, tid);
+		const int lt = lt_of(tid);
+		ConvpPre<LN, UL, 1>::run(buf_of(tid), st, lt);
+		if constexpr (G::NPRE > 2) ConvpPre<LN, UL, 2>::prefetch(L, st, lt);
+		else cp_hp_prefetch<LN, UL>(L, st, lt);
 	};
 	auto s_pre2 = [&](int tid, St& st)
 	{
-		ConvpPre<LN, UL, 2>::run(buf, st, tid);
-		cp_hp_prefetch<LN, UL>(L, st, tid);
+		const int lt = lt_of(tid);
+		ConvpPre<LN, UL, 2>::run(buf_of(tid), st, lt);
+		cp_hp_prefetch<LN, UL>(L, st, lt);
 	};
 	// (two steps: every lane has read its forward data before any lane's backward data overwrites it --
 	// on the GPU program order alone guarantees that, LDS serves a wave's accesses in issue order)
 	auto s_midc = [&](int tid, St& st)
 	{
-		cp_middle_compute<LN, UL>(buf, st, tid);
-		ptw_fetch<16>(st.tw, L.ptw, 3, tid);
+		const int lt = lt_of(tid);
+		cp_middle_compute<LN, UL>(buf_of(tid), st, lt);
+		ptw_fetch<16, G::NT>(st.tw, L.ptw, 3, lt);
 	};
-	auto s_midw = [&](int tid, St& st) { cp_middle_write<LN, UL>(buf, st, tid); };
+	auto s_midw = [&](int tid, St& st) { cp_middle_write<LN, UL>(buf_of(tid), st, lt_of(tid)); };
 	auto s_b1 = [&](int tid, St& st)
 	{
-		cp_back1<LN, UL>(buf, st, tid);
-		ptw_fetch<16>(st.tw, L.ptw, 4, tid);
+		const int lt = lt_of(tid);
+		cp_back1<LN, UL>(buf_of(tid), st, lt);
+		cp_back2_prefetch<LN, UL>(L, st, lt);
 	};
-	static_assert(G::NPRE == 2 || G::NPRE == 3, "pair kernel: two or three forward passes before the middle");
+	static_assert(G::NPRE >= 1 && G::NPRE <= 3, "pair kernel: one to three forward passes before the middle");
 	if constexpr (G::NPRE == 3) ex.wave_steps(s_pre1, s_pre2, s_midc, s_midw, s_b1);
-	else ex.wave_steps(s_pre1, s_midc, s_midw, s_b1);
+	else if constexpr (G::NPRE == 2) ex.wave_steps(s_pre1, s_midc, s_midw, s_b1);
+	else ex.wave_steps(s_midc, s_midw, s_b1);
 	// history for the next call (stage 0 only): the first block's workgroup copies the tail of
 	// the caller's buffers into the other history ring; the stores need no wait
-	if (L.tail_ring != nullptr && k == L.k0)
+	if (L.tail_ring != nullptr && cur.k == L.k0)
 	{
 		ex.each([&](int tid, St&)
 		{
@@ -659,45 +762,58 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	{
 		ex.each([&](int tid, St& st)
 		{
-			cp_back2<LN, UL>(buf, st, tid);
-			cp_store_conv<LN, UL>(L, st, k, chA, chB, bvalid, tid);
+			const int lt = lt_of(tid);
+			cp_back2<LN, UL>(buf_of(tid), st, lt);
+			if (live(tid)) cp_store_conv<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
 		});
 	}
 	else if constexpr (MODE == 4)
 	{
 		ex.phase([&](int tid, St& st)
 		{
-			cp_back2<LN, UL>(buf, st, tid);
+			cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
 			cp_rows2_fetch(X, st.rows2, &st.pt, tid);
 		});
-		ex.phase([&](int tid, St& st) { cp_final_store<LN, UL>(L, buf + X.run_off, st, k, tid); });
-		ex.each([&](int tid, St& st)
+		ex.phase([&](int tid, St& st)
 		{
-			cp_whole2_compute(X, buf, st.rows2, st.pt, k, chA, chB, bvalid);
+			cp_final_store<LN, UL>(L, buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
+		});
+		// the interpolator: all 256 threads over the run of one block pair after the other
+		ex.each([&](int, St& st)
+		{
+			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
+				cp_whole2_compute(X, buf + sb * G::N2, st.rows2, st.pt, cur.k + sb, chA, chB, bvalid);
 		});
 	}
 	else
 	{
 		ex.phase([&](int tid, St& st)
 		{
-			cp_back2<LN, UL>(buf, st, tid);
+			cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
 			cx_whole_row<FLENP>(X, st.row, tid);
 		});
-		ex.phase([&](int tid, St& st) { cp_final_store<LN, UL>(L, buf, st, k, tid); });
+		ex.phase([&](int tid, St& st)
+		{
+			cp_final_store<LN, UL>(L, buf_of(tid), st, k_of(tid), lt_of(tid));
+		});
 		ex.each([&](int tid, St& st)
 		{
-			cp_whole_compute<FLENP>(X, buf, st.row, k, chA, chB, bvalid, tid);
+			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
+				cp_whole_compute<FLENP>(X, buf + sb * G::N2, st.row, cur.k + sb, chA, chB, bvalid, tid);
 		});
 	}
 }
 
-// item i of a launch, pair major: blocks of one channel pair are consecutive (a persistent
-// workgroup walks them back to back: the overlap-save history is re-read from its own caches)
+// workgroup i of a launch, pair major: the block groups of one channel pair are consecutive
+template<int SUB>
 R8B_HD ConvpItem convp_item(const ConvLaunch& L, long long i)
 {
 	ConvpItem it;
-	const int pr = (int) (i / L.nblk);
-	it.k = L.k0 + (i - (long long) pr * L.nblk);
+	const int nbg = (L.nblk + SUB - 1) / SUB;
+	const int pr = (int) (i / nbg);
+	const int b0 = (int) (i - (long long) pr * nbg) * SUB;
+	it.k = L.k0 + b0;
+	it.nvalid = L.nblk - b0 < SUB ? L.nblk - b0 : SUB;
 	it.chA = 2 * pr;
 	it.bvalid = it.chA + 1 < L.nch;
 	it.chB = it.bvalid ? it.chA + 1 : it.chA;

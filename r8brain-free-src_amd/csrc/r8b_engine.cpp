@@ -327,7 +327,7 @@ std::vector<double> spectral_constants_by_position(const std::vector<double>& sc
 
 std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n_out)
 {
-	const int N = n_in, N2 = n_out, up = N2 / N;
+	const int N = n_in, N2 = n_out, up = N2 / N, NT = N2 / 16;
 	int ln = 0;
 	while ((1 << ln) < N) ln++;
 	auto Hf = [&](int m) -> long double { return H[(size_t) (m <= N2 / 2 ? m : N2 - m)]; };
@@ -338,11 +338,11 @@ std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n
 			if (v & (1 << b)) r |= 1 << (bits - 1 - b);
 		return r;
 	};
-	std::vector<double> out((size_t) 8 * 256 * 2, 0.0);
-	for (int t = 0; t < 256; t++)
+	std::vector<double> out((size_t) 8 * NT * 2, 0.0);
+	for (int t = 0; t < NT; t++)
 		for (int c = 0; c < 8; c++)
 		{
-			double* o = &out[((size_t) c * 256 + t) * 2];
+			double* o = &out[((size_t) c * NT + t) * 2];
 			if (up == 2)
 			{
 				const int k = rev(8 * t + c, ln);
@@ -358,22 +358,32 @@ std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n
 	return out;
 }
 
-std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int n_in)
+std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int n_in, int n_out)
 {
-	std::vector<double> out((size_t) 5 * 6 * 256 * 2, 0.0);
+	// rows of NT entries (r8b_convp.h ptw_fetch): 6 per slot; slots 0-2 forward passes (radix e1), 3 the
+	// backward pass with sub-length 256, 4 + m butterfly m of the last backward pass (sub-length n_out)
+	const int NT = n_out / 16, e1 = n_in / NT, r2 = n_out / 256, nb2 = r2 > 1 ? 16 / r2 : 0;
+	const int nslots = 4 + nb2;
+	std::vector<double> out((size_t) nslots * 6 * NT * 2, 0.0);
 	static const int mult[6] = { 1, 2, 3, 4, 8, 12 };
-	// (sub-length, j mask) per slot; forward passes have radix n_in / 256
-	const int e1 = n_in / 256;
-	int n[5] = { n_in, n_in / e1, n_in / e1 / e1, 256, 4096 };
-	int jm[5] = { 255, n[1] / e1 - 1, n[2] / e1 - 1, 15, 255 };
-	for (int slot = 0; slot < 5; slot++)
+	for (int slot = 0; slot < nslots; slot++)
 	{
-		if (n[slot] < 2 || jm[slot] < 0) continue;
-		for (int t = 0; t < 256; t++)
+		int n, jmod, joff = 0;
+		if (slot < 3)
+		{
+			n = n_in;
+			for (int i = 0; i < slot; i++) n /= e1;
+			jmod = n / e1; // butterflies per sub-transform
+			if (n < 2 * e1) continue;
+		}
+		else if (slot == 3) { n = 256; jmod = 16; }
+		else { n = n_out; jmod = n_out; joff = NT * (slot - 4); }
+		for (int t = 0; t < NT; t++)
 			for (int c = 0; c < 6; c++)
 			{
-				const long long e = (long long) (tw_len / n[slot]) * (t & jm[slot]) * mult[c];
-				const size_t o = (((size_t) slot * 6 + c) * 256 + t) * 2, i = (size_t) (e % tw_len) * 2;
+				const long long j = (t % jmod) + joff;
+				const long long e = (long long) (tw_len / n) * j * mult[c];
+				const size_t o = (((size_t) slot * 6 + c) * NT + t) * 2, i = (size_t) (e % tw_len) * 2;
 				out[o] = tw[i];
 				out[o + 1] = tw[i + 1];
 			}
@@ -510,15 +520,15 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 						d.spec2 = (cd*) dev_alloc(s2.size() * sizeof(double));
 						dev_upload(d.spec2, s2.data(), s2.size() * sizeof(double));
 					}
-					if (convp_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
-					{
-						const std::vector<double> hp = pair_constants(H, g.n_in, g.n_out);
-						d.hp = (cd*) dev_alloc(hp.size() * sizeof(double));
-						dev_upload(d.hp, hp.data(), hp.size() * sizeof(double));
-						const std::vector<double> pt = pair_twiddles(tw, g.bl2, g.n_in);
-						d.ptw = (cd*) dev_alloc(pt.size() * sizeof(double));
-						dev_upload(d.ptw, pt.data(), pt.size() * sizeof(double));
-					}
+				}
+				if (convp_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
+				{
+					const std::vector<double> hp = pair_constants(H, g.n_in, g.n_out);
+					d.hp = (cd*) dev_alloc(hp.size() * sizeof(double));
+					dev_upload(d.hp, hp.data(), hp.size() * sizeof(double));
+					const std::vector<double> pt = pair_twiddles(tw, g.bl2, g.n_in, g.n_out);
+					d.ptw = (cd*) dev_alloc(pt.size() * sizeof(double));
+					dev_upload(d.ptw, pt.data(), pt.size() * sizeof(double));
 				}
 			}
 			else if (sp.desc.kind == kFrac)
@@ -745,7 +755,7 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 				sp.cg.complex_h ? "k_conv" :
 				((opt_.at("fast_conv") || !generic_conv_fits(sp.cg)) && (convx_mode3_ok(sp.cg.n_in,
 				sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2, sp.cg.down_pow2) ||
-				convx_geometry_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2)) ?
+				fast_geometry(sp.cg)) ?
 				(use_pair(sp.cg) && !convx_mode3_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down,
 				sp.cg.up_pow2, sp.cg.down_pow2) ? "k_convp" : "k_convx") : "k_conv");
 			break;
@@ -947,8 +957,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		L.a = a; L.b = b;
 		L.dst = dst;
 		const bool m3 = convx_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
-		if (!g.complex_h && (opt_.at("fast_conv") || !generic_conv_fits(g)) &&
-			(m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2)))
+		if (!g.complex_h && (opt_.at("fast_conv") || !generic_conv_fits(g)) && (m3 || fast_geometry(g)))
 		{
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0; X.run_off = 0;
 			X.ptab = nullptr; X.ctab = nullptr; X.nsets = 0;
@@ -1308,6 +1317,12 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 	launch_hbcascade(L, stream);
 }
 
+// some compile-time-sized kernel (r8b_convx.h or r8b_convp.h) is instantiated for the geometry
+bool Engine::fast_geometry(const ConvGeom& g) const
+{
+	return convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2) || use_pair(g);
+}
+
 bool Engine::use_pair(const ConvGeom& g) const
 {
 	return opt_.at("pair_conv") &&
@@ -1329,7 +1344,9 @@ bool Engine::fuse_with_next(size_t s) const
 	const StagePlan& c = plan_.stages[s];
 	const StagePlan& w = plan_.stages[s + 1];
 	if (c.desc.kind != kConv || w.desc.kind != kFrac || !w.whole || c.cg.down != 1) return false;
-	if (!convx_geometry_ok(c.cg.n_in, c.cg.n_out, c.cg.up, c.cg.down, c.cg.up_pow2)) return false;
+	if (!fast_geometry(c.cg)) return false;
+	// (the linear output run and the zeros behind it live in the block's own part of the array)
+	if (use_pair(c.cg) && c.cg.in_len + 32 > c.cg.n_out) return false;
 	return w.out_step <= 256 && w.flen <= 32 && c.cg.in_len >= 4 * w.flen;
 }
 

@@ -456,36 +456,43 @@ struct GpuExecP
 };
 
 // 64 KB of LDS per workgroup: two workgroups per CU, i.e. two waves per SIMD and 256 registers each
+#ifndef R8B_CONVP_WGS
+#define R8B_CONVP_WGS 2
+#endif
 template<int LN, int UL, int MODE, int FLENP>
-__global__ __launch_bounds__(kConvpThreads, 2) void k_convp(const ConvxLaunch X)
+__global__ __launch_bounds__(kConvpThreads, R8B_CONVP_WGS) void k_convp(const ConvxLaunch X)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
-	// XCD-aware mapping as in k_convx, over channel PAIRS
-	const unsigned w = blockIdx.x, nblk = (unsigned) X.c.nblk, npair = ((unsigned) X.c.nch + 1u) >> 1;
-	unsigned blk, pr;
-	if (nblk == 1)
+	// XCD-aware mapping as in k_convx, over channel PAIRS and groups of SUB consecutive blocks
+	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
+	const unsigned w = blockIdx.x, npair = ((unsigned) X.c.nch + 1u) >> 1;
+	const unsigned nbg = ((unsigned) X.c.nblk + SUB - 1u) / SUB;
+	unsigned bg, pr;
+	if (nbg == 1)
 	{
-		blk = 0;
+		bg = 0;
 		pr = w;
 	}
 	else if ((npair & 7u) == 0)
 	{
 		const unsigned i = w >> 3, qd = convp_div(i, X.nblk_magic);
-		blk = i - qd * nblk;
+		bg = i - qd * nbg;
 		pr = (qd << 3) + (w & 7u);
 	}
 	else
 	{
 		pr = convp_div(w, X.nblk_magic);
-		blk = w - pr * nblk;
+		bg = w - pr * nbg;
 	}
-	blk = (unsigned) __builtin_amdgcn_readfirstlane((int) blk);
+	bg = (unsigned) __builtin_amdgcn_readfirstlane((int) bg);
 	pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
 	const int chA = (int) (2u * pr);
 	const bool bvalid = chA + 1 < X.c.nch;
 	GpuExecP<LN, UL> ex;
 	ConvpItem cur;
-	cur.k = X.c.k0 + blk;
+	const int b0 = (int) bg * SUB;
+	cur.k = X.c.k0 + b0;
+	cur.nvalid = X.c.nblk - b0 < SUB ? X.c.nblk - b0 : SUB;
 	cur.chA = chA;
 	cur.chB = bvalid ? chA + 1 : chA;
 	cur.bvalid = bvalid;
@@ -496,13 +503,19 @@ template<int LN, int UL, int MODE, int FLENP>
 void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 {
 	ConvxLaunch X = X0;
-	// (nblk = 1: floor(2^32 / 1) + 1 does not fit; 0 makes convp_div return 0, handled by the kernel)
-	X.nblk_magic = X.c.nblk > 1 ? (unsigned) (0x100000000ull / (unsigned) X.c.nblk) + 1u : 0u;
+	// (one block group: floor(2^32 / 1) + 1 does not fit; 0 makes convp_div return 0, handled by the kernel)
+	constexpr unsigned SUB = ConvpGeom<LN, UL>::SUB;
+	const unsigned nbg = ((unsigned) X.c.nblk + SUB - 1u) / SUB;
+	X.nblk_magic = nbg > 1 ? (unsigned) (0x100000000ull / nbg) + 1u : 0u;
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
-	const size_t lds = (size_t) convp_lds_bytes(LN + UL);
+#ifdef R8B_CONVP_LDS_TIMING_ONLY // occupancy experiments: results are wrong
+	const size_t lds = R8B_CONVP_LDS_TIMING_ONLY;
+#else
+	const size_t lds = (size_t) convp_lds_bytes();
+#endif
 	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
 	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
-	hipLaunchKernelGGL(kern, dim3((unsigned) X.c.nblk * npair), dim3(kConvpThreads), lds, stream, X);
+	hipLaunchKernelGGL(kern, dim3(nbg * npair), dim3(kConvpThreads), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
 }
 

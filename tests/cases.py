@@ -48,6 +48,24 @@ STREAM_CASES = [
 ]
 
 
+# Shorter filters (wider transition band / lower attenuation than the 24-bit preset): backward
+# transforms of 256 ... 2048 points, where a workgroup of the pair kernel (r8b_convp.h) carries 2 ... 16
+# consecutive blocks of its channel pair.  Ragged chunks leave block groups partly filled.
+# (src, dst, maxin, chunk, n_in, tb, atten, expected describe() fragment)
+SHORT_CASES = [
+    (44100.0, 96000.0, 4096, 1000, 14000, 2.0, 109.56, "fft=1024/2048"),   # 16IR preset, 2x up, fused
+    (96000.0, 44100.0, 4096, 4096, 16384, 2.0, 109.56, "fft=2048/2048"),   # 16IR preset, 1:1, fused
+    (44100.0, 88200.0, 2048, 777, 9000, 5.0, 109.56, "fft=512/1024"),      # convolver alone
+    (96000.0, 44100.0, 4096, 1500, 16000, 5.0, 136.45, "fft=1024/1024"),
+    (44100.0, 96000.0, 4096, 4096, 12288, 10.0, 109.56, "fft=256/512"),
+    (96000.0, 44100.0, 2048, 900, 9000, 10.0, 109.56, "fft=512/512"),
+    (44100.0, 96000.0, 4096, 333, 6000, 20.0, 109.56, "fft=128/256"),
+    (96000.0, 44100.0, 2048, 2048, 8192, 20.0, 109.56, "fft=256/256"),
+    (44100.0, 44101.0, 1024, 1024, 5000, 5.0, 109.56, "fft=512/1024"),     # polynomial bank behind it
+    (44100.0, 705600.0, 512, 300, 2000, 5.0, 109.56, "fft=512/1024"),      # half-band cascade behind it
+]
+
+
 # Filters too long for the reference's own block to fit LDS (32768-point blocks: transition band 0.5 %
 # at 180 dB with a radix-3 factor): the engine runs the same filter on 16384-point blocks.  Exact for
 # plain and strided decimation; where the reference decimates by TRUNCATING the block spectrum (2^k

@@ -234,17 +234,18 @@ struct EmulExecP
 template<int LN, int UL, int MODE, int FLENP>
 void emul_convp_t(const ConvxLaunch& X)
 {
-	std::vector<double> lds((size_t) convp_lds_bytes(LN + UL) / sizeof(double) + 2);
+	std::vector<double> lds((size_t) convp_lds_bytes() / sizeof(double) + 2);
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
-	const long long items = (long long) X.c.nblk * ((X.c.nch + 1) / 2);
+	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
+	const long long items = (long long) ((X.c.nblk + SUB - 1) / SUB) * ((X.c.nch + 1) / 2);
 	for (long long i = 0; i < items; i++)
 	{
 		EmulExecP<LN, UL> ex;
 		for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
 		for (auto& s : ex.st)
 			for (int j = 0; j < 16; j++) s.vr[j] = s.vi[j] = std::numeric_limits<double>::quiet_NaN();
-		convp_body<LN, UL, MODE, FLENP>(ex, X, reinterpret_cast<cd*>(base), convp_item(X.c, i));
+		convp_body<LN, UL, MODE, FLENP>(ex, X, reinterpret_cast<cd*>(base), convp_item<SUB>(X.c, i));
 	}
 }
 

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import (STREAM_CASES, REBLOCK_CASES, MINPHASE_CASES, RMS_TOL, PEAK_TOL, compare_stream,
+from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, MINPHASE_CASES, RMS_TOL, PEAK_TOL, compare_stream,
                    make_input)
 from conftest import ROOT
 
@@ -29,6 +29,21 @@ def test_emulated_engine_matches_oracle(emul, case):
     src, dst, maxin, chunk, n, tb, att = case
     b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, lib=emul)
     rms, pk = compare_stream(b, src, dst, maxin, chunk, n, tb, att, 2)
+    assert rms <= RMS_TOL and pk <= PEAK_TOL, (rms, pk)
+
+
+@pytest.mark.parametrize("nch", [3, 2])
+@pytest.mark.parametrize("case", SHORT_CASES)
+def test_emulated_short_filters_in_block_groups(emul, case, nch):
+    """shorter filters: the pair kernel with 2 ... 16 blocks per workgroup (r8b_convp.h); odd channel
+    count = the last channel without a partner"""
+    src, dst, maxin, chunk, n, tb, att, frag = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, lib=emul)
+    assert frag in b.describe(), b.describe()
+    b.set_option("timing", 1)
+    assert b.stage_timings()[0][0].startswith("k_convp"), b.stage_timings()
+    b.set_option("timing", 0)
+    rms, pk = compare_stream(b, src, dst, maxin, chunk, n, tb, att, nch)
     assert rms <= RMS_TOL and pk <= PEAK_TOL, (rms, pk)
 
 

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import (STREAM_CASES, REBLOCK_CASES, MINPHASE_CASES, RMS_TOL, PEAK_TOL, compare_stream,
+from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, MINPHASE_CASES, RMS_TOL, PEAK_TOL, compare_stream,
                    make_input)
 from conftest import rms, peak
 
@@ -241,6 +241,21 @@ def test_hip_full_size_properties(torch, cfg):
     yn = np.concatenate([b3.process_host(loud[:, i * L:(i + 1) * L]) for i in range(calls)], axis=1)
     assert peak(yq[0] - yn[0]) <= 4e-15
     assert peak(yq[1]) <= 4e-15  # a silent channel beside a loud one: residue only
+
+
+@pytest.mark.parametrize("nch", [5, 16])
+@pytest.mark.parametrize("case", SHORT_CASES)
+def test_hip_short_filters_in_block_groups(torch, case, nch):
+    """shorter filters (16IR preset, 5 ... 20 % transition bands): the pair kernel with 2 ... 16 blocks per
+    workgroup; every channel against its oracle, ragged calls, odd channel count"""
+    src, dst, maxin, chunk, n, tb, att, frag = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, device=0)
+    assert frag in b.describe(), b.describe()
+    b.set_option("timing", 1)
+    assert b.stage_timings()[0][0].startswith("k_convp"), b.stage_timings()
+    b.set_option("timing", 0)
+    r, p = compare_stream(b, src, dst, maxin, chunk, n, tb, att, nch)
+    assert r <= RMS_TOL and p <= PEAK_TOL, (r, p)
 
 
 @pytest.mark.parametrize("case", REBLOCK_CASES)
