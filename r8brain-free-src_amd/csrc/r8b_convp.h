@@ -26,7 +26,7 @@
 // 4096-point backward transform), two workgroups per CU; the XOR swizzle pswz() makes every pass
 // conflict free for 16-byte accesses without pad slots.
 //
-// Geometries: backward transforms of 256 ... 4096 points, 1:1 or 2x up-sampling (4096: BASELINE configs
+// Geometries: backward transforms of 64 ... 4096 points, 1:1 or 2x up-sampling (4096: BASELINE configs
 // 2-5).  A thread always owns 16 elements of the backward transform, so a block pair takes NT = N2 / 16
 // threads and a 256-thread workgroup carries SUB = 4096 / N2 consecutive blocks of its channel pair, each
 // in its own N2-element part of the 64 KB array (short filters: the per-workgroup fixed costs and the
@@ -55,7 +55,7 @@ template<int LN, int UL>
 struct ConvpGeom
 {
 	static constexpr int N = 1 << LN, LN2 = LN + UL, N2 = 1 << LN2;
-	static_assert(N2 >= 256 && N2 <= 4096 && (UL == 0 || UL == 1), "pair kernel: 256 ... 4096-point backward transforms");
+	static_assert(N2 >= 64 && N2 <= 4096 && (UL == 0 || UL == 1), "pair kernel: 64 ... 4096-point backward transforms");
 	static constexpr int NT = N2 / 16;            // threads per block pair
 	static constexpr int SUB = kConvpThreads / NT; // block pairs per workgroup
 	static constexpr int E1 = N / NT, E2 = 16;    // elements per thread, forward / backward
@@ -63,8 +63,10 @@ struct ConvpGeom
 	static constexpr int NPRE = (LN - 1) / EB1;   // forward passes before the middle one (radix E1)
 	static constexpr int MB = LN - NPRE * EB1;    // log2 radix of the forward butterflies in the middle pass
 	static constexpr int RM = 1 << MB, NBF = E1 / RM;
-	// last backward pass (sub-length N2; none when N2 = 256): radix R2, NB2 butterflies per thread
-	static constexpr int R2 = N2 / 256, NB2 = R2 > 1 ? 16 / R2 : 0;
+	// backward passes after the middle one (sub-length 16): sub-length 256 (radix 16; B1: only when N2 >=
+	// 256), then sub-length N2 (none when N2 = 256): radix R2, NB2 butterflies per thread
+	static constexpr bool B1 = N2 >= 256;
+	static constexpr int R2 = B1 ? N2 / 256 : N2 / 16, NB2 = R2 > 1 ? 16 / R2 : 0;
 	static constexpr int NBASE2 = R2 >= 16 ? 6 : (R2 >= 8 ? 4 : (R2 >= 4 ? 3 : 1));
 	static constexpr int NTW = NB2 * NBASE2 > 6 ? NB2 * NBASE2 : 6;
 	// Wave w of a block pair (NW waves each) owns forward positions [w N/NW, (w+1) N/NW) after the first
@@ -358,7 +360,8 @@ R8B_HD void cp_middle_write(cd* buf, const ConvpState<LN, UL>& st, int lt)
 template<int LN, int UL>
 R8B_HD void cp_back1(cd* buf, ConvpState<LN, UL>& st, int lt)
 {
-	if constexpr (ConvpGeom<LN, UL>::R2 == 1) pdit_regs<16, true>(buf, 256, lt, st.tw, st.vr, st.vi);
+	if constexpr (!ConvpGeom<LN, UL>::B1) return; // (no such pass below 256 points)
+	else if constexpr (ConvpGeom<LN, UL>::R2 == 1) pdit_regs<16, true>(buf, 256, lt, st.tw, st.vr, st.vi);
 	else
 	{
 		double vr[16], vi[16];
@@ -729,7 +732,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	{
 		const int lt = lt_of(tid);
 		cp_middle_compute<LN, UL>(buf_of(tid), st, lt);
-		ptw_fetch<16, G::NT>(st.tw, L.ptw, 3, lt);
+		if constexpr (G::B1) ptw_fetch<16, G::NT>(st.tw, L.ptw, 3, lt);
+		else cp_back2_prefetch<LN, UL>(L, st, lt);
 	};
 	auto s_midw = [&](int tid, St& st) { cp_middle_write<LN, UL>(buf_of(tid), st, lt_of(tid)); };
 	auto s_b1 = [&](int tid, St& st)
@@ -740,8 +744,10 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	};
 	static_assert(G::NPRE >= 1 && G::NPRE <= 3, "pair kernel: one to three forward passes before the middle");
 	if constexpr (G::NPRE == 3) ex.wave_steps(s_pre1, s_pre2, s_midc, s_midw, s_b1);
-	else if constexpr (G::NPRE == 2) ex.wave_steps(s_pre1, s_midc, s_midw, s_b1);
-	else ex.wave_steps(s_midc, s_midw, s_b1);
+	else if constexpr (G::NPRE == 2 && G::B1) ex.wave_steps(s_pre1, s_midc, s_midw, s_b1);
+	else if constexpr (G::NPRE == 2) ex.wave_steps(s_pre1, s_midc, s_midw);
+	else if constexpr (G::B1) ex.wave_steps(s_midc, s_midw, s_b1);
+	else ex.wave_steps(s_midc, s_midw);
 	// history for the next call (stage 0 only): the first block's workgroup copies the tail of
 	// the caller's buffers into the other history ring; the stores need no wait
 	if (L.tail_ring != nullptr && cur.k == L.k0)

@@ -362,7 +362,8 @@ std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int
 {
 	// rows of NT entries (r8b_convp.h ptw_fetch): 6 per slot; slots 0-2 forward passes (radix e1), 3 the
 	// backward pass with sub-length 256, 4 + m butterfly m of the last backward pass (sub-length n_out)
-	const int NT = n_out / 16, e1 = n_in / NT, r2 = n_out / 256, nb2 = r2 > 1 ? 16 / r2 : 0;
+	const int NT = n_out / 16, e1 = n_in / NT, r2 = n_out >= 256 ? n_out / 256 : n_out / 16;
+	const int nb2 = r2 > 1 ? 16 / r2 : 0;
 	const int nslots = 4 + nb2;
 	std::vector<double> out((size_t) nslots * 6 * NT * 2, 0.0);
 	static const int mult[6] = { 1, 2, 3, 4, 8, 12 };
@@ -376,7 +377,11 @@ std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int
 			jmod = n / e1; // butterflies per sub-transform
 			if (n < 2 * e1) continue;
 		}
-		else if (slot == 3) { n = 256; jmod = 16; }
+		else if (slot == 3)
+		{
+			if (n_out < 256) continue;
+			n = 256; jmod = 16;
+		}
 		else { n = n_out; jmod = n_out; joff = NT * (slot - 4); }
 		for (int t = 0; t < NT; t++)
 			for (int c = 0; c < 6; c++)

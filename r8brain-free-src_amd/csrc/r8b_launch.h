@@ -180,7 +180,7 @@ struct SpanInfo
 	int pad;
 };
 
-static const int kConvxMaxBlocks = 24; // blocks per fused launch (longer calls are split)
+static const int kConvxMaxBlocks = 64; // blocks per fused launch (longer calls are split)
 
 struct ConvxLaunch
 {
@@ -241,13 +241,14 @@ inline bool convx_mode3_ok(int n_in, int n_out, int up, int down, bool up_pow2, 
 }
 
 // pair form of the fast path (r8b_convp.h): two channels as one complex transform; backward transforms
-// of 256 ... 4096 points, 1:1 or 2x up-sampled (below 4096 points a workgroup carries several blocks)
+// of 64 ... 4096 points, 1:1 or 2x up-sampled (below 4096 points a workgroup carries several blocks)
 inline bool convp_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
 {
 	if (!up_pow2 || down != 1 || (up != 1 && up != 2) || n_out != n_in * up) return false;
-	return n_out == 256 || n_out == 512 || n_out == 1024 || n_out == 2048 || n_out == 4096;
+	return n_out == 64 || n_out == 128 || n_out == 256 || n_out == 512 || n_out == 1024 || n_out == 2048 || n_out == 4096;
 }
-#define R8B_CONVP_GEOMS(M) M(11, 1) M(12, 0) M(10, 1) M(11, 0) M(9, 1) M(10, 0) M(8, 1) M(9, 0) M(7, 1) M(8, 0)
+#define R8B_CONVP_GEOMS(M) M(11, 1) M(12, 0) M(10, 1) M(11, 0) M(9, 1) M(10, 0) M(8, 1) M(9, 0) M(7, 1) M(8, 0) \
+	M(6, 1) M(7, 0) M(5, 1) M(6, 0)
 
 // launchers (asynchronous on `stream`, a hipStream_t)
 void launch_conv(const ConvLaunch& L, void* stream);

@@ -29,7 +29,7 @@ STREAM_CASES = [
     (44100.0, 48000.0, 512, 512, 9000, 0.5, 109.56),            # narrow transition band (long filter)
     (44100.0, 88200.0, 512, 512, 6000, 45.0, 49.0),             # widest band, lowest attenuation
     (44100.0, 44100.0, 512, 512, 1024, 2.0, 180.15),            # Src == Dst passthrough
-    (44100.0, 96000.0, 70000, 70000, 140000, 2.0, 180.15),      # > 24 FFT blocks per call (split launches)
+    (44100.0, 96000.0, 70000, 70000, 140000, 2.0, 180.15),      # 53 FFT blocks per call
     (44100.0, 529200.0, 512, 300, 3000, 2.0, 180.15),           # 3x convolver + two third-band half-bands
     (44100.0, 705600.0, 256, 256, 1024, 2.0, 136.45),           # 2x + three half-bands, 16-bit preset
     # narrowest transition band at 24-bit attenuation: 16384-point blocks, in-place kernels only
@@ -63,6 +63,11 @@ SHORT_CASES = [
     (96000.0, 44100.0, 2048, 2048, 8192, 20.0, 109.56, "fft=256/256"),
     (44100.0, 44101.0, 1024, 1024, 5000, 5.0, 109.56, "fft=512/1024"),     # polynomial bank behind it
     (44100.0, 705600.0, 512, 300, 2000, 5.0, 109.56, "fft=512/1024"),      # half-band cascade behind it
+    (44100.0, 96000.0, 50000, 50000, 100000, 5.0, 109.56, "fft=512/1024"), # 148 blocks per call: split launches
+    (44100.0, 96000.0, 2048, 700, 6000, 30.0, 109.56, "fft=64/128"),       # 8 threads per block, fused
+    (96000.0, 44100.0, 2048, 2048, 8192, 45.0, 109.56, "fft=128/128"),
+    (44100.0, 96000.0, 2048, 1111, 6000, 45.0, 49.0, "fft=32/64"),         # 4 threads per block; run does not
+    (96000.0, 44100.0, 1024, 1024, 6000, 45.0, 49.0, "fft=64/64"),         # fit the block's array: unfused
 ]
 
 
