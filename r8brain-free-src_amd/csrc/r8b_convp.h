@@ -20,7 +20,8 @@
 //   * MODE 1: the block's valid outputs of both channels as one linear run of (A, B) pairs in LDS;
 //     the whole-step interpolator reads a pair per tap (one 16-byte LDS read feeds two
 //     multiply-adds with the same coefficient);  MODE 0: straight from the registers to the
-//     destination, nothing goes back to LDS.
+//     destination, nothing goes back to LDS;  MODE 3: the same behind a 3x zero-stuffing load and / or
+//     in front of a 3x strided store (ratios 3/1, 1/3, 2/3).
 // Per block and channel: half as many barrier-separated phases as the one-channel form, no spectral
 // stage, ~45 % less LDS traffic in the transforms.  LDS: one array of N2 complex (64 KB for the
 // 4096-point backward transform), two workgroups per CU; the XOR swizzle pswz() makes every pass
@@ -200,11 +201,34 @@ R8B_HD void pdit_regs(const cd* buf, int n, int b, const cd* twr, double* vr, do
 // K1: thread lt owns the radix-E1 butterfly over elements lt + NT p of the first pass; element i of the
 // circular block is sample i of channel A (real part) and of channel B (imaginary part).  A wave
 // reads 64 consecutive samples of each channel per load.
-template<int LN, int UL>
+template<int LN, int UL, int MODE = 0>
 R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, int chA, int chB, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int R = G::E1, q = G::N / R;
+	if constexpr (MODE == 3)
+	{
+		// 3x zero stuffing folded into the load (cf. cx_prefetch, reference CDSPBlockConvolver.h:414-496):
+		// element i of the block is virtual sample base_v + rel, i.e. x[(base_v + rel) / up] when up divides
+		// it, else 0
+		if (!L.up_pow2)
+		{
+			const long long base_v = k * (long long) L.blk_stride + L.blk_offset;
+			const long long B = base_v / L.up;
+			const int bm = (int) (base_v - B * L.up);
+			const int bias = L.up * (G::N / L.up + 2);
+			const SrcBlock sa = src_block(L.src, chA, B), sb = src_block(L.src, chB, B);
+#pragma unroll
+			for (int p = 0; p < R; p++)
+			{
+				const int i = lt + p * q;
+				const int rel = i < L.in_len ? i : i - G::N;
+				st.pr[p] = cx_stuffed_sample(sa, L.up, bm, rel, bias);
+				st.pi[p] = cx_stuffed_sample(sb, L.up, bm, rel, bias);
+			}
+			return;
+		}
+	}
 	const int iln = L.in_len >> UL; // (L.up == 1 << UL)
 	const long long base = (k * (long long) L.blk_stride + L.blk_offset) >> UL; // (>= 0, even)
 	// most blocks of a call lie entirely inside the caller's buffer: one uniform row pointer per channel
@@ -479,14 +503,39 @@ R8B_HD void cp_final_store(const ConvLaunch& L, cd* y, const ConvpState<LN, UL>&
 	}
 }
 
-// MODE 0: K7 straight from the registers
-template<int LN, int UL>
+// MODE 0 / 3: K7 straight from the registers
+template<int LN, int UL, int MODE = 0>
 R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int chA,
 	int chB, bool bvalid, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int mask = G::N2 - 1;
 	const long long t0 = cx_block_t0(L, k);
+	if constexpr (MODE == 3)
+	{
+		// strided decimation (3x): output q sits at virtual time q * down (reference
+		// CDSPBlockConvolver.h:564-583); the thread's element p is virtual time t0 + u
+		if (!L.down_pow2 && L.down > 1)
+		{
+			const int down = L.down;
+			const long long qf = t0 >= 0 ? t0 / down : -((-t0 + down - 1) / down); // floor
+			const unsigned r0 = (unsigned) (t0 - qf * down);
+#pragma unroll
+			for (int p = 0; p < 16; p++)
+			{
+				const int u = (lt + G::NT * p + L.fl2) & mask;
+				const unsigned w = r0 + (unsigned) u;
+				const unsigned wq = down == 3 ? w / 3u : w / (unsigned) down;
+				const long long q = qf + wq;
+				if (u < L.in_len && wq * (unsigned) down == w && q >= L.a && q < L.b)
+				{
+					dst_store(L.dst, chA, q, st.vr[p]);
+					if (bvalid) dst_store(L.dst, chB, q, st.vi[p]);
+				}
+			}
+			return;
+		}
+	}
 #pragma unroll
 	for (int p = 0; p < 16; p++)
 	{
@@ -706,7 +755,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	ex.phase([&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
-		cp_load<LN, UL>(L, st, k_of(tid), chA, chB, lt);
+		cp_load<LN, UL, MODE>(L, st, k_of(tid), chA, chB, lt);
 		cp_first<LN, UL>(L, buf_of(tid), st, lt);
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
 		else cp_hp_prefetch<LN, UL>(L, st, lt);
@@ -764,13 +813,13 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 			}
 		});
 	}
-	if constexpr (MODE == 0)
+	if constexpr (MODE == 0 || MODE == 3)
 	{
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
 			cp_back2<LN, UL>(buf_of(tid), st, lt);
-			if (live(tid)) cp_store_conv<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
+			if (live(tid)) cp_store_conv<LN, UL, MODE>(L, st, k_of(tid), chA, chB, bvalid, lt);
 		});
 	}
 	else if constexpr (MODE == 4)

@@ -526,7 +526,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 						dev_upload(d.spec2, s2.data(), s2.size() * sizeof(double));
 					}
 				}
-				if (convp_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2))
+				if (convp_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2) ||
+					convp_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2))
 				{
 					const std::vector<double> hp = pair_constants(H, g.n_in, g.n_out);
 					d.hp = (cd*) dev_alloc(hp.size() * sizeof(double));
@@ -758,11 +759,8 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 			*kernel = fuse_with_next(stage) ?
 				(use_pair(sp.cg) ? "k_convp_whole" : "k_convx_whole") :
 				sp.cg.complex_h ? "k_conv" :
-				((opt_.at("fast_conv") || !generic_conv_fits(sp.cg)) && (convx_mode3_ok(sp.cg.n_in,
-				sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2, sp.cg.down_pow2) ||
-				fast_geometry(sp.cg)) ?
-				(use_pair(sp.cg) && !convx_mode3_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down,
-				sp.cg.up_pow2, sp.cg.down_pow2) ? "k_convp" : "k_convx") : "k_conv");
+				conv_path(sp.cg) == kPathGeneric ? "k_conv" :
+				(conv_path(sp.cg) == kPathPair || conv_path(sp.cg) == kPathPair3 ? "k_convp" : "k_convx");
 			break;
 		case kFrac: *kernel = sp.whole ? "k_whole" : "k_poly"; break;
 		case kHBUp: *kernel = group_len(stage) > 1 ? "k_hbcascade" : "k_hbup"; break;
@@ -961,14 +959,15 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		L.nblk = (int) (k1 - L.k0 + 1);
 		L.a = a; L.b = b;
 		L.dst = dst;
-		const bool m3 = convx_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
-		if (!g.complex_h && (opt_.at("fast_conv") || !generic_conv_fits(g)) && (m3 || fast_geometry(g)))
+		const int path = conv_path(g);
+		if (path != kPathGeneric)
 		{
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0; X.run_off = 0;
 			X.ptab = nullptr; X.ctab = nullptr; X.nsets = 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
-			if (m3) launch_convx(X, 3, stream);
-			else if (use_pair(g)) launch_convp(X, 0, stream);
+			if (path == kPathPair3) launch_convp(X, 3, stream);
+			else if (path == kPathConvx3) launch_convx(X, 3, stream);
+			else if (path == kPathPair) launch_convp(X, 0, stream);
 			else launch_convx(X, 0, stream);
 			if (L.tail_ring != nullptr) tail_done_ = true;
 		}
@@ -1322,6 +1321,18 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 	launch_hbcascade(L, stream);
 }
 
+// which kernel family runs a (not fused) convolver stage
+int Engine::conv_path(const ConvGeom& g) const
+{
+	if (g.complex_h || !(opt_.at("fast_conv") || !generic_conv_fits(g))) return kPathGeneric;
+	if (opt_.at("pair_conv") && convp_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2))
+		return kPathPair3;
+	if (convx_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2)) return kPathConvx3;
+	if (use_pair(g)) return kPathPair;
+	if (convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2)) return kPathConvx;
+	return kPathGeneric;
+}
+
 // some compile-time-sized kernel (r8b_convx.h or r8b_convp.h) is instantiated for the geometry
 bool Engine::fast_geometry(const ConvGeom& g) const
 {
@@ -1379,7 +1390,13 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	for (int i = 0; i < L.n_inv; i++) L.inv_radix[i] = d.inv_radix[(size_t) i];
 	L.H = d.H; L.Hc = d.Hc; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.spec2 = d.spec2; L.hp = d.hp; L.ptw = d.ptw;
 	L.nch = nch_;
-	L.threads = opt_.at("conv_threads");
+	// (short transforms: fewer threads per block -- a 64-point transform on 256 threads is four waves
+	// meeting at barriers with nothing to do)
+	{
+		int th = 64;
+		while (th < opt_.at("conv_threads") && th * 8 < std::max(g.n_in, g.n_out)) th *= 2;
+		L.threads = std::min(th, opt_.at("conv_threads"));
+	}
 	L.src = src;
 	L.tail_ring = nullptr; L.tail_p0 = L.tail_p1 = 0;
 	if (s == 0 && opt_.at("fold_tail"))

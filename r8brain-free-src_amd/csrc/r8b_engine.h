@@ -93,6 +93,8 @@ private:
 	bool fuse_with_next(size_t s) const;
 	bool use_pair(const ConvGeom& g) const;
 	bool fast_geometry(const ConvGeom& g) const;
+	enum { kPathGeneric, kPathConvx, kPathConvx3, kPathPair, kPathPair3 };
+	int conv_path(const ConvGeom& g) const;
 	bool latency_chain() const; // some stage carries fractional-latency state (minimum phase): no fusing
 	bool use_pair_two(size_t s, int* run_off) const;
 	void prepare_two_phase(size_t s);

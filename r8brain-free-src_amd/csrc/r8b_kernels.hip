@@ -633,10 +633,12 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 	int ln = 0;
 	while ((1 << ln) < X.c.n_in) ln++;
 	const bool wide = X.flen > 24;
+	const int up = X.c.up_pow2 ? X.c.up : 1; // (mode 3: a 3x zero-stuffed input is 1:1 for the transforms)
 #define R8B_CONVP_DISPATCH(LN, UL) \
-	if (ln == LN && X.c.up == (1 << UL)) \
+	if (ln == LN && up == (1 << UL)) \
 	{ \
 		if (mode == 0) launch_convp_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
+		else if (mode == 3) launch_convp_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
 		else if (mode == 4) launch_convp_t<LN, UL, 4, 24>(X, (hipStream_t) stream); \
 		else if (wide) launch_convp_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
 		else launch_convp_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \

@@ -247,6 +247,16 @@ inline bool convp_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow
 	if (!up_pow2 || down != 1 || (up != 1 && up != 2) || n_out != n_in * up) return false;
 	return n_out == 64 || n_out == 128 || n_out == 256 || n_out == 512 || n_out == 1024 || n_out == 2048 || n_out == 4096;
 }
+// MODE 3 of the pair form: 3x zero stuffing in the load and / or 3x strided decimation in the store
+// around a 1:1 or 2x-up transform pair -- ratios 3/1, 1/3, 2/3 (3/2 and 3/4 decimate by a power of two
+// in the spectrum: r8b_convx.h)
+inline bool convp_mode3_ok(int n_in, int n_out, int up, int down, bool up_pow2, bool down_pow2)
+{
+	if (!((!up_pow2 && up == 3) || (!down_pow2 && down == 3))) return false;
+	if (up_pow2 ? (up != 1 && up != 2) : up != 3) return false;
+	if (down != 1 && (down_pow2 || down != 3)) return false; // (down_pow2 is false for down = 1)
+	return convp_geometry_ok(n_in, n_out, up_pow2 ? up : 1, 1, true);
+}
 #define R8B_CONVP_GEOMS(M) M(11, 1) M(12, 0) M(10, 1) M(11, 0) M(9, 1) M(10, 0) M(8, 1) M(9, 0) M(7, 1) M(8, 0) \
 	M(6, 1) M(7, 0) M(5, 1) M(6, 0)
 
@@ -264,7 +274,7 @@ void launch_pcm_in(const PcmLaunch& L, void* stream);  // PCM -> planar fp64
 void launch_pcm_out(const PcmLaunch& L, void* stream); // planar fp64 -> PCM
 // mode 0: convolver output to X.c.dst; mode 1: fused interpolator output to X.wdst; mode 3: radix-3 edges
 void launch_convx(const ConvxLaunch& X, int mode, void* stream);
-// the same work in pair form (modes 0, 1 and 4; needs X.c.hp)
+// the same work in pair form (modes 0, 1, 3 and 4; needs X.c.hp)
 void launch_convp(const ConvxLaunch& X, int mode, void* stream);
 
 // memory helpers; all throw std::runtime_error with the HIP error text on failure

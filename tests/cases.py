@@ -68,6 +68,11 @@ SHORT_CASES = [
     (96000.0, 44100.0, 2048, 2048, 8192, 45.0, 109.56, "fft=128/128"),
     (44100.0, 96000.0, 2048, 1111, 6000, 45.0, 49.0, "fft=32/64"),         # 4 threads per block; run does not
     (96000.0, 44100.0, 1024, 1024, 6000, 45.0, 49.0, "fft=64/64"),         # fit the block's array: unfused
+    (44100.0, 132300.0, 2048, 1500, 9000, 10.0, 109.56, "io=3/1"),         # 3x zero stuffing in the pair load
+    (96000.0, 32000.0, 4096, 4096, 20000, 10.0, 109.56, "io=1/3"),         # 3x strided store from registers
+    (48000.0, 32000.0, 2048, 900, 12000, 5.0, 109.56, "io=2/3"),           # 2x up transform + strided store
+    (44100.0, 132300.0, 1024, 1024, 6000, 45.0, 49.0, "io=3/1"),
+    (48000.0, 16000.0, 2048, 2048, 12000, 2.0, 109.56, "io=1/3"),          # 4096-point blocks
 ]
 
 

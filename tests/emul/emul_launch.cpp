@@ -254,10 +254,12 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 	int ln = 0;
 	while ((1 << ln) < X.c.n_in) ln++;
 	const bool wide = X.flen > 24;
+	const int up = X.c.up_pow2 ? X.c.up : 1;
 #define R8B_CONVP_DISPATCH(LN, UL) \
-	if (ln == LN && X.c.up == (1 << UL)) \
+	if (ln == LN && up == (1 << UL)) \
 	{ \
 		if (mode == 0) emul_convp_t<LN, UL, 0, 24>(X); \
+		else if (mode == 3) emul_convp_t<LN, UL, 3, 24>(X); \
 		else if (mode == 4) emul_convp_t<LN, UL, 4, 24>(X); \
 		else if (wide) emul_convp_t<LN, UL, 1, 32>(X); \
 		else emul_convp_t<LN, UL, 1, 24>(X); \
