@@ -55,26 +55,37 @@ R8B_HD int pswz(int e) { return e ^ ((e >> 4) & 15); }
 template<int LN, int UL>
 struct ConvpGeom
 {
+	// UL = 0: 1:1; 1: 2x up-sampling; -1 / -2: 2x / 4x decimation in the spectrum
 	static constexpr int N = 1 << LN, LN2 = LN + UL, N2 = 1 << LN2;
-	static_assert(N2 >= 64 && N2 <= 4096 && (UL == 0 || UL == 1), "pair kernel: 64 ... 4096-point backward transforms");
-	static constexpr int NT = N2 / 16;            // threads per block pair
-	static constexpr int SUB = kConvpThreads / NT; // block pairs per workgroup
-	static constexpr int E1 = N / NT, E2 = 16;    // elements per thread, forward / backward
-	static constexpr int EB1 = 4 - UL;
+	static constexpr int DL = UL < 0 ? -UL : 0;
+	static_assert(N <= 4096 && N2 <= 4096 && (N >= 64 || N2 >= 64) && N2 >= 16 && UL >= -2 && UL <= 1,
+		"pair kernel: transforms of 64 ... 4096 points");
+	static constexpr int NA = N > N2 ? N : N2;        // a block pair's part of the array (complex elements)
+	static constexpr int NT = NA / 16;                // threads per block pair
+	static constexpr int SUB = kConvpThreads / NT;     // block pairs per workgroup
+	static constexpr int E1 = N / NT, E2 = N2 / NT;    // elements per thread, forward / backward
+	static constexpr int EB1 = UL == 1 ? 3 : 4;
 	static constexpr int NPRE = (LN - 1) / EB1;   // forward passes before the middle one (radix E1)
 	static constexpr int MB = LN - NPRE * EB1;    // log2 radix of the forward butterflies in the middle pass
 	static constexpr int RM = 1 << MB, NBF = E1 / RM;
-	// backward passes after the middle one (sub-length 16): sub-length 256 (radix 16; B1: only when N2 >=
-	// 256), then sub-length N2 (none when N2 = 256): radix R2, NB2 butterflies per thread
+	// backward passes after the middle one, E2 = 16 (sub-length 16): sub-length 256 (radix 16; B1: only
+	// when N2 >= 256), then sub-length N2 (none when N2 = 256): radix R2, NB2 butterflies per thread
 	static constexpr bool B1 = N2 >= 256;
 	static constexpr int R2 = B1 ? N2 / 256 : N2 / 16, NB2 = R2 > 1 ? 16 / R2 : 0;
 	static constexpr int NBASE2 = R2 >= 16 ? 6 : (R2 >= 8 ? 4 : (R2 >= 4 ? 3 : 1));
 	static constexpr int NTW = NB2 * NBASE2 > 6 ? NB2 * NBASE2 : 6;
+	// decimating form (E2 = 8 or 4), the mirror image of the forward side: the middle pass does the
+	// first MB2 bits (NBB butterflies of radix RMB over the thread's E2 consecutive positions), then
+	// NPOST passes of radix E2, one butterfly per thread, sub-lengths RMB E2, RMB E2^2, ..., N2
+	static constexpr int EB2 = 4 - DL;
+	static constexpr int NPOST = DL ? (LN2 - 1) / EB2 : 0;
+	static constexpr int MB2 = LN2 - NPOST * EB2, RMB = 1 << MB2, NBB = E2 / RMB;
 	// Wave w of a block pair (NW waves each) owns forward positions [w N/NW, (w+1) N/NW) after the first
 	// pass and backward positions [w N2/NW, (w+1) N2/NW) up to the last pass: the passes in between
-	// never leave that range (their butterflies span at most 64 E1 / 1024 consecutive elements), so they
-	// need no workgroup barrier -- provided the wave's forward data lives where its backward data will:
-	// forward position p sits at slot fslot(p) = (p / FW) * BW + p mod FW  (the identity when N2 = N or
+	// never leave that range (their butterflies span at most 64 E1 / 64 E2 consecutive elements), so they
+	// need no workgroup barrier -- provided the wave's forward and backward data share one part of the
+	// array: with 2x up-sampling forward position p sits at slot fslot(p) = (p / FW) * BW + p mod FW, when
+	// decimating backward position p at bslot(p) = (p / BW) * FW + p mod BW  (the identity when N2 = N or
 	// when a block pair fits one wave).
 	static constexpr int NW = NT >= 64 ? NT / 64 : 1;
 	static constexpr int FW = N / NW, BW = N2 / NW;
@@ -96,8 +107,16 @@ template<int LN, int UL>
 R8B_HD int fslot(int p)
 {
 	typedef ConvpGeom<LN, UL> G;
-	if constexpr (UL == 0 || G::NW == 1) return pswz(p);
+	if constexpr (UL <= 0 || G::NW == 1) return pswz(p);
 	else return pswz((p / G::FW) * G::BW + (p & (G::FW - 1)));
+}
+
+template<int LN, int UL>
+R8B_HD int bslot(int p)
+{
+	typedef ConvpGeom<LN, UL> G;
+	if constexpr (UL >= 0 || G::NW == 1) return pswz(p);
+	else return pswz((p / G::BW) * G::FW + (p & (G::BW - 1)));
 }
 
 template<int LN, int UL>
@@ -229,8 +248,9 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 			return;
 		}
 	}
-	const int iln = L.in_len >> UL; // (L.up == 1 << UL)
-	const long long base = (k * (long long) L.blk_stride + L.blk_offset) >> UL; // (>= 0, even)
+	constexpr int US = UL > 0 ? UL : 0; // (L.up == 1 << US)
+	const int iln = L.in_len >> US;
+	const long long base = (k * (long long) L.blk_stride + L.blk_offset) >> US; // (>= 0, even)
 	// most blocks of a call lie entirely inside the caller's buffer: one uniform row pointer per channel
 	// and a 32-bit offset per load (the general form selects ring / buffer / zero per sample: ~12
 	// vector instructions per load)
@@ -315,8 +335,10 @@ struct ConvpPre
 template<int LN, int UL>
 R8B_HD void cp_hp_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 {
+	// (decimating form: H of the thread's kept positions 2c, 2c + 1)
+	constexpr int NHP = UL < 0 ? ConvpGeom<LN, UL>::E2 / 2 : 8;
 #pragma unroll
-	for (int c = 0; c < 8; c++)
+	for (int c = 0; c < NHP; c++)
 	{
 		st.hp[c] = L.hp[c * ConvpGeom<LN, UL>::NT + lt];
 	}
@@ -449,6 +471,142 @@ R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 				st.vr[m + NB * p] = ar[p];
 				st.vi[m + NB * p] = ai[p];
 			}
+		}
+	}
+}
+
+// ---- decimating form (UL < 0) -------------------------------------------------------------------------
+// The reference decimates by 2^d in the spectrum (CDSPBlockConvolver.h:329-344): the backward transform has
+// N2 = N / D points and keeps the bins below the new Nyquist frequency, k < N2/2 and k > N - N2/2 -- in the
+// bit-reversed order the forward transform leaves them in, the positions p with p mod 2D = 0 or 2D - 1,
+// which land at backward position p >> d.  A thread therefore keeps E2 = 16 / D of its 16 consecutive
+// forward positions, as its E2 consecutive backward positions.  The new Nyquist bin (backward position 1,
+// thread 0) is the reference's fix-up: per channel the REAL value H[m] (Re X[m] + Im X[m]), m = N2 / 2,
+// X = that channel's spectrum, from the forward bins m and N - m (positions D and 2D - 1).
+// hp[c * NT + t] = H of the thread's kept positions 2c, 2c + 1.
+template<int LN, int UL>
+R8B_HD void cp_middle_compute_down(const cd* buf, ConvpState<LN, UL>& st, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int D = 1 << G::DL;
+	double zr[16], zi[16];
+#pragma unroll
+	for (int c = 0; c < 16; c++)
+	{
+		const cd v = buf[pswz(16 * lt + c)];
+		zr[c] = v.re;
+		zi[c] = v.im;
+	}
+#pragma unroll
+	for (int f = 0; f < G::NBF; f++) dif_regs<G::RM>(zr + G::RM * f, zi + G::RM * f);
+#pragma unroll
+	for (int c = 0; c < G::E2; c++)
+	{
+		const int src = 2 * D * (c >> 1) + ((c & 1) ? 2 * D - 1 : 0);
+		const double h = (c & 1) ? st.hp[c >> 1].im : st.hp[c >> 1].re;
+		st.vr[c] = zr[src] * h;
+		st.vi[c] = zi[src] * h;
+	}
+	if (lt == 0)
+	{
+		// P = Z[m], Q = Z[N - m]: X_A = (P + conj Q) / 2, X_B = (P - conj Q) / 2i
+		const double pr = zr[D], pi = zi[D], qr = zr[2 * D - 1], qi = zi[2 * D - 1];
+		const double h = st.hp[0].im;
+		st.vr[1] = h * (0.5 * ((pr + qr) + (pi - qi)));
+		st.vi[1] = h * (0.5 * ((pi + qi) - (pr - qr)));
+	}
+#pragma unroll
+	for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
+}
+
+template<int LN, int UL>
+R8B_HD void cp_middle_write_down(cd* buf, const ConvpState<LN, UL>& st, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+#pragma unroll
+	for (int p = 0; p < G::E2; p++)
+	{
+		cd v;
+		v.re = st.vr[p];
+		v.im = st.vi[p];
+		buf[bslot<LN, UL>(G::E2 * lt + p)] = v;
+	}
+}
+
+// backward pass I (1 <= I <= NPOST) of the decimating form: sub-length RMB E2^I, radix E2, one butterfly
+// per thread; twiddles in slot 2 + I.  The last one (sub-length N2: the thread's elements lt + NT p = (y_A,
+// y_B) at circular time lt + NT p of the decimated block) keeps its results in st.vr / st.vi.
+template<int LN, int UL, int I>
+struct ConvpPost
+{
+	typedef ConvpGeom<LN, UL> G;
+	static constexpr int n = G::RMB << (I * G::EB2);
+	static R8B_HD void prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
+	{
+		ptw_fetch<G::E2, G::NT>(st.tw, L.ptw, 2 + I, lt);
+	}
+	static R8B_HD void run(cd* buf, ConvpState<LN, UL>& st, int lt)
+	{
+		constexpr int R = G::E2, q = n / R;
+		const int blk = lt / q, j = lt - blk * q;
+		const int e0 = blk * n + j;
+		double vr[R], vi[R];
+#pragma unroll
+		for (int p = 0; p < R; p++)
+		{
+			const cd v = buf[bslot<LN, UL>(e0 + p * q)];
+			vr[p] = v.re;
+			vi[p] = v.im;
+		}
+#pragma unroll
+		for (int p = 1; p < R; p++)
+		{
+			const cd w = tw_get(st.tw, bitrev_c<R>(p));
+			const double tr = vr[p] * w.re + vi[p] * w.im;
+			const double ti = vi[p] * w.re - vr[p] * w.im;
+			vr[p] = tr;
+			vi[p] = ti;
+		}
+		dit_regs<R>(vr, vi);
+#pragma unroll
+		for (int p = 0; p < R; p++)
+		{
+			if constexpr (I == G::NPOST)
+			{
+				st.vr[p] = vr[p];
+				st.vi[p] = vi[p];
+			}
+			else
+			{
+				cd v;
+				v.re = vr[p];
+				v.im = vi[p];
+				buf[bslot<LN, UL>(e0 + p * q)] = v;
+			}
+		}
+	}
+};
+
+// K7 of the decimating form, from the registers: output q sits at virtual time q * down; the block's first
+// one is (block start) / down - floor(fl2 / down), in_len and the block starts being multiples of down
+// (reference CDSPBlockConvolver.h:150-165; cf. cx_store_conv)
+template<int LN, int UL>
+R8B_HD void cp_store_conv_down(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int chA,
+	int chB, bool bvalid, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int mask = G::N2 - 1;
+	const int fl2 = L.fl2 >> G::DL, n = L.in_len >> G::DL;
+	const long long q0 = ((k * (long long) L.blk_stride + L.blk_offset) >> G::DL) - fl2;
+#pragma unroll
+	for (int p = 0; p < G::E2; p++)
+	{
+		const int u = (lt + G::NT * p + fl2) & mask;
+		const long long q = q0 + u;
+		if (u < n && q >= L.a && q < L.b)
+		{
+			dst_store(L.dst, chA, q, st.vr[p]);
+			if (bvalid) dst_store(L.dst, chB, q, st.vi[p]);
 		}
 	}
 }
@@ -737,7 +895,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	// (they take part in every barrier) and store nothing
 	auto sub_of = [&](int tid) { return convp_sub<LN, UL>(tid); };
 	auto lt_of = [&](int tid) { return convp_lt<LN, UL>(tid); };
-	auto buf_of = [&](int tid) { return buf + sub_of(tid) * G::N2; };
+	auto buf_of = [&](int tid) { return buf + sub_of(tid) * G::NA; };
 	auto k_of = [&](int tid)
 	{
 		if constexpr (G::SUB == 1) return cur.k;
@@ -777,6 +935,52 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	};
 	// (two steps: every lane has read its forward data before any lane's backward data overwrites it --
 	// on the GPU program order alone guarantees that, LDS serves a wave's accesses in issue order)
+	if constexpr (UL < 0)
+	{
+		// decimating form: steps a geometry does not have are empty
+		auto d_pre1 = [&](int tid, St& st)
+		{
+			if constexpr (G::NPRE > 1) s_pre1(tid, st);
+		};
+		auto d_midc = [&](int tid, St& st)
+		{
+			const int lt = lt_of(tid);
+			cp_middle_compute_down<LN, UL>(buf_of(tid), st, lt);
+			ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
+		};
+		auto d_midw = [&](int tid, St& st) { cp_middle_write_down<LN, UL>(buf_of(tid), st, lt_of(tid)); };
+		auto d_post1 = [&](int tid, St& st)
+		{
+			if constexpr (G::NPOST > 1)
+			{
+				const int lt = lt_of(tid);
+				ConvpPost<LN, UL, 1>::run(buf_of(tid), st, lt);
+				ConvpPost<LN, UL, 2>::prefetch(L, st, lt);
+			}
+		};
+		auto d_post2 = [&](int tid, St& st)
+		{
+			if constexpr (G::NPOST > 2)
+			{
+				const int lt = lt_of(tid);
+				ConvpPost<LN, UL, 2>::run(buf_of(tid), st, lt);
+				ConvpPost<LN, UL, 3>::prefetch(L, st, lt);
+			}
+		};
+		auto d_post3 = [&](int tid, St& st)
+		{
+			if constexpr (G::NPOST > 3)
+			{
+				const int lt = lt_of(tid);
+				ConvpPost<LN, UL, 3>::run(buf_of(tid), st, lt);
+				ConvpPost<LN, UL, 4>::prefetch(L, st, lt);
+			}
+		};
+		static_assert(G::NPRE <= 2 && G::NPOST >= 1 && G::NPOST <= 4, "pair kernel, decimating: pass plan");
+		ex.wave_steps(d_pre1, d_midc, d_midw, d_post1, d_post2, d_post3);
+	}
+	else
+	{
 	auto s_midc = [&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
@@ -797,6 +1001,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	else if constexpr (G::NPRE == 2) ex.wave_steps(s_pre1, s_midc, s_midw);
 	else if constexpr (G::B1) ex.wave_steps(s_midc, s_midw, s_b1);
 	else ex.wave_steps(s_midc, s_midw);
+	}
 	// history for the next call (stage 0 only): the first block's workgroup copies the tail of
 	// the caller's buffers into the other history ring; the stores need no wait
 	if (L.tail_ring != nullptr && cur.k == L.k0)
@@ -813,7 +1018,17 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 			}
 		});
 	}
-	if constexpr (MODE == 0 || MODE == 3)
+	if constexpr (UL < 0)
+	{
+		static_assert(MODE == 0 || MODE == 3, "the decimating form has no fused interpolator");
+		ex.each([&](int tid, St& st)
+		{
+			const int lt = lt_of(tid);
+			ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
+			if (live(tid)) cp_store_conv_down<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
+		});
+	}
+	else if constexpr (MODE == 0 || MODE == 3)
 	{
 		ex.each([&](int tid, St& st)
 		{
@@ -837,7 +1052,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		ex.each([&](int, St& st)
 		{
 			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
-				cp_whole2_compute(X, buf + sb * G::N2, st.rows2, st.pt, cur.k + sb, chA, chB, bvalid);
+				cp_whole2_compute(X, buf + sb * G::NA, st.rows2, st.pt, cur.k + sb, chA, chB, bvalid);
 		});
 	}
 	else
@@ -854,7 +1069,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		ex.each([&](int tid, St& st)
 		{
 			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
-				cp_whole_compute<FLENP>(X, buf + sb * G::N2, st.row, cur.k + sb, chA, chB, bvalid, tid);
+				cp_whole_compute<FLENP>(X, buf + sb * G::NA, st.row, cur.k + sb, chA, chB, bvalid, tid);
 		});
 	}
 }

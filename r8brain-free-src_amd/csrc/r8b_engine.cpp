@@ -327,10 +327,11 @@ std::vector<double> spectral_constants_by_position(const std::vector<double>& sc
 
 std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n_out)
 {
-	const int N = n_in, N2 = n_out, up = N2 / N, NT = N2 / 16;
+	const int N = n_in, N2 = n_out, NT = std::max(N, N2) / 16;
 	int ln = 0;
 	while ((1 << ln) < N) ln++;
-	auto Hf = [&](int m) -> long double { return H[(size_t) (m <= N2 / 2 ? m : N2 - m)]; };
+	const int NH = std::max(N, N2);
+	auto Hf = [&](int m) -> long double { return H[(size_t) (m <= NH / 2 ? m : NH - m)]; };
 	auto rev = [](int v, int bits)
 	{
 		int r = 0;
@@ -339,6 +340,20 @@ std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n
 		return r;
 	};
 	std::vector<double> out((size_t) 8 * NT * 2, 0.0);
+	if (N2 < N)
+	{
+		// decimating form (r8b_convp.h cp_middle_compute_down): thread t keeps the forward positions
+		// 16 t + 2 D (c' / 2) + (c' odd ? 2 D - 1 : 0), c' = 0 .. 16 / D - 1; entry (c, t) = H of c' = 2c, 2c + 1
+		const int D = N / N2, E2 = 16 / D;
+		for (int t = 0; t < NT; t++)
+			for (int cp = 0; cp < E2; cp++)
+			{
+				const int p = 16 * t + 2 * D * (cp >> 1) + ((cp & 1) ? 2 * D - 1 : 0);
+				out[((size_t) (cp >> 1) * NT + t) * 2 + (cp & 1)] = (double) Hf(rev(p, ln));
+			}
+		return out;
+	}
+	const int up = N2 / N;
 	for (int t = 0; t < NT; t++)
 		for (int c = 0; c < 8; c++)
 		{
@@ -360,11 +375,23 @@ std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n
 
 std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int n_in, int n_out)
 {
-	// rows of NT entries (r8b_convp.h ptw_fetch): 6 per slot; slots 0-2 forward passes (radix e1), 3 the
-	// backward pass with sub-length 256, 4 + m butterfly m of the last backward pass (sub-length n_out)
-	const int NT = n_out / 16, e1 = n_in / NT, r2 = n_out >= 256 ? n_out / 256 : n_out / 16;
+	// rows of NT entries (r8b_convp.h ptw_fetch): 6 per slot; slots 0-2 forward passes (radix e1); then,
+	// 1:1 / 2x up: 3 the backward pass with sub-length 256, 4 + m butterfly m of the last backward pass
+	// (sub-length n_out); decimating: 2 + I backward pass I (radix e2, sub-length rmb e2^I)
+	const int NT = std::max(n_in, n_out) / 16, e1 = n_in / NT, e2 = n_out / NT;
+	const bool dec = n_out < n_in;
+	int npost = 0, rmb = 1;
+	if (dec)
+	{
+		int ln2 = 0, eb2 = 0;
+		while ((1 << ln2) < n_out) ln2++;
+		while ((1 << eb2) < e2) eb2++;
+		npost = (ln2 - 1) / eb2;
+		rmb = 1 << (ln2 - npost * eb2);
+	}
+	const int r2 = n_out >= 256 ? n_out / 256 : n_out / 16;
 	const int nb2 = r2 > 1 ? 16 / r2 : 0;
-	const int nslots = 4 + nb2;
+	const int nslots = dec ? 3 + npost : 4 + nb2;
 	std::vector<double> out((size_t) nslots * 6 * NT * 2, 0.0);
 	static const int mult[6] = { 1, 2, 3, 4, 8, 12 };
 	for (int slot = 0; slot < nslots; slot++)
@@ -376,6 +403,12 @@ std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int
 			for (int i = 0; i < slot; i++) n /= e1;
 			jmod = n / e1; // butterflies per sub-transform
 			if (n < 2 * e1) continue;
+		}
+		else if (dec)
+		{
+			n = rmb;
+			for (int i = 0; i < slot - 2; i++) n *= e2;
+			jmod = n / e2;
 		}
 		else if (slot == 3)
 		{

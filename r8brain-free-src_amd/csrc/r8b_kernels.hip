@@ -644,6 +644,19 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 		else launch_convp_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
 		return; \
 	}
+	if (X.c.down_pow2 && X.c.down > 1)
+	{
+#define R8B_CONVP_DISPATCH_DOWN(LN, DL) \
+		if (ln == LN && X.c.down == (1 << DL)) \
+		{ \
+			if (mode == 3) launch_convp_t<LN, -DL, 3, 24>(X, (hipStream_t) stream); \
+			else launch_convp_t<LN, -DL, 0, 24>(X, (hipStream_t) stream); \
+			return; \
+		}
+		R8B_CONVP_GEOMS_DOWN(R8B_CONVP_DISPATCH_DOWN)
+#undef R8B_CONVP_DISPATCH_DOWN
+		throw std::runtime_error("launch_convp: decimating geometry not instantiated");
+	}
 	R8B_CONVP_GEOMS(R8B_CONVP_DISPATCH)
 #undef R8B_CONVP_DISPATCH
 	throw std::runtime_error("launch_convp: geometry not instantiated");

@@ -244,21 +244,33 @@ inline bool convx_mode3_ok(int n_in, int n_out, int up, int down, bool up_pow2, 
 // of 64 ... 4096 points, 1:1 or 2x up-sampled (below 4096 points a workgroup carries several blocks)
 inline bool convp_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
 {
-	if (!up_pow2 || down != 1 || (up != 1 && up != 2) || n_out != n_in * up) return false;
-	return n_out == 64 || n_out == 128 || n_out == 256 || n_out == 512 || n_out == 1024 || n_out == 2048 || n_out == 4096;
+	if (!up_pow2 || (up != 1 && up != 2)) return false;
+	if (down == 2 || down == 4)
+	{
+		// 2x / 4x decimation in the spectrum (the caller passes down_pow2 geometries only)
+		if (up != 1 || n_out * down != n_in) return false;
+		return n_in <= 4096 && n_in >= 64 && (n_in & (n_in - 1)) == 0;
+	}
+	if (down != 1 || n_out != n_in * up) return false;
+	return n_out == 64 || n_out == 128 || n_out == 256 || n_out == 512 || n_out == 1024 || n_out == 2048 ||
+		n_out == 4096;
 }
 // MODE 3 of the pair form: 3x zero stuffing in the load and / or 3x strided decimation in the store
 // around a 1:1 or 2x-up transform pair -- ratios 3/1, 1/3, 2/3 (3/2 and 3/4 decimate by a power of two
-// in the spectrum: r8b_convx.h)
+// in the spectrum as well: the decimating form of the pair transforms)
 inline bool convp_mode3_ok(int n_in, int n_out, int up, int down, bool up_pow2, bool down_pow2)
 {
 	if (!((!up_pow2 && up == 3) || (!down_pow2 && down == 3))) return false;
 	if (up_pow2 ? (up != 1 && up != 2) : up != 3) return false;
-	if (down != 1 && (down_pow2 || down != 3)) return false; // (down_pow2 is false for down = 1)
-	return convp_geometry_ok(n_in, n_out, up_pow2 ? up : 1, 1, true);
+	// (down_pow2 is false for down = 1)
+	if (down != 1 && !(down_pow2 ? (down == 2 || down == 4) : down == 3)) return false;
+	return convp_geometry_ok(n_in, n_out, up_pow2 ? up : 1, down_pow2 ? down : 1, true);
 }
 #define R8B_CONVP_GEOMS(M) M(11, 1) M(12, 0) M(10, 1) M(11, 0) M(9, 1) M(10, 0) M(8, 1) M(9, 0) M(7, 1) M(8, 0) \
 	M(6, 1) M(7, 0) M(5, 1) M(6, 0)
+// decimating form: (log2 forward length, log2 decimation)
+#define R8B_CONVP_GEOMS_DOWN(M) M(12, 1) M(11, 1) M(10, 1) M(9, 1) M(8, 1) M(7, 1) M(6, 1) \
+	M(12, 2) M(11, 2) M(10, 2) M(9, 2) M(8, 2) M(7, 2) M(6, 2)
 
 // launchers (asynchronous on `stream`, a hipStream_t)
 void launch_conv(const ConvLaunch& L, void* stream);

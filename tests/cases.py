@@ -73,6 +73,18 @@ SHORT_CASES = [
     (48000.0, 32000.0, 2048, 900, 12000, 5.0, 109.56, "io=2/3"),           # 2x up transform + strided store
     (44100.0, 132300.0, 1024, 1024, 6000, 45.0, 49.0, "io=3/1"),
     (48000.0, 16000.0, 2048, 2048, 12000, 2.0, 109.56, "io=1/3"),          # 4096-point blocks
+    # 2x / 4x decimation in the spectrum (incl. the reference's Nyquist fix-up, visible at low attenuation)
+    (88200.0, 44100.0, 4096, 1000, 24000, 2.0, 180.15, "fft=4096/2048"),
+    (88200.0, 44100.0, 4096, 4096, 24000, 2.0, 109.56, "fft=2048/1024"),
+    (96000.0, 48000.0, 2048, 700, 16000, 10.0, 109.56, "io=1/2"),
+    (88200.0, 44100.0, 2048, 2048, 12000, 30.0, 60.0, "io=1/2"),
+    (88200.0, 44100.0, 2048, 333, 8000, 45.0, 49.0, "fft=64/32"),
+    (176400.0, 44100.0, 4096, 3000, 30000, 5.0, 109.56, "io=1/2"),         # half-band down, then 2x decimating
+    (32000.0, 48000.0, 2048, 2048, 16000, 2.0, 109.56, "io=3/2"),          # 3x zero stuffing + 2x decimation
+    (32000.0, 48000.0, 1024, 500, 8000, 45.0, 49.0, "io=3/2"),
+    (64000.0, 48000.0, 2048, 1100, 16000, 2.0, 109.56, "io=3/4"),          # 4x decimation
+    (64000.0, 48000.0, 2048, 2048, 12000, 10.0, 109.56, "io=3/4"),
+    (64000.0, 48000.0, 1024, 1024, 8000, 45.0, 49.0, "io=3/4"),
 ]
 
 

@@ -252,7 +252,7 @@ def test_hip_short_filters_in_block_groups(torch, case, nch):
     b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, device=0)
     assert frag in b.describe(), b.describe()
     b.set_option("timing", 1)
-    assert b.stage_timings()[0][0].startswith("k_convp"), b.stage_timings()
+    assert any(t[0].startswith("k_convp") for t in b.stage_timings()), b.stage_timings()
     b.set_option("timing", 0)
     r, p = compare_stream(b, src, dst, maxin, chunk, n, tb, att, nch)
     assert r <= RMS_TOL and p <= PEAK_TOL, (r, p)
