@@ -58,11 +58,12 @@ struct ConvpGeom
 	// UL = 0: 1:1; 1: 2x up-sampling; -1 / -2: 2x / 4x decimation in the spectrum
 	static constexpr int N = 1 << LN, LN2 = LN + UL, N2 = 1 << LN2;
 	static constexpr int DL = UL < 0 ? -UL : 0;
-	static_assert(N <= 4096 && N2 <= 4096 && (N >= 64 || N2 >= 64) && N2 >= 16 && UL >= -2 && UL <= 1,
-		"pair kernel: transforms of 64 ... 4096 points");
+	static_assert(N <= 8192 && N2 <= 8192 && (N >= 64 || N2 >= 64) && N2 >= 16 && UL >= -2 && UL <= 1,
+		"pair kernel: transforms of 64 ... 8192 points");
 	static constexpr int NA = N > N2 ? N : N2;        // a block pair's part of the array (complex elements)
 	static constexpr int NT = NA / 16;                // threads per block pair
-	static constexpr int SUB = kConvpThreads / NT;     // block pairs per workgroup
+	static constexpr int WT = NT > kConvpThreads ? NT : kConvpThreads; // threads per workgroup (512 for 8192 points)
+	static constexpr int SUB = WT / NT;               // block pairs per workgroup
 	static constexpr int E1 = N / NT, E2 = N2 / NT;    // elements per thread, forward / backward
 	static constexpr int EB1 = UL == 1 ? 3 : 4;
 	static constexpr int NPRE = (LN - 1) / EB1;   // forward passes before the middle one (radix E1)
@@ -74,11 +75,13 @@ struct ConvpGeom
 	static constexpr int R2 = B1 ? N2 / 256 : N2 / 16, NB2 = R2 > 1 ? 16 / R2 : 0;
 	static constexpr int NBASE2 = R2 >= 16 ? 6 : (R2 >= 8 ? 4 : (R2 >= 4 ? 3 : 1));
 	static constexpr int NTW = NB2 * NBASE2 > 6 ? NB2 * NBASE2 : 6;
-	// decimating form (E2 = 8 or 4), the mirror image of the forward side: the middle pass does the
-	// first MB2 bits (NBB butterflies of radix RMB over the thread's E2 consecutive positions), then
-	// NPOST passes of radix E2, one butterfly per thread, sub-lengths RMB E2, RMB E2^2, ..., N2
+	// decimating form (E2 = 8 or 4) and 8192-point backward transforms (E2 = 16), the mirror image of the
+	// forward side: the middle pass does the first MB2 bits (NBB butterflies of radix RMB over the thread's
+	// E2 consecutive positions), then NPOST passes of radix E2, one butterfly per thread, sub-lengths RMB E2,
+	// RMB E2^2, ..., N2
+	static constexpr bool POST = DL > 0 || N2 > 4096;
 	static constexpr int EB2 = 4 - DL;
-	static constexpr int NPOST = DL ? (LN2 - 1) / EB2 : 0;
+	static constexpr int NPOST = POST ? (LN2 - 1) / EB2 : 0;
 	static constexpr int MB2 = LN2 - NPOST * EB2, RMB = 1 << MB2, NBB = E2 / RMB;
 	// Wave w of a block pair (NW waves each) owns forward positions [w N/NW, (w+1) N/NW) after the first
 	// pass and backward positions [w N2/NW, (w+1) N2/NW) up to the last pass: the passes in between
@@ -131,7 +134,7 @@ struct ConvpState
 	int pt;               // ... and its entry of X.ptab
 };
 
-constexpr int convp_lds_bytes() { return 4096 * 16; } // SUB arrays of N2 complex
+template<int LN, int UL> constexpr int convp_lds_bytes() { return ConvpGeom<LN, UL>::SUB * ConvpGeom<LN, UL>::NA * 16; }
 
 // Twiddle base powers of a pass, pre-gathered per thread by the host (pair_twiddles() in
 // r8b_engine.cpp): entry (row * NT + t) = w_n^(j(t) m_c), row = 6 slot + c, m = {1, 2, 3, 4, 8, 12}; a
@@ -372,7 +375,8 @@ R8B_HD void cp_middle_compute(const cd* buf, ConvpState<LN, UL>& st, int lt)
 			st.vr[2 * c + 1] = zr[c] * st.hp[c].im;
 			st.vi[2 * c + 1] = zi[c] * st.hp[c].im;
 		}
-		DitSt<16, 2>::run(st.vr, st.vi);
+		if constexpr (!G::POST) DitSt<16, 2>::run(st.vr, st.vi);
+		else static_assert(!G::POST || G::RMB == 2, "8192 points: the folded radix-2 stage is the whole middle part");
 	}
 	else
 	{
@@ -384,7 +388,12 @@ R8B_HD void cp_middle_compute(const cd* buf, ConvpState<LN, UL>& st, int lt)
 			st.vr[2 * c + 1] = zr[2 * c + 1] * st.hp[c].im;
 			st.vi[2 * c + 1] = zi[2 * c + 1] * st.hp[c].im;
 		}
-		dit_regs<16>(st.vr, st.vi);
+		if constexpr (!G::POST) dit_regs<16>(st.vr, st.vi);
+		else
+		{
+#pragma unroll
+			for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
+		}
 	}
 }
 
@@ -935,20 +944,29 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	};
 	// (two steps: every lane has read its forward data before any lane's backward data overwrites it --
 	// on the GPU program order alone guarantees that, LDS serves a wave's accesses in issue order)
-	if constexpr (UL < 0)
+	if constexpr (G::POST)
 	{
-		// decimating form: steps a geometry does not have are empty
+		// decimating form / 8192 points: steps a geometry does not have are empty
 		auto d_pre1 = [&](int tid, St& st)
 		{
 			if constexpr (G::NPRE > 1) s_pre1(tid, st);
 		};
+		auto d_pre2 = [&](int tid, St& st)
+		{
+			if constexpr (G::NPRE > 2) s_pre2(tid, st);
+		};
 		auto d_midc = [&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
-			cp_middle_compute_down<LN, UL>(buf_of(tid), st, lt);
+			if constexpr (UL < 0) cp_middle_compute_down<LN, UL>(buf_of(tid), st, lt);
+			else cp_middle_compute<LN, UL>(buf_of(tid), st, lt);
 			ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
 		};
-		auto d_midw = [&](int tid, St& st) { cp_middle_write_down<LN, UL>(buf_of(tid), st, lt_of(tid)); };
+		auto d_midw = [&](int tid, St& st)
+		{
+			if constexpr (UL < 0) cp_middle_write_down<LN, UL>(buf_of(tid), st, lt_of(tid));
+			else cp_middle_write<LN, UL>(buf_of(tid), st, lt_of(tid));
+		};
 		auto d_post1 = [&](int tid, St& st)
 		{
 			if constexpr (G::NPOST > 1)
@@ -976,8 +994,22 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 				ConvpPost<LN, UL, 4>::prefetch(L, st, lt);
 			}
 		};
-		static_assert(G::NPRE <= 2 && G::NPOST >= 1 && G::NPOST <= 4, "pair kernel, decimating: pass plan");
-		ex.wave_steps(d_pre1, d_midc, d_midw, d_post1, d_post2, d_post3);
+		auto d_post4 = [&](int tid, St& st)
+		{
+			if constexpr (G::NPOST > 4)
+			{
+				const int lt = lt_of(tid);
+				ConvpPost<LN, UL, 4>::run(buf_of(tid), st, lt);
+				ConvpPost<LN, UL, 5>::prefetch(L, st, lt);
+			}
+		};
+		static_assert(G::NPRE <= 3 && G::NPOST >= 1 && G::NPOST <= 5, "pair kernel, decimating / 8192 points: pass plan");
+		// (every pass but the last stays inside a wave's range when its sub-length N2 / E2 <= 64 E2; the one
+		// geometry where the last but one does not -- 8192 points decimated by 4 -- takes a barrier more)
+		static_assert(G::NPOST < 5 || G::N2 / G::E2 > 64 * G::E2, "pass plan");
+		static_assert(G::NPOST == 5 || G::NW == 1 || G::N2 / G::E2 <= 64 * G::E2, "pass plan");
+		ex.wave_steps(d_pre1, d_pre2, d_midc, d_midw, d_post1, d_post2, d_post3);
+		if constexpr (G::NPOST > 4) ex.wave_steps(d_post4);
 	}
 	else
 	{
@@ -1008,7 +1040,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	{
 		ex.each([&](int tid, St&)
 		{
-			for (long long i = L.tail_p0 + tid; i < L.tail_p1; i += kConvpThreads)
+			for (long long i = L.tail_p0 + tid; i < L.tail_p1; i += G::WT)
 			{
 				L.tail_ring[(long long) chA * L.src.ring_stride + (i & L.src.ring_mask)] =
 					src_load(L.src, chA, i);
@@ -1018,14 +1050,18 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 			}
 		});
 	}
-	if constexpr (UL < 0)
+	if constexpr (G::POST)
 	{
-		static_assert(MODE == 0 || MODE == 3, "the decimating form has no fused interpolator");
+		static_assert(MODE == 0 || MODE == 3, "the decimating form / 8192 points: no fused interpolator");
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
 			ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
-			if (live(tid)) cp_store_conv_down<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
+			if (live(tid))
+			{
+				if constexpr (UL < 0) cp_store_conv_down<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
+				else cp_store_conv<LN, UL, MODE>(L, st, k_of(tid), chA, chB, bvalid, lt);
+			}
 		});
 	}
 	else if constexpr (MODE == 0 || MODE == 3)

@@ -379,7 +379,7 @@ std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int
 	// 1:1 / 2x up: 3 the backward pass with sub-length 256, 4 + m butterfly m of the last backward pass
 	// (sub-length n_out); decimating: 2 + I backward pass I (radix e2, sub-length rmb e2^I)
 	const int NT = std::max(n_in, n_out) / 16, e1 = n_in / NT, e2 = n_out / NT;
-	const bool dec = n_out < n_in;
+	const bool dec = n_out < n_in || n_out > 4096; // (the mirrored backward side: decimating, or 8192 points)
 	int npost = 0, rmb = 1;
 	if (dec)
 	{
@@ -677,7 +677,7 @@ bool Engine::use_pair_two(size_t s, int* run_off) const
 	const StagePlan& c = plan_.stages[s];
 	const StagePlan& w = plan_.stages[s + 1];
 	const StageDev& dw = dev_[s + 1];
-	if (!opt_.at("pair_two") || !use_pair(c.cg) || dw.ptab == nullptr) return false;
+	if (!opt_.at("pair_two") || !use_pair_fused(c.cg) || dw.ptab == nullptr) return false;
 	const int off = (w.in_step + 16 + 15) / 16 * 16;
 	if (off + c.cg.in_len + w.in_step + 32 + 16 > c.cg.n_out) return false;
 	if (run_off) *run_off = off;
@@ -790,7 +790,7 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 		{
 		case kConv:
 			*kernel = fuse_with_next(stage) ?
-				(use_pair(sp.cg) ? "k_convp_whole" : "k_convx_whole") :
+				(use_pair_fused(sp.cg) ? "k_convp_whole" : "k_convx_whole") :
 				sp.cg.complex_h ? "k_conv" :
 				conv_path(sp.cg) == kPathGeneric ? "k_conv" :
 				(conv_path(sp.cg) == kPathPair || conv_path(sp.cg) == kPathPair3 ? "k_convp" : "k_convx");
@@ -1372,6 +1372,11 @@ bool Engine::fast_geometry(const ConvGeom& g) const
 	return convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2) || use_pair(g);
 }
 
+bool Engine::use_pair_fused(const ConvGeom& g) const
+{
+	return opt_.at("pair_conv") && convp_fused_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2);
+}
+
 bool Engine::use_pair(const ConvGeom& g) const
 {
 	return opt_.at("pair_conv") &&
@@ -1393,9 +1398,10 @@ bool Engine::fuse_with_next(size_t s) const
 	const StagePlan& c = plan_.stages[s];
 	const StagePlan& w = plan_.stages[s + 1];
 	if (c.desc.kind != kConv || w.desc.kind != kFrac || !w.whole || c.cg.down != 1) return false;
-	if (!fast_geometry(c.cg)) return false;
+	if (!convx_geometry_ok(c.cg.n_in, c.cg.n_out, c.cg.up, c.cg.down, c.cg.up_pow2) && !use_pair_fused(c.cg))
+		return false;
 	// (the linear output run and the zeros behind it live in the block's own part of the array)
-	if (use_pair(c.cg) && c.cg.in_len + 32 > c.cg.n_out) return false;
+	if (use_pair_fused(c.cg) && c.cg.in_len + 32 > c.cg.n_out) return false;
 	return w.out_step <= 256 && w.flen <= 32 && c.cg.in_len >= 4 * w.flen;
 }
 
@@ -1524,7 +1530,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			}
 			launch_convp(X, 4, stream);
 		}
-		else if (use_pair(c.cg)) launch_convp(X, 1, stream);
+		else if (use_pair_fused(c.cg)) launch_convp(X, 1, stream);
 		else launch_convx(X, 1, stream);
 		if (X.c.tail_ring != nullptr) tail_done_ = true;
 		X.c.tail_ring = nullptr; // once per call

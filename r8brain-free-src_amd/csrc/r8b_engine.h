@@ -92,6 +92,7 @@ private:
 	void ensure_ring(size_t s);
 	bool fuse_with_next(size_t s) const;
 	bool use_pair(const ConvGeom& g) const;
+	bool use_pair_fused(const ConvGeom& g) const;
 	bool fast_geometry(const ConvGeom& g) const;
 	enum { kPathGeneric, kPathConvx, kPathConvx3, kPathPair, kPathPair3 };
 	int conv_path(const ConvGeom& g) const;

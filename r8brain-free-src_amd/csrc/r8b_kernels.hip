@@ -460,7 +460,7 @@ struct GpuExecP
 #define R8B_CONVP_WGS 2
 #endif
 template<int LN, int UL, int MODE, int FLENP>
-__global__ __launch_bounds__(kConvpThreads, R8B_CONVP_WGS) void k_convp(const ConvxLaunch X)
+__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) > 256 ? 1 : R8B_CONVP_WGS)) void k_convp(const ConvxLaunch X)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	// XCD-aware mapping as in k_convx, over channel PAIRS and groups of SUB consecutive blocks
@@ -511,11 +511,11 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 #ifdef R8B_CONVP_LDS_TIMING_ONLY // occupancy experiments: results are wrong
 	const size_t lds = R8B_CONVP_LDS_TIMING_ONLY;
 #else
-	const size_t lds = (size_t) convp_lds_bytes();
+	const size_t lds = (size_t) convp_lds_bytes<LN, UL>();
 #endif
 	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
 	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
-	hipLaunchKernelGGL(kern, dim3(nbg * npair), dim3(kConvpThreads), lds, stream, X);
+	hipLaunchKernelGGL(kern, dim3(nbg * npair), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
 }
 
@@ -657,6 +657,16 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 #undef R8B_CONVP_DISPATCH_DOWN
 		throw std::runtime_error("launch_convp: decimating geometry not instantiated");
 	}
+#define R8B_CONVP_DISPATCH_BIG(LN, UL) \
+	if (ln == LN && up == (1 << UL)) \
+	{ \
+		if (mode == 3) launch_convp_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
+		else if (mode == 0) launch_convp_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
+		else throw std::runtime_error("launch_convp: 8192-point blocks have no fused form"); \
+		return; \
+	}
+	R8B_CONVP_GEOMS_BIG(R8B_CONVP_DISPATCH_BIG)
+#undef R8B_CONVP_DISPATCH_BIG
 	R8B_CONVP_GEOMS(R8B_CONVP_DISPATCH)
 #undef R8B_CONVP_DISPATCH
 	throw std::runtime_error("launch_convp: geometry not instantiated");

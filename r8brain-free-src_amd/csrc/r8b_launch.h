@@ -241,7 +241,7 @@ inline bool convx_mode3_ok(int n_in, int n_out, int up, int down, bool up_pow2, 
 }
 
 // pair form of the fast path (r8b_convp.h): two channels as one complex transform; backward transforms
-// of 64 ... 4096 points, 1:1 or 2x up-sampled (below 4096 points a workgroup carries several blocks)
+// of 64 ... 8192 points, 1:1 or 2x up-sampled (below 4096 points a workgroup carries several blocks)
 inline bool convp_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
 {
 	if (!up_pow2 || (up != 1 && up != 2)) return false;
@@ -249,11 +249,16 @@ inline bool convp_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow
 	{
 		// 2x / 4x decimation in the spectrum (the caller passes down_pow2 geometries only)
 		if (up != 1 || n_out * down != n_in) return false;
-		return n_in <= 4096 && n_in >= 64 && (n_in & (n_in - 1)) == 0;
+		return n_in <= 8192 && n_in >= 64 && (n_in & (n_in - 1)) == 0;
 	}
 	if (down != 1 || n_out != n_in * up) return false;
 	return n_out == 64 || n_out == 128 || n_out == 256 || n_out == 512 || n_out == 1024 || n_out == 2048 ||
-		n_out == 4096;
+		n_out == 4096 || n_out == 8192;
+}
+// ... with the whole-step interpolator fused in (modes 1 and 4): up to 4096 points
+inline bool convp_fused_ok(int n_in, int n_out, int up, int down, bool up_pow2)
+{
+	return down == 1 && n_out <= 4096 && convp_geometry_ok(n_in, n_out, up, down, up_pow2);
 }
 // MODE 3 of the pair form: 3x zero stuffing in the load and / or 3x strided decimation in the store
 // around a 1:1 or 2x-up transform pair -- ratios 3/1, 1/3, 2/3 (3/2 and 3/4 decimate by a power of two
@@ -268,9 +273,11 @@ inline bool convp_mode3_ok(int n_in, int n_out, int up, int down, bool up_pow2, 
 }
 #define R8B_CONVP_GEOMS(M) M(11, 1) M(12, 0) M(10, 1) M(11, 0) M(9, 1) M(10, 0) M(8, 1) M(9, 0) M(7, 1) M(8, 0) \
 	M(6, 1) M(7, 0) M(5, 1) M(6, 0)
+// 8192-point blocks (512-thread workgroups, modes 0 and 3 only)
+#define R8B_CONVP_GEOMS_BIG(M) M(13, 0) M(12, 1)
 // decimating form: (log2 forward length, log2 decimation)
-#define R8B_CONVP_GEOMS_DOWN(M) M(12, 1) M(11, 1) M(10, 1) M(9, 1) M(8, 1) M(7, 1) M(6, 1) \
-	M(12, 2) M(11, 2) M(10, 2) M(9, 2) M(8, 2) M(7, 2) M(6, 2)
+#define R8B_CONVP_GEOMS_DOWN(M) M(13, 1) M(12, 1) M(11, 1) M(10, 1) M(9, 1) M(8, 1) M(7, 1) M(6, 1) \
+	M(13, 2) M(12, 2) M(11, 2) M(10, 2) M(9, 2) M(8, 2) M(7, 2) M(6, 2)
 
 // launchers (asynchronous on `stream`, a hipStream_t)
 void launch_conv(const ConvLaunch& L, void* stream);

@@ -202,17 +202,18 @@ void emul_convx_t(const ConvxLaunch& X)
 template<int LN, int UL>
 struct EmulExecP
 {
+	static constexpr int WT = ConvpGeom<LN, UL>::WT;
 	std::vector<ConvpState<LN, UL>> st;
-	EmulExecP() : st((size_t) kConvpThreads) {}
+	EmulExecP() : st((size_t) WT) {}
 	template<class F>
 	void phase(F f)
 	{
-		for (int t = 0; t < kConvpThreads; t++) f(t, st[(size_t) t]);
+		for (int t = 0; t < WT; t++) f(t, st[(size_t) t]);
 	}
 	template<class F>
 	void each(F f)
 	{
-		for (int t = 0; t < kConvpThreads; t++) f(t, st[(size_t) t]);
+		for (int t = 0; t < WT; t++) f(t, st[(size_t) t]);
 	}
 	// wave-local steps: a wave runs ALL its steps before the next wave starts (so any dependence on
 	// another wave's data inside the sequence shows as a wrong result); within a step the lanes run
@@ -227,14 +228,14 @@ struct EmulExecP
 	template<class... F>
 	void wave_steps(F... f)
 	{
-		for (int w = 0; w < kConvpThreads / 64; w++) (run_step(f, w), ...);
+		for (int w = 0; w < WT / 64; w++) (run_step(f, w), ...);
 	}
 };
 
 template<int LN, int UL, int MODE, int FLENP>
 void emul_convp_t(const ConvxLaunch& X)
 {
-	std::vector<double> lds((size_t) convp_lds_bytes() / sizeof(double) + 2);
+	std::vector<double> lds((size_t) convp_lds_bytes<LN, UL>() / sizeof(double) + 2);
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
@@ -278,6 +279,16 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 #undef R8B_CONVP_DISPATCH_DOWN
 		throw std::runtime_error("launch_convp: decimating geometry not instantiated");
 	}
+#define R8B_CONVP_DISPATCH_BIG(LN, UL) \
+	if (ln == LN && up == (1 << UL)) \
+	{ \
+		if (mode == 3) emul_convp_t<LN, UL, 3, 24>(X); \
+		else if (mode == 0) emul_convp_t<LN, UL, 0, 24>(X); \
+		else throw std::runtime_error("emul launch_convp: 8192-point blocks have no fused form"); \
+		return; \
+	}
+	R8B_CONVP_GEOMS_BIG(R8B_CONVP_DISPATCH_BIG)
+#undef R8B_CONVP_DISPATCH_BIG
 	R8B_CONVP_GEOMS(R8B_CONVP_DISPATCH)
 #undef R8B_CONVP_DISPATCH
 	throw std::runtime_error("emul launch_convp: geometry not instantiated");
