@@ -772,6 +772,12 @@ static const int kConvpTaps2 = 25;
 
 R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int* pt, int tid)
 {
+	// (the tables are laid out for 256 lanes: in a 512-thread workgroup the upper half sits this phase out)
+	if (tid >= kConvpThreads)
+	{
+		*pt = -1;
+		return;
+	}
 	*pt = X.ptab[tid];
 	// X.ctab holds the 50 values of a thread as 25 pairs, pair i of thread t at [(i * 256 + t) * 2]: a
 	// wave reads 64 consecutive 16-byte entries per load
@@ -1050,9 +1056,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 			}
 		});
 	}
-	if constexpr (G::POST)
+	if constexpr (G::POST && (MODE == 0 || MODE == 3))
 	{
-		static_assert(MODE == 0 || MODE == 3, "the decimating form / 8192 points: no fused interpolator");
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
@@ -1075,9 +1080,11 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	}
 	else if constexpr (MODE == 4)
 	{
+		static_assert(UL >= 0, "the decimating form has no fused interpolator");
 		ex.phase([&](int tid, St& st)
 		{
-			cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
+			if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
+			else cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
 			cp_rows2_fetch(X, st.rows2, &st.pt, tid);
 		});
 		ex.phase([&](int tid, St& st)
@@ -1093,9 +1100,11 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	}
 	else
 	{
+		static_assert(UL >= 0, "the decimating form has no fused interpolator");
 		ex.phase([&](int tid, St& st)
 		{
-			cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
+			if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
+			else cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
 			cx_whole_row<FLENP>(X, st.row, tid);
 		});
 		ex.phase([&](int tid, St& st)

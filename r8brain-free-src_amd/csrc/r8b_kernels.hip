@@ -662,7 +662,9 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 	{ \
 		if (mode == 3) launch_convp_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
 		else if (mode == 0) launch_convp_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
-		else throw std::runtime_error("launch_convp: 8192-point blocks have no fused form"); \
+		else if (mode == 4) launch_convp_t<LN, UL, 4, 24>(X, (hipStream_t) stream); \
+		else if (wide) launch_convp_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
+		else launch_convp_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
 		return; \
 	}
 	R8B_CONVP_GEOMS_BIG(R8B_CONVP_DISPATCH_BIG)

@@ -255,10 +255,10 @@ inline bool convp_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow
 	return n_out == 64 || n_out == 128 || n_out == 256 || n_out == 512 || n_out == 1024 || n_out == 2048 ||
 		n_out == 4096 || n_out == 8192;
 }
-// ... with the whole-step interpolator fused in (modes 1 and 4): up to 4096 points
+// ... with the whole-step interpolator fused in (modes 1 and 4)
 inline bool convp_fused_ok(int n_in, int n_out, int up, int down, bool up_pow2)
 {
-	return down == 1 && n_out <= 4096 && convp_geometry_ok(n_in, n_out, up, down, up_pow2);
+	return down == 1 && convp_geometry_ok(n_in, n_out, up, down, up_pow2);
 }
 // MODE 3 of the pair form: 3x zero stuffing in the load and / or 3x strided decimation in the store
 // around a 1:1 or 2x-up transform pair -- ratios 3/1, 1/3, 2/3 (3/2 and 3/4 decimate by a power of two
@@ -273,7 +273,7 @@ inline bool convp_mode3_ok(int n_in, int n_out, int up, int down, bool up_pow2, 
 }
 #define R8B_CONVP_GEOMS(M) M(11, 1) M(12, 0) M(10, 1) M(11, 0) M(9, 1) M(10, 0) M(8, 1) M(9, 0) M(7, 1) M(8, 0) \
 	M(6, 1) M(7, 0) M(5, 1) M(6, 0)
-// 8192-point blocks (512-thread workgroups, modes 0 and 3 only)
+// 8192-point blocks (512-thread workgroups)
 #define R8B_CONVP_GEOMS_BIG(M) M(13, 0) M(12, 1)
 // decimating form: (log2 forward length, log2 decimation)
 #define R8B_CONVP_GEOMS_DOWN(M) M(13, 1) M(12, 1) M(11, 1) M(10, 1) M(9, 1) M(8, 1) M(7, 1) M(6, 1) \

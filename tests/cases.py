@@ -85,6 +85,11 @@ SHORT_CASES = [
     (64000.0, 48000.0, 2048, 1100, 16000, 2.0, 109.56, "io=3/4"),          # 4x decimation
     (64000.0, 48000.0, 2048, 2048, 12000, 10.0, 109.56, "io=3/4"),
     (64000.0, 48000.0, 1024, 1024, 8000, 45.0, 49.0, "io=3/4"),
+    # 8192-point blocks: 512-thread workgroups
+    (44100.0, 96000.0, 8192, 5000, 40000, 1.0, 180.15, "fft=4096/8192"),   # fused, two phases per thread
+    (96000.0, 44100.0, 8192, 8192, 50000, 1.0, 180.15, "fft=8192/8192"),   # fused, one phase per thread
+    (88200.0, 44100.0, 8192, 3000, 50000, 1.0, 180.15, "fft=8192/4096"),   # decimating
+    (64000.0, 48000.0, 4096, 4096, 40000, 2.0, 180.15, "fft=8192/2048"),   # 4x decimating: one barrier more
 ]
 
 

@@ -284,7 +284,9 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 	{ \
 		if (mode == 3) emul_convp_t<LN, UL, 3, 24>(X); \
 		else if (mode == 0) emul_convp_t<LN, UL, 0, 24>(X); \
-		else throw std::runtime_error("emul launch_convp: 8192-point blocks have no fused form"); \
+		else if (mode == 4) emul_convp_t<LN, UL, 4, 24>(X); \
+		else if (wide) emul_convp_t<LN, UL, 1, 32>(X); \
+		else emul_convp_t<LN, UL, 1, 24>(X); \
 		return; \
 	}
 	R8B_CONVP_GEOMS_BIG(R8B_CONVP_DISPATCH_BIG)

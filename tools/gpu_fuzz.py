@@ -1,18 +1,28 @@
+"""tools/gpu_fuzz.py [n] [seed] [wide]: one-off GPU fuzz (the test suite's fuzz function on fresh random
+cases); `wide` draws the filter from the reference's whole range (transition band 0.5 ... 45 %, attenuation
+49 ... 218 dB) so that every block geometry of the pair kernel is hit.  Test infrastructure."""
 import sys, os
 sys.path.insert(0, 'tests'); sys.path.insert(0, 'oracle')
 import pytest, numpy as np
 import test_fuzz as T
 import refwrap as R
-bad = 0; n = 0; skipped = 0
-for seed in (101, 102, 103):
-    for case in [c for c in T._cases(150, seed) if c[2] >= 300][:60]:
-        n += 1
-        try:
-            T.test_fuzz_gpu_vs_reference(R, case)
-        except pytest.skip.Exception:
-            skipped += 1
-        except AssertionError as e:
-            bad += 1; print("FAIL", case, str(e)[:300])
-        except Exception as e:
-            bad += 1; print("ERR", case, repr(e)[:300])
-print("gpu fuzz done", n, "bad", bad, "skipped", skipped)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 180
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 101
+wide = len(sys.argv) > 3
+rng = np.random.default_rng(seed)
+bad = 0; done = 0; skipped = 0
+for case in [c for c in T._cases(3 * n, seed) if c[2] >= 300][:n]:
+    if wide:
+        tb = float(np.round(np.exp(rng.uniform(np.log(0.5), np.log(45.0))), 2))
+        att = float(np.round(rng.uniform(49.0, 218.0), 2))
+        case = (case[0], case[1], case[2], tb, att, case[5])
+    done += 1
+    try:
+        T.test_fuzz_gpu_vs_reference(R, case)
+    except pytest.skip.Exception:
+        skipped += 1
+    except AssertionError as e:
+        bad += 1; print("FAIL", case, str(e)[:300])
+    except Exception as e:
+        bad += 1; print("ERR", case, repr(e)[:300])
+print("gpu fuzz done", done, "bad", bad, "skipped", skipped)
