@@ -52,7 +52,7 @@ def measured_traffic(kernel, cfg="cfg2"):
     try:
         with open(path) as f:
             rec = json.load(f)
-        return rec.get(cfg + ":" + kernel, rec.get(kernel, {})).get("hbm_bytes_per_launch")
+        return rec.get(cfg + ":" + kernel, {}).get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
 
@@ -213,8 +213,8 @@ def main():
         args.src, args.dst = 96000.0, 44100.0
     elif args.config == "cfg5":
         args.src, args.dst, args.block, args.channels = 44100.0, 2822400.0, 1024, 64
-    cfg_name = args.config or ("cfg2" if (args.src, args.dst, args.block, args.channels) ==
-                               (44100.0, 96000.0, 16384, 1024) else "custom")
+    cfg_name = args.config or ("cfg2" if (args.src, args.dst, args.block, args.channels, args.tb, args.atten) ==
+                               (44100.0, 96000.0, 16384, 1024, 2.0, 180.15) else "custom")
 
     import numpy as np
     import torch

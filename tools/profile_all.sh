@@ -33,4 +33,8 @@ prof cfg5x1024 --src 44100 --dst 2822400 --block 1024 --channels 1024
 prof poly --src 44100 --dst 44101
 prof hbdown --src 176400 --dst 44100
 prof up2 --src 44100 --dst 88200
+prof down2 --src 88200 --dst 44100
+prof ir16 --src 44100 --dst 96000 --atten 109.56
+prof tb10 --src 44100 --dst 96000 --tb 10 --atten 109.56
+prof r23 --src 48000 --dst 32000
 ls $out/*
