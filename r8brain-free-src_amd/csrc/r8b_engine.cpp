@@ -1348,9 +1348,10 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 	L.nch = nch_;
 	L.src = src; L.dst = dst;
 	L.in_end = plan_.stages[s].m;
-	// output q is even for the first of a pair: its element index is even when the offset is
-	L.pair_ok = dst.fmt == kPcmF64 && ((size_t) dst.p & 15) == 0 && (dst.stride & 1) == 0 &&
-		(dst.off & 1) == 0 ? 1 : 0;
+	// 16-byte stores of output pairs: output q is even for the first of an (even, odd) pair, whose element
+	// index is even when the offset is (1); with an odd offset the aligned pairs are (odd, next even) (2)
+	L.pair_ok = dst.fmt == kPcmF64 && ((size_t) dst.p & 15) == 0 && (dst.stride & 1) == 0 ?
+		((dst.off & 1) == 0 ? 1 : 2) : 0;
 	launch_hbcascade(L, stream);
 }
 

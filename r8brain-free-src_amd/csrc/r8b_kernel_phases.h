@@ -809,6 +809,22 @@ R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, int s, const double* xin, long
 		const int o = qoff + 2 * i;
 		if (last)
 		{
+			if (L.pair_ok == 2)
+			{
+				// odd destination offset: the aligned pairs are (odd output of this thread, even output of
+				// the next = its input sample x[1]); the tile's first even output goes alone
+				if (i == 0 && o >= 0 && o < nout) dst_store(L.dst, ch, q, ev);
+				if (o + 2 < nout)
+				{
+					cd v;
+					v.re = od;
+					v.im = q + 2 < 0 ? 0.0 : x[1];
+					*reinterpret_cast<cd*>(L.dst.p + ((long long) ch * L.dst.stride +
+						((q + 1 + L.dst.off) & L.dst.mask))) = v;
+				}
+				else if (o + 1 < nout) dst_store(L.dst, ch, q + 1, od);
+				continue;
+			}
 			if (L.pair_ok && o >= 0 && o + 1 < nout)
 			{
 				// the even/odd output pair as one 16-byte store (full 128-byte lines per wave
