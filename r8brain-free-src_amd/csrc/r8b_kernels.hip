@@ -249,22 +249,43 @@ __global__ void k_hbcascade(const HBCascadeLaunch L)
 	const long long q0 = L.a + (long long) blockIdx.x * L.tile;
 	long long q1 = q0 + L.tile;
 	if (q1 > L.b) q1 = L.b;
+#ifdef R8B_HBC_STAMPS
+	long long ts[10]; int nts = 0;
+	ts[nts++] = clock64();
+#endif
 	HBCRanges R;
 	hbc_ranges(L, q0, q1, R);
 	double* xin = ((L.nst - 1) & 1) ? small : big;
 	double* yout = ((L.nst - 1) & 1) ? big : small;
+#ifdef R8B_HBC_STAMPS
+	ts[nts++] = clock64();
+#endif
 	hbc_load(L, R, xin, ch, tid, nthr);
 	__syncthreads();
+#ifdef R8B_HBC_STAMPS
+	ts[nts++] = clock64();
+#endif
 	long long in_lo = R.in_lo;
-	for (int s = 0; s < L.nst; s++)
+	// (unrolled: compile-time stage indices keep R and the taps out of scratch memory)
+#pragma unroll
+	for (int s = 0; s < kMaxCascade; s++)
 	{
+		if (s >= L.nst) break;
 		hbc_stage(L, s, xin, in_lo, R.lo[s], R.hi[s], yout, s + 1 == L.nst, ch, tid, nthr);
 		__syncthreads();
+#ifdef R8B_HBC_STAMPS
+		ts[nts++] = clock64();
+#endif
 		in_lo = R.lo[s];
 		double* t = xin;
 		xin = yout;
 		yout = t;
 	}
+#ifdef R8B_HBC_STAMPS
+	if (tid == 0 && ch == 517 && blockIdx.x == 3 && L.a > 400000 && L.a < 600000)
+		printf("hbc stamps tile %d nst %d: ranges %lld load %lld st %lld %lld %lld %lld %lld\n", L.tile, L.nst,
+			ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5], ts[7] - ts[6]);
+#endif
 }
 
 // ------------------------------------------------------------------ decimating half-band cascade
@@ -289,8 +310,10 @@ __global__ void k_hbdcascade(const HBCascadeLaunch L)
 	}
 	__syncthreads();
 	long long in_lo = R.in_lo;
-	for (int s = 0; s < L.nst; s++)
+#pragma unroll
+	for (int s = 0; s < kMaxCascade; s++)
 	{
+		if (s >= L.nst) break;
 		hbd_stage(L, s, (s & 1) ? odd : even, in_lo, R.lo[s], R.hi[s], (s & 1) ? even : odd,
 			s + 1 == L.nst, ch, tid, nthr);
 		__syncthreads();
