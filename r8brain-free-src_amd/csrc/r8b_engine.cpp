@@ -1435,7 +1435,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	{
 		int th = 64;
 		while (th < opt_.at("conv_threads") && th * 8 < std::max(g.n_in, g.n_out)) th *= 2;
-		L.threads = std::min(th, opt_.at("conv_threads"));
+		L.threads = std::min(std::min(th, opt_.at("conv_threads")), 256); // (the kernels are built for <= 256)
 	}
 	L.src = src;
 	L.tail_ring = nullptr; L.tail_p0 = L.tail_p1 = 0;
