@@ -336,7 +336,11 @@ def main():
         value = in_samples / dt / 1e6
         # dominant kernel and its algorithmic bytes: 8*(samples read + samples written) by that
         # kernel per launch (tables excluded)
-        dom = max(range(len(timings)), key=lambda i: timings[i][1])
+        # (kernels within 10 % of the longest: the one that moves more bytes, so that the choice does not
+        # flip from run to run when two launches take the same time -- cfg5)
+        tmax = max(t[1] for t in timings)
+        dom = max((i for i in range(len(timings)) if timings[i][1] >= 0.9 * tmax),
+                  key=lambda i: timings[i][3] + timings[i][4])
         name, ms_sum, launches, s_in, s_out = timings[dom]
         avg_ms = ms_sum / max(launches, 1)
         plan_out = n_out / args.steps  # average final outputs per channel per step

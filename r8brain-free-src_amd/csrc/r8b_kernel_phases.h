@@ -595,7 +595,10 @@ R8B_HD double poly_one(const PolyLaunch& L, int ch, long long i)
 // In the compute phase thread (o, g) pulls output o's taps into registers once and walks channels
 // g, g+4, ...: one LDS read per multiply-add, and a wave stores 64 consecutive outputs of one
 // channel (lanes = channels, as before, wrote 64 scattered 8-byte words per store).
-static const int kPolyTC = 16; // channels per workgroup
+#ifndef R8B_POLY_TC
+#define R8B_POLY_TC 16
+#endif
+static const int kPolyTC = R8B_POLY_TC; // channels per workgroup
 static const int kPolyTO = 64; // outputs per workgroup
 
 R8B_HD int poly_pitch(int span) { return span | 1; }

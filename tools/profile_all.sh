@@ -7,8 +7,10 @@ R=$PWD
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+# PROF_ONLY="name name ..." restricts the run to those configurations
 prof() {
   name=$1; shift
+  if [ -n "$PROF_ONLY" ] && ! echo " $PROF_ONLY " | grep -q " $name "; then return; fi
   mkdir -p $out/$name
   # driver-style bench line (20 steps) and the long one, no profiler attached
   (cd $R && timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu "$@" > $out/$name/bench_20.json 2>/dev/null)
