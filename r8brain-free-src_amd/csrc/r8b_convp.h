@@ -717,44 +717,54 @@ R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 }
 
 // MODE 1: K8 on the pair run (cf. cx_whole_compute): one 16-byte LDS read per tap feeds both channels
+// (more phases than threads -- e.g. 32000 -> 44100: 441: a thread takes phases tid, tid + wt, ...; the row of
+// the first one was fetched ahead (st.row), the others are fetched here)
 template<int FLEN>
-R8B_HD void cp_whole_compute(const ConvxLaunch& X, const cd* y, const double* row, long long k,
-	int chA, int chB, bool bvalid, int tid)
+R8B_HD void cp_whole_compute(const ConvxLaunch& X, const cd* y, double* row, int* row_t, long long k,
+	int chA, int chB, bool bvalid, int tid, int wt)
 {
+	// *row_t: the phase whose row `row` holds
 	const ConvLaunch& L = X.c;
-	if (tid >= X.out_step) return;
 	const SpanInfo& B = X.blk[k - L.k0];
-	int d = tid - B.jlo_mod;
-	if (d < 0) d += X.out_step;
-	long long j = B.jlo + d;
 	const long long jhi = B.jhi;
-	if (j >= jhi) return;
-	int u = B.u_lo + (int) ((unsigned) (B.ph_lo + d * X.in_step) / (unsigned) X.out_step);
-	for (; j < jhi; j += X.out_step, u += X.in_step)
+	for (int t = tid; t < X.out_step; t += wt)
 	{
-		double sa[2] = { 0.0, 0.0 }, sb[2] = { 0.0, 0.0 };
-		// taps in chunks of eight, each chunk's reads issued one chunk ahead of its multiply-adds
-		cd v[2][8];
-#pragma unroll
-		for (int i = 0; i < 8; i++) v[0][i] = y[u + i];
-#pragma unroll
-		for (int c = 0; c < FLEN / 8; c++)
+		if (t != *row_t)
 		{
-			R8B_SCHED_FENCE();
-			if (c + 1 < FLEN / 8)
-			{
-#pragma unroll
-				for (int i = 0; i < 8; i++) v[(c + 1) & 1][i] = y[u + 8 * (c + 1) + i];
-			}
-#pragma unroll
-			for (int i = 0; i < 8; i++)
-			{
-				sa[i & 1] += row[8 * c + i] * v[c & 1][i].re;
-				sb[i & 1] += row[8 * c + i] * v[c & 1][i].im;
-			}
+			cx_whole_row<FLEN>(X, row, t);
+			*row_t = t;
 		}
-		dst_store(X.wdst, chA, j, sa[0] + sa[1]);
-		if (bvalid) dst_store(X.wdst, chB, j, sb[0] + sb[1]);
+		int d = t - B.jlo_mod;
+		if (d < 0) d += X.out_step;
+		long long j = B.jlo + d;
+		if (j >= jhi) continue;
+		int u = B.u_lo + (int) ((unsigned) (B.ph_lo + d * X.in_step) / (unsigned) X.out_step);
+		for (; j < jhi; j += X.out_step, u += X.in_step)
+		{
+			double sa[2] = { 0.0, 0.0 }, sb[2] = { 0.0, 0.0 };
+			// taps in chunks of eight, each chunk's reads issued one chunk ahead of its multiply-adds
+			cd v[2][8];
+#pragma unroll
+			for (int i = 0; i < 8; i++) v[0][i] = y[u + i];
+#pragma unroll
+			for (int c = 0; c < FLEN / 8; c++)
+			{
+				R8B_SCHED_FENCE();
+				if (c + 1 < FLEN / 8)
+				{
+#pragma unroll
+					for (int i = 0; i < 8; i++) v[(c + 1) & 1][i] = y[u + 8 * (c + 1) + i];
+				}
+#pragma unroll
+				for (int i = 0; i < 8; i++)
+				{
+					sa[i & 1] += row[8 * c + i] * v[c & 1][i].re;
+					sb[i & 1] += row[8 * c + i] * v[c & 1][i].im;
+				}
+			}
+			dst_store(X.wdst, chA, j, sa[0] + sa[1]);
+			if (bvalid) dst_store(X.wdst, chB, j, sb[0] + sb[1]);
+		}
 	}
 }
 
@@ -1113,8 +1123,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		});
 		ex.each([&](int tid, St& st)
 		{
+			int row_t = tid < X.out_step ? tid : 0; // (what cx_whole_row fetched ahead)
 			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
-				cp_whole_compute<FLENP>(X, buf + sb * G::NA, st.row, cur.k + sb, chA, chB, bvalid, tid);
+				cp_whole_compute<FLENP>(X, buf + sb * G::NA, st.row, &row_t, cur.k + sb, chA, chB, bvalid, tid, G::WT);
 		});
 	}
 }

@@ -1403,7 +1403,8 @@ bool Engine::fuse_with_next(size_t s) const
 		return false;
 	// (the linear output run and the zeros behind it live in the block's own part of the array)
 	if (use_pair_fused(c.cg) && c.cg.in_len + 32 > c.cg.n_out) return false;
-	return w.out_step <= 256 && w.flen <= 32 && c.cg.in_len >= 4 * w.flen;
+	// (one phase per thread in the one-channel kernel; the pair kernel walks tid, tid + 256, ...)
+	return w.out_step <= (use_pair_fused(c.cg) ? 2048 : 256) && w.flen <= 32 && c.cg.in_len >= 4 * w.flen;
 }
 
 void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const

@@ -85,6 +85,11 @@ SHORT_CASES = [
     (64000.0, 48000.0, 2048, 1100, 16000, 2.0, 109.56, "io=3/4"),          # 4x decimation
     (64000.0, 48000.0, 2048, 2048, 12000, 10.0, 109.56, "io=3/4"),
     (64000.0, 48000.0, 1024, 1024, 8000, 45.0, 49.0, "io=3/4"),
+    # more interpolator phases than threads (fused: a thread walks phases tid, tid + 256, ...)
+    (32000.0, 44100.0, 4096, 3000, 20000, 2.0, 180.15, "step=640/441"),
+    (32000.0, 44100.0, 4096, 1000, 12000, 5.0, 109.56, "step=640/441"),    # ... with 4 blocks per workgroup
+    (16000.0, 44100.0, 2048, 2048, 10000, 2.0, 180.15, "step=320/441"),    # two phases per thread, one group set
+    (8000.0, 44100.0, 1024, 700, 6000, 2.0, 136.45, "step=640/441"),       # ... inside a longer chain
     # 8192-point blocks: 512-thread workgroups
     (44100.0, 96000.0, 8192, 5000, 40000, 1.0, 180.15, "fft=4096/8192"),   # fused, two phases per thread
     (96000.0, 44100.0, 8192, 8192, 50000, 1.0, 180.15, "fft=8192/8192"),   # fused, one phase per thread
