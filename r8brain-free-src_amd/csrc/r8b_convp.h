@@ -717,8 +717,12 @@ R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 }
 
 // MODE 1: K8 on the pair run (cf. cx_whole_compute): one 16-byte LDS read per tap feeds both channels
-// (more phases than threads -- e.g. 32000 -> 44100: 441: a thread takes phases tid, tid + wt, ...; the row of
-// the first one was fetched ahead (st.row), the others are fetched here)
+// Thread -> (phase, group set).  Fewer phases than threads (88200 -> 48000: 40): nsets = wt / out_step lanes
+// share a phase and take its output groups in turn (set, set + nsets, ...).  More phases than threads
+// (32000 -> 44100: 441): a thread takes phases tid, tid + wt, ...; the row of the first one was fetched ahead
+// (st.row), the others are fetched here.
+R8B_HD int cp_whole_phase(const ConvxLaunch& X, int tid) { return tid % X.out_step; }
+
 template<int FLEN>
 R8B_HD void cp_whole_compute(const ConvxLaunch& X, const cd* y, double* row, int* row_t, long long k,
 	int chA, int chB, bool bvalid, int tid, int wt)
@@ -727,7 +731,11 @@ R8B_HD void cp_whole_compute(const ConvxLaunch& X, const cd* y, double* row, int
 	const ConvLaunch& L = X.c;
 	const SpanInfo& B = X.blk[k - L.k0];
 	const long long jhi = B.jhi;
-	for (int t = tid; t < X.out_step; t += wt)
+	const int nsets = wt >= X.out_step ? wt / X.out_step : 1;
+	const int set = wt >= X.out_step ? tid / X.out_step : 0;
+	if (set >= nsets) return;
+	const int jstep = nsets * X.out_step, ustep = nsets * X.in_step;
+	for (int t = wt >= X.out_step ? tid - set * X.out_step : tid; t < X.out_step; t += wt)
 	{
 		if (t != *row_t)
 		{
@@ -736,10 +744,10 @@ R8B_HD void cp_whole_compute(const ConvxLaunch& X, const cd* y, double* row, int
 		}
 		int d = t - B.jlo_mod;
 		if (d < 0) d += X.out_step;
-		long long j = B.jlo + d;
+		long long j = B.jlo + d + (long long) set * X.out_step;
 		if (j >= jhi) continue;
-		int u = B.u_lo + (int) ((unsigned) (B.ph_lo + d * X.in_step) / (unsigned) X.out_step);
-		for (; j < jhi; j += X.out_step, u += X.in_step)
+		int u = B.u_lo + (int) ((unsigned) (B.ph_lo + d * X.in_step) / (unsigned) X.out_step) + set * X.in_step;
+		for (; j < jhi; j += jstep, u += ustep)
 		{
 			double sa[2] = { 0.0, 0.0 }, sb[2] = { 0.0, 0.0 };
 			// taps in chunks of eight, each chunk's reads issued one chunk ahead of its multiply-adds
@@ -1115,7 +1123,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		{
 			if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
 			else cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
-			cx_whole_row<FLENP>(X, st.row, tid);
+			cx_whole_row<FLENP>(X, st.row, cp_whole_phase(X, tid));
 		});
 		ex.phase([&](int tid, St& st)
 		{
@@ -1123,7 +1131,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		});
 		ex.each([&](int tid, St& st)
 		{
-			int row_t = tid < X.out_step ? tid : 0; // (what cx_whole_row fetched ahead)
+			int row_t = cp_whole_phase(X, tid); // (what cx_whole_row fetched ahead)
 			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
 				cp_whole_compute<FLENP>(X, buf + sb * G::NA, st.row, &row_t, cur.k + sb, chA, chB, bvalid, tid, G::WT);
 		});

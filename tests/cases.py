@@ -90,6 +90,9 @@ SHORT_CASES = [
     (32000.0, 44100.0, 4096, 1000, 12000, 5.0, 109.56, "step=640/441"),    # ... with 4 blocks per workgroup
     (16000.0, 44100.0, 2048, 2048, 10000, 2.0, 180.15, "step=320/441"),    # two phases per thread, one group set
     (8000.0, 44100.0, 1024, 700, 6000, 2.0, 136.45, "step=640/441"),       # ... inside a longer chain
+    # fewer phases than threads: several lanes share a phase and take its output groups in turn
+    (88200.0, 48000.0, 4096, 3000, 30000, 2.0, 180.15, "step=147/40"),     # 40 phases, 512 threads (12 sets)
+    (88200.0, 96000.0, 4096, 1500, 20000, 10.0, 109.56, "step=147/80"),    # 80 phases, 256 threads (3 sets), 8 blocks
     # 8192-point blocks: 512-thread workgroups
     (44100.0, 96000.0, 8192, 5000, 40000, 1.0, 180.15, "fft=4096/8192"),   # fused, two phases per thread
     (96000.0, 44100.0, 8192, 8192, 50000, 1.0, 180.15, "fft=8192/8192"),   # fused, one phase per thread
