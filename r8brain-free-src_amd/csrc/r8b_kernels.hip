@@ -481,11 +481,8 @@ struct GpuExecP
 };
 
 // 64 KB of LDS per workgroup: two workgroups per CU, i.e. two waves per SIMD and 256 registers each
-#ifndef R8B_CONVP_WGS
-#define R8B_CONVP_WGS 2
-#endif
 template<int LN, int UL, int MODE, int FLENP>
-__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) > 256 ? 1 : R8B_CONVP_WGS)) void k_convp(const ConvxLaunch X)
+__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) > 256 ? 1 : 2)) void k_convp(const ConvxLaunch X)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
 	// XCD-aware mapping as in k_convx, over channel PAIRS and groups of SUB consecutive blocks
@@ -533,11 +530,7 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	const unsigned nbg = ((unsigned) X.c.nblk + SUB - 1u) / SUB;
 	X.nblk_magic = nbg > 1 ? (unsigned) (0x100000000ull / nbg) + 1u : 0u;
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
-#ifdef R8B_CONVP_LDS_TIMING_ONLY // occupancy experiments: results are wrong
-	const size_t lds = R8B_CONVP_LDS_TIMING_ONLY;
-#else
 	const size_t lds = (size_t) convp_lds_bytes<LN, UL>();
-#endif
 	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
 	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
 	hipLaunchKernelGGL(kern, dim3(nbg * npair), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
