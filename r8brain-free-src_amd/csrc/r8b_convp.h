@@ -130,7 +130,7 @@ struct ConvpState
 	cd tw[ConvpGeom<LN, UL>::NTW];
 	cd hp[8];
 	double row[32];
-	double rows2[2 * 25]; // mode 4: the two rows of the thread's phase pair
+	double rows2[2 * 27]; // modes 4 / 5: the two rows of the thread's phase pair (25 or 27 entries each)
 	int pt;               // ... and its entry of X.ptab
 };
 
@@ -786,8 +786,9 @@ R8B_HD void cp_whole_compute(const ConvxLaunch& X, const cd* y, double* row, int
 // windows in 16 different bank groups (window starts of consecutive phase pairs are ~1.84 slots
 // apart: in natural order they collide two to three ways).  Groups cut by the block's output range are
 // computed whole and masked at the store (slots outside the run hold finite transform data).
-static const int kConvpTaps2 = 25;
-
+// MODE 5: the same with In > Out (down-sampling interpolators, cfg3: 320 / 147): the windows of adjacent
+// phases start 2 or 3 samples apart, the rows have 27 entries, 27 reads feed four outputs.
+template<int T2>
 R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int* pt, int tid)
 {
 	// (the tables are laid out for 256 lanes: in a 512-thread workgroup the upper half sits this phase out)
@@ -797,11 +798,11 @@ R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int* pt, int tid)
 		return;
 	}
 	*pt = X.ptab[tid];
-	// X.ctab holds the 50 values of a thread as 25 pairs, pair i of thread t at [(i * 256 + t) * 2]: a
+	// X.ctab holds the 2 T2 values of a thread as T2 pairs, pair i of thread t at [(i * 256 + t) * 2]: a
 	// wave reads 64 consecutive 16-byte entries per load
 	const cd* ct = reinterpret_cast<const cd*>(X.ctab) + tid;
 #pragma unroll
-	for (int i = 0; i < kConvpTaps2; i++)
+	for (int i = 0; i < T2; i++)
 	{
 		const cd v = ct[i * kConvpThreads];
 		rows[2 * i] = v.re;
@@ -809,6 +810,7 @@ R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int* pt, int tid)
 	}
 }
 
+template<int T2>
 R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* rows, int pt, long long k,
 	int chA, int chB, bool bvalid)
 {
@@ -835,7 +837,8 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* r
 		// the window in chunks of five taps, each chunk's reads issued one chunk ahead of its
 		// multiply-adds (two chunks of 16-byte values are live: the scheduler, left alone, reads all 25
 		// first -- 100 registers the prefetched samples of the next block then have to leave for)
-		constexpr int CH = 5, NCH = kConvpTaps2 / CH;
+		constexpr int CH = T2 == 25 ? 5 : 3, NCH = T2 / CH;
+		static_assert(CH * NCH == T2, "chunks");
 		cd v[2][CH];
 #pragma unroll
 		for (int i = 0; i < CH; i++) v[0][i] = w[i];
@@ -854,8 +857,8 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* r
 				const int t = CH * c + i;
 				a0[t & 1] += rows[t] * v[c & 1][i].re;
 				b0[t & 1] += rows[t] * v[c & 1][i].im;
-				a1[t & 1] += rows[kConvpTaps2 + t] * v[c & 1][i].re;
-				b1[t & 1] += rows[kConvpTaps2 + t] * v[c & 1][i].im;
+				a1[t & 1] += rows[T2 + t] * v[c & 1][i].re;
+				b1[t & 1] += rows[T2 + t] * v[c & 1][i].im;
 			}
 		}
 		const bool v0 = (gl > 0 || f0) && (gl < gmax || l0);
@@ -1096,14 +1099,15 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 			if (live(tid)) cp_store_conv<LN, UL, MODE>(L, st, k_of(tid), chA, chB, bvalid, lt);
 		});
 	}
-	else if constexpr (MODE == 4)
+	else if constexpr (MODE == 4 || MODE == 5)
 	{
+		constexpr int T2 = MODE == 4 ? 25 : 27;
 		static_assert(UL >= 0, "the decimating form has no fused interpolator");
 		ex.phase([&](int tid, St& st)
 		{
 			if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
 			else cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
-			cp_rows2_fetch(X, st.rows2, &st.pt, tid);
+			cp_rows2_fetch<T2>(X, st.rows2, &st.pt, tid);
 		});
 		ex.phase([&](int tid, St& st)
 		{
@@ -1113,7 +1117,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		ex.each([&](int, St& st)
 		{
 			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
-				cp_whole2_compute(X, buf + sb * G::NA, st.rows2, st.pt, cur.k + sb, chA, chB, bvalid);
+				cp_whole2_compute<T2>(X, buf + sb * G::NA, st.rows2, st.pt, cur.k + sb, chA, chB, bvalid);
 		});
 	}
 	else

@@ -76,6 +76,7 @@ private:
 		int* ptab = nullptr;
 		double* ctab = nullptr;
 		int nsets = 0;
+		int taps2 = 25; // entries per row: 25 (In <= Out) or 27
 		std::vector<int> fwd_radix, inv_radix;
 		std::vector<std::pair<void*, void*>> pending; // (start, stop) events not yet read
 		std::vector<void*> free_events;

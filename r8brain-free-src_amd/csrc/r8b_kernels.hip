@@ -658,6 +658,7 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 		if (mode == 0) launch_convp_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
 		else if (mode == 3) launch_convp_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
 		else if (mode == 4) launch_convp_t<LN, UL, 4, 24>(X, (hipStream_t) stream); \
+		else if (mode == 5) launch_convp_t<LN, UL, 5, 24>(X, (hipStream_t) stream); \
 		else if (wide) launch_convp_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
 		else launch_convp_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
 		return; \
@@ -681,6 +682,7 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 		if (mode == 3) launch_convp_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
 		else if (mode == 0) launch_convp_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
 		else if (mode == 4) launch_convp_t<LN, UL, 4, 24>(X, (hipStream_t) stream); \
+		else if (mode == 5) launch_convp_t<LN, UL, 5, 24>(X, (hipStream_t) stream); \
 		else if (wide) launch_convp_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
 		else launch_convp_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
 		return; \

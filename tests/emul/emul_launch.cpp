@@ -262,6 +262,7 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 		if (mode == 0) emul_convp_t<LN, UL, 0, 24>(X); \
 		else if (mode == 3) emul_convp_t<LN, UL, 3, 24>(X); \
 		else if (mode == 4) emul_convp_t<LN, UL, 4, 24>(X); \
+		else if (mode == 5) emul_convp_t<LN, UL, 5, 24>(X); \
 		else if (wide) emul_convp_t<LN, UL, 1, 32>(X); \
 		else emul_convp_t<LN, UL, 1, 24>(X); \
 		return; \
@@ -285,6 +286,7 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 		if (mode == 3) emul_convp_t<LN, UL, 3, 24>(X); \
 		else if (mode == 0) emul_convp_t<LN, UL, 0, 24>(X); \
 		else if (mode == 4) emul_convp_t<LN, UL, 4, 24>(X); \
+		else if (mode == 5) emul_convp_t<LN, UL, 5, 24>(X); \
 		else if (wide) emul_convp_t<LN, UL, 1, 32>(X); \
 		else emul_convp_t<LN, UL, 1, 24>(X); \
 		return; \
