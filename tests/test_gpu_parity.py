@@ -285,18 +285,23 @@ def test_hip_minimum_phase_chains(torch, refwrap, case):
     run_minphase_case({"device": 0}, refwrap, case)
 
 
-def test_hip_soak_ragged_calls_vs_reference(torch, refwrap):
-    """2400 ragged process() calls of one stream per channel on the real kernels (position wrap,
-    ring masks, block schedule over a long run), every call's count and samples against the
-    compiled reference"""
-    src, dst, maxin, nch = 44100.0, 96000.0, 2048, 3
+@pytest.mark.parametrize("topo", [(44100.0, 96000.0, 2048, 2.0, 180.15, 2400),   # cfg2 topology
+                                  (44100.0, 96000.0, 2048, 10.0, 109.56, 1200),  # 8 blocks per workgroup, fused
+                                  (88200.0, 44100.0, 2048, 5.0, 109.56, 1200),   # decimating, 4 blocks per workgroup
+                                  (48000.0, 32000.0, 2048, 2.0, 180.15, 1200)])  # 8192-point blocks, 3x strided store
+def test_hip_soak_ragged_calls_vs_reference(torch, refwrap, topo):
+    """thousands of ragged process() calls of one stream per channel on the real kernels (position
+    wrap, ring masks, block schedule and partly filled block groups over a long run), every call's
+    count and samples against the compiled reference"""
+    src, dst, maxin, tb, att, ncalls = topo
+    nch = 3
     rng = np.random.default_rng(2024)
-    lens = rng.integers(1, maxin + 1, size=2400).astype(np.int32)
+    lens = rng.integers(1, maxin + 1, size=ncalls).astype(np.int32)
     lens[::7] = maxin
     lens[3::11] = 1
     n = int(lens.sum())
     x = make_input(nch, n, 31)
-    b = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=nch, device=0)
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, device=0)
     xd = torch.from_numpy(x).cuda()
     out = torch.empty((nch, b.max_out_len), dtype=torch.float64, device="cuda")
     ys, counts, pos = [], [], 0
@@ -307,7 +312,7 @@ def test_hip_soak_ragged_calls_vs_reference(torch, refwrap):
             ys.append(yv.clone())
         pos += int(l)
     y = torch.cat(ys, dim=1).cpu().numpy()
-    r, p = refwrap.batch_check(src, dst, maxin, lens, x, y, counts)
+    r, p = refwrap.batch_check(src, dst, maxin, lens, x, y, counts, tb, att)
     assert r.max() <= RMS_TOL and p.max() <= PEAK_TOL, (r.max(), p.max())
 
 
