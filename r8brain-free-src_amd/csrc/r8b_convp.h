@@ -128,7 +128,7 @@ struct ConvpState
 	double vr[16], vi[16];
 	double pr[16], pi[16]; // the block's input samples (channel A, channel B) of the first pass
 	cd tw[ConvpGeom<LN, UL>::NTW];
-	cd hp[8];
+	cd hp[16]; // (8 pairs of reals; 16 complex values when the kernel spectrum is complex)
 	double row[32];
 	double rows2[2 * 27]; // modes 4 / 5: the two rows of the thread's phase pair (25 or 27 entries each)
 	int pt;               // ... and its entry of X.ptab
@@ -335,11 +335,14 @@ struct ConvpPre
 
 // kernel constants of the middle pass, hp[c * NT + t] (a wave reads consecutive 16-byte entries):
 //   2x up: (Hs, Hd) of forward position 8 t + c;   1:1: H of backward positions 16 t + 2 c, + 1
-template<int LN, int UL>
+//   complex kernel spectrum (CX: minimum phase, or an alignment moved by inherited latency; reference
+//   CDSPRealFFT.h:186-274 multiplyBlocks): one complex value per entry -- 1:1: H of backward position 16 t + c;
+//   2x up: Hs (c < 8) / Hd (c >= 8) of forward position 8 t + (c & 7); decimating: H of kept position c
+template<int LN, int UL, bool CX = false>
 R8B_HD void cp_hp_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 {
 	// (decimating form: H of the thread's kept positions 2c, 2c + 1)
-	constexpr int NHP = UL < 0 ? ConvpGeom<LN, UL>::E2 / 2 : 8;
+	constexpr int NHP = CX ? (UL < 0 ? ConvpGeom<LN, UL>::E2 : 16) : (UL < 0 ? ConvpGeom<LN, UL>::E2 / 2 : 8);
 #pragma unroll
 	for (int c = 0; c < NHP; c++)
 	{
@@ -349,7 +352,7 @@ R8B_HD void cp_hp_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 
 // middle pass, compute part: results (the backward array's positions 16 t + p after the first
 // backward pass) stay in st.vr / st.vi
-template<int LN, int UL>
+template<int LN, int UL, bool CX = false>
 R8B_HD void cp_middle_compute(const cd* buf, ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
@@ -363,7 +366,29 @@ R8B_HD void cp_middle_compute(const cd* buf, ConvpState<LN, UL>& st, int lt)
 	}
 #pragma unroll
 	for (int f = 0; f < G::NBF; f++) dif_regs<G::RM>(zr + G::RM * f, zi + G::RM * f);
-	if constexpr (UL > 0)
+	if constexpr (CX)
+	{
+		// complex kernel spectrum: a complex multiplication per backward position
+#pragma unroll
+		for (int p = 0; p < 16; p++)
+		{
+			const int src = UL > 0 ? p >> 1 : p;
+			const cd h = st.hp[UL > 0 ? (p >> 1) + 8 * (p & 1) : p];
+			st.vr[p] = zr[src] * h.re - zi[src] * h.im;
+			st.vi[p] = zr[src] * h.im + zi[src] * h.re;
+		}
+		if constexpr (G::POST)
+		{
+			if constexpr (UL == 0)
+			{
+#pragma unroll
+				for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
+			}
+		}
+		else if constexpr (UL > 0) DitSt<16, 2>::run(st.vr, st.vi);
+		else dit_regs<16>(st.vr, st.vi);
+	}
+	else if constexpr (UL > 0)
 	{
 		// forward position p -> backward positions 2p, 2p+1 already combined by the first radix-2
 		// stage: Z (H[k] + H[k+N]), Z (H[k] - H[k+N])
@@ -493,7 +518,7 @@ R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 // thread 0) is the reference's fix-up: per channel the REAL value H[m] (Re X[m] + Im X[m]), m = N2 / 2,
 // X = that channel's spectrum, from the forward bins m and N - m (positions D and 2D - 1).
 // hp[c * NT + t] = H of the thread's kept positions 2c, 2c + 1.
-template<int LN, int UL>
+template<int LN, int UL, bool CX = false>
 R8B_HD void cp_middle_compute_down(const cd* buf, ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
@@ -508,6 +533,31 @@ R8B_HD void cp_middle_compute_down(const cd* buf, ConvpState<LN, UL>& st, int lt
 	}
 #pragma unroll
 	for (int f = 0; f < G::NBF; f++) dif_regs<G::RM>(zr + G::RM * f, zi + G::RM * f);
+	if constexpr (CX)
+	{
+#pragma unroll
+		for (int c = 0; c < G::E2; c++)
+		{
+			const int src = 2 * D * (c >> 1) + ((c & 1) ? 2 * D - 1 : 0);
+			const cd h = st.hp[c];
+			st.vr[c] = zr[src] * h.re - zi[src] * h.im;
+			st.vi[c] = zr[src] * h.im + zi[src] * h.re;
+		}
+		if (lt == 0)
+		{
+			// complex kernel: the new Nyquist bin is Re(H[m] X[m]) per channel (reference
+			// CDSPBlockConvolver.h:340 after multiplyBlocks); the table entry of kept position 1 is
+			// H[N - m] = conj H[m].  X_A = (P + conj Q) / 2, X_B = (P - conj Q) / 2i
+			const double pr = zr[D], pi = zi[D], qr = zr[2 * D - 1], qi = zi[2 * D - 1];
+			const double hr = st.hp[1].re, hi = -st.hp[1].im;
+			const double ar = 0.5 * (pr + qr), ai = 0.5 * (pi - qi); // X_A
+			const double br = 0.5 * (pi + qi), bi = -0.5 * (pr - qr); // X_B
+			st.vr[1] = hr * ar - hi * ai;
+			st.vi[1] = hr * br - hi * bi;
+		}
+	}
+	else
+	{
 #pragma unroll
 	for (int c = 0; c < G::E2; c++)
 	{
@@ -523,6 +573,7 @@ R8B_HD void cp_middle_compute_down(const cd* buf, ConvpState<LN, UL>& st, int lt
 		const double h = st.hp[0].im;
 		st.vr[1] = h * (0.5 * ((pr + qr) + (pi - qi)));
 		st.vi[1] = h * (0.5 * ((pi + qi) - (pr - qr)));
+	}
 	}
 #pragma unroll
 	for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
@@ -924,6 +975,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 {
 	typedef ConvpGeom<LN, UL> G;
 	typedef ConvpState<LN, UL> St;
+	// modes 6 / 7: modes 0 / 3 with a complex kernel spectrum
+	constexpr bool CX = MODE == 6 || MODE == 7;
+	constexpr int BM = MODE == 6 ? 0 : (MODE == 7 ? 3 : MODE);
 	const ConvLaunch& L = X.c;
 	const int chA = cur.chA, chB = cur.chB;
 	const bool bvalid = cur.bvalid;
@@ -949,10 +1003,10 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	ex.phase([&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
-		cp_load<LN, UL, MODE>(L, st, k_of(tid), chA, chB, lt);
+		cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
 		cp_first<LN, UL>(L, buf_of(tid), st, lt);
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
-		else cp_hp_prefetch<LN, UL>(L, st, lt);
+		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
 	});
 	// forward passes 1 .., the middle pass and the first backward pass stay inside each wave's own range
 	// of the array (ConvpGeom): wave-level ordering points instead of workgroup barriers between them
@@ -961,13 +1015,13 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		const int lt = lt_of(tid);
 		ConvpPre<LN, UL, 1>::run(buf_of(tid), st, lt);
 		if constexpr (G::NPRE > 2) ConvpPre<LN, UL, 2>::prefetch(L, st, lt);
-		else cp_hp_prefetch<LN, UL>(L, st, lt);
+		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
 	};
 	auto s_pre2 = [&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
 		ConvpPre<LN, UL, 2>::run(buf_of(tid), st, lt);
-		cp_hp_prefetch<LN, UL>(L, st, lt);
+		cp_hp_prefetch<LN, UL, CX>(L, st, lt);
 	};
 	// (two steps: every lane has read its forward data before any lane's backward data overwrites it --
 	// on the GPU program order alone guarantees that, LDS serves a wave's accesses in issue order)
@@ -985,8 +1039,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		auto d_midc = [&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
-			if constexpr (UL < 0) cp_middle_compute_down<LN, UL>(buf_of(tid), st, lt);
-			else cp_middle_compute<LN, UL>(buf_of(tid), st, lt);
+			if constexpr (UL < 0) cp_middle_compute_down<LN, UL, CX>(buf_of(tid), st, lt);
+			else cp_middle_compute<LN, UL, CX>(buf_of(tid), st, lt);
 			ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
 		};
 		auto d_midw = [&](int tid, St& st)
@@ -1043,7 +1097,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	auto s_midc = [&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
-		cp_middle_compute<LN, UL>(buf_of(tid), st, lt);
+		cp_middle_compute<LN, UL, CX>(buf_of(tid), st, lt);
 		if constexpr (G::B1) ptw_fetch<16, G::NT>(st.tw, L.ptw, 3, lt);
 		else cp_back2_prefetch<LN, UL>(L, st, lt);
 	};
@@ -1077,7 +1131,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 			}
 		});
 	}
-	if constexpr (G::POST && (MODE == 0 || MODE == 3))
+	if constexpr (G::POST && (BM == 0 || BM == 3))
 	{
 		ex.each([&](int tid, St& st)
 		{
@@ -1086,17 +1140,17 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 			if (live(tid))
 			{
 				if constexpr (UL < 0) cp_store_conv_down<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
-				else cp_store_conv<LN, UL, MODE>(L, st, k_of(tid), chA, chB, bvalid, lt);
+				else cp_store_conv<LN, UL, BM>(L, st, k_of(tid), chA, chB, bvalid, lt);
 			}
 		});
 	}
-	else if constexpr (MODE == 0 || MODE == 3)
+	else if constexpr (BM == 0 || BM == 3)
 	{
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
 			cp_back2<LN, UL>(buf_of(tid), st, lt);
-			if (live(tid)) cp_store_conv<LN, UL, MODE>(L, st, k_of(tid), chA, chB, bvalid, lt);
+			if (live(tid)) cp_store_conv<LN, UL, BM>(L, st, k_of(tid), chA, chB, bvalid, lt);
 		});
 	}
 	else if constexpr (MODE == 4 || MODE == 5)

@@ -373,6 +373,57 @@ std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n
 	return out;
 }
 
+// The same with a complex kernel spectrum Hc (bl2/2 + 1 complex bins, Hermitian beyond): one complex value
+// per entry (r8b_convp.h cp_hp_prefetch, CX) -- 1:1: H of backward position 16 t + c; 2x up: Hs (c < 8) / Hd
+// (c >= 8) of forward position 8 t + (c & 7); decimating: H of the thread's kept position c.
+std::vector<double> pair_constants_complex(const std::vector<double>& Hc, int n_in, int n_out)
+{
+	typedef std::complex<long double> C;
+	const int N = n_in, N2 = n_out, NT = std::max(N, N2) / 16, NH = std::max(N, N2);
+	int ln = 0;
+	while ((1 << ln) < N) ln++;
+	auto Hf = [&](int m) -> C
+	{
+		m &= NH - 1;
+		if (m <= NH / 2) return C(Hc[(size_t) m * 2], Hc[(size_t) m * 2 + 1]);
+		return std::conj(C(Hc[(size_t) (NH - m) * 2], Hc[(size_t) (NH - m) * 2 + 1]));
+	};
+	auto rev = [](int v, int bits)
+	{
+		int r = 0;
+		for (int b = 0; b < bits; b++)
+			if (v & (1 << b)) r |= 1 << (bits - 1 - b);
+		return r;
+	};
+	std::vector<double> out((size_t) 16 * NT * 2, 0.0);
+	auto put = [&](int c, int t, C v)
+	{
+		out[((size_t) c * NT + t) * 2] = (double) v.real();
+		out[((size_t) c * NT + t) * 2 + 1] = (double) v.imag();
+	};
+	for (int t = 0; t < NT; t++)
+	{
+		if (N2 < N)
+		{
+			const int D = N / N2, E2 = 16 / D;
+			for (int cp = 0; cp < E2; cp++)
+				put(cp, t, Hf(rev(16 * t + 2 * D * (cp >> 1) + ((cp & 1) ? 2 * D - 1 : 0), ln)));
+		}
+		else if (N2 == 2 * N)
+		{
+			for (int c = 0; c < 8; c++)
+			{
+				const int k = rev(8 * t + c, ln);
+				put(c, t, Hf(k) + Hf(k + N));
+				put(c + 8, t, Hf(k) - Hf(k + N));
+			}
+		}
+		else
+			for (int c = 0; c < 16; c++) put(c, t, Hf(rev(16 * t + c, ln)));
+	}
+	return out;
+}
+
 std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int n_in, int n_out)
 {
 	// rows of NT entries (r8b_convp.h ptw_fetch): 6 per slot; slots 0-2 forward passes (radix e1); then,
@@ -523,8 +574,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 						"block convolver (transition band too narrow)");
 				if (g.complex_h)
 				{
-					// minimum phase (or an alignment moved by inherited latency): complex spectrum, generic
-					// kernel only
+					// minimum phase (or an alignment moved by inherited latency): complex spectrum for the
+					// generic kernel ...
 					if (!generic_conv_fits(g))
 						throw std::runtime_error("minimum-phase filter too long for the generic block convolver");
 					const std::vector<double> hc = kernel_spectrum_complex(*sp.lp, g.bl2, g.fl2, 1.0 / g.bl2);
@@ -534,6 +585,17 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 					d.tw_len = g.bl2;
 					d.tw = (cd*) dev_alloc(tw.size() * sizeof(double));
 					dev_upload(d.tw, tw.data(), tw.size() * sizeof(double));
+					if (convp_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2) ||
+						convp_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2))
+					{
+						// ... and the pair kernel with one complex multiplication per bin
+						const std::vector<double> hp = pair_constants_complex(hc, g.n_in, g.n_out);
+						d.hp = (cd*) dev_alloc(hp.size() * sizeof(double));
+						dev_upload(d.hp, hp.data(), hp.size() * sizeof(double));
+						const std::vector<double> pt = pair_twiddles(tw, g.bl2, g.n_in, g.n_out);
+						d.ptw = (cd*) dev_alloc(pt.size() * sizeof(double));
+						dev_upload(d.ptw, pt.data(), pt.size() * sizeof(double));
+					}
 					continue;
 				}
 				const std::vector<double> H = kernel_spectrum(*sp.lp, g.bl2, 1.0 / g.bl2);
@@ -797,7 +859,6 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 		case kConv:
 			*kernel = fuse_with_next(stage) ?
 				(use_pair_fused(sp.cg) ? "k_convp_whole" : "k_convx_whole") :
-				sp.cg.complex_h ? "k_conv" :
 				conv_path(sp.cg) == kPathGeneric ? "k_conv" :
 				(conv_path(sp.cg) == kPathPair || conv_path(sp.cg) == kPathPair3 ? "k_convp" : "k_convx");
 			break;
@@ -1004,9 +1065,9 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0; X.run_off = 0;
 			X.ptab = nullptr; X.ctab = nullptr; X.nsets = 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
-			if (path == kPathPair3) launch_convp(X, 3, stream);
+			if (path == kPathPair3) launch_convp(X, g.complex_h ? 7 : 3, stream);
 			else if (path == kPathConvx3) launch_convx(X, 3, stream);
-			else if (path == kPathPair) launch_convp(X, 0, stream);
+			else if (path == kPathPair) launch_convp(X, g.complex_h ? 6 : 0, stream);
 			else launch_convx(X, 0, stream);
 			if (L.tail_ring != nullptr) tail_done_ = true;
 		}
@@ -1364,9 +1425,10 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 // which kernel family runs a (not fused) convolver stage
 int Engine::conv_path(const ConvGeom& g) const
 {
-	if (g.complex_h || !(opt_.at("fast_conv") || !generic_conv_fits(g))) return kPathGeneric;
+	if (!(opt_.at("fast_conv") || !generic_conv_fits(g))) return kPathGeneric;
 	if (opt_.at("pair_conv") && convp_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2))
 		return kPathPair3;
+	if (g.complex_h) return use_pair(g) ? kPathPair : kPathGeneric; // (complex spectrum: pair kernel or generic)
 	if (convx_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2)) return kPathConvx3;
 	if (use_pair(g)) return kPathPair;
 	if (convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2)) return kPathConvx;

@@ -657,6 +657,8 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 	{ \
 		if (mode == 0) launch_convp_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
 		else if (mode == 3) launch_convp_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
+		else if (mode == 6) launch_convp_t<LN, UL, 6, 24>(X, (hipStream_t) stream); \
+		else if (mode == 7) launch_convp_t<LN, UL, 7, 24>(X, (hipStream_t) stream); \
 		else if (mode == 4) launch_convp_t<LN, UL, 4, 24>(X, (hipStream_t) stream); \
 		else if (mode == 5) launch_convp_t<LN, UL, 5, 24>(X, (hipStream_t) stream); \
 		else if (wide) launch_convp_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
@@ -669,6 +671,8 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 		if (ln == LN && X.c.down == (1 << DL)) \
 		{ \
 			if (mode == 3) launch_convp_t<LN, -DL, 3, 24>(X, (hipStream_t) stream); \
+			else if (mode == 6) launch_convp_t<LN, -DL, 6, 24>(X, (hipStream_t) stream); \
+			else if (mode == 7) launch_convp_t<LN, -DL, 7, 24>(X, (hipStream_t) stream); \
 			else launch_convp_t<LN, -DL, 0, 24>(X, (hipStream_t) stream); \
 			return; \
 		}
@@ -680,6 +684,8 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 	if (ln == LN && up == (1 << UL)) \
 	{ \
 		if (mode == 3) launch_convp_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
+		else if (mode == 6) launch_convp_t<LN, UL, 6, 24>(X, (hipStream_t) stream); \
+		else if (mode == 7) launch_convp_t<LN, UL, 7, 24>(X, (hipStream_t) stream); \
 		else if (mode == 0) launch_convp_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
 		else if (mode == 4) launch_convp_t<LN, UL, 4, 24>(X, (hipStream_t) stream); \
 		else if (mode == 5) launch_convp_t<LN, UL, 5, 24>(X, (hipStream_t) stream); \

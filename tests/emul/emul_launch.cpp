@@ -261,6 +261,8 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 	{ \
 		if (mode == 0) emul_convp_t<LN, UL, 0, 24>(X); \
 		else if (mode == 3) emul_convp_t<LN, UL, 3, 24>(X); \
+		else if (mode == 6) emul_convp_t<LN, UL, 6, 24>(X); \
+		else if (mode == 7) emul_convp_t<LN, UL, 7, 24>(X); \
 		else if (mode == 4) emul_convp_t<LN, UL, 4, 24>(X); \
 		else if (mode == 5) emul_convp_t<LN, UL, 5, 24>(X); \
 		else if (wide) emul_convp_t<LN, UL, 1, 32>(X); \
@@ -273,6 +275,8 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 		if (ln == LN && X.c.down == (1 << DL)) \
 		{ \
 			if (mode == 3) emul_convp_t<LN, -DL, 3, 24>(X); \
+			else if (mode == 6) emul_convp_t<LN, -DL, 6, 24>(X); \
+			else if (mode == 7) emul_convp_t<LN, -DL, 7, 24>(X); \
 			else emul_convp_t<LN, -DL, 0, 24>(X); \
 			return; \
 		}
@@ -284,6 +288,8 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 	if (ln == LN && up == (1 << UL)) \
 	{ \
 		if (mode == 3) emul_convp_t<LN, UL, 3, 24>(X); \
+		else if (mode == 6) emul_convp_t<LN, UL, 6, 24>(X); \
+		else if (mode == 7) emul_convp_t<LN, UL, 7, 24>(X); \
 		else if (mode == 0) emul_convp_t<LN, UL, 0, 24>(X); \
 		else if (mode == 4) emul_convp_t<LN, UL, 4, 24>(X); \
 		else if (mode == 5) emul_convp_t<LN, UL, 5, 24>(X); \

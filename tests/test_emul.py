@@ -67,6 +67,36 @@ def test_emulated_long_filters_on_shorter_blocks(emul, refwrap, case):
     assert r.max() <= rtol and p.max() <= ptol, (r.max(), p.max())
 
 
+MINPHASE_PAIR_TOPOLOGIES = [(44100.0, 96000.0, 2.0, 180.15), (96000.0, 44100.0, 5.0, 109.56),
+                            (88200.0, 44100.0, 2.0, 180.15), (176400.0, 44100.0, 20.0, 80.0),
+                            (44100.0, 132300.0, 5.0, 109.56), (48000.0, 32000.0, 2.0, 180.15),
+                            (32000.0, 48000.0, 20.0, 80.0), (64000.0, 48000.0, 5.0, 109.56)]
+
+
+def run_minphase_pair_vs_generic(lib_kw, topo):
+    src, dst, tb, att = topo
+    x = make_input(3, 24000, 9)
+    ys = []
+    for pair in (1, 0):
+        b = r8b.BatchResampler(src, dst, 4096, tb, att, nch=3, phase=1, **lib_kw)
+        b.set_option("pair_conv", pair)
+        b.set_option("timing", 1)
+        names = [t[0] for t in b.stage_timings()]
+        assert any(n.startswith("k_convp") for n in names) == bool(pair), names
+        b.set_option("timing", 0)
+        ys.append(np.concatenate([b.process_host(x[:, i:i + 3000]) for i in range(0, 24000, 3000)], axis=1))
+    assert ys[0].shape == ys[1].shape and ys[0].shape[1] > 1000
+    assert np.abs(ys[0] - ys[1]).max() <= 5e-15, np.abs(ys[0] - ys[1]).max()
+
+
+@pytest.mark.parametrize("topo", MINPHASE_PAIR_TOPOLOGIES)
+def test_emulated_minphase_pair_kernel_vs_generic(emul, topo):
+    """complex kernel spectrum (minimum phase) on the pair kernel -- 1:1, 2x up, decimating incl. the
+    Nyquist fix-up, radix-3 edges -- against the generic kernel (which the loose reference tolerance of
+    the minimum-phase cases cannot pin): the same samples to rounding"""
+    run_minphase_pair_vs_generic({"lib": emul}, topo)
+
+
 def run_minphase_case(lib_kw, refwrap, case):
     src, dst, maxin, chunk, n, tb, att, rtol, ptol = case
     b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, phase=1, **lib_kw)

@@ -285,6 +285,13 @@ def test_hip_minimum_phase_chains(torch, refwrap, case):
     run_minphase_case({"device": 0}, refwrap, case)
 
 
+def test_hip_minphase_pair_kernel_vs_generic(torch):
+    """complex kernel spectrum on the pair kernel against the generic kernel, real GPU"""
+    from test_emul import run_minphase_pair_vs_generic, MINPHASE_PAIR_TOPOLOGIES
+    for topo in MINPHASE_PAIR_TOPOLOGIES:
+        run_minphase_pair_vs_generic({"device": 0}, topo)
+
+
 @pytest.mark.parametrize("topo", [(44100.0, 96000.0, 2048, 2.0, 180.15, 2400),   # cfg2 topology
                                   (44100.0, 96000.0, 2048, 10.0, 109.56, 1200),  # 8 blocks per workgroup, fused
                                   (88200.0, 44100.0, 2048, 5.0, 109.56, 1200),   # decimating, 4 blocks per workgroup
