@@ -1088,11 +1088,11 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			L.table = d.table;
 			L.a = a; L.b = b;
 			L.tile = opt_.at("whole_tile");
-			L.span_max = (int) ((long long) L.tile * sp.in_step / sp.out_step) + sp.flen + 4;
+			L.span_max = (int) ((long long) L.tile * sp.in_step / sp.out_step) + sp.flen + 4 + 32;
 			while (L.span_max > 12288 && L.tile > 64)
 			{
 				L.tile /= 2;
-				L.span_max = (int) ((long long) L.tile * sp.in_step / sp.out_step) + sp.flen + 4;
+				L.span_max = (int) ((long long) L.tile * sp.in_step / sp.out_step) + sp.flen + 4 + 32;
 			}
 			L.nch = nch_;
 			L.src = src; L.dst = dst;

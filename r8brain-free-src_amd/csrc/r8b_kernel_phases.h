@@ -523,26 +523,63 @@ R8B_HD void whole_tile_span(const WholeLaunch& L, long long j0, long long j1, lo
 	*len = (int) (r1 - r0 + 1);
 }
 
+static const int kWholePad = 32; // zeros behind a tile's input span (read by the zero-padded rows)
+
 R8B_HD void whole_load(const WholeLaunch& L, double* xs, long long lo, int len, int ch, int tid,
 	int nthr)
 {
 	for (int i = tid; i < len; i += nthr) xs[i] = src_load(L.src, ch, lo + i);
+	for (int i = tid; i < kWholePad; i += nthr) xs[len + i] = 0.0;
+}
+
+// A thread keeps ONE phase (outputs j0 + t, j0 + t + Out, ...: the same polyphase row, input positions In
+// apart): the position arithmetic (a 64-bit division) and the row fetch happen once per thread and tile,
+// not once per output, and the row lives in registers.  Fewer phases than threads: lanes share a phase in
+// group sets; more: a thread walks phases t, t + nthr, ...
+template<int FLENP>
+R8B_HD void whole_compute_t(const WholeLaunch& L, const double* xs, long long lo, long long j0,
+	long long j1, int ch, int tid, int nthr)
+{
+	const int Out = L.out_step, In = L.in_step;
+	const int nsets = nthr >= Out ? nthr / Out : 1;
+	const int set = nthr >= Out ? tid / Out : 0;
+	if (set >= nsets) return;
+	const int ustep = nsets * In;
+	const long long jstep = (long long) nsets * Out;
+	for (int t = nthr >= Out ? tid - set * Out : tid; t < Out; t += nthr)
+	{
+		long long j = j0 + t + (long long) set * Out;
+		if (j >= j1) continue;
+		const long long p = j * In + L.pos0;
+		const long long r = p / Out;
+		const int ph = (int) (p - r * Out);
+		const double* tr = L.table + (long) ph * L.flen;
+		double row[FLENP];
+#pragma unroll
+		for (int i = 0; i < FLENP; i++) row[i] = i < L.flen ? tr[i] : 0.0;
+		int u = (int) (r - L.fll - lo);
+		for (; j < j1; j += jstep, u += ustep)
+		{
+			const double* x = xs + u;
+			double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+			for (int i = 0; i < FLENP; i += 2)
+			{
+				s0 += row[i] * x[i];
+				s1 += row[i + 1] * x[i + 1];
+			}
+			dst_store(L.dst, ch, j, s0 + s1);
+		}
+	}
 }
 
 R8B_HD void whole_compute(const WholeLaunch& L, const double* xs, long long lo, long long j0,
 	long long j1, int ch, int tid, int nthr)
 {
-	for (long long j = j0 + tid; j < j1; j += nthr)
-	{
-		const long long p = j * L.in_step + L.pos0;
-		const long long r = p / L.out_step;
-		const int ph = (int) (p - r * L.out_step);
-		const double* row = L.table + (long) ph * L.flen;
-		const double* x = xs + (r - L.fll - lo);
-		double s = 0.0;
-		for (int i = 0; i < L.flen; i++) s += row[i] * x[i];
-		dst_store(L.dst, ch, j, s);
-	}
+	if (L.flen <= 8) whole_compute_t<8>(L, xs, lo, j0, j1, ch, tid, nthr);
+	else if (L.flen <= 16) whole_compute_t<16>(L, xs, lo, j0, j1, ch, tid, nthr);
+	else if (L.flen <= 24) whole_compute_t<24>(L, xs, lo, j0, j1, ch, tid, nthr);
+	else whole_compute_t<32>(L, xs, lo, j0, j1, ch, tid, nthr);
 }
 
 // polynomial-interpolated bank: output number i of this call (absolute index L.a + i)

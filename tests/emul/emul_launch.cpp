@@ -78,7 +78,7 @@ void launch_whole(const WholeLaunch& L, void*)
 			long long lo;
 			int len;
 			whole_tile_span(L, j0, j1, &lo, &len);
-			if (len > L.span_max) throw std::runtime_error("emul: whole-step tile overflows LDS");
+			if (len + kWholePad > L.span_max) throw std::runtime_error("emul: whole-step tile overflows LDS");
 			for (int t = 0; t < nthr; t++) whole_load(L, xs.data(), lo, len, ch, t, nthr);
 			for (int t = 0; t < nthr; t++) whole_compute(L, xs.data(), lo, j0, j1, ch, t, nthr);
 		}
