@@ -514,6 +514,42 @@ std::vector<int> plan_radices(int N, int max_radix)
 	return r;
 }
 
+// LDS row pitch of the tiled polynomial interpolator (doubles).  Lanes 0..15 and 16..31 of an LDS lane group
+// read the windows of 16 consecutive outputs (input offsets floor(o * step + phase)) in two ADJACENT channel
+// rows; banks repeat every 32 doubles, so the pitch's residue mod 32 decides whether the two rows' slots
+// interleave (step 2: any odd residue) or collide.  Chosen by counting, for the step at hand.
+static int poly_row_pitch(int span_max, double step)
+{
+	if (span_max <= 0) return 0;
+	int best = 1;
+	long best_cost = -1;
+	for (int P = 0; P < 32; P++)
+	{
+		long cost = 0;
+		for (int ph = 0; ph < 8; ph++)
+		{
+			int cnt[32] = { 0 };
+			for (int o = 0; o < 16; o++)
+			{
+				const int xo = (int) std::floor(o * step + ph / 8.0);
+				cnt[xo & 31]++;
+				cnt[(xo + P) & 31]++;
+			}
+			int mx = 0;
+			for (int i = 0; i < 32; i++) mx = std::max(mx, cnt[i]);
+			cost += mx;
+		}
+		if (best_cost < 0 || cost < best_cost)
+		{
+			best_cost = cost;
+			best = P;
+		}
+	}
+	int pitch = span_max;
+	while ((pitch & 31) != best) pitch++;
+	return pitch;
+}
+
 static long long pow2_at_least(long long v)
 {
 	long long p = 1;
@@ -1111,6 +1147,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			// counter's rounding)
 			L.span_max = opt_.at("poly_tiled") ?
 				(int) std::ceil(64.0 * sp.ssr / sp.dsr) + sp.flen + 4 : 0;
+			L.pitch = poly_row_pitch(L.span_max, sp.ssr / sp.dsr);
 			L.src = src; L.dst = dst;
 			launch_poly(L, stream);
 		}

@@ -136,6 +136,38 @@ R8B_HD double src_block_load1(const SrcBlock& b, int rel)
 	return rel < b.z_rel ? 0.0 : v;
 }
 
+// Staging loop of the tile kernels: positions base + [0, len) of one channel into LDS (zeros from `end`
+// on).  A thread issues U loads before its first LDS store, so U of its HBM round trips overlap; the
+// plain loop (load, wait, store per pass) keeps ONE load per lane in flight, which holds a streaming kernel
+// at the latency-bandwidth product of its resident waves instead of the HBM rate.  Out-of-range lanes load
+// a clamped (valid) element and store nothing.
+template<int U>
+R8B_HD void src_block_stage(const SrcBlock& b, double* xs, int len, int end, int tid, int nthr)
+{
+	const int lim = end < len ? end : len;
+	if (lim <= 0)
+	{
+		for (int i = tid; i < len; i += nthr) xs[i] = 0.0;
+		return;
+	}
+	for (int i0 = tid; i0 < len; i0 += U * nthr)
+	{
+		double v[U];
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int i = i0 + u * nthr;
+			v[u] = src_block_load1(b, i < lim ? i : lim - 1);
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int i = i0 + u * nthr;
+			if (i < len) xs[i] = i < lim ? v[u] : 0.0;
+		}
+	}
+}
+
 
 // ------------------------------------------------------------------------------------ small DFTs
 
@@ -528,7 +560,8 @@ static const int kWholePad = 32; // zeros behind a tile's input span (read by th
 R8B_HD void whole_load(const WholeLaunch& L, double* xs, long long lo, int len, int ch, int tid,
 	int nthr)
 {
-	for (int i = tid; i < len; i += nthr) xs[i] = src_load(L.src, ch, lo + i);
+	const SrcBlock sb = src_block(L.src, ch, lo);
+	src_block_stage<4>(sb, xs, len, len, tid, nthr);
 	for (int i = tid; i < kWholePad; i += nthr) xs[len + i] = 0.0;
 }
 
@@ -638,11 +671,9 @@ R8B_HD double poly_one(const PolyLaunch& L, int ch, long long i)
 static const int kPolyTC = R8B_POLY_TC; // channels per workgroup
 static const int kPolyTO = 64; // outputs per workgroup
 
-R8B_HD int poly_pitch(int span) { return span | 1; }
-
-R8B_HD int poly_lds_doubles(int span_max, int flen)
+R8B_HD int poly_lds_doubles(int pitch, int flen)
 {
-	return (span_max | 1) * kPolyTC + kPolyTO * flen + 3 * kPolyTO;
+	return pitch * kPolyTC + kPolyTO * flen + 3 * kPolyTO;
 }
 
 // input span [lo, lo + len) needed by outputs i0 .. i1-1 of this call
@@ -659,11 +690,13 @@ R8B_HD void poly_tile_span(const PolyLaunch& L, long long i0, long long i1, long
 R8B_HD void poly_tile_load(const PolyLaunch& L, double* xs, int pitch, long long lo, int len, int ch0,
 	int tid, int nthr)
 {
-	for (int c = 0; c < kPolyTC && ch0 + c < L.nch; c++)
-	{
-		const SrcBlock sb = src_block(L.src, ch0 + c, lo);
-		for (int i = tid; i < len; i += nthr) xs[c * pitch + i] = src_block_load1(sb, i);
-	}
+	// nthr / kPolyTC lanes per channel row, all rows at once: a thread's loads (5 per round) are in flight
+	// together (one row after the other was 16 dependent HBM round trips per workgroup)
+	const int lpc = nthr / kPolyTC;
+	const int c = tid / lpc;
+	if (c >= kPolyTC || ch0 + c >= L.nch) return;
+	const SrcBlock sb = src_block(L.src, ch0 + c, lo);
+	src_block_stage<5>(sb, xs + c * pitch, len, len, tid - c * lpc, lpc);
 }
 
 // per output: x-row offset, bank entry and its fractional argument (xoff[o], xoff[64 + o],
@@ -695,19 +728,38 @@ R8B_HD void poly_tile_pos(const PolyLaunch& L, double* xoff, long long lo, long 
 R8B_HD void poly_tile_coefs(const PolyLaunch& L, double* cf, const double* xoff, long long i0,
 	long long i1, int tid, int nthr)
 {
+	// thread (o, q) evaluates taps q, q + nq, ... of output o; the table entries of its taps are fetched
+	// together (a wave reads one tap of 64 consecutive outputs: mostly one bank entry, i.e. one address)
 	const int nout = (int) (i1 - i0);
-	for (int idx = tid; idx < nout * L.flen; idx += nthr)
+	const int o = tid % kPolyTO, q = tid / kPolyTO, nq = nthr / kPolyTO;
+	if (o >= nout || q >= nq) return;
+	const int fti = (int) xoff[kPolyTO + o];
+	const double x = xoff[2 * kPolyTO + o];
+	double x2;
 	{
-		const int o = idx / L.flen, t = idx - o * L.flen;
-		const int fti = (int) xoff[kPolyTO + o];
-		const double x = xoff[2 * kPolyTO + o];
-		double x2;
-		{
 #pragma clang fp contract(off)
-			x2 = x * x;
+		x2 = x * x;
+	}
+	const double* const row = L.table + (long) fti * L.flen * 3;
+	constexpr int U = 4;
+	for (int t0 = q; t0 < L.flen; t0 += U * nq)
+	{
+		double c0[U], c1[U], c2[U];
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int t = t0 + u * nq;
+			const double* c = row + (t < L.flen ? t : t0) * 3;
+			c0[u] = c[0];
+			c1[u] = c[1];
+			c2[u] = c[2];
 		}
-		const double* c = L.table + ((long) fti * L.flen + t) * 3;
-		cf[t * kPolyTO + o] = c[0] + c[1] * x + c[2] * x2;
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int t = t0 + u * nq;
+			if (t < L.flen) cf[t * kPolyTO + o] = c0[u] + c1[u] * x + c2[u] * x2;
+		}
 	}
 }
 
@@ -715,7 +767,13 @@ template<int FLENP>
 R8B_HD void poly_tile_compute_t(const PolyLaunch& L, const double* xs, int pitch, const double* cf,
 	const double* xoff, long long i0, long long i1, int ch0, int tid, int nthr)
 {
-	const int o = tid % kPolyTO, g = tid / kPolyTO, ng = nthr / kPolyTO;
+	// a wave = 16 consecutive outputs x 4 channel classes: the 32 lanes LDS serves together read two
+	// ADJACENT channel rows, whose pitch (r8b_engine.cpp poly_row_pitch) interleaves their 8-byte slots for
+	// this step -- 64 outputs of one row at a step of ~2 samples were a 2- to 3-way bank conflict on
+	// every read; 16 lanes still store 128 consecutive bytes of a channel
+	const int ow = kPolyTO / (nthr / 64); // outputs per wave
+	const int lane = tid & 63;
+	const int o = (tid >> 6) * ow + lane % ow, g = lane / ow, ng = 64 / ow;
 	if (i0 + o >= i1) return;
 	double row[FLENP];
 #pragma unroll
@@ -745,19 +803,46 @@ R8B_HD void poly_tile_compute(const PolyLaunch& L, const double* xs, int pitch, 
 
 // ------------------------------------------------------------------------------------ half-band
 
+// Inner loops of the half-band kernels: a thread takes kHbIlp of its outputs per round and issues the LDS
+// reads of all of them tap by tap before the first sum is needed (one output per round left every read
+// exposed: a round was one LDS round trip per tap).  The sums keep their order per output.
+static const int kHbIlp = 4;
+
 // 2x up: tile of input indices [n0, n1); xs holds x[n0 - T + 1 .. n1 + T - 1 + 1)
 R8B_HD void hbup_compute(const HBLaunch& L, const double* xs, long long n0, long long n1, int ch,
 	int tid, int nthr)
 {
+	constexpr int U = kHbIlp;
 	const int T = L.ntaps;
-	for (long long n = n0 + tid; n < n1; n += nthr)
+	const int cnt = (int) (n1 - n0);
+	for (int i0 = tid; i0 < cnt; i0 += U * nthr)
 	{
-		const double* x = xs + (n - n0) + (T - 1); // x[0] == stream x[n]
-		double s = 0.0;
-		for (int k = 0; k < T; k++) s += L.taps[k] * (x[1 + k] + x[-k]);
-		const long long q = 2 * n;
-		if (q >= L.a && q < L.b) dst_store(L.dst, ch, q, x[0]);
-		if (q + 1 >= L.a && q + 1 < L.b) dst_store(L.dst, ch, q + 1, s);
+		const double* x[U]; // x[u][0] == stream x[n]
+		double s[U];
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int i = i0 + u * nthr;
+			x[u] = xs + (i < cnt ? i : i0) + (T - 1);
+			s[u] = 0.0;
+		}
+#pragma unroll
+		for (int k = 0; k < 16; k++)
+		{
+			if (k >= T) break;
+			const double f = L.taps[k];
+#pragma unroll
+			for (int u = 0; u < U; u++) s[u] += f * (x[u][1 + k] + x[u][-k]);
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int i = i0 + u * nthr;
+			if (i >= cnt) continue;
+			const long long q = 2 * (n0 + i);
+			if (q >= L.a && q < L.b) dst_store(L.dst, ch, q, x[u][0]);
+			if (q + 1 >= L.a && q + 1 < L.b) dst_store(L.dst, ch, q + 1, s[u]);
+		}
 	}
 }
 
@@ -765,13 +850,34 @@ R8B_HD void hbup_compute(const HBLaunch& L, const double* xs, long long n0, long
 R8B_HD void hbdown_compute(const HBLaunch& L, const double* xs, long long n0, long long n1, int ch,
 	int tid, int nthr)
 {
+	constexpr int U = kHbIlp;
 	const int T = L.ntaps;
-	for (long long n = n0 + tid; n < n1; n += nthr)
+	const int cnt = (int) (n1 - n0);
+	for (int i0 = tid; i0 < cnt; i0 += U * nthr)
 	{
-		const double* x = xs + 2 * (n - n0) + (2 * T - 1); // x[0] == stream x[2n]
-		double s = x[0];
-		for (int k = 0; k < T; k++) s += L.taps[k] * (x[1 + 2 * k] + x[-1 - 2 * k]);
-		dst_store(L.dst, ch, n, s);
+		const double* x[U]; // x[u][0] == stream x[2n]
+		double s[U];
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int i = i0 + u * nthr;
+			x[u] = xs + 2 * (i < cnt ? i : i0) + (2 * T - 1);
+			s[u] = x[u][0];
+		}
+#pragma unroll
+		for (int k = 0; k < 16; k++)
+		{
+			if (k >= T) break;
+			const double f = L.taps[k];
+#pragma unroll
+			for (int u = 0; u < U; u++) s[u] += f * (x[u][1 + 2 * k] + x[u][-1 - 2 * k]);
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int i = i0 + u * nthr;
+			if (i < cnt) dst_store(L.dst, ch, n0 + i, s[u]);
+		}
 	}
 }
 
@@ -817,17 +923,18 @@ R8B_HD void hbc_load(const HBCascadeLaunch& L, const HBCRanges& R, double* buf, 
 	const int len = (int) (R.in_hi - R.in_lo);
 	const SrcBlock sb = src_block(L.src, ch, R.in_lo);
 	const int end = clamp_rel(L.in_end - R.in_lo);
-	for (int i = tid; i < len; i += nthr) buf[i] = i < end ? src_block_load1(sb, i) : 0.0;
+	src_block_stage<4>(sb, buf, len, end, tid, nthr);
 }
 
 // one stage: input x[] (LDS, xin[0] = stream position in_lo) -> outputs [lo, hi) either into LDS
 // (yout[0] = position lo) or, for the last stage, to the destination.  TP = tap count rounded up
 // (4, 8 or 14): L.ntaps[] already holds the rounded count (so the input ranges cover the wider
 // window) and the extra taps are zero.
-template<int TP>
+template<int TP, bool LAST>
 R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, int s, const double* xin, long long in_lo,
-	long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr)
+	long long lo, long long hi, double* yout, int ch, int tid, int nthr)
 {
+	constexpr int U = TP <= 4 ? 4 : (TP <= 8 ? 2 : 1); // inputs of a thread per round (see kHbIlp): ~32 reads in flight
 	double f[TP];
 #pragma unroll
 	for (int k = 0; k < TP; k++) f[k] = L.taps[s][k];
@@ -836,68 +943,91 @@ R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, int s, const double* xin, long
 	const int xoff = (int) (n0 - in_lo);  // index of x[n0] in xin
 	const int qoff = (int) (2 * n0 - lo); // index of output 2*n0 relative to lo (0 or -1)
 	const int nout = (int) (hi - lo);
-	for (int i = tid; i < cnt; i += nthr)
+	for (int i0 = tid; i0 < cnt; i0 += U * nthr)
 	{
-		const double* x = xin + xoff + i; // x[0] == stream x[n0 + i]
-		double a0 = 0.0, a1 = 0.0;
+		double ev[U], od[U], nx[U];
 #pragma unroll
-		for (int k = 0; k < TP; k += 2)
+		for (int u = 0; u < U; u++)
 		{
-			a0 += f[k] * (x[1 + k] + x[-k]);
-			a1 += f[k + 1] * (x[2 + k] + x[-k - 1]);
-		}
-		const long long q = 2 * (n0 + i);
-		// a stage's stream starts at position 0: earlier outputs do not exist for the next stage
-		const double ev = q < 0 ? 0.0 : x[0];
-		const double od = q + 1 < 0 ? 0.0 : a0 + a1;
-		const int o = qoff + 2 * i;
-		if (last)
-		{
-			if (L.pair_ok == 2)
+			const int i = i0 + u * nthr;
+			const double* x = xin + xoff + (i < cnt ? i : i0); // x[0] == stream x[n0 + i]
+			double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+			for (int k = 0; k < TP; k += 2)
 			{
-				// odd destination offset: the aligned pairs are (odd output of this thread, even output of
-				// the next = its input sample x[1]); the tile's first even output goes alone
-				if (i == 0 && o >= 0 && o < nout) dst_store(L.dst, ch, q, ev);
-				if (o + 2 < nout)
+				a0 += f[k] * (x[1 + k] + x[-k]);
+				a1 += f[k + 1] * (x[2 + k] + x[-k - 1]);
+			}
+			ev[u] = x[0];
+			nx[u] = x[1];
+			od[u] = a0 + a1;
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int i = i0 + u * nthr;
+			if (i >= cnt) continue;
+			const long long q = 2 * (n0 + i);
+			// a stage's stream starts at position 0: earlier outputs do not exist for the next stage
+			const double e = q < 0 ? 0.0 : ev[u];
+			const double d = q + 1 < 0 ? 0.0 : od[u];
+			const int o = qoff + 2 * i;
+			if (LAST)
+			{
+				if (L.pair_ok == 2)
 				{
-					cd v;
-					v.re = od;
-					v.im = q + 2 < 0 ? 0.0 : x[1];
-					*reinterpret_cast<cd*>(L.dst.p + ((long long) ch * L.dst.stride +
-						((q + 1 + L.dst.off) & L.dst.mask))) = v;
+					// odd destination offset: the aligned pairs are (odd output of this thread, even output of
+					// the next = its input sample x[1]); the tile's first even output goes alone
+					if (i == 0 && o >= 0 && o < nout) dst_store(L.dst, ch, q, e);
+					if (o + 2 < nout)
+					{
+						cd v;
+						v.re = d;
+						v.im = q + 2 < 0 ? 0.0 : nx[u];
+						*reinterpret_cast<cd*>(L.dst.p + ((long long) ch * L.dst.stride +
+							((q + 1 + L.dst.off) & L.dst.mask))) = v;
+					}
+					else if (o + 1 < nout) dst_store(L.dst, ch, q + 1, d);
+					continue;
 				}
-				else if (o + 1 < nout) dst_store(L.dst, ch, q + 1, od);
-				continue;
+				if (L.pair_ok && o >= 0 && o + 1 < nout)
+				{
+					// the even/odd output pair as one 16-byte store (full 128-byte lines per wave
+					// instruction instead of two half-used ones)
+					cd v;
+					v.re = e;
+					v.im = d;
+					*reinterpret_cast<cd*>(L.dst.p + ((long long) ch * L.dst.stride +
+						((q + L.dst.off) & L.dst.mask))) = v;
+					continue;
+				}
+				if (o >= 0 && o < nout) dst_store(L.dst, ch, q, e);
+				if (o + 1 >= 0 && o + 1 < nout) dst_store(L.dst, ch, q + 1, d);
 			}
-			if (L.pair_ok && o >= 0 && o + 1 < nout)
+			else
 			{
-				// the even/odd output pair as one 16-byte store (full 128-byte lines per wave
-				// instruction instead of two half-used ones)
-				cd v;
-				v.re = ev;
-				v.im = od;
-				*reinterpret_cast<cd*>(L.dst.p + ((long long) ch * L.dst.stride +
-					((q + L.dst.off) & L.dst.mask))) = v;
-				continue;
+				if (o >= 0 && o < nout) yout[o] = e;
+				if (o + 1 >= 0 && o + 1 < nout) yout[o + 1] = d;
 			}
-			if (o >= 0 && o < nout) dst_store(L.dst, ch, q, ev);
-			if (o + 1 >= 0 && o + 1 < nout) dst_store(L.dst, ch, q + 1, od);
-		}
-		else
-		{
-			if (o >= 0 && o < nout) yout[o] = ev;
-			if (o + 1 >= 0 && o + 1 < nout) yout[o + 1] = od;
 		}
 	}
+}
+
+template<int TP>
+R8B_HD void hbc_stage_tp(const HBCascadeLaunch& L, int s, const double* xin, long long in_lo,
+	long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr)
+{
+	if (last) hbc_stage_t<TP, true>(L, s, xin, in_lo, lo, hi, yout, ch, tid, nthr);
+	else hbc_stage_t<TP, false>(L, s, xin, in_lo, lo, hi, yout, ch, tid, nthr);
 }
 
 R8B_HD void hbc_stage(const HBCascadeLaunch& L, int s, const double* xin, long long in_lo,
 	long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr)
 {
 	const int T = L.ntaps[s];
-	if (T <= 4) hbc_stage_t<4>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
-	else if (T <= 8) hbc_stage_t<8>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
-	else hbc_stage_t<14>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
+	if (T <= 4) hbc_stage_tp<4>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
+	else if (T <= 8) hbc_stage_tp<8>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
+	else hbc_stage_tp<14>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
 }
 
 // ------------------------------------------------------------------------------------ decimating cascade
@@ -935,20 +1065,34 @@ R8B_HD void hbd_stage_t(const HBCascadeLaunch& L, int s, const double* xin, long
 	for (int k = 0; k < TP; k++) f[k] = L.taps[s][k];
 	const int cnt = (int) (hi - lo);
 	const int xoff = (int) (2 * lo - in_lo); // index of x[2 lo] in xin
-	for (int i = tid; i < cnt; i += nthr)
+	constexpr int U = TP <= 4 ? 4 : (TP <= 8 ? 2 : 1); // outputs of a thread per round (see kHbIlp)
+	for (int i0 = tid; i0 < cnt; i0 += U * nthr)
 	{
-		const double* x = xin + xoff + 2 * i; // x[0] == stream x[2 (lo + i)]
-		double a0 = x[0], a1 = 0.0;
+		double v[U];
 #pragma unroll
-		for (int k = 0; k < TP; k += 2)
+		for (int u = 0; u < U; u++)
 		{
-			a0 += f[k] * (x[1 + 2 * k] + x[-1 - 2 * k]);
-			a1 += f[k + 1] * (x[3 + 2 * k] + x[-3 - 2 * k]);
+			const int i = i0 + u * nthr;
+			const double* x = xin + xoff + 2 * (i < cnt ? i : i0); // x[0] == stream x[2 (lo + i)]
+			double a0 = x[0], a1 = 0.0;
+#pragma unroll
+			for (int k = 0; k < TP; k += 2)
+			{
+				a0 += f[k] * (x[1 + 2 * k] + x[-1 - 2 * k]);
+				a1 += f[k + 1] * (x[3 + 2 * k] + x[-3 - 2 * k]);
+			}
+			v[u] = a0 + a1;
 		}
-		// a stage's stream starts at position 0: earlier outputs do not exist for the next stage
-		const double v = lo + i < 0 ? 0.0 : a0 + a1;
-		if (last) dst_store(L.dst, ch, lo + i, v);
-		else yout[i] = v;
+#pragma unroll
+		for (int u = 0; u < U; u++)
+		{
+			const int i = i0 + u * nthr;
+			if (i >= cnt) continue;
+			// a stage's stream starts at position 0: earlier outputs do not exist for the next stage
+			const double w = lo + i < 0 ? 0.0 : v[u];
+			if (last) dst_store(L.dst, ch, lo + i, w);
+			else yout[i] = w;
+		}
 	}
 }
 

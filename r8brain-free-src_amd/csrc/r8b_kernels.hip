@@ -74,11 +74,11 @@
 			"+v"(v[(N) - 2]), "+v"(v[(N) - 1])); \
 	}
 #endif
-#include "r8b_kernel_phases.h"
 // nothing is scheduled across this point (no instruction is emitted)
 #ifndef R8B_NO_SCHED_FENCE
 #define R8B_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
+#include "r8b_kernel_phases.h"
 #include "r8b_convx.h"
 #include "r8b_convp.h"
 #include "r8b_pcm.h"
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 4) void k_poly_tiled(const PolyLaunch L)
 	long long lo;
 	int len;
 	poly_tile_span(L, i0, i1, &lo, &len);
-	const int pitch = poly_pitch(L.span_max);
+	const int pitch = L.pitch;
 	double* const cf = xs + pitch * kPolyTC;
 	double* const xoff = cf + kPolyTO * L.flen;
 	poly_tile_load(L, xs, pitch, lo, len, ch0, tid, nthr);
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_hbup(const HBLaunch L)
 	const int len = (int) (n1 - n0) + 2 * T - 1;
 	{
 		const SrcBlock sb = src_block(L.src, ch, lo);
-		for (int i = tid; i < len; i += nthr) xs[i] = src_block_load1(sb, i);
+		src_block_stage<4>(sb, xs, len, len, tid, nthr);
 	}
 	__syncthreads();
 	hbup_compute(L, xs, n0, n1, ch, tid, nthr);
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_hbdown(const HBLaunch L)
 	const int len = (int) (2 * (n1 - n0 - 1) + 1) + 2 * (2 * T - 1);
 	{
 		const SrcBlock sb = src_block(L.src, ch, lo);
-		for (int i = tid; i < len; i += nthr) xs[i] = src_block_load1(sb, i);
+		src_block_stage<4>(sb, xs, len, len, tid, nthr);
 	}
 	__syncthreads();
 	hbdown_compute(L, xs, n0, n1, ch, tid, nthr);
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_hbdcascade(const HBCascadeLaunch L)
 	{
 		const SrcBlock sb = src_block(L.src, ch, R.in_lo);
 		const int end = clamp_rel(L.in_end - R.in_lo);
-		for (int i = tid; i < len; i += nthr) even[i] = i < end ? src_block_load1(sb, i) : 0.0;
+		src_block_stage<4>(sb, even, len, end, tid, nthr);
 	}
 	__syncthreads();
 	long long in_lo = R.in_lo;
@@ -582,8 +582,8 @@ void R8B_LAUNCH(launch_poly)(const PolyLaunch& L, void* stream)
 	const long long n = L.b - L.a;
 	if (L.span_max > 0)
 	{
-		// x rows (poly_pitch) + interpolated taps + row offsets: poly_lds_doubles()
-		const size_t lds = ((size_t) (L.span_max | 1) * kPolyTC + (size_t) kPolyTO * L.flen +
+		// x rows + interpolated taps + row offsets: poly_lds_doubles()
+		const size_t lds = ((size_t) L.pitch * kPolyTC + (size_t) kPolyTO * L.flen +
 			3 * kPolyTO) * sizeof(double);
 		hipLaunchKernelGGL(k_poly_tiled, dim3((unsigned) ((n + kPolyTO - 1) / kPolyTO),
 			(unsigned) ((L.nch + kPolyTC - 1) / kPolyTC)), dim3(256), lds, (hipStream_t) stream, L);

@@ -107,7 +107,8 @@ struct PolyLaunch
 	double shift;
 	long long a, b;
 	int nch;
-	int span_max; // tiled kernel: LDS doubles per channel row (max input span of an output tile)
+	int span_max; // tiled kernel: max input span of an output tile (0: one output per thread)
+	int pitch;    // tiled kernel: LDS doubles per channel row (>= span_max; residue mod 32 chosen for the step)
 	SrcView src;
 	DstView dst;
 };

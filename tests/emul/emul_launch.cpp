@@ -88,8 +88,8 @@ void launch_poly(const PolyLaunch& L, void*)
 {
 	if (L.span_max > 0)
 	{
-		const int nthr = 256, pitch = poly_pitch(L.span_max);
-		std::vector<double> xs((size_t) poly_lds_doubles(L.span_max, L.flen));
+		const int nthr = 256, pitch = L.pitch;
+		std::vector<double> xs((size_t) poly_lds_doubles(L.pitch, L.flen));
 		double* const cf = xs.data() + pitch * kPolyTC;
 		double* const xoff = cf + kPolyTO * L.flen;
 		const long long n = L.b - L.a;
