@@ -1146,7 +1146,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			// tile of 64 outputs spans at most 64*Src/Dst + taps input samples (+ slack for the
 			// counter's rounding)
 			L.span_max = opt_.at("poly_tiled") ?
-				(int) std::ceil(64.0 * sp.ssr / sp.dsr) + sp.flen + 4 : 0;
+				(int) std::ceil(64.0 * sp.ssr / sp.dsr) + sp.flen + 4 + 8 : 0; // (+ kPolyPad zeros)
 			L.pitch = poly_row_pitch(L.span_max, sp.ssr / sp.dsr);
 			L.src = src; L.dst = dst;
 			launch_poly(L, stream);

@@ -30,6 +30,17 @@ struct alignas(16) cd
 	double re, im;
 };
 
+// A tap window in LDS.  On the GPU the pointer is volatile in the LDS address space: every tap becomes ONE
+// ds_read_b64 (256 B/clk per CU) with the compiler's own per-read wait counts; left alone, the compiler
+// pairs neighbouring taps into ds_read2_b64, which moves half as many bytes per LDS cycle
+// (MI355X_MICROARCH.md, LDS table) -- the half-band and interpolator loops are LDS-read bound.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const volatile __attribute__((address_space(3))) double* LdsWin;
+#else
+typedef const double* LdsWin;
+#endif
+R8B_HD LdsWin lds_win(const double* p) { return (LdsWin) p; }
+
 // ------------------------------------------------------------------------------------ views
 
 R8B_HD double src_load(const SrcView& s, int ch, long long pos)
@@ -141,13 +152,27 @@ R8B_HD double src_block_load1(const SrcBlock& b, int rel)
 // plain loop (load, wait, store per pass) keeps ONE load per lane in flight, which holds a streaming kernel
 // at the latency-bandwidth product of its resident waves instead of the HBM rate.  Out-of-range lanes load
 // a clamped (valid) element and store nothing.
-template<int U>
-R8B_HD void src_block_stage(const SrcBlock& b, double* xs, int len, int end, int tid, int nthr)
+struct SlotLinear
+{
+	R8B_HD int operator()(int i) const { return i; }
+};
+
+// even elements first, odd elements from `odd` on: a stride-2 reader (2x decimator) finds its taps at
+// consecutive slots
+struct SlotParity
+{
+	int odd;
+	R8B_HD int operator()(int i) const { return (i >> 1) + ((i & 1) ? odd : 0); }
+};
+
+template<int U, class Slot>
+R8B_HD void src_block_stage_to(const SrcBlock& b, double* xs, const Slot& slot, int len, int end, int tid,
+	int nthr)
 {
 	const int lim = end < len ? end : len;
 	if (lim <= 0)
 	{
-		for (int i = tid; i < len; i += nthr) xs[i] = 0.0;
+		for (int i = tid; i < len; i += nthr) xs[slot(i)] = 0.0;
 		return;
 	}
 	for (int i0 = tid; i0 < len; i0 += U * nthr)
@@ -163,11 +188,16 @@ R8B_HD void src_block_stage(const SrcBlock& b, double* xs, int len, int end, int
 		for (int u = 0; u < U; u++)
 		{
 			const int i = i0 + u * nthr;
-			if (i < len) xs[i] = i < lim ? v[u] : 0.0;
+			if (i < len) xs[slot(i)] = i < lim ? v[u] : 0.0;
 		}
 	}
 }
 
+template<int U>
+R8B_HD void src_block_stage(const SrcBlock& b, double* xs, int len, int end, int tid, int nthr)
+{
+	src_block_stage_to<U>(b, xs, SlotLinear(), len, end, tid, nthr);
+}
 
 // ------------------------------------------------------------------------------------ small DFTs
 
@@ -593,7 +623,7 @@ R8B_HD void whole_compute_t(const WholeLaunch& L, const double* xs, long long lo
 		int u = (int) (r - L.fll - lo);
 		for (; j < j1; j += jstep, u += ustep)
 		{
-			const double* x = xs + u;
+			const LdsWin x = lds_win(xs + u);
 			double s0 = 0.0, s1 = 0.0;
 #pragma unroll
 			for (int i = 0; i < FLENP; i += 2)
@@ -670,6 +700,7 @@ R8B_HD double poly_one(const PolyLaunch& L, int ch, long long i)
 #endif
 static const int kPolyTC = R8B_POLY_TC; // channels per workgroup
 static const int kPolyTO = 64; // outputs per workgroup
+static const int kPolyPad = 8; // zeroed doubles behind a row's span (engine: span_max includes them)
 
 R8B_HD int poly_lds_doubles(int pitch, int flen)
 {
@@ -697,11 +728,31 @@ R8B_HD void poly_tile_load(const PolyLaunch& L, double* xs, int pitch, long long
 	if (c >= kPolyTC || ch0 + c >= L.nch) return;
 	const SrcBlock sb = src_block(L.src, ch0 + c, lo);
 	src_block_stage<5>(sb, xs + c * pitch, len, len, tid - c * lpc, lpc);
+	// the compute loop runs over the tap count rounded up to 8 (zero taps): what it reads behind the span
+	// must be finite
+	const int l = tid - c * lpc;
+	if (l < kPolyPad) xs[c * pitch + len + l] = 0.0;
 }
 
 // per output: x-row offset, bank entry and its fractional argument (xoff[o], xoff[64 + o],
 // xoff[128 + o]) -- the position arithmetic (an fp64 division among it) once per output, not once
 // per tap
+R8B_HD void poly_tile_pos_write(const PolyLaunch& L, double* xoff, long long lo, int o, long long rpos,
+	double fpos)
+{
+	double x;
+	int fti;
+	{
+#pragma clang fp contract(off)
+		x = fpos * L.fracs;
+		fti = (int) x;
+		x -= fti;
+	}
+	xoff[o] = (double) (rpos - L.fll - lo);
+	xoff[kPolyTO + o] = (double) fti;
+	xoff[2 * kPolyTO + o] = x;
+}
+
 R8B_HD void poly_tile_pos(const PolyLaunch& L, double* xoff, long long lo, long long i0, long long i1,
 	int tid, int nthr)
 {
@@ -711,17 +762,7 @@ R8B_HD void poly_tile_pos(const PolyLaunch& L, double* xoff, long long lo, long 
 		long long rpos;
 		double fpos;
 		poly_position(L, i0 + o, &rpos, &fpos);
-		double x;
-		int fti;
-		{
-#pragma clang fp contract(off)
-			x = fpos * L.fracs;
-			fti = (int) x;
-			x -= fti;
-		}
-		xoff[o] = (double) (rpos - L.fll - lo);
-		xoff[kPolyTO + o] = (double) fti;
-		xoff[2 * kPolyTO + o] = x;
+		poly_tile_pos_write(L, xoff, lo, o, rpos, fpos);
 	}
 }
 
@@ -777,18 +818,18 @@ R8B_HD void poly_tile_compute_t(const PolyLaunch& L, const double* xs, int pitch
 	if (i0 + o >= i1) return;
 	double row[FLENP];
 #pragma unroll
-	for (int t = 0; t < FLENP; t++) row[t] = t < L.flen ? cf[t * kPolyTO + o] : 0.0;
+	for (int t = 0; t < FLENP; t++) row[t] = t < L.flen ? lds_win(cf)[t * kPolyTO + o] : 0.0;
 	const int xo = (int) xoff[o];
 	for (int c = g; c < kPolyTC && ch0 + c < L.nch; c += ng)
 	{
-		const double* xv = xs + c * pitch + xo;
+		const LdsWin xv = lds_win(xs + c * pitch + xo);
 		double s0 = 0.0, s1 = 0.0;
 #pragma unroll
 		for (int t = 0; t < FLENP; t += 2)
 		{
-			// (taps beyond flen are zero; their x slots are not read)
-			s0 += row[t] * (t < L.flen ? xv[t] : 0.0);
-			s1 += row[t + 1] * (t + 1 < L.flen ? xv[t + 1] : 0.0);
+			// (taps beyond flen are zero; their x slots hold samples or the zeros behind the span)
+			s0 += row[t] * xv[t];
+			s1 += row[t + 1] * xv[t + 1];
 		}
 		dst_store(L.dst, ch0 + c, L.a + i0 + o, s0 + s1);
 	}
@@ -797,7 +838,9 @@ R8B_HD void poly_tile_compute_t(const PolyLaunch& L, const double* xs, int pitch
 R8B_HD void poly_tile_compute(const PolyLaunch& L, const double* xs, int pitch, const double* cf,
 	const double* xoff, long long i0, long long i1, int ch0, int tid, int nthr)
 {
-	if (L.flen <= 24) poly_tile_compute_t<24>(L, xs, pitch, cf, xoff, i0, i1, ch0, tid, nthr);
+	if (L.flen <= 8) poly_tile_compute_t<8>(L, xs, pitch, cf, xoff, i0, i1, ch0, tid, nthr);
+	else if (L.flen <= 16) poly_tile_compute_t<16>(L, xs, pitch, cf, xoff, i0, i1, ch0, tid, nthr);
+	else if (L.flen <= 24) poly_tile_compute_t<24>(L, xs, pitch, cf, xoff, i0, i1, ch0, tid, nthr);
 	else poly_tile_compute_t<32>(L, xs, pitch, cf, xoff, i0, i1, ch0, tid, nthr);
 }
 
@@ -817,13 +860,13 @@ R8B_HD void hbup_compute(const HBLaunch& L, const double* xs, long long n0, long
 	const int cnt = (int) (n1 - n0);
 	for (int i0 = tid; i0 < cnt; i0 += U * nthr)
 	{
-		const double* x[U]; // x[u][0] == stream x[n]
+		LdsWin x[U]; // x[u][0] == stream x[n]
 		double s[U];
 #pragma unroll
 		for (int u = 0; u < U; u++)
 		{
 			const int i = i0 + u * nthr;
-			x[u] = xs + (i < cnt ? i : i0) + (T - 1);
+			x[u] = lds_win(xs + (i < cnt ? i : i0) + (T - 1));
 			s[u] = 0.0;
 		}
 #pragma unroll
@@ -846,23 +889,50 @@ R8B_HD void hbup_compute(const HBLaunch& L, const double* xs, long long n0, long
 	}
 }
 
-// 2x down: tile of output indices [n0, n1); xs holds x[2 n0 - 2T + 1 .. 2 (n1-1) + 2T - 1]
+// 2x down: tile of output indices [n0, n1) from x[2 n0 - 2T + 1 .. 2 (n1-1) + 2T - 1].  The span is staged
+// DE-INTERLEAVED: element i of the span (position 2 n0 - 2T + 1 + i) with i even -- the taps' samples
+// x[2n +- (2k+1)] -- at xs[i / 2], with i odd -- the centre samples x[2n] -- behind them, so that the 32
+// lanes LDS serves together read 32 consecutive doubles per tap (interleaved, the stride of two doubles was a
+// 2-way bank conflict on every read: 47 % of the LDS cycles of a kernel whose LDS unit was 57 % busy).
+// (constexpr: callable from the kernels and from the launchers)
+constexpr int hbdown_odd_base(int tile, int T)
+{
+	// even-slot count of the longest span, moved to 8 (mod 16) doubles: a 16-lane group of the staging
+	// store writes 8 even and 8 odd slots, which then fall into different halves of the 32 store banks
+	return ((tile + 2 * T + 7) & ~15) + 8;
+}
+
+constexpr int hbdown_lds_doubles(int tile, int T) { return hbdown_odd_base(tile, T) + tile + 2 * T; }
+
+R8B_HD void hbdown_load(const HBLaunch& L, double* xs, long long n0, long long n1, int ch, int tid, int nthr)
+{
+	const int T = L.ntaps;
+	const long long lo = 2 * n0 - (2 * T - 1);
+	const int len = (int) (2 * (n1 - n0 - 1) + 1) + 2 * (2 * T - 1);
+	const SrcBlock sb = src_block(L.src, ch, lo);
+	SlotParity slot;
+	slot.odd = hbdown_odd_base(L.tile, T);
+	src_block_stage_to<4>(sb, xs, slot, len, len, tid, nthr);
+}
+
 R8B_HD void hbdown_compute(const HBLaunch& L, const double* xs, long long n0, long long n1, int ch,
 	int tid, int nthr)
 {
 	constexpr int U = kHbIlp;
 	const int T = L.ntaps;
 	const int cnt = (int) (n1 - n0);
+	const double* const ctr = xs + hbdown_odd_base(L.tile, T) + (T - 1); // ctr[m] == stream x[2 (n0 + m)]
 	for (int i0 = tid; i0 < cnt; i0 += U * nthr)
 	{
-		const double* x[U]; // x[u][0] == stream x[2n]
+		LdsWin e[U]; // e[u][k] == x[2n + 1 + 2k], e[u][-1 - k] == x[2n - 1 - 2k]
 		double s[U];
 #pragma unroll
 		for (int u = 0; u < U; u++)
 		{
 			const int i = i0 + u * nthr;
-			x[u] = xs + 2 * (i < cnt ? i : i0) + (2 * T - 1);
-			s[u] = x[u][0];
+			const int m = i < cnt ? i : i0;
+			e[u] = lds_win(xs + m + T);
+			s[u] = lds_win(ctr)[m];
 		}
 #pragma unroll
 		for (int k = 0; k < 16; k++)
@@ -870,7 +940,7 @@ R8B_HD void hbdown_compute(const HBLaunch& L, const double* xs, long long n0, lo
 			if (k >= T) break;
 			const double f = L.taps[k];
 #pragma unroll
-			for (int u = 0; u < U; u++) s[u] += f * (x[u][1 + 2 * k] + x[u][-1 - 2 * k]);
+			for (int u = 0; u < U; u++) s[u] += f * (e[u][k] + e[u][-1 - k]);
 		}
 #pragma unroll
 		for (int u = 0; u < U; u++)
@@ -950,7 +1020,7 @@ R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, int s, const double* xin, long
 		for (int u = 0; u < U; u++)
 		{
 			const int i = i0 + u * nthr;
-			const double* x = xin + xoff + (i < cnt ? i : i0); // x[0] == stream x[n0 + i]
+			const LdsWin x = lds_win(xin + xoff + (i < cnt ? i : i0)); // x[0] == stream x[n0 + i]
 			double a0 = 0.0, a1 = 0.0;
 #pragma unroll
 			for (int k = 0; k < TP; k += 2)
@@ -1073,7 +1143,7 @@ R8B_HD void hbd_stage_t(const HBCascadeLaunch& L, int s, const double* xin, long
 		for (int u = 0; u < U; u++)
 		{
 			const int i = i0 + u * nthr;
-			const double* x = xin + xoff + 2 * (i < cnt ? i : i0); // x[0] == stream x[2 (lo + i)]
+			const LdsWin x = lds_win(xin + xoff + 2 * (i < cnt ? i : i0)); // x[0] == stream x[2 (lo + i)]
 			double a0 = x[0], a1 = 0.0;
 #pragma unroll
 			for (int k = 0; k < TP; k += 2)

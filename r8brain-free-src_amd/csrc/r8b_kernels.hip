@@ -182,14 +182,25 @@ __global__ __launch_bounds__(256, 4) void k_poly_tiled(const PolyLaunch L)
 	const long long i0 = (long long) blockIdx.x * kPolyTO;
 	long long i1 = i0 + kPolyTO;
 	if (i1 > n) i1 = n;
-	long long lo;
-	int len;
-	poly_tile_span(L, i0, i1, &lo, &len);
+	// Every wave evaluates the positions of the tile's (up to 64) outputs once, lane = output: the span's
+	// ends are lanes 0 and nout - 1 (read across the wave), and the first wave also records them for the
+	// later phases -- one fp64 division sequence per wave instead of three (span ends + positions).
+	const int nout = (int) (i1 - i0);
+	const int o = (tid & 63) < nout ? (tid & 63) : nout - 1;
+	long long rpos;
+	double fpos;
+	poly_position(L, i0 + o, &rpos, &fpos);
+	const long long r0 = ((long long) __builtin_amdgcn_readfirstlane((int) (rpos >> 32)) << 32) |
+		(unsigned) __builtin_amdgcn_readfirstlane((int) rpos);
+	const long long r1 = ((long long) __builtin_amdgcn_readlane((int) (rpos >> 32), nout - 1) << 32) |
+		(unsigned) __builtin_amdgcn_readlane((int) rpos, nout - 1);
+	const long long lo = r0 - L.fll; // (poly_tile_span)
+	const int len = (int) (r1 + L.fl2 - lo + 1);
 	const int pitch = L.pitch;
 	double* const cf = xs + pitch * kPolyTC;
 	double* const xoff = cf + kPolyTO * L.flen;
 	poly_tile_load(L, xs, pitch, lo, len, ch0, tid, nthr);
-	poly_tile_pos(L, xoff, lo, i0, i1, tid, nthr);
+	if (tid < nout) poly_tile_pos_write(L, xoff, lo, tid, rpos, fpos);
 	__syncthreads();
 	poly_tile_coefs(L, cf, xoff, i0, i1, tid, nthr);
 	__syncthreads();
@@ -224,16 +235,10 @@ __global__ __launch_bounds__(256) void k_hbdown(const HBLaunch L)
 	double* const xs = reinterpret_cast<double*>(smem);
 	const int tid = threadIdx.x, nthr = blockDim.x;
 	const int ch = blockIdx.y;
-	const int T = L.ntaps;
 	const long long n0 = L.a + (long long) blockIdx.x * L.tile;
 	long long n1 = n0 + L.tile;
 	if (n1 > L.b) n1 = L.b;
-	const long long lo = 2 * n0 - (2 * T - 1);
-	const int len = (int) (2 * (n1 - n0 - 1) + 1) + 2 * (2 * T - 1);
-	{
-		const SrcBlock sb = src_block(L.src, ch, lo);
-		src_block_stage<4>(sb, xs, len, len, tid, nthr);
-	}
+	hbdown_load(L, xs, n0, n1, ch, tid, nthr);
 	__syncthreads();
 	hbdown_compute(L, xs, n0, n1, ch, tid, nthr);
 }
@@ -609,7 +614,7 @@ void R8B_LAUNCH(launch_hbdown)(const HBLaunch& L, void* stream)
 	const long long n = L.b - L.a;
 	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
 	hipLaunchKernelGGL(k_hbdown, dim3(tiles, (unsigned) L.nch), dim3(256),
-		(size_t) (2 * L.tile + 4 * L.ntaps) * sizeof(double), (hipStream_t) stream, L);
+		(size_t) hbdown_lds_doubles(L.tile, L.ntaps) * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_hbdown");
 }
 

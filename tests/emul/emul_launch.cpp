@@ -101,7 +101,7 @@ void launch_poly(const PolyLaunch& L, void*)
 				long long lo;
 				int len;
 				poly_tile_span(L, i0, i1, &lo, &len);
-				if (len > L.span_max) throw std::runtime_error("emul: poly tile span overflows LDS");
+				if (len + kPolyPad > L.span_max) throw std::runtime_error("emul: poly tile span overflows LDS");
 				for (int t = 0; t < nthr; t++)
 					poly_tile_load(L, xs.data(), pitch, lo, len, by * kPolyTC, t, nthr);
 				for (int t = 0; t < nthr; t++) poly_tile_pos(L, xoff, lo, i0, i1, t, nthr);
@@ -137,7 +137,7 @@ void launch_hbup(const HBLaunch& L, void*)
 void launch_hbdown(const HBLaunch& L, void*)
 {
 	const int nthr = 256, T = L.ntaps;
-	std::vector<double> xs((size_t) (2 * L.tile + 4 * T));
+	std::vector<double> xs((size_t) hbdown_lds_doubles(L.tile, T));
 	const long long n = L.b - L.a;
 	const int tiles = (int) ((n + L.tile - 1) / L.tile);
 	for (int ch = 0; ch < L.nch; ch++)
@@ -146,9 +146,7 @@ void launch_hbdown(const HBLaunch& L, void*)
 			const long long n0 = L.a + (long long) bx * L.tile;
 			long long n1 = n0 + L.tile;
 			if (n1 > L.b) n1 = L.b;
-			const long long lo = 2 * n0 - (2 * T - 1);
-			const int len = (int) (2 * (n1 - n0 - 1) + 1) + 2 * (2 * T - 1);
-			for (int i = 0; i < len; i++) xs[(size_t) i] = src_load(L.src, ch, lo + i);
+			for (int t = 0; t < nthr; t++) hbdown_load(L, xs.data(), n0, n1, ch, t, nthr);
 			for (int t = 0; t < nthr; t++) hbdown_compute(L, xs.data(), n0, n1, ch, t, nthr);
 		}
 }

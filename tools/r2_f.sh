@@ -13,7 +13,5 @@ run --src 44100 --dst 2822400 --block 1024 --channels 64
 run --src 2822400 --dst 176400 --block 65536 --channels 256
 run --src 44100 --dst 96000 --tb 45 --atten 49
 run
-R8B_HIP_LIB=$PWD/variants/tc32.so run --src 44100 --dst 44101
-R8B_HIP_LIB=$PWD/variants/tc32.so run --src 48000 --dst 44111
 timeout 200 python tools/minphase_probe.py > $out/minphase.txt 2>&1
 cat $out/bench.txt; head -3 $out/minphase.txt; tail -3 $out/pytest.log
