@@ -1148,6 +1148,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			L.span_max = opt_.at("poly_tiled") ?
 				(int) std::ceil(64.0 * sp.ssr / sp.dsr) + sp.flen + 4 + 8 : 0; // (+ kPolyPad zeros)
 			L.pitch = poly_row_pitch(L.span_max, sp.ssr / sp.dsr);
+			L.front = L.span_max > 0 && L.span_max - 8 <= 16 * 12; // (kPolyPad, kPolyNV)
 			L.src = src; L.dst = dst;
 			launch_poly(L, stream);
 		}

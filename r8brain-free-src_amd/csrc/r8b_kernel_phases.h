@@ -734,6 +734,40 @@ R8B_HD void poly_tile_load(const PolyLaunch& L, double* xs, int pitch, long long
 	if (l < kPolyPad) xs[c * pitch + len + l] = 0.0;
 }
 
+// The same in two halves for the pipelined kernel: the loads of the NEXT tile are issued into registers
+// before the current tile's arithmetic and stored to LDS after it (spans up to kPolyNV elements per lane).
+static const int kPolyNV = 12;
+
+R8B_HD void poly_tile_fetch(const PolyLaunch& L, long long lo, int len, int ch0, int tid, int nthr,
+	double (&v)[kPolyNV])
+{
+	const int lpc = nthr / kPolyTC;
+	const int c = tid / lpc, l = tid - c * lpc;
+	if (c >= kPolyTC || ch0 + c >= L.nch) return;
+	const SrcBlock sb = src_block(L.src, ch0 + c, lo);
+#pragma unroll
+	for (int u = 0; u < kPolyNV; u++)
+	{
+		const int i = l + u * lpc;
+		v[u] = src_block_load1(sb, i < len ? i : len - 1);
+	}
+}
+
+R8B_HD void poly_tile_commit(const PolyLaunch& L, double* xs, int pitch, int len, int ch0, int tid, int nthr,
+	const double (&v)[kPolyNV])
+{
+	const int lpc = nthr / kPolyTC;
+	const int c = tid / lpc, l = tid - c * lpc;
+	if (c >= kPolyTC || ch0 + c >= L.nch) return;
+#pragma unroll
+	for (int u = 0; u < kPolyNV; u++)
+	{
+		const int i = l + u * lpc;
+		if (i < len) xs[c * pitch + i] = v[u];
+	}
+	if (l < kPolyPad) xs[c * pitch + len + l] = 0.0;
+}
+
 // per output: x-row offset, bank entry and its fractional argument (xoff[o], xoff[64 + o],
 // xoff[128 + o]) -- the position arithmetic (an fp64 division among it) once per output, not once
 // per tap
@@ -802,6 +836,54 @@ R8B_HD void poly_tile_coefs(const PolyLaunch& L, double* cf, const double* xoff,
 			if (t < L.flen) cf[t * kPolyTO + o] = c0[u] + c1[u] * x + c2[u] * x2;
 		}
 	}
+}
+
+// Front half of a tile as ONE phase: the samples and the bank entries are fetched together (both only need
+// the output positions, which every wave has computed lane = output), then stored to LDS -- load, barrier,
+// table fetch, barrier in turn exposed two memory round trips (8 000 + 5 500 cycles of a 18 000-cycle
+// workgroup).  (rpos, fpos): position of output (tid % 64, clamped to the tile) as poly_position gives it.
+R8B_HD void poly_tile_front(const PolyLaunch& L, double* xs, int pitch, double* cf, double* xoff, long long lo,
+	int len, int nout, long long rpos, double fpos, int ch0, int tid, int nthr)
+{
+	double v[kPolyNV];
+	poly_tile_fetch(L, lo, len, ch0, tid, nthr, v);
+	const int o = tid % kPolyTO, q = tid / kPolyTO, nq = nthr / kPolyTO;
+	const bool mine = o < nout && q < nq;
+	double x, x2;
+	int fti;
+	{
+#pragma clang fp contract(off)
+		x = fpos * L.fracs;
+		fti = (int) x;
+		x -= fti;
+		x2 = x * x;
+	}
+	const double* const row = L.table + (long) fti * L.flen * 3;
+	constexpr int UT = 8; // taps q, q + nq, ... of a thread: 8 x 4 thread rows cover the longest bank (32 taps)
+	double c0[UT], c1[UT], c2[UT];
+	if (mine)
+	{
+#pragma unroll
+		for (int u = 0; u < UT; u++)
+		{
+			const int t = q + u * nq;
+			const double* c = row + (t < L.flen ? t : q) * 3;
+			c0[u] = c[0];
+			c1[u] = c[1];
+			c2[u] = c[2];
+		}
+	}
+	poly_tile_commit(L, xs, pitch, len, ch0, tid, nthr, v);
+	if (mine)
+	{
+#pragma unroll
+		for (int u = 0; u < UT; u++)
+		{
+			const int t = q + u * nq;
+			if (t < L.flen) cf[t * kPolyTO + o] = c0[u] + c1[u] * x + c2[u] * x2;
+		}
+	}
+	if (tid < nout) poly_tile_pos_write(L, xoff, lo, tid, rpos, fpos);
 }
 
 template<int FLENP>
@@ -987,117 +1069,244 @@ R8B_HD void hbc_ranges(const HBCascadeLaunch& L, long long q0, long long q1, HBC
 	R.in_hi = hi;
 }
 
+// the output range [lo, hi) of stage s alone, walked back from the tile (run-time s: the kernel keeps its
+// stage loop rolled -- one copy of each stage routine instead of one per stage -- and no table of ranges,
+// which a run-time index would push into scratch memory)
+R8B_HD void hbc_stage_range(const HBCascadeLaunch& L, long long q0, long long q1, int s, long long* lo,
+	long long* hi)
+{
+	long long l = q0, h = q1;
+	for (int t = L.nst - 1; t > s; t--)
+	{
+		const int T = L.ntaps[t];
+		const long long il = floor_half(l) - (T - 1), ih = floor_half(h - 1) + T + 1;
+		l = il;
+		h = ih;
+	}
+	*lo = l;
+	*hi = h;
+}
+
+R8B_HD void hbc_load_span(const HBCascadeLaunch& L, long long in_lo, long long in_hi, double* buf, int ch,
+	int tid, int nthr)
+{
+	const int len = (int) (in_hi - in_lo);
+	const SrcBlock sb = src_block(L.src, ch, in_lo);
+	const int end = clamp_rel(L.in_end - in_lo);
+	src_block_stage<4>(sb, buf, len, end, tid, nthr);
+}
+
 R8B_HD void hbc_load(const HBCascadeLaunch& L, const HBCRanges& R, double* buf, int ch, int tid,
 	int nthr)
 {
-	const int len = (int) (R.in_hi - R.in_lo);
-	const SrcBlock sb = src_block(L.src, ch, R.in_lo);
-	const int end = clamp_rel(L.in_end - R.in_lo);
-	src_block_stage<4>(sb, buf, len, end, tid, nthr);
+	hbc_load_span(L, R.in_lo, R.in_hi, buf, ch, tid, nthr);
 }
 
 // one stage: input x[] (LDS, xin[0] = stream position in_lo) -> outputs [lo, hi) either into LDS
 // (yout[0] = position lo) or, for the last stage, to the destination.  TP = tap count rounded up
 // (4, 8 or 14): L.ntaps[] already holds the rounded count (so the input ranges cover the wider
 // window) and the extra taps are zero.
+// one input sample of a stage: x[0] == stream x[n0 + i]; even output x[0], odd output the filter's sum
+template<int TP>
+R8B_HD void hbc_point(const double (&f)[TP], LdsWin x, double& ev, double& od, double& nx)
+{
+	double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+	for (int k = 0; k < TP; k += 2)
+	{
+		a0 += f[k] * (x[1 + k] + x[-k]);
+		a1 += f[k + 1] * (x[2 + k] + x[-k - 1]);
+	}
+	ev = x[0];
+	nx = x[1];
+	od = a0 + a1;
+}
+
 template<int TP, bool LAST>
-R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, int s, const double* xin, long long in_lo,
+R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, const double (&taps)[14], const double* xin, long long in_lo,
 	long long lo, long long hi, double* yout, int ch, int tid, int nthr)
 {
 	constexpr int U = TP <= 4 ? 4 : (TP <= 8 ? 2 : 1); // inputs of a thread per round (see kHbIlp): ~32 reads in flight
 	double f[TP];
 #pragma unroll
-	for (int k = 0; k < TP; k++) f[k] = L.taps[s][k];
+	for (int k = 0; k < TP; k++) f[k] = taps[k];
 	const long long n0 = floor_half(lo);
 	const int cnt = (int) (floor_half(hi - 1) + 1 - n0);
 	const int xoff = (int) (n0 - in_lo);  // index of x[n0] in xin
 	const int qoff = (int) (2 * n0 - lo); // index of output 2*n0 relative to lo (0 or -1)
 	const int nout = (int) (hi - lo);
-	for (int i0 = tid; i0 < cnt; i0 += U * nthr)
+	// A stage's stream starts at position 0: input index i lies before it iff i < ineg (first tile only).
+	const int ineg = n0 >= 0 ? 0 : (n0 < -(long long) cnt ? cnt : (int) -n0);
+	// last stage into a plain fp64 row: pq[2 i] is output 2 (n0 + i)
+	const bool linear = LAST && L.dst.mask == -1 && L.dst.fmt == kPcmF64;
+	double* const pq = linear ? L.dst.p + ((long long) ch * L.dst.stride + (2 * n0 + L.dst.off)) : nullptr;
+	const double* const xb = xin + xoff;
+
+	// Interior of the tile, [ia, ib): both outputs of an input exist and lie inside the tile, the store is
+	// one unconditional 16-byte (pair) or two 8-byte stores at a 32-bit offset -- no per-sample range tests,
+	// masks or 64-bit positions (they were 7 integer instructions per useful multiply-add).  The (at most
+	// two) inputs outside it and tiles at a stream's start take the general loop below.
+	int ia = 0, ib = 0;
+	const int mode = !LAST ? 0 : (!linear ? -1 : L.pair_ok);
+	if (ineg == 0 && mode >= 0)
 	{
-		double ev[U], od[U], nx[U];
-#pragma unroll
-		for (int u = 0; u < U; u++)
+		if (mode == 2)
 		{
-			const int i = i0 + u * nthr;
-			const LdsWin x = lds_win(xin + xoff + (i < cnt ? i : i0)); // x[0] == stream x[n0 + i]
-			double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-			for (int k = 0; k < TP; k += 2)
-			{
-				a0 += f[k] * (x[1 + k] + x[-k]);
-				a1 += f[k + 1] * (x[2 + k] + x[-k - 1]);
-			}
-			ev[u] = x[0];
-			nx[u] = x[1];
-			od[u] = a0 + a1;
+			// the pair (odd output of i, even output of i + 1) ends inside the tile; input 0 also owns the
+			// tile's first even output: general loop
+			ia = 1;
+			ib = (nout - qoff - 1) / 2;
 		}
-#pragma unroll
-		for (int u = 0; u < U; u++)
+		else
 		{
-			const int i = i0 + u * nthr;
-			if (i >= cnt) continue;
-			const long long q = 2 * (n0 + i);
-			// a stage's stream starts at position 0: earlier outputs do not exist for the next stage
-			const double e = q < 0 ? 0.0 : ev[u];
-			const double d = q + 1 < 0 ? 0.0 : od[u];
-			const int o = qoff + 2 * i;
-			if (LAST)
+			ia = qoff < 0 ? 1 : 0;
+			ib = (nout - qoff) / 2;
+		}
+		if (ib > cnt) ib = cnt;
+		if (ib < ia) ib = ia;
+		int i = ia + tid;
+		for (; i + (U - 1) * nthr < ib; i += U * nthr)
+		{
+			double ev[U], od[U], nx[U];
+#pragma unroll
+			for (int u = 0; u < U; u++) hbc_point<TP>(f, lds_win(xb + i + u * nthr), ev[u], od[u], nx[u]);
+#pragma unroll
+			for (int u = 0; u < U; u++)
 			{
-				if (L.pair_ok == 2)
+				const int o = qoff + 2 * (i + u * nthr);
+				cd v;
+				if (mode == 2)
 				{
-					// odd destination offset: the aligned pairs are (odd output of this thread, even output of
-					// the next = its input sample x[1]); the tile's first even output goes alone
-					if (i == 0 && o >= 0 && o < nout) dst_store(L.dst, ch, q, e);
-					if (o + 2 < nout)
-					{
-						cd v;
-						v.re = d;
-						v.im = q + 2 < 0 ? 0.0 : nx[u];
-						*reinterpret_cast<cd*>(L.dst.p + ((long long) ch * L.dst.stride +
-							((q + 1 + L.dst.off) & L.dst.mask))) = v;
-					}
-					else if (o + 1 < nout) dst_store(L.dst, ch, q + 1, d);
-					continue;
+					v.re = od[u];
+					v.im = nx[u];
+					*reinterpret_cast<cd*>(pq + 2 * (i + u * nthr) + 1) = v;
 				}
-				if (L.pair_ok && o >= 0 && o + 1 < nout)
+				else if (mode == 1)
 				{
-					// the even/odd output pair as one 16-byte store (full 128-byte lines per wave
-					// instruction instead of two half-used ones)
-					cd v;
-					v.re = e;
-					v.im = d;
-					*reinterpret_cast<cd*>(L.dst.p + ((long long) ch * L.dst.stride +
-						((q + L.dst.off) & L.dst.mask))) = v;
-					continue;
+					v.re = ev[u];
+					v.im = od[u];
+					*reinterpret_cast<cd*>(pq + 2 * (i + u * nthr)) = v;
 				}
-				if (o >= 0 && o < nout) dst_store(L.dst, ch, q, e);
-				if (o + 1 >= 0 && o + 1 < nout) dst_store(L.dst, ch, q + 1, d);
+				else if (LAST)
+				{
+					pq[2 * (i + u * nthr)] = ev[u];
+					pq[2 * (i + u * nthr) + 1] = od[u];
+				}
+				else
+				{
+					yout[o] = ev[u];
+					yout[o + 1] = od[u];
+				}
+			}
+		}
+		for (; i < ib; i += nthr)
+		{
+			double ev, od, nx;
+			hbc_point<TP>(f, lds_win(xb + i), ev, od, nx);
+			const int o = qoff + 2 * i;
+			cd v;
+			if (mode == 2)
+			{
+				v.re = od;
+				v.im = nx;
+				*reinterpret_cast<cd*>(pq + 2 * i + 1) = v;
+			}
+			else if (mode == 1)
+			{
+				v.re = ev;
+				v.im = od;
+				*reinterpret_cast<cd*>(pq + 2 * i) = v;
+			}
+			else if (LAST)
+			{
+				pq[2 * i] = ev;
+				pq[2 * i + 1] = od;
 			}
 			else
 			{
-				if (o >= 0 && o < nout) yout[o] = e;
-				if (o + 1 >= 0 && o + 1 < nout) yout[o + 1] = d;
+				yout[o] = ev;
+				yout[o + 1] = od;
 			}
+		}
+	}
+	// everything else: inputs j = 0 .. cnt - (ib - ia) - 1 of the list with [ia, ib) cut out
+	const int rest = cnt - (ib - ia);
+	for (int j = tid; j < rest; j += nthr)
+	{
+		const int i = j < ia ? j : j + (ib - ia);
+		double ev, od, nx;
+		hbc_point<TP>(f, lds_win(xb + i), ev, od, nx);
+		// outputs 2 (n0 + i) and 2 (n0 + i) + 1 exist iff n0 + i >= 0
+		const double e = i < ineg ? 0.0 : ev;
+		const double d = i < ineg ? 0.0 : od;
+		const int o = qoff + 2 * i;
+		if (LAST)
+		{
+			if (mode == 2)
+			{
+				// odd destination offset: the aligned pairs are (odd output of this input, even output of
+				// the next = its input sample x[1]); the tile's first even output goes alone
+				double* const p = pq + 2 * i;
+				if (i == 0 && o >= 0 && o < nout) p[0] = e;
+				if (o + 2 < nout)
+				{
+					cd v;
+					v.re = d;
+					v.im = i + 1 < ineg ? 0.0 : nx;
+					*reinterpret_cast<cd*>(p + 1) = v;
+				}
+				else if (o + 1 < nout) p[1] = d;
+				continue;
+			}
+			if (mode == 1 && o >= 0 && o + 1 < nout)
+			{
+				// the even/odd output pair as one 16-byte store (full 128-byte lines per wave
+				// instruction instead of two half-used ones)
+				cd v;
+				v.re = e;
+				v.im = d;
+				*reinterpret_cast<cd*>(pq + 2 * i) = v;
+				continue;
+			}
+			const long long q = 2 * (n0 + i);
+			if (o >= 0 && o < nout) dst_store(L.dst, ch, q, e);
+			if (o + 1 >= 0 && o + 1 < nout) dst_store(L.dst, ch, q + 1, d);
+		}
+		else
+		{
+			if (o >= 0 && o < nout) yout[o] = e;
+			if (o + 1 >= 0 && o + 1 < nout) yout[o + 1] = d;
 		}
 	}
 }
 
-template<int TP>
-R8B_HD void hbc_stage_tp(const HBCascadeLaunch& L, int s, const double* xin, long long in_lo,
-	long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr)
+// stage with T taps (already rounded up to 4 / 8 / 14) whose values the caller holds
+R8B_HD void hbc_stage_f(const HBCascadeLaunch& L, const double (&taps)[14], int T, const double* xin,
+	long long in_lo, long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr)
 {
-	if (last) hbc_stage_t<TP, true>(L, s, xin, in_lo, lo, hi, yout, ch, tid, nthr);
-	else hbc_stage_t<TP, false>(L, s, xin, in_lo, lo, hi, yout, ch, tid, nthr);
+	if (T <= 4)
+	{
+		if (last) hbc_stage_t<4, true>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr);
+		else hbc_stage_t<4, false>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr);
+	}
+	else if (T <= 8)
+	{
+		if (last) hbc_stage_t<8, true>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr);
+		else hbc_stage_t<8, false>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr);
+	}
+	else
+	{
+		if (last) hbc_stage_t<14, true>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr);
+		else hbc_stage_t<14, false>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr);
+	}
 }
 
 R8B_HD void hbc_stage(const HBCascadeLaunch& L, int s, const double* xin, long long in_lo,
 	long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr)
 {
-	const int T = L.ntaps[s];
-	if (T <= 4) hbc_stage_tp<4>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
-	else if (T <= 8) hbc_stage_tp<8>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
-	else hbc_stage_tp<14>(L, s, xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
+	double taps[14];
+	for (int k = 0; k < 14; k++) taps[k] = L.taps[s][k];
+	hbc_stage_f(L, taps, L.ntaps[s], xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
 }
 
 // ------------------------------------------------------------------------------------ decimating cascade

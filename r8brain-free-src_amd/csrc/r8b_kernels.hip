@@ -172,6 +172,31 @@ __global__ __launch_bounds__(256) void k_poly(const PolyLaunch L)
 
 // (four workgroups per CU: capping the registers at 128 costs a few spilled values and is 17 % faster than
 // 137 registers at three waves per SIMD)
+// positions of the (up to 64) outputs of tile t, lane = output, once per wave: the span's ends are lanes 0 and
+// nout - 1 (read across the wave) -- one fp64 division sequence per wave and tile
+struct PolyTilePos
+{
+	long long rpos, lo;
+	double fpos;
+	int len, nout;
+};
+
+__device__ __forceinline__ PolyTilePos poly_tile_positions(const PolyLaunch& L, long long t, long long n, int tid)
+{
+	PolyTilePos P;
+	const long long i0 = t * kPolyTO;
+	P.nout = (int) (n - i0 < kPolyTO ? n - i0 : kPolyTO);
+	const int o = (tid & 63) < P.nout ? (tid & 63) : P.nout - 1;
+	poly_position(L, i0 + o, &P.rpos, &P.fpos);
+	const long long r0 = ((long long) __builtin_amdgcn_readfirstlane((int) (P.rpos >> 32)) << 32) |
+		(unsigned) __builtin_amdgcn_readfirstlane((int) P.rpos);
+	const long long r1 = ((long long) __builtin_amdgcn_readlane((int) (P.rpos >> 32), P.nout - 1) << 32) |
+		(unsigned) __builtin_amdgcn_readlane((int) P.rpos, P.nout - 1);
+	P.lo = r0 - L.fll; // (poly_tile_span)
+	P.len = (int) (r1 + L.fl2 - P.lo + 1);
+	return P;
+}
+
 __global__ __launch_bounds__(256, 4) void k_poly_tiled(const PolyLaunch L)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
@@ -179,32 +204,47 @@ __global__ __launch_bounds__(256, 4) void k_poly_tiled(const PolyLaunch L)
 	const int tid = threadIdx.x, nthr = blockDim.x;
 	const int ch0 = (int) blockIdx.y * kPolyTC;
 	const long long n = L.b - L.a;
-	const long long i0 = (long long) blockIdx.x * kPolyTO;
-	long long i1 = i0 + kPolyTO;
-	if (i1 > n) i1 = n;
-	// Every wave evaluates the positions of the tile's (up to 64) outputs once, lane = output: the span's
-	// ends are lanes 0 and nout - 1 (read across the wave), and the first wave also records them for the
-	// later phases -- one fp64 division sequence per wave instead of three (span ends + positions).
-	const int nout = (int) (i1 - i0);
-	const int o = (tid & 63) < nout ? (tid & 63) : nout - 1;
-	long long rpos;
-	double fpos;
-	poly_position(L, i0 + o, &rpos, &fpos);
-	const long long r0 = ((long long) __builtin_amdgcn_readfirstlane((int) (rpos >> 32)) << 32) |
-		(unsigned) __builtin_amdgcn_readfirstlane((int) rpos);
-	const long long r1 = ((long long) __builtin_amdgcn_readlane((int) (rpos >> 32), nout - 1) << 32) |
-		(unsigned) __builtin_amdgcn_readlane((int) rpos, nout - 1);
-	const long long lo = r0 - L.fll; // (poly_tile_span)
-	const int len = (int) (r1 + L.fl2 - lo + 1);
 	const int pitch = L.pitch;
 	double* const cf = xs + pitch * kPolyTC;
 	double* const xoff = cf + kPolyTO * L.flen;
-	poly_tile_load(L, xs, pitch, lo, len, ch0, tid, nthr);
-	if (tid < nout) poly_tile_pos_write(L, xoff, lo, tid, rpos, fpos);
+#ifdef R8B_POLY_STAMPS
+	long long ts[8]; int nts = 0;
+	ts[nts++] = clock64();
+#define R8B_PSTAMP() ts[nts++] = clock64()
+#else
+#define R8B_PSTAMP()
+#endif
+	const long long t = blockIdx.x;
+	const PolyTilePos P = poly_tile_positions(L, t, n, tid);
+	R8B_PSTAMP();
+	const long long i0 = t * kPolyTO, i1 = i0 + P.nout;
+	if (L.front)
+	{
+		// samples and bank entries fetched together, one barrier (spans up to 16 lanes x kPolyNV registers)
+		poly_tile_front(L, xs, pitch, cf, xoff, P.lo, P.len, P.nout, P.rpos, P.fpos, ch0, tid, nthr);
+		R8B_PSTAMP();
+		R8B_PSTAMP();
+		R8B_PSTAMP();
+	}
+	else
+	{
+		poly_tile_load(L, xs, pitch, P.lo, P.len, ch0, tid, nthr);
+		if (tid < P.nout) poly_tile_pos_write(L, xoff, P.lo, tid, P.rpos, P.fpos);
+		R8B_PSTAMP();
+		__syncthreads();
+		R8B_PSTAMP();
+		poly_tile_coefs(L, cf, xoff, i0, i1, tid, nthr);
+		R8B_PSTAMP();
+	}
 	__syncthreads();
-	poly_tile_coefs(L, cf, xoff, i0, i1, tid, nthr);
-	__syncthreads();
+	R8B_PSTAMP();
 	poly_tile_compute(L, xs, pitch, cf, xoff, i0, i1, ch0, tid, nthr);
+	R8B_PSTAMP();
+#ifdef R8B_POLY_STAMPS
+	if ((tid & 63) == 0 && blockIdx.y == 17 && blockIdx.x == 100)
+		printf("poly stamps wave %d: pos %lld load %lld bar %lld coefs %lld bar %lld compute %lld\n", tid >> 6,
+			ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5]);
+#endif
 }
 
 // ------------------------------------------------------------------ half-band stages
@@ -257,41 +297,49 @@ __global__ __launch_bounds__(256) void k_hbcascade(const HBCascadeLaunch L)
 	long long q1 = q0 + L.tile;
 	if (q1 > L.b) q1 = L.b;
 #ifdef R8B_HBC_STAMPS
-	long long ts[10]; int nts = 0;
+	long long ts[12]; int nts = 0;
 	ts[nts++] = clock64();
 #endif
-	HBCRanges R;
-	hbc_ranges(L, q0, q1, R);
 	double* xin = ((L.nst - 1) & 1) ? small : big;
 	double* yout = ((L.nst - 1) & 1) ? big : small;
-#ifdef R8B_HBC_STAMPS
-	ts[nts++] = clock64();
-#endif
-	hbc_load(L, R, xin, ch, tid, nthr);
+	{
+		long long lo, hi;
+		hbc_stage_range(L, q0, q1, 0, &lo, &hi);
+		const int T = L.ntaps[0];
+		hbc_load_span(L, floor_half(lo) - (T - 1), floor_half(hi - 1) + T + 1, xin, ch, tid, nthr);
+	}
 	__syncthreads();
 #ifdef R8B_HBC_STAMPS
 	ts[nts++] = clock64();
 #endif
-	long long in_lo = R.in_lo;
-	// (unrolled: compile-time stage indices keep R and the taps out of scratch memory)
-#pragma unroll
-	for (int s = 0; s < kMaxCascade; s++)
+	// Rolled: the stage number is a run-time value, what it indexes (tap counts, taps) are scalar loads of
+	// kernel arguments, and a stage's range is recomputed by hbc_stage_range instead of kept in a table (a
+	// run-time index would push the table into scratch memory).  One copy of each stage routine instead of
+	// one per stage: the unrolled form was five times the code (78 KB, beyond the instruction cache) and
+	// slower.  Measured and not kept (tools/ubench/gen_stream_bench.py, cfg5 x 1024 channels, 0.138 ms as
+	// built): tap counts / taps held in scalar registers across the loop or fetched a stage ahead (0.150 -
+	// 0.161 ms: scalar register pressure, and scalar loads in flight make every LDS wait a full drain); a
+	// workgroup walking 2 - 8 consecutive tiles with the next tile's input prefetched into registers (0.142 -
+	// 0.187 ms: with three workgroups per CU the load of one already overlaps the stages of the others).
+#pragma unroll 1
+	for (int s = 0; s < L.nst; s++)
 	{
-		if (s >= L.nst) break;
-		hbc_stage(L, s, xin, in_lo, R.lo[s], R.hi[s], yout, s + 1 == L.nst, ch, tid, nthr);
+		long long lo, hi;
+		hbc_stage_range(L, q0, q1, s, &lo, &hi);
+		const long long in_lo = floor_half(lo) - (L.ntaps[s] - 1);
+		hbc_stage(L, s, xin, in_lo, lo, hi, yout, s + 1 == L.nst, ch, tid, nthr);
 		__syncthreads();
 #ifdef R8B_HBC_STAMPS
-		ts[nts++] = clock64();
+		if (nts < 12) ts[nts++] = clock64();
 #endif
-		in_lo = R.lo[s];
 		double* t = xin;
 		xin = yout;
 		yout = t;
 	}
 #ifdef R8B_HBC_STAMPS
-	if (tid == 0 && ch == 517 && blockIdx.x == 3 && L.a > 400000 && L.a < 600000)
-		printf("hbc stamps tile %d nst %d: ranges %lld load %lld st %lld %lld %lld %lld %lld\n", L.tile, L.nst,
-			ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5], ts[7] - ts[6]);
+	if (tid == 0 && ch == 517 && blockIdx.x == 3) // (tools/ubench/gen_stream_bench.py -DR8B_HBC_STAMPS)
+		printf("hbc stamps tile %d nst %d: load %lld st %lld %lld %lld %lld %lld\n", L.tile, L.nst,
+			ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3], ts[5] - ts[4], ts[6] - ts[5]);
 #endif
 }
 

@@ -109,6 +109,7 @@ struct PolyLaunch
 	int nch;
 	int span_max; // tiled kernel: max input span of an output tile (0: one output per thread)
 	int pitch;    // tiled kernel: LDS doubles per channel row (>= span_max; residue mod 32 chosen for the step)
+	int front;    // tiled kernel: samples and bank entries fetched in one phase (spans up to 16 * kPolyNV)
 	SrcView src;
 	DstView dst;
 };

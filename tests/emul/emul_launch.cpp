@@ -102,10 +102,27 @@ void launch_poly(const PolyLaunch& L, void*)
 				int len;
 				poly_tile_span(L, i0, i1, &lo, &len);
 				if (len + kPolyPad > L.span_max) throw std::runtime_error("emul: poly tile span overflows LDS");
-				for (int t = 0; t < nthr; t++)
-					poly_tile_load(L, xs.data(), pitch, lo, len, by * kPolyTC, t, nthr);
-				for (int t = 0; t < nthr; t++) poly_tile_pos(L, xoff, lo, i0, i1, t, nthr);
-				for (int t = 0; t < nthr; t++) poly_tile_coefs(L, cf, xoff, i0, i1, t, nthr);
+				if (L.front)
+				{
+					// (the kernel's single front phase; a lane's own output position as the wave computes it)
+					if (len > 16 * kPolyNV) throw std::runtime_error("emul: poly tile span beyond the front phase");
+					const int nout = (int) (i1 - i0);
+					for (int t = 0; t < nthr; t++)
+					{
+						const int o = (t & 63) < nout ? (t & 63) : nout - 1;
+						long long rpos;
+						double fpos;
+						poly_position(L, i0 + o, &rpos, &fpos);
+						poly_tile_front(L, xs.data(), pitch, cf, xoff, lo, len, nout, rpos, fpos, by * kPolyTC, t, nthr);
+					}
+				}
+				else
+				{
+					for (int t = 0; t < nthr; t++)
+						poly_tile_load(L, xs.data(), pitch, lo, len, by * kPolyTC, t, nthr);
+					for (int t = 0; t < nthr; t++) poly_tile_pos(L, xoff, lo, i0, i1, t, nthr);
+					for (int t = 0; t < nthr; t++) poly_tile_coefs(L, cf, xoff, i0, i1, t, nthr);
+				}
 				for (int t = 0; t < nthr; t++)
 					poly_tile_compute(L, xs.data(), pitch, cf, xoff, i0, i1, by * kPolyTC, t, nthr);
 			}
