@@ -568,7 +568,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	plan_.init(descs, maxin);
 	opt_["conv_radix"] = 8;
 	opt_["conv_threads"] = 256;
-	opt_["whole_tile"] = 1024;
+	opt_["whole_tile"] = 4096;
 	opt_["hb_tile"] = 1024;
 	opt_["fuse_hbd"] = 2;    // runs of half-band decimators as one kernel: 0 never, 1 always, 2 by batch size
 	opt_["hbd_span"] = 2048; // first-stage input samples per workgroup of the decimating cascade
@@ -1123,9 +1123,12 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			L.pos0 = sp.pos0;
 			L.table = d.table;
 			L.a = a; L.b = b;
+			// as large as keeps the tile's input span within 32 KB of LDS (four to five workgroups per CU): a
+			// thread's set-up -- a 64-bit division and its row fetch -- is paid once per tile (44100 -> 96000,
+			// 1024 channels: tile 1024 0.237 ms, 2048 0.191, 4096 0.156)
 			L.tile = opt_.at("whole_tile");
 			L.span_max = (int) ((long long) L.tile * sp.in_step / sp.out_step) + sp.flen + 4 + 32;
-			while (L.span_max > 12288 && L.tile > 64)
+			while ((L.span_max > 4096 && L.tile > 1024) || (L.span_max > 12288 && L.tile > 64))
 			{
 				L.tile /= 2;
 				L.span_max = (int) ((long long) L.tile * sp.in_step / sp.out_step) + sp.flen + 4 + 32;

@@ -599,6 +599,10 @@ R8B_HD void whole_load(const WholeLaunch& L, double* xs, long long lo, int len, 
 // apart): the position arithmetic (a 64-bit division) and the row fetch happen once per thread and tile,
 // not once per output, and the row lives in registers.  Fewer phases than threads: lanes share a phase in
 // group sets; more: a thread walks phases t, t + nthr, ...
+#ifndef R8B_SCHED_FENCE
+#define R8B_SCHED_FENCE() // (a scheduling barrier in the GPU build, r8b_kernels.hip)
+#endif
+
 template<int FLENP>
 R8B_HD void whole_compute_t(const WholeLaunch& L, const double* xs, long long lo, long long j0,
 	long long j1, int ch, int tid, int nthr)
@@ -624,12 +628,25 @@ R8B_HD void whole_compute_t(const WholeLaunch& L, const double* xs, long long lo
 		for (; j < j1; j += jstep, u += ustep)
 		{
 			const LdsWin x = lds_win(xs + u);
+			// the window first, then the sums: left to itself the compiler gave all taps ONE register and
+			// drained the LDS queue before every multiply-add (an exposed round trip per tap); in two halves from
+			// 24 taps on (the whole window live would cost a resident wave per SIMD)
+			constexpr int CH = FLENP >= 24 ? FLENP / 2 : FLENP;
 			double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-			for (int i = 0; i < FLENP; i += 2)
+			for (int c = 0; c < FLENP; c += CH)
 			{
-				s0 += row[i] * x[i];
-				s1 += row[i + 1] * x[i + 1];
+				double xv[CH];
+#pragma unroll
+				for (int i = 0; i < CH; i++) xv[i] = x[c + i];
+				R8B_SCHED_FENCE();
+#pragma unroll
+				for (int i = 0; i < CH; i += 2)
+				{
+					s0 += row[c + i] * xv[i];
+					s1 += row[c + i + 1] * xv[i + 1];
+				}
+				R8B_SCHED_FENCE();
 			}
 			dst_store(L.dst, ch, j, s0 + s1);
 		}

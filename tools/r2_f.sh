@@ -12,6 +12,8 @@ run --src 44100 --dst 2822400 --block 1024 --channels 1024
 run --src 44100 --dst 2822400 --block 1024 --channels 64
 run --src 2822400 --dst 176400 --block 65536 --channels 256
 run --src 44100 --dst 96000 --tb 45 --atten 49
+run --src 96000 --dst 44100 --tb 45 --atten 49
+run --src 32000 --dst 44100
 run
 timeout 200 python tools/minphase_probe.py > $out/minphase.txt 2>&1
-cat $out/bench.txt; head -3 $out/minphase.txt; tail -3 $out/pytest.log
+cat $out/bench.txt; cat $out/minphase.txt; tail -3 $out/pytest.log

@@ -18,7 +18,8 @@ def cut(start, end):
     return src[a:src.index(end, a)]
 
 
-kernels = cut("// positions of the (up to 64) outputs of tile t, lane = output, once per wave", "// ------------------------------------------------------------------ decimating half-band cascade")
+kernels = cut("__global__ __launch_bounds__(", "// ------------------------------------------------------------------ polynomial-interpolated bank") if False else ""
+kernels = cut("// ------------------------------------------------------------------ whole-step polyphase FIR", "// ------------------------------------------------------------------ polynomial-interpolated bank") + cut("// positions of the (up to 64) outputs of tile t, lane = output, once per wave", "// ------------------------------------------------------------------ decimating half-band cascade")
 main = r'''
 #include <cstdio>
 #include <vector>
@@ -141,6 +142,35 @@ int main()
 			CK(hipGetLastError());
 			printf("k_poly_tiled front %d: %.4f ms  %.2f TB/s (lds %zu)\n", k, ms, 8.0 * nch * (32768 + out_per) / ms * 1e-9, lds);
 		}
+		hipFree(x); hipFree(y); hipFree(ring); hipFree(tab);
+	}
+	// ---- whole-step polyphase FIR (unfused interpolator), 88200 -> 96000 (147/160, 24 taps), 1024 ch x 32768 -> 35666
+	{
+		const long long in_per = 32768 + 256, out_per = 35666;
+		double *x, *y, *ring, *tab;
+		CK(hipMalloc(&x, sizeof(double) * nch * in_per));
+		CK(hipMalloc(&y, sizeof(double) * nch * out_per));
+		CK(hipMalloc(&ring, sizeof(double) * nch * 4096));
+		CK(hipMalloc(&tab, sizeof(double) * 160 * 24));
+		CK(hipMemset(x, 0, sizeof(double) * nch * in_per));
+		CK(hipMemset(tab, 0, sizeof(double) * 160 * 24));
+		WholeLaunch L = {};
+		L.in_step = 147; L.out_step = 160; L.flen = 24; L.fl2 = 12; L.fll = 11; L.pos0 = 0; L.table = tab;
+		L.a = 200; L.b = 200 + out_per - 400; L.tile = 1024; L.nch = nch;
+		L.span_max = (int) ((long long) L.tile * 147 / 160) + 24 + 4 + 32;
+		L.src.ring = ring; L.src.ring_stride = 4096; L.src.ring_mask = 4095;
+		L.src.cur = x; L.src.cur_stride = in_per; L.src.cur_base = 0; L.src.cur_fmt = 0;
+		L.dst.p = y; L.dst.stride = out_per; L.dst.mask = -1; L.dst.off = 0; L.dst.fmt = 0;
+		for (int thr : { 256 })
+			for (int tile : { 1024, 2048, 4096 })
+			{
+				L.tile = tile;
+				L.span_max = (int) ((long long) L.tile * 147 / 160) + 24 + 4 + 32;
+				const unsigned tiles = (unsigned) ((L.b - L.a + L.tile - 1) / L.tile);
+				const float ms = time_ms([&] { hipLaunchKernelGGL(k_whole, dim3(tiles, nch), dim3(thr), (size_t) L.span_max * sizeof(double), 0, L); }, 50);
+				CK(hipGetLastError());
+				printf("k_whole %d threads, tile %d: %.4f ms  %.2f TB/s\n", thr, tile, ms, 8.0 * nch * (32768 + out_per) / ms * 1e-9);
+			}
 		hipFree(x); hipFree(y); hipFree(ring); hipFree(tab);
 	}
 	return 0;
