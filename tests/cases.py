@@ -45,6 +45,11 @@ STREAM_CASES = [
     (20.0, 21.0, 300, 300, 6000, 1.0, 49.0),                    # 8-tap interpolator rows (zero padding)
     (32000.0, 96000.0, 2048, 2048, 30000, 1.0, 180.15),         # 3x zero stuffing, 16384-point, in place
     (96000.0, 32000.0, 4096, 4096, 60000, 1.0, 180.15),         # strided 3x decimation, 16384-point
+    # polynomial interpolator at other steps: 3.2 inputs per output with 18 taps (tile spans beyond the one-phase
+    # front of the tiled kernel, tap loop over zero-padded rows), ~1 and 1.84 (row pitch chosen per step)
+    (96000.0, 30001.0, 1024, 777, 12000, 2.0, 180.15),
+    (22050.0, 44101.0, 1024, 500, 6000, 2.0, 180.15),
+    (44100.0, 48001.0, 1024, 1024, 6000, 2.0, 180.15),
 ]
 
 

@@ -99,17 +99,21 @@ int main()
 		CK(hipMalloc(&ring, sizeof(double) * nch * 4096));
 		CK(hipMemset(x, 0, sizeof(double) * nch * in_per * 2));
 		HBLaunch L = {};
-		L.ntaps = 7;
-		for (int k = 0; k < 7; k++) L.taps[k] = 0.3 / (k + 1);
-		L.a = 4000; L.b = 4000 + out_per; L.tile = 1024; L.nch = nch;
+		L.ntaps = 11;
+		for (int k = 0; k < 11; k++) L.taps[k] = 0.3 / (k + 1);
+		L.a = 4000; L.b = 4000 + out_per; L.nch = nch;
 		L.src.ring = ring; L.src.ring_stride = 4096; L.src.ring_mask = 4095;
 		L.src.cur = x; L.src.cur_stride = in_per * 2; L.src.cur_base = 0; L.src.cur_fmt = 0;
 		L.dst.p = y; L.dst.stride = out_per; L.dst.mask = -1; L.dst.off = -4000; L.dst.fmt = 0;
-		const unsigned tiles = (unsigned) ((out_per + L.tile - 1) / L.tile);
-		const size_t lds = (size_t) hbdown_lds_doubles(L.tile, L.ntaps) * sizeof(double);
-		const float ms = time_ms([&] { hipLaunchKernelGGL(k_hbdown, dim3(tiles, nch), dim3(256), lds, 0, L); }, 50);
-		CK(hipGetLastError());
-		printf("k_hbdown: %.4f ms  %.2f TB/s\n", ms, 8.0 * nch * (in_per + out_per) / ms * 1e-9);
+		for (int tile : { 512, 1024, 2048, 4096 })
+		{
+			L.tile = tile;
+			const unsigned tiles = (unsigned) ((out_per + L.tile - 1) / L.tile);
+			const size_t lds = (size_t) hbdown_lds_doubles(L.tile, L.ntaps) * sizeof(double);
+			const float ms = time_ms([&] { hipLaunchKernelGGL(k_hbdown, dim3(tiles, nch), dim3(256), lds, 0, L); }, 50);
+			CK(hipGetLastError());
+			printf("k_hbdown 11 taps, tile %d: %.4f ms  %.2f TB/s\n", tile, ms, 8.0 * nch * (in_per + out_per) / ms * 1e-9);
+		}
 		hipFree(x); hipFree(y); hipFree(ring);
 	}
 	// ---- polynomial-interpolated bank, 88200 -> 44101, 1024 channels x 32768 -> 16385
