@@ -1122,6 +1122,17 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			L.fl2 = sp.fl2; L.fll = sp.fll;
 			L.pos0 = sp.pos0;
 			L.table = d.table;
+			// transposed table in output order (built for whole-step stages at construction): usable when
+			// in_step is invertible mod out_step and the product phase * inverse stays in 32 bits
+			L.wtab = nullptr; L.inv_in = 0;
+			if (d.wtab != nullptr && sp.out_step < 46340)
+			{
+				long long inv = 0;
+				for (long long k = 1; k < sp.out_step; k++) // (out_step is a few hundred at most; once per call)
+					if (k * (sp.in_step % sp.out_step) % sp.out_step == 1) { inv = k; break; }
+				if (sp.out_step == 1) inv = 0;
+				if (inv != 0 || sp.out_step == 1) { L.wtab = d.wtab; L.inv_in = (int) inv; }
+			}
 			L.a = a; L.b = b;
 			// as large as keeps the tile's input span within 32 KB of LDS (four to five workgroups per CU): a
 			// thread's set-up -- a 64-bit division and its row fetch -- is paid once per tile (44100 -> 96000,

@@ -620,10 +620,21 @@ R8B_HD void whole_compute_t(const WholeLaunch& L, const double* xs, long long lo
 		const long long p = j * In + L.pos0;
 		const long long r = p / Out;
 		const int ph = (int) (p - r * Out);
-		const double* tr = L.table + (long) ph * L.flen;
 		double row[FLENP];
+		if (L.wtab != nullptr)
+		{
+			// transposed table in output order: the lanes of a wave (consecutive outputs) read consecutive
+			// doubles per tap (row-major, every lane fetched its own 192-byte row: 64 cache lines per load)
+			const double* tc = L.wtab + (unsigned) (ph * L.inv_in) % (unsigned) Out;
 #pragma unroll
-		for (int i = 0; i < FLENP; i++) row[i] = i < L.flen ? tr[i] : 0.0;
+			for (int i = 0; i < FLENP; i++) row[i] = i < L.flen ? tc[(long) i * Out] : 0.0;
+		}
+		else
+		{
+			const double* tr = L.table + (long) ph * L.flen;
+#pragma unroll
+			for (int i = 0; i < FLENP; i++) row[i] = i < L.flen ? tr[i] : 0.0;
+		}
 		int u = (int) (r - L.fll - lo);
 		for (; j < j1; j += jstep, u += ustep)
 		{
@@ -707,7 +718,7 @@ R8B_HD double poly_one(const PolyLaunch& L, int ch, long long i)
 // Tiled form: a workgroup takes kPolyTC channels x kPolyTO consecutive outputs.  All channels
 // follow the same position schedule, so the interpolated taps c0 + c1 x + c2 x^2 (reference
 // CDSPFracInterpolator.h:1088-1150) depend on the output index only: they are evaluated once per
-// output into LDS (cf[t * kPolyTO + o], plus the x-row offset of output o) and shared by the 16
+// output into LDS (cf[o * poly_cf_pitch + t], plus the x-row offset of output o) and shared by the 16
 // channels; each channel's input span is staged in LDS (row pitch odd against bank conflicts).
 // In the compute phase thread (o, g) pulls output o's taps into registers once and walks channels
 // g, g+4, ...: one LDS read per multiply-add, and a wave stores 64 consecutive outputs of one
@@ -719,9 +730,13 @@ static const int kPolyTC = R8B_POLY_TC; // channels per workgroup
 static const int kPolyTO = 64; // outputs per workgroup
 static const int kPolyPad = 8; // zeroed doubles behind a row's span (engine: span_max includes them)
 
-R8B_HD int poly_lds_doubles(int pitch, int flen)
+// doubles per output in the tap table cf[o * pitch + t]: odd, so that the 16 consecutive outputs a lane group
+// reads for one tap and the consecutive taps of an output a lane group writes both spread over the banks
+constexpr int poly_cf_pitch(int flen) { return flen | 1; }
+
+constexpr int poly_lds_doubles(int pitch, int flen)
 {
-	return pitch * kPolyTC + kPolyTO * flen + 3 * kPolyTO;
+	return pitch * kPolyTC + kPolyTO * poly_cf_pitch(flen) + 3 * kPolyTO;
 }
 
 // input span [lo, lo + len) needed by outputs i0 .. i1-1 of this call
@@ -755,6 +770,9 @@ R8B_HD void poly_tile_load(const PolyLaunch& L, double* xs, int pitch, long long
 // before the current tile's arithmetic and stored to LDS after it (spans up to kPolyNV elements per lane).
 static const int kPolyNV = 12;
 
+// (16 lanes per channel row, all 16 rows at once.  Measured and not kept: a wave reading whole rows, 64
+// consecutive samples per load -- 5 cache lines instead of up to 32 per instruction, and twice as slow: a
+// load then goes to one or two memory channels instead of sixteen.)
 R8B_HD void poly_tile_fetch(const PolyLaunch& L, long long lo, int len, int ch0, int tid, int nthr,
 	double (&v)[kPolyNV])
 {
@@ -820,37 +838,42 @@ R8B_HD void poly_tile_pos(const PolyLaunch& L, double* xoff, long long lo, long 
 R8B_HD void poly_tile_coefs(const PolyLaunch& L, double* cf, const double* xoff, long long i0,
 	long long i1, int tid, int nthr)
 {
-	// thread (o, q) evaluates taps q, q + nq, ... of output o; the table entries of its taps are fetched
-	// together (a wave reads one tap of 64 consecutive outputs: mostly one bank entry, i.e. one address)
+	// record tid, tid + nthr, ... of the tile's nout x flen bank records: consecutive lanes read consecutive
+	// 24-byte records of a row (see poly_tile_front)
 	const int nout = (int) (i1 - i0);
-	const int o = tid % kPolyTO, q = tid / kPolyTO, nq = nthr / kPolyTO;
-	if (o >= nout || q >= nq) return;
-	const int fti = (int) xoff[kPolyTO + o];
-	const double x = xoff[2 * kPolyTO + o];
-	double x2;
-	{
-#pragma clang fp contract(off)
-		x2 = x * x;
-	}
-	const double* const row = L.table + (long) fti * L.flen * 3;
+	const int nrec = nout * L.flen;
+	const int cfp = poly_cf_pitch(L.flen);
+	const float rfl = 1.0f / (float) L.flen;
 	constexpr int U = 4;
-	for (int t0 = q; t0 < L.flen; t0 += U * nq)
+	for (int T0 = tid; T0 < nrec; T0 += U * nthr)
 	{
-		double c0[U], c1[U], c2[U];
+		double c0[U], c1[U], c2[U], xr[U];
+		int slot[U];
 #pragma unroll
 		for (int u = 0; u < U; u++)
 		{
-			const int t = t0 + u * nq;
-			const double* c = row + (t < L.flen ? t : t0) * 3;
+			const int T = T0 + u * nthr;
+			const int Tc = T < nrec ? T : T0;
+			const int o = (int) (((float) Tc + 0.5f) * rfl);
+			const int t = Tc - o * L.flen;
+			const int fti = (int) xoff[kPolyTO + o];
+			const double* c = L.table + ((long) fti * L.flen + t) * 3;
 			c0[u] = c[0];
 			c1[u] = c[1];
 			c2[u] = c[2];
+			xr[u] = xoff[2 * kPolyTO + o];
+			slot[u] = T < nrec ? o * cfp + t : -1;
 		}
 #pragma unroll
 		for (int u = 0; u < U; u++)
 		{
-			const int t = t0 + u * nq;
-			if (t < L.flen) cf[t * kPolyTO + o] = c0[u] + c1[u] * x + c2[u] * x2;
+			if (slot[u] < 0) continue;
+			double x2;
+			{
+#pragma clang fp contract(off)
+				x2 = xr[u] * xr[u];
+			}
+			cf[slot[u]] = c0[u] + c1[u] * xr[u] + c2[u] * x2;
 		}
 	}
 }
@@ -858,47 +881,60 @@ R8B_HD void poly_tile_coefs(const PolyLaunch& L, double* cf, const double* xoff,
 // Front half of a tile as ONE phase: the samples and the bank entries are fetched together (both only need
 // the output positions, which every wave has computed lane = output), then stored to LDS -- load, barrier,
 // table fetch, barrier in turn exposed two memory round trips (8 000 + 5 500 cycles of a 18 000-cycle
-// workgroup).  (rpos, fpos): position of output (tid % 64, clamped to the tile) as poly_position gives it.
+// workgroup).  (rpos, fpos): position of output (tid % 64, clamped to the tile) as poly_position gives it;
+// fpos_of(o): the fractional position of output o of the tile (on the GPU a lane shuffle within the wave).
+// The bank entries of the tile -- nout rows of flen (c0, c1, c2) records, 24 bytes each -- are fetched record
+// tid, tid + nthr, ...: consecutive lanes read consecutive records of a row.  (One thread per (output, tap
+// class) read 64 different rows per load instruction whenever the step is not close to an integer -- the
+// bank row then changes with every output -- and the fetch, not the samples, set the kernel's time:
+// 96000 -> 44111 0.174 ms against 0.104 for 88200 -> 44101.)
+template<class FposOf>
 R8B_HD void poly_tile_front(const PolyLaunch& L, double* xs, int pitch, double* cf, double* xoff, long long lo,
-	int len, int nout, long long rpos, double fpos, int ch0, int tid, int nthr)
+	int len, int nout, long long rpos, double fpos, const FposOf& fpos_of, int ch0, int tid, int nthr)
 {
 	double v[kPolyNV];
 	poly_tile_fetch(L, lo, len, ch0, tid, nthr, v);
-	const int o = tid % kPolyTO, q = tid / kPolyTO, nq = nthr / kPolyTO;
-	const bool mine = o < nout && q < nq;
-	double x, x2;
-	int fti;
-	{
-#pragma clang fp contract(off)
-		x = fpos * L.fracs;
-		fti = (int) x;
-		x -= fti;
-		x2 = x * x;
-	}
-	const double* const row = L.table + (long) fti * L.flen * 3;
-	constexpr int UT = 8; // taps q, q + nq, ... of a thread: 8 x 4 thread rows cover the longest bank (32 taps)
-	double c0[UT], c1[UT], c2[UT];
-	if (mine)
-	{
+	constexpr int UR = 8; // records per thread: 64 outputs x up to 32 taps over 256 threads
+	const int nrec = nout * L.flen;
+	const int cfp = poly_cf_pitch(L.flen);
+	const float rfl = 1.0f / (float) L.flen;
+	double c0[UR], c1[UR], c2[UR], xr[UR];
+	int slot[UR];
 #pragma unroll
-		for (int u = 0; u < UT; u++)
+	for (int u = 0; u < UR; u++)
+	{
+		slot[u] = -1;
+		if (u * nthr >= nrec) continue; // (uniform)
+		const int T = tid + u * nthr;
+		const int Tc = T < nrec ? T : 0;
+		const int o = (int) (((float) Tc + 0.5f) * rfl); // Tc / flen (exact: Tc < 2048, the quotient's fraction >= 1/64)
+		const int t = Tc - o * L.flen;
+		double x;
+		int fti;
 		{
-			const int t = q + u * nq;
-			const double* c = row + (t < L.flen ? t : q) * 3;
-			c0[u] = c[0];
-			c1[u] = c[1];
-			c2[u] = c[2];
+#pragma clang fp contract(off)
+			x = fpos_of(o) * L.fracs;
+			fti = (int) x;
+			x -= fti;
 		}
+		const double* c = L.table + ((long) fti * L.flen + t) * 3;
+		c0[u] = c[0];
+		c1[u] = c[1];
+		c2[u] = c[2];
+		xr[u] = x;
+		if (T < nrec) slot[u] = o * cfp + t;
 	}
 	poly_tile_commit(L, xs, pitch, len, ch0, tid, nthr, v);
-	if (mine)
-	{
 #pragma unroll
-		for (int u = 0; u < UT; u++)
+	for (int u = 0; u < UR; u++)
+	{
+		if (slot[u] < 0) continue;
+		double x2;
 		{
-			const int t = q + u * nq;
-			if (t < L.flen) cf[t * kPolyTO + o] = c0[u] + c1[u] * x + c2[u] * x2;
+#pragma clang fp contract(off)
+			x2 = xr[u] * xr[u];
 		}
+		cf[slot[u]] = c0[u] + c1[u] * xr[u] + c2[u] * x2;
 	}
 	if (tid < nout) poly_tile_pos_write(L, xoff, lo, tid, rpos, fpos);
 }
@@ -917,7 +953,7 @@ R8B_HD void poly_tile_compute_t(const PolyLaunch& L, const double* xs, int pitch
 	if (i0 + o >= i1) return;
 	double row[FLENP];
 #pragma unroll
-	for (int t = 0; t < FLENP; t++) row[t] = t < L.flen ? lds_win(cf)[t * kPolyTO + o] : 0.0;
+	for (int t = 0; t < FLENP; t++) row[t] = t < L.flen ? lds_win(cf)[o * poly_cf_pitch(L.flen) + t] : 0.0;
 	const int xo = (int) xoff[o];
 	for (int c = g; c < kPolyTC && ch0 + c < L.nch; c += ng)
 	{

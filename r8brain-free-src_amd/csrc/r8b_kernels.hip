@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 4) void k_poly_tiled(const PolyLaunch L)
 	const long long n = L.b - L.a;
 	const int pitch = L.pitch;
 	double* const cf = xs + pitch * kPolyTC;
-	double* const xoff = cf + kPolyTO * L.flen;
+	double* const xoff = cf + kPolyTO * poly_cf_pitch(L.flen);
 #ifdef R8B_POLY_STAMPS
 	long long ts[8]; int nts = 0;
 	ts[nts++] = clock64();
@@ -221,7 +221,10 @@ __global__ __launch_bounds__(256, 4) void k_poly_tiled(const PolyLaunch L)
 	if (L.front)
 	{
 		// samples and bank entries fetched together, one barrier (spans up to 16 lanes x kPolyNV registers)
-		poly_tile_front(L, xs, pitch, cf, xoff, P.lo, P.len, P.nout, P.rpos, P.fpos, ch0, tid, nthr);
+		// (every lane holds the position of output lane of the tile: another output's is a shuffle away)
+		const double fp = P.fpos;
+		poly_tile_front(L, xs, pitch, cf, xoff, P.lo, P.len, P.nout, P.rpos, P.fpos,
+			[fp](int o) { return __shfl(fp, o); }, ch0, tid, nthr);
 		R8B_PSTAMP();
 		R8B_PSTAMP();
 		R8B_PSTAMP();
@@ -636,8 +639,7 @@ void R8B_LAUNCH(launch_poly)(const PolyLaunch& L, void* stream)
 	if (L.span_max > 0)
 	{
 		// x rows + interpolated taps + row offsets: poly_lds_doubles()
-		const size_t lds = ((size_t) L.pitch * kPolyTC + (size_t) kPolyTO * L.flen +
-			3 * kPolyTO) * sizeof(double);
+		const size_t lds = (size_t) poly_lds_doubles(L.pitch, L.flen) * sizeof(double);
 		hipLaunchKernelGGL(k_poly_tiled, dim3((unsigned) ((n + kPolyTO - 1) / kPolyTO),
 			(unsigned) ((L.nch + kPolyTC - 1) / kPolyTC)), dim3(256), lds, (hipStream_t) stream, L);
 		check(hipGetLastError(), "launch k_poly_tiled");

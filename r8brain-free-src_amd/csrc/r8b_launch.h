@@ -87,6 +87,9 @@ struct WholeLaunch
 	int in_step, out_step, flen, fl2, fll;
 	int pos0;            // output j sits at position j*in_step + pos0 (reference InitFracPosW; 0 for linear phase)
 	const double* table; // out_step rows x flen
+	const double* wtab;  // the same rows transposed and in output order, [tap][k] = table[(k * in_step) % out_step][tap]
+	                     // (null: not available); consecutive outputs then read consecutive doubles per tap
+	int inv_in;          // in_step^-1 mod out_step: output with phase ph is row k = (ph * inv_in) % out_step of wtab
 	long long a, b;      // outputs to produce
 	int tile;            // outputs per workgroup
 	int span_max;        // LDS doubles per workgroup

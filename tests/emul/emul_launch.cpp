@@ -91,7 +91,7 @@ void launch_poly(const PolyLaunch& L, void*)
 		const int nthr = 256, pitch = L.pitch;
 		std::vector<double> xs((size_t) poly_lds_doubles(L.pitch, L.flen));
 		double* const cf = xs.data() + pitch * kPolyTC;
-		double* const xoff = cf + kPolyTO * L.flen;
+		double* const xoff = cf + kPolyTO * poly_cf_pitch(L.flen);
 		const long long n = L.b - L.a;
 		for (int by = 0; by < (L.nch + kPolyTC - 1) / kPolyTC; by++)
 			for (long long i0 = 0; i0 < n; i0 += kPolyTO)
@@ -113,7 +113,15 @@ void launch_poly(const PolyLaunch& L, void*)
 						long long rpos;
 						double fpos;
 						poly_position(L, i0 + o, &rpos, &fpos);
-						poly_tile_front(L, xs.data(), pitch, cf, xoff, lo, len, nout, rpos, fpos, by * kPolyTC, t, nthr);
+						auto fpos_of = [&](int oo)
+						{
+							long long r;
+							double f;
+							poly_position(L, i0 + oo, &r, &f);
+							return f;
+						};
+						poly_tile_front(L, xs.data(), pitch, cf, xoff, lo, len, nout, rpos, fpos, fpos_of,
+							by * kPolyTC, t, nthr);
 					}
 				}
 				else

@@ -137,7 +137,7 @@ int main()
 		L.src.ring = ring; L.src.ring_stride = 4096; L.src.ring_mask = 4095;
 		L.src.cur = x; L.src.cur_stride = in_per; L.src.cur_base = 0; L.src.cur_fmt = 0;
 		L.dst.p = y; L.dst.stride = out_per; L.dst.mask = -1; L.dst.off = 0; L.dst.fmt = 0;
-		const size_t lds = ((size_t) L.pitch * kPolyTC + (size_t) kPolyTO * flen + 3 * kPolyTO) * sizeof(double);
+		const size_t lds = (size_t) poly_lds_doubles(L.pitch, flen) * sizeof(double);
 		for (int k : { 0, 1 })
 		{
 			L.front = k;
@@ -145,6 +145,20 @@ int main()
 			const float ms = time_ms([&] { hipLaunchKernelGGL(k_poly_tiled, grid, dim3(256), lds, 0, L); }, 50);
 			CK(hipGetLastError());
 			printf("k_poly_tiled front %d: %.4f ms  %.2f TB/s (lds %zu)\n", k, ms, 8.0 * nch * (32768 + out_per) / ms * 1e-9, lds);
+		}
+		// a step that is not close to an integer (96000 -> 44111): time against the row pitch's residue mod 32
+		L.ssr = 96000.0; L.dsr = 44111.0; L.front = 1;
+		L.span_max = 140 + flen + 4 + 8;
+		for (int res : { 1, 16 })
+		{
+			L.pitch = L.span_max; while ((L.pitch & 31) != res) L.pitch++;
+			const size_t lds2 = (size_t) poly_lds_doubles(L.pitch, flen) * sizeof(double);
+			const long long outs = 15000;
+			L.b = outs;
+			const dim3 grid((unsigned) ((outs + kPolyTO - 1) / kPolyTO), (unsigned) ((nch + kPolyTC - 1) / kPolyTC));
+			const float ms = time_ms([&] { hipLaunchKernelGGL(k_poly_tiled, grid, dim3(256), lds2, 0, L); }, 20);
+			CK(hipGetLastError());
+			printf("k_poly_tiled step 2.176 pitch %d (res %d): %.4f ms\n", L.pitch, res, ms);
 		}
 		hipFree(x); hipFree(y); hipFree(ring); hipFree(tab);
 	}
@@ -160,20 +174,22 @@ int main()
 		CK(hipMemset(tab, 0, sizeof(double) * 160 * 24));
 		WholeLaunch L = {};
 		L.in_step = 147; L.out_step = 160; L.flen = 24; L.fl2 = 12; L.fll = 11; L.pos0 = 0; L.table = tab;
+		L.wtab = tab; L.inv_in = 123; // 147 * 123 = 18081 = 113 * 160 + 1
 		L.a = 200; L.b = 200 + out_per - 400; L.tile = 1024; L.nch = nch;
 		L.span_max = (int) ((long long) L.tile * 147 / 160) + 24 + 4 + 32;
 		L.src.ring = ring; L.src.ring_stride = 4096; L.src.ring_mask = 4095;
 		L.src.cur = x; L.src.cur_stride = in_per; L.src.cur_base = 0; L.src.cur_fmt = 0;
 		L.dst.p = y; L.dst.stride = out_per; L.dst.mask = -1; L.dst.off = 0; L.dst.fmt = 0;
-		for (int thr : { 256 })
+		for (int wt : { 0, 1 })
 			for (int tile : { 1024, 2048, 4096 })
 			{
+				L.wtab = wt ? tab : nullptr; const int thr = 256;
 				L.tile = tile;
 				L.span_max = (int) ((long long) L.tile * 147 / 160) + 24 + 4 + 32;
 				const unsigned tiles = (unsigned) ((L.b - L.a + L.tile - 1) / L.tile);
 				const float ms = time_ms([&] { hipLaunchKernelGGL(k_whole, dim3(tiles, nch), dim3(thr), (size_t) L.span_max * sizeof(double), 0, L); }, 50);
 				CK(hipGetLastError());
-				printf("k_whole %d threads, tile %d: %.4f ms  %.2f TB/s\n", thr, tile, ms, 8.0 * nch * (32768 + out_per) / ms * 1e-9);
+				printf("k_whole wtab %d, tile %d: %.4f ms  %.2f TB/s\n", L.wtab != nullptr, tile, ms, 8.0 * nch * (32768 + out_per) / ms * 1e-9);
 			}
 		hipFree(x); hipFree(y); hipFree(ring); hipFree(tab);
 	}
