@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """tools/ubench/gen_stream_bench.py : builds tools/ubench/_build/stream_bench, a stand-alone timing harness
-for the streaming kernels of r8b_kernels.hip (half-band cascade, 2x decimator, polynomial interpolator).
+for the streaming kernels of r8b_kernels.hip (half-band cascade, 2x decimator, polynomial interpolator,
+unfused whole-step interpolator).  Note: it launches the same buffers over and over, so read-heavy kernels see
+part of their input in the 256 MB last-level cache (k_hbdown: 5.1 TB/s here, 4.0 in the product).
 
 The kernel bodies are cut out of r8b_kernels.hip as they are (so the harness times the product's code) and
 compiled with r8b_kernel_phases.h, without the convolver families -- seconds instead of the ten minutes
@@ -18,7 +20,6 @@ def cut(start, end):
     return src[a:src.index(end, a)]
 
 
-kernels = cut("__global__ __launch_bounds__(", "// ------------------------------------------------------------------ polynomial-interpolated bank") if False else ""
 kernels = cut("// ------------------------------------------------------------------ whole-step polyphase FIR", "// ------------------------------------------------------------------ polynomial-interpolated bank") + cut("// positions of the (up to 64) outputs of tile t, lane = output, once per wave", "// ------------------------------------------------------------------ decimating half-band cascade")
 main = r'''
 #include <cstdio>
@@ -45,7 +46,7 @@ int main()
 	const int nch = 1024;
 	// ---- half-band cascade, cfg5 x 1024 channels: 5 stages, 2048 -> 65536 samples per channel and call
 	{
-		const long long in_per = 2048, out_per = 65536, calls = 3;
+		const long long in_per = 2048, out_per = 65536, calls = 20;
 		double *x, *y, *ring;
 		CK(hipMalloc(&x, sizeof(double) * nch * in_per * calls));
 		CK(hipMalloc(&y, sizeof(double) * nch * out_per));
@@ -78,6 +79,20 @@ int main()
 			CK(hipGetLastError());
 			const double bytes = 8.0 * nch * (in_per + out_per);
 			printf("k_hbcascade tile %d: %.4f ms  %.2f TB/s\n", tile, ms, bytes / ms * 1e-9);
+		}
+		// shallower runs (the heavy up-sampling chains of the rate table: 2 or 3 stages, taps 14 / 8 / 4 first)
+		for (int nst : { 2, 3 })
+		{
+			HBCascadeLaunch M = L;
+			M.nst = nst;
+			M.a = out_per; M.b = 2 * out_per; M.in_end = (2 * out_per) >> nst; M.nch = nch;
+			M.src.cur_stride = in_per * calls; // (x holds 6144 samples per channel: only the first tiles' spans are real; timing only)
+			M.tile = 8192; M.buf = M.tile / 2 + 96; M.buf2 = M.tile / 4 + 96;
+			const unsigned tiles = (unsigned) ((M.b - M.a + M.tile - 1) / M.tile);
+			const size_t lds = (size_t) (M.buf + M.buf2) * sizeof(double);
+			const float ms = time_ms([&] { hipLaunchKernelGGL(k_hbcascade, dim3(tiles, nch), dim3(256), lds, 0, M); }, 50);
+			CK(hipGetLastError());
+			printf("k_hbcascade %d stages, tile 8192: %.4f ms  %.2f TB/s\n", nst, ms, 8.0 * nch * (out_per + (out_per >> nst)) / ms * 1e-9);
 		}
 		// the same run at BASELINE config 5's own size: 64 channels x 1024 -> 32768 outputs, 4096-sample tiles
 		L.nch = 64; L.a = 32768; L.b = 65536; L.in_end = 2048; L.dst.off = -32768;
