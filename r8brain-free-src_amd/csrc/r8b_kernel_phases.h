@@ -993,6 +993,12 @@ R8B_HD void hbup_compute(const HBLaunch& L, const double* xs, long long n0, long
 	constexpr int U = kHbIlp;
 	const int T = L.ntaps;
 	const int cnt = (int) (n1 - n0);
+	// plain fp64 destination row: pq[2 i] is output 2 (n0 + i); 16-byte aligned when that element index is even
+	const bool linear = L.dst.mask == -1 && L.dst.fmt == kPcmF64;
+	double* const pq = linear ? L.dst.p + ((long long) ch * L.dst.stride + (2 * n0 + L.dst.off)) : nullptr;
+	const bool pair16 = linear && ((size_t) pq & 15) == 0;
+	// odd element index: the aligned pairs are (odd output of an input, even output of the next input = x[1])
+	const bool pair16b = linear && !pair16 && ((size_t) (pq + 1) & 15) == 0;
 	for (int i0 = tid; i0 < cnt; i0 += U * nthr)
 	{
 		LdsWin x[U]; // x[u][0] == stream x[n]
@@ -1018,8 +1024,37 @@ R8B_HD void hbup_compute(const HBLaunch& L, const double* xs, long long n0, long
 			const int i = i0 + u * nthr;
 			if (i >= cnt) continue;
 			const long long q = 2 * (n0 + i);
-			if (q >= L.a && q < L.b) dst_store(L.dst, ch, q, x[u][0]);
-			if (q + 1 >= L.a && q + 1 < L.b) dst_store(L.dst, ch, q + 1, s[u]);
+			const bool in0 = q >= L.a && q < L.b, in1 = q + 1 >= L.a && q + 1 < L.b;
+			if (pair16 && in0 && in1)
+			{
+				// the even/odd output pair as one 16-byte store: a wave writes 1 KB of consecutive bytes (two
+				// 8-byte stores at a 16-byte lane stride each fill half of every cache line they touch)
+				cd v;
+				v.re = x[u][0];
+				v.im = s[u];
+				*reinterpret_cast<cd*>(pq + 2 * i) = v;
+				continue;
+			}
+			if (pair16b)
+			{
+				// an even output is written by the pair of the input before it, unless that pair starts
+				// before the range
+				if (in0 && q - 1 < L.a) pq[2 * i] = x[u][0];
+				if (in1)
+				{
+					if (q + 2 < L.b)
+					{
+						cd v;
+						v.re = s[u];
+						v.im = x[u][1];
+						*reinterpret_cast<cd*>(pq + 2 * i + 1) = v;
+					}
+					else pq[2 * i + 1] = s[u];
+				}
+				continue;
+			}
+			if (in0) dst_store(L.dst, ch, q, x[u][0]);
+			if (in1) dst_store(L.dst, ch, q + 1, s[u]);
 		}
 	}
 }

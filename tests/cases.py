@@ -50,6 +50,9 @@ STREAM_CASES = [
     (96000.0, 30001.0, 1024, 777, 12000, 2.0, 180.15),
     (22050.0, 44101.0, 1024, 500, 6000, 2.0, 180.15),
     (44100.0, 48001.0, 1024, 1024, 6000, 2.0, 180.15),
+    # a 2x half-band up-sampler as the LAST stage behind a fused interpolator: its 16-byte output pairs start at even
+    # and at odd elements of the caller's rows from call to call (ragged chunks)
+    (8000.0, 44100.0, 1024, 777, 6000, 2.0, 180.15),
 ]
 
 

@@ -131,6 +131,33 @@ int main()
 		}
 		hipFree(x); hipFree(y); hipFree(ring);
 	}
+	// ---- 2x up-sampler alone, 1024 channels x 32768 -> 65536 (8000 -> 32000's second stage)
+	{
+		const long long in_per = 32768 + 64, out_per = 65536;
+		double *x, *y, *ring;
+		CK(hipMalloc(&x, sizeof(double) * nch * in_per));
+		CK(hipMalloc(&y, sizeof(double) * nch * (out_per + 2)));
+		CK(hipMalloc(&ring, sizeof(double) * nch * 4096));
+		CK(hipMemset(x, 0, sizeof(double) * nch * in_per));
+		HBLaunch L = {};
+		L.ntaps = 11;
+		for (int k = 0; k < 11; k++) L.taps[k] = 0.3 / (k + 1);
+		L.tile = 1024; L.nch = nch;
+		L.src.ring = ring; L.src.ring_stride = 4096; L.src.ring_mask = 4095;
+		L.src.cur = x; L.src.cur_stride = in_per; L.src.cur_base = 0; L.src.cur_fmt = 0;
+		L.dst.p = y; L.dst.stride = out_per + 2; L.dst.mask = -1; L.dst.fmt = 0;
+		for (int odd : { 0, 1 })
+		{
+			// outputs [40, 40 + out_per - 100) land at element 0 (aligned pairs) or 1 (odd offset: single stores)
+			L.a = 40; L.b = 40 + out_per - 100; L.dst.off = -40 + odd;
+			const long long nin = (L.b + 1) / 2 - L.a / 2;
+			const unsigned tiles = (unsigned) ((nin + L.tile - 1) / L.tile);
+			const float ms = time_ms([&] { hipLaunchKernelGGL(k_hbup, dim3(tiles, nch), dim3(256), (size_t) (L.tile + 2 * L.ntaps) * sizeof(double), 0, L); }, 50);
+			CK(hipGetLastError());
+			printf("k_hbup 11 taps, offset %d: %.4f ms  %.2f TB/s\n", odd, ms, 8.0 * nch * 1.5 * (out_per - 100) / ms * 1e-9);
+		}
+		hipFree(x); hipFree(y); hipFree(ring);
+	}
 	// ---- polynomial-interpolated bank, 88200 -> 44101, 1024 channels x 32768 -> 16385
 	{
 		const long long in_per = 32768 + 256, out_per = 16385;
