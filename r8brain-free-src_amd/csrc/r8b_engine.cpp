@@ -1452,6 +1452,7 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 		L.ntaps[g] = sp.hb_n <= 4 ? 4 : (sp.hb_n <= 8 ? 8 : 14);
 		for (int k = 0; k < sp.hb_n; k++) L.taps[g][k] = sp.hb_taps[k];
 	}
+	hbc_fill_ranges(L);
 	L.a = fa; L.b = fb;
 	// last-stage outputs per workgroup: a multiple of 2^glen.  A tile costs ~1.7 us of a CU
 	// whatever its size (six dependent phases), so large batches take 8192 (51 KB LDS, 3

@@ -1163,16 +1163,10 @@ R8B_HD void hbc_ranges(const HBCascadeLaunch& L, long long q0, long long q1, HBC
 R8B_HD void hbc_stage_range(const HBCascadeLaunch& L, long long q0, long long q1, int s, long long* lo,
 	long long* hi)
 {
-	long long l = q0, h = q1;
-	for (int t = L.nst - 1; t > s; t--)
-	{
-		const int T = L.ntaps[t];
-		const long long il = floor_half(l) - (T - 1), ih = floor_half(h - 1) + T + 1;
-		l = il;
-		h = ih;
-	}
-	*lo = l;
-	*hi = h;
+	// closed form (r8b_launch.h hbc_fill_ranges; s == nst: the input span of stage 0)
+	const int k = s < L.nst ? L.nst - 1 - s : L.nst;
+	*lo = (q0 - L.rlo[s]) >> k;
+	*hi = ((q1 - 1 + L.rhi[s]) >> k) + 1;
 }
 
 R8B_HD void hbc_load_span(const HBCascadeLaunch& L, long long in_lo, long long in_hi, double* buf, int ch,

@@ -307,17 +307,16 @@ __global__ __launch_bounds__(256) void k_hbcascade(const HBCascadeLaunch L)
 	double* yout = ((L.nst - 1) & 1) ? big : small;
 	{
 		long long lo, hi;
-		hbc_stage_range(L, q0, q1, 0, &lo, &hi);
-		const int T = L.ntaps[0];
-		hbc_load_span(L, floor_half(lo) - (T - 1), floor_half(hi - 1) + T + 1, xin, ch, tid, nthr);
+		hbc_stage_range(L, q0, q1, L.nst, &lo, &hi);
+		hbc_load_span(L, lo, hi, xin, ch, tid, nthr);
 	}
 	__syncthreads();
 #ifdef R8B_HBC_STAMPS
 	ts[nts++] = clock64();
 #endif
 	// Rolled: the stage number is a run-time value, what it indexes (tap counts, taps) are scalar loads of
-	// kernel arguments, and a stage's range is recomputed by hbc_stage_range instead of kept in a table (a
-	// run-time index would push the table into scratch memory).  One copy of each stage routine instead of
+	// kernel arguments, and a stage's range comes in closed form from the tile (hbc_stage_range) instead of a
+	// table (a run-time index would push the table into scratch memory).  One copy of each stage routine instead of
 	// one per stage: the unrolled form was five times the code (78 KB, beyond the instruction cache) and
 	// slower.  Measured and not kept (tools/ubench/gen_stream_bench.py, cfg5 x 1024 channels, 0.138 ms as
 	// built): tap counts / taps held in scalar registers across the loop or fetched a stage ahead (0.150 -

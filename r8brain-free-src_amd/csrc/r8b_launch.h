@@ -141,12 +141,32 @@ struct HBCascadeLaunch
 	int tile;                      // last-stage outputs per workgroup (multiple of 2^nst)
 	int buf, buf2;                 // doubles of the two LDS buffers: tile/2 + slack, tile/4 + slack
 	int pair_ok;                   // the destination admits aligned 16-byte stores of output pairs
+	// up-sampling run only: the output range of stage s for the tile [q0, q1) in closed form,
+	//   lo_s = (q0 - rlo[s]) >> (nst-1-s),  hi_s = ((q1 - 1 + rhi[s]) >> (nst-1-s)) + 1,
+	// and the input span of stage 0 with rlo[nst] / rhi[nst] and a shift of nst (hbc_fill_ranges); equal to
+	// walking the stages back from the tile (floors of halves compose), without a chain of dependent loads
+	long long rlo[kMaxCascade + 1], rhi[kMaxCascade + 1];
 	long long in_end;              // input positions >= in_end have not arrived: the zero-padded
 	                               // taps reach past the real filter, those loads must not happen
 	int nch;
 	SrcView src;                   // input stream of the first stage
 	DstView dst;
 };
+
+inline void hbc_fill_ranges(HBCascadeLaunch& L)
+{
+	long long cl = 0, ch = 0;
+	for (int s = L.nst - 1; s >= 0; s--)
+	{
+		const int k = L.nst - 1 - s;
+		L.rlo[s] = cl;
+		L.rhi[s] = ch;
+		cl += (long long) (L.ntaps[s] - 1) << (k + 1);
+		ch += (long long) L.ntaps[s] << (k + 1);
+	}
+	L.rlo[L.nst] = cl;
+	L.rhi[L.nst] = ch;
+}
 
 struct TailLaunch
 {

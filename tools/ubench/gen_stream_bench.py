@@ -61,6 +61,7 @@ int main()
 			L.ntaps[s] = nt[s];
 			for (int k = 0; k < 14; k++) L.taps[s][k] = k < nt[s] - 1 ? 0.3 / (k + 1) : 0.0;
 		}
+		hbc_fill_ranges(L);
 		// the second call of a stream: inputs [2048, 4096), outputs [65536, 131072)
 		L.a = out_per; L.b = 2 * out_per;
 		L.nch = nch;
@@ -85,6 +86,7 @@ int main()
 		{
 			HBCascadeLaunch M = L;
 			M.nst = nst;
+			hbc_fill_ranges(M);
 			M.a = out_per; M.b = 2 * out_per; M.in_end = (2 * out_per) >> nst; M.nch = nch;
 			M.src.cur_stride = in_per * calls; // (x holds 6144 samples per channel: only the first tiles' spans are real; timing only)
 			M.tile = 8192; M.buf = M.tile / 2 + 96; M.buf2 = M.tile / 4 + 96;
