@@ -98,12 +98,13 @@ int main()
 		}
 		// the same run at BASELINE config 5's own size: 64 channels x 1024 -> 32768 outputs, 4096-sample tiles
 		L.nch = 64; L.a = 32768; L.b = 65536; L.in_end = 2048; L.dst.off = -32768;
-		L.tile = 4096; L.buf = L.tile / 2 + 96; L.buf2 = L.tile / 4 + 96;
+		for (int tile : { 1024, 2048, 4096, 8192 })
 		{
+			L.tile = tile; L.buf = L.tile / 2 + 96; L.buf2 = L.tile / 4 + 96;
 			const size_t lds = (size_t) (L.buf + L.buf2) * sizeof(double);
-			const float ms = time_ms([&] { hipLaunchKernelGGL(k_hbcascade, dim3(8, 64), dim3(256), lds, 0, L); }, 200);
+			const float ms = time_ms([&] { hipLaunchKernelGGL(k_hbcascade, dim3(32768 / tile, 64), dim3(256), lds, 0, L); }, 200);
 			CK(hipGetLastError());
-			printf("k_hbcascade 64 ch x 32768, tile 4096: %.4f ms\n", ms);
+			printf("k_hbcascade 64 ch x 32768, tile %d: %.4f ms\n", tile, ms);
 		}
 		hipFree(x); hipFree(y); hipFree(ring);
 	}
