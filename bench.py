@@ -38,8 +38,8 @@ def channel_shard(total_channels, rank, world):
     # transform, so a shard boundary between them would change which channels share a transform (and
     # with it the last bits of their samples); with pairs kept together sharded == unsharded bit for bit
     pairs = (total_channels + 1) // 2
-    lo = min(2 * (pairs * rank // world), total_channels)
-    hi = min(2 * (pairs * (rank + 1) // world), total_channels)
+    lo = min(2 * -(-pairs * rank // world), total_channels)
+    hi = min(2 * -(-pairs * (rank + 1) // world), total_channels)
     return lo, hi
 
 

@@ -970,11 +970,14 @@ struct ConvpItem
 	bool bvalid;
 };
 
-template<int LN, int UL, int MODE, int FLENP, class Exec>
-R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem& cur)
+// PF (walker form, k_convpw): the samples of block cur.k already sit in st.pr / st.pi; those of block knext (if
+// knext >= 0) are fetched into them ahead of the last stage, whose length then covers their memory latency.
+template<int LN, int UL, int MODE, int FLENP, bool PF = false, class Exec>
+R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem& cur, long long knext = -1)
 {
 	typedef ConvpGeom<LN, UL> G;
 	typedef ConvpState<LN, UL> St;
+	static_assert(!PF || G::SUB == 1, "walker form: one block pair per workgroup at a time");
 	// modes 6 / 7: modes 0 / 3 with a complex kernel spectrum
 	constexpr bool CX = MODE == 6 || MODE == 7;
 	constexpr int BM = MODE == 6 ? 0 : (MODE == 7 ? 3 : MODE);
@@ -1003,7 +1006,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	ex.phase([&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
-		cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
+		if constexpr (!PF) cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
 		cp_first<LN, UL>(L, buf_of(tid), st, lt);
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
 		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
@@ -1136,6 +1139,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
+			if constexpr (PF) if (knext >= 0) cp_load<LN, UL, BM>(L, st, knext, chA, chB, lt);
 			ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
 			if (live(tid))
 			{
@@ -1149,6 +1153,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
+			if constexpr (PF) if (knext >= 0) cp_load<LN, UL, BM>(L, st, knext, chA, chB, lt);
 			cp_back2<LN, UL>(buf_of(tid), st, lt);
 			if (live(tid)) cp_store_conv<LN, UL, BM>(L, st, k_of(tid), chA, chB, bvalid, lt);
 		});
@@ -1166,6 +1171,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		ex.phase([&](int tid, St& st)
 		{
 			cp_final_store<LN, UL>(L, buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
+			if constexpr (PF) if (knext >= 0) cp_load<LN, UL, BM>(L, st, knext, chA, chB, lt_of(tid));
 		});
 		// the interpolator: all 256 threads over the run of one block pair after the other
 		ex.each([&](int, St& st)
@@ -1186,6 +1192,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		ex.phase([&](int tid, St& st)
 		{
 			cp_final_store<LN, UL>(L, buf_of(tid), st, k_of(tid), lt_of(tid));
+			if constexpr (PF) if (knext >= 0) cp_load<LN, UL, BM>(L, st, knext, chA, chB, lt_of(tid));
 		});
 		ex.each([&](int tid, St& st)
 		{

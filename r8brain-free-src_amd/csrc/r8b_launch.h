@@ -228,14 +228,22 @@ struct ConvxLaunch
 	const double* ctab;
 	int nsets;
 	unsigned nblk_magic; // floor(2^32 / c.nblk) + 1 (filled in by the launcher; r8b_convp.h convp_div)
+	// walker form (k_convpw): a workgroup takes segment seg of nseg of its channel pair's blocks,
+	// blocks [seg * seg_len, min(nblk, (seg + 1) * seg_len)); workgroup w = pair * nseg + seg
+	int nseg, seg_len;
+	unsigned nseg_magic; // floor(2^32 / nseg) + 1 (0: nseg = 1)
 };
 
 // geometries the fast path is instantiated for: (log2 of the forward complex length, up shift), and
 // for the 2x-decimating convolver (log2 of the forward complex length, down shift)
+// (R8B_DEV_GEOMS: a development build that instantiates only the geometries named on the compiler's command line --
+// tools/variant.sh; a one-geometry build takes a minute instead of ten)
+#ifndef R8B_DEV_GEOMS
 #define R8B_CONVX_GEOMS(M) M(8, 1) M(9, 0) M(9, 1) M(10, 0) M(10, 1) M(11, 0) M(11, 1) M(12, 0) \
 	M(12, 1) M(13, 0)
 #define R8B_CONVX_GEOMS_DOWN(M) M(8, 1) M(9, 1) M(10, 1) M(11, 1) M(12, 1) M(13, 1) \
 	M(10, 2) M(11, 2) M(12, 2) M(13, 2)
+#endif
 
 inline bool convx_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
 {
@@ -296,6 +304,7 @@ inline bool convp_mode3_ok(int n_in, int n_out, int up, int down, bool up_pow2, 
 	if (down != 1 && !(down_pow2 ? (down == 2 || down == 4) : down == 3)) return false;
 	return convp_geometry_ok(n_in, n_out, up_pow2 ? up : 1, down_pow2 ? down : 1, true);
 }
+#ifndef R8B_DEV_GEOMS
 #define R8B_CONVP_GEOMS(M) M(11, 1) M(12, 0) M(10, 1) M(11, 0) M(9, 1) M(10, 0) M(8, 1) M(9, 0) M(7, 1) M(8, 0) \
 	M(6, 1) M(7, 0) M(5, 1) M(6, 0)
 // 8192-point blocks (512-thread workgroups)
@@ -303,6 +312,7 @@ inline bool convp_mode3_ok(int n_in, int n_out, int up, int down, bool up_pow2, 
 // decimating form: (log2 forward length, log2 decimation)
 #define R8B_CONVP_GEOMS_DOWN(M) M(13, 1) M(12, 1) M(11, 1) M(10, 1) M(9, 1) M(8, 1) M(7, 1) M(6, 1) \
 	M(13, 2) M(12, 2) M(11, 2) M(10, 2) M(9, 2) M(8, 2) M(7, 2) M(6, 2)
+#endif
 
 // launchers (asynchronous on `stream`, a hipStream_t)
 void launch_conv(const ConvLaunch& L, void* stream);

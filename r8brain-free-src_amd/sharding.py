@@ -26,10 +26,17 @@ def channel_shard(total_channels, rank, world):
     # whole channel PAIRS per rank: the pair kernel packs channels 2c and 2c+1 into one complex
     # transform, so a shard boundary between them would change which channels share a transform (and
     # with it the last bits of their samples); with pairs kept together sharded == unsharded bit for bit
+    # (ceilings: when there are fewer pairs than ranks the LOW ranks get them, so that rank 0 -- the usual
+    # root of scatter / gather -- owns channels whenever anybody does)
     pairs = (total_channels + 1) // 2
-    lo = min(2 * (pairs * rank // world), total_channels)
-    hi = min(2 * (pairs * (rank + 1) // world), total_channels)
+    lo = min(2 * -(-pairs * rank // world), total_channels)
+    hi = min(2 * -(-pairs * (rank + 1) // world), total_channels)
     return lo, hi
+
+
+def _some_shard_empty(total_channels, world):
+    return any(channel_shard(total_channels, r, world)[1] <= channel_shard(total_channels, r, world)[0]
+               for r in range(world))
 
 
 def _run_p2p(ops):
@@ -66,18 +73,28 @@ def scatter_channels(x_full, total_channels, length, src=0, device=None, dtype=t
     return local
 
 
-def gather_channels(y_local, total_channels, dst=0):
-    """Inverse of scatter_channels for the per-rank outputs [hi-lo, n] (same n on every rank: all
-    ranks follow the same schedule).  Returns [total_channels, n] on `dst`, None elsewhere."""
+def gather_channels(y_local, total_channels, dst=0, n=None):
+    """Inverse of scatter_channels for the per-rank outputs [hi-lo, n] (same n on every rank that owns
+    channels: all ranks follow the same schedule).  Returns [total_channels, n] on `dst`, None elsewhere.
+    A rank WITHOUT channels (fewer channel pairs than ranks) has no resampler and so no n of its own:
+    whenever some shard is empty -- every rank can tell from (total_channels, world) alone -- the ranks
+    agree on n with one all_reduce(MAX) first (or the caller passes n), so that a channel-less `dst`
+    still allocates the full result and posts a receive for every sender."""
     rank, world = _rank_world()
-    n = y_local.shape[1]
+    if n is None:
+        n = y_local.shape[1]
+        if world > 1 and _some_shard_empty(total_channels, world):
+            t = torch.tensor([n], dtype=torch.int64, device=y_local.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            n = int(t.item())
     if rank == dst:
         out = torch.empty((total_channels, n), dtype=y_local.dtype, device=y_local.device)
         ops = []
         for r in range(world):
             a, b = channel_shard(total_channels, r, world)
             if r == dst:
-                out[a:b].copy_(y_local)
+                if b > a:
+                    out[a:b].copy_(y_local)
             elif b > a and n > 0:
                 ops.append(dist.P2POp(dist.irecv, out[a:b], r))
         _run_p2p(ops)
@@ -122,6 +139,13 @@ class RootPipeline:
         self.device = torch.device(device if device is not None else "cpu")
         self.cuda = self.device.type == "cuda"
         self.side = torch.cuda.Stream(self.device) if self.cuda else None
+        self._ybuf = [None, None]  # two output buffers in rotation (process(out=)): no copy per call
+        import inspect
+        loc = sharded.local
+        try:
+            self._has_out = loc is not None and "out" in inspect.signature(loc.process).parameters
+        except (TypeError, ValueError):
+            self._has_out = False
 
     def _on_side(self):
         import contextlib
@@ -162,9 +186,24 @@ class RootPipeline:
             if self.cuda:
                 torch.cuda.current_stream(self.device).wait_event(ready[i])
             x = shards[i]
-            y = self.sh.local.process(x) if self.sh.local is not None else x[:, :0]
             if self.cuda:
-                y = y.clone()  # the resampler reuses its output buffer on the next call
+                # allocated on the side stream, read on this one: tell the caching allocator
+                x.record_stream(torch.cuda.current_stream(self.device))
+            if self.sh.local is None:
+                y = x[:, :0]
+            elif self._has_out and hasattr(self.sh.local, "max_out_len"):
+                # the gather of call i-2 out of this buffer was queued on the side stream before scatter(i),
+                # which `ready[i]` (waited for above) follows: the buffer is free again
+                if self._ybuf[i & 1] is None:
+                    self._ybuf[i & 1] = torch.empty((x.shape[0], self.sh.local.max_out_len), dtype=x.dtype,
+                                                    device=x.device)
+                y = self.sh.local.process(x, out=self._ybuf[i & 1])
+            else:
+                y = self.sh.local.process(x)
+                if self.cuda:
+                    y = y.clone()  # the resampler reuses its output buffer on the next call
+            if self.cuda:
+                y.record_stream(self.side)
                 done[i] = torch.cuda.Event()
                 done[i].record(torch.cuda.current_stream(self.device))
             gather(i, y)
