@@ -42,6 +42,14 @@
 
 #include "r8b_convx.h"
 
+// R8B_ABL (development builds only, tools/variant.sh: timing ablations, results are wrong): bit 0 no interpolator,
+// bit 1 no transform passes between the first forward and the last backward one, bit 2 no last backward pass,
+// bit 3 no global loads of samples, bit 4 no first pass, bit 5 interpolator without its stores,
+// bit 6 convolver-only modes without their stores, bit 7 twiddles / bit 8 kernel constants / bit 9 interpolator rows without table fetches
+#ifndef R8B_ABL
+#define R8B_ABL 0
+#endif
+
 namespace r8bhip {
 
 static const int kConvpThreads = 256;
@@ -134,17 +142,69 @@ struct ConvpState
 	int pt;               // ... and its entry of X.ptab
 };
 
-template<int LN, int UL> constexpr int convp_lds_bytes() { return ConvpGeom<LN, UL>::SUB * ConvpGeom<LN, UL>::NA * 16; }
+// (+ 64 bytes behind the array: one word per wave for the workgroup-wide "channel has a non-zero sample" bits)
+static const int kConvpFlagBytes = 64;
+template<int LN, int UL> constexpr int convp_array_bytes() { return ConvpGeom<LN, UL>::SUB * ConvpGeom<LN, UL>::NA * 16; }
+template<int LN, int UL> constexpr int convp_lds_bytes() { return convp_array_bytes<LN, UL>() + kConvpFlagBytes; }
+
+// Silence stays silence.  Two channels share one complex transform, so each picks up rounding residue of the
+// order of 1e-16 of its PARTNER's amplitude; for a channel whose samples are all zero that residue would be the
+// whole output, where the reference -- one object per channel -- returns exact zeros.  Every thread therefore
+// reports whether its samples of channel A / B hold anything but zero (bits 0 / 1; -0.0 counts as zero, NaN does
+// not); the bits are combined over the workgroup (Exec::post_bits / collect_bits, across the barrier that ends the
+// first pass) and a channel without a non-zero sample in any of the workgroup's blocks gets its results replaced
+// by zeros before they are stored or interpolated.
+template<int LN, int UL>
+R8B_HD unsigned cp_nonzero_bits(const ConvpState<LN, UL>& st)
+{
+	bool a = false, b = false;
+#pragma unroll
+	for (int p = 0; p < ConvpGeom<LN, UL>::E1; p++)
+	{
+		a = a || st.pr[p] != 0.0;
+		b = b || st.pi[p] != 0.0;
+	}
+	return (a ? 1u : 0u) | (b ? 2u : 0u);
+}
+
+template<int LN, int UL>
+R8B_HD void cp_silence(ConvpState<LN, UL>& st, unsigned nzbits)
+{
+	if (nzbits == 3u) return; // (uniform over the workgroup: the usual case costs one scalar branch)
+	const bool za = !(nzbits & 1u), zb = !(nzbits & 2u);
+#pragma unroll
+	for (int p = 0; p < 16; p++)
+	{
+		if (za) st.vr[p] = 0.0;
+		if (zb) st.vi[p] = 0.0;
+	}
+}
 
 // Twiddle base powers of a pass, pre-gathered per thread by the host (pair_twiddles() in
 // r8b_engine.cpp): entry (row * NT + t) = w_n^(j(t) m_c), row = 6 slot + c, m = {1, 2, 3, 4, 8, 12}; a
 // wave reads consecutive 16-byte entries per load (the strided reads of the shared exp() table touch up
 // to 64 cache lines per load).  Slots: 0 first pass, 1 / 2 forward passes 1 / 2, 3 backward pass with
 // sub-length 256, 4 + m butterfly m of the last backward pass (sub-length N2, j = t + NT m).
-template<int R, int NT>
+// JM: the butterflies of a sub-transform (j = t mod JM): a row holds only JM distinct entries, and reading them at
+// t mod JM instead of t keeps a pass's whole table to JM x 16 bytes per row -- a few cache lines that stay in
+// the CU's L1 instead of a kilobyte per wave from L2 (the passes between the first forward and the last backward
+// one have 4 ... 32 distinct entries per row)
+template<int R, int NT, int JM = NT>
 R8B_HD void ptw_fetch(cd* twr, const cd* ptw, int slot, int lt)
 {
 	constexpr int NB = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
+	if constexpr (JM < NT) lt &= JM - 1;
+	if constexpr ((R8B_ABL & 128) != 0)
+	{
+		// (timing ablation: no table traffic)
+#pragma unroll
+		for (int c = 0; c < NB; c++)
+		{
+			twr[c].re = 0.7 + 0.01 * lt;
+			twr[c].im = 0.3 * c;
+		}
+		return;
+	}
 	const cd* p = ptw + (slot * 6 * NT + lt);
 #pragma unroll
 	for (int c = 0; c < NB; c++) twr[c] = p[c * NT];
@@ -325,7 +385,7 @@ struct ConvpPre
 	static constexpr int n = G::N >> (I * G::EB1);
 	static R8B_HD void prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 	{
-		ptw_fetch<G::E1, G::NT>(st.tw, L.ptw, I, lt);
+		ptw_fetch<G::E1, G::NT, (n / G::E1 < G::NT ? n / G::E1 : G::NT)>(st.tw, L.ptw, I, lt);
 	}
 	static R8B_HD void run(cd* buf, const ConvpState<LN, UL>& st, int lt)
 	{
@@ -346,7 +406,12 @@ R8B_HD void cp_hp_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 #pragma unroll
 	for (int c = 0; c < NHP; c++)
 	{
-		st.hp[c] = L.hp[c * ConvpGeom<LN, UL>::NT + lt];
+		if constexpr ((R8B_ABL & 256) != 0)
+		{
+			st.hp[c].re = 1.0 + 1e-3 * lt;
+			st.hp[c].im = 0.5 - 1e-3 * c;
+		}
+		else st.hp[c] = L.hp[c * ConvpGeom<LN, UL>::NT + lt];
 	}
 }
 
@@ -603,7 +668,7 @@ struct ConvpPost
 	static constexpr int n = G::RMB << (I * G::EB2);
 	static R8B_HD void prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 	{
-		ptw_fetch<G::E2, G::NT>(st.tw, L.ptw, 2 + I, lt);
+		ptw_fetch<G::E2, G::NT, (n / G::E2 < G::NT ? n / G::E2 : G::NT)>(st.tw, L.ptw, 2 + I, lt);
 	}
 	static R8B_HD void run(cd* buf, ConvpState<LN, UL>& st, int lt)
 	{
@@ -849,6 +914,12 @@ R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int* pt, int tid)
 		return;
 	}
 	*pt = X.ptab[tid];
+	if constexpr ((R8B_ABL & 512) != 0)
+	{
+#pragma unroll
+		for (int i = 0; i < 2 * T2; i++) rows[i] = 0.01 * i + 1e-3 * tid;
+		return;
+	}
 	// X.ctab holds the 2 T2 values of a thread as T2 pairs, pair i of thread t at [(i * 256 + t) * 2]: a
 	// wave reads 64 consecutive 16-byte entries per load
 	const cd* ct = reinterpret_cast<const cd*>(X.ctab) + tid;
@@ -873,14 +944,68 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* r
 	const int hi_mod = Bm.pad, gmax = Bm.ph_lo, lo_mod = Bm.jlo_mod, u_lo = Bm.u_lo;
 	if (hi_mod == 0) return;
 	const int in_step = X.in_step, out_step = X.out_step, nsets = X.nsets;
-	const long long jg = Bm.jlo - lo_mod + 2 * q;
+	const long long jg0 = Bm.jlo - lo_mod, jg = jg0 + 2 * q;
 	// group 0 starts at the block's first output (phase lo_mod), the last group ends before phase hi_mod
 	const bool f0 = 2 * q >= lo_mod, f1 = 2 * q + 1 >= lo_mod && 2 * q + 1 < out_step;
 	const bool l0 = 2 * q < hi_mod, l1 = 2 * q + 1 < hi_mod && 2 * q + 1 < out_step;
 	const bool linear = X.wdst.mask == -1 && X.wdst.fmt == kPcmF64;
-	double* const pa = X.wdst.p + ((long long) chA * X.wdst.stride + (jg + X.wdst.off));
-	double* const pb = X.wdst.p + ((long long) chB * X.wdst.stride + (jg + X.wdst.off));
-	const bool pair16 = (((size_t) pa | (size_t) pb) & 15) == 0 && (out_step & 1) == 0;
+	// (row pointers of the block's first group: uniform over the workgroup, so is the alignment test)
+	double* const pa0 = X.wdst.p + ((long long) chA * X.wdst.stride + (jg0 + X.wdst.off));
+	double* const pb0 = X.wdst.p + ((long long) chB * X.wdst.stride + (jg0 + X.wdst.off));
+	double* const pa = pa0 + 2 * q;
+	double* const pb = pb0 + 2 * q;
+	const bool pair16 = (((size_t) pa0 | (size_t) pb0) & 15) == 0 && (out_step & 1) == 0;
+	constexpr int CH = T2 == 25 ? 5 : 3, NCH = T2 / CH;
+	static_assert(CH * NCH == T2, "chunks");
+	if (lo_mod == 0 && hi_mod == out_step && linear && pair16 && (R8B_ABL & 32) == 0)
+	{
+		// Whole groups only (every block of a call but those cut by its ends, when the blocks are aligned to
+		// groups -- Engine::launch_fused): nothing to mask, every output pair is one 16-byte store.
+		for (int gl = set; gl <= gmax; gl += nsets)
+		{
+			const cd* w = y + (u_lo + in_step * gl + rq);
+			double a0[2] = { 0.0, 0.0 }, b0[2] = { 0.0, 0.0 }, a1[2] = { 0.0, 0.0 }, b1[2] = { 0.0, 0.0 };
+			cd v[2][CH];
+#pragma unroll
+			for (int i = 0; i < CH; i++) v[0][i] = w[(R8B_ABL & 1024) ? 0 : i];
+#pragma unroll
+			for (int c = 0; c < NCH; c++)
+			{
+				R8B_SCHED_FENCE();
+				if (c + 1 < NCH)
+				{
+#pragma unroll
+					for (int i = 0; i < CH; i++)
+					{
+						// (timing ablation, bit 10: the window without its LDS reads)
+						if constexpr ((R8B_ABL & 1024) != 0)
+						{
+							v[(c + 1) & 1][i] = v[c & 1][i];
+						}
+						else v[(c + 1) & 1][i] = w[CH * (c + 1) + i];
+					}
+				}
+#pragma unroll
+				for (int i = 0; i < CH; i++)
+				{
+					const int t = CH * c + i;
+					a0[t & 1] += rows[t] * v[c & 1][i].re;
+					b0[t & 1] += rows[t] * v[c & 1][i].im;
+					a1[t & 1] += rows[T2 + t] * v[c & 1][i].re;
+					b1[t & 1] += rows[T2 + t] * v[c & 1][i].im;
+				}
+			}
+			const int o = out_step * gl;
+			cd va, vb;
+			va.re = a0[0] + a0[1];
+			va.im = a1[0] + a1[1];
+			vb.re = b0[0] + b0[1];
+			vb.im = b1[0] + b1[1];
+			*reinterpret_cast<cd*>(pa + o) = va;
+			if (bvalid) *reinterpret_cast<cd*>(pb + o) = vb;
+		}
+		return;
+	}
 	for (int gl = set; gl <= gmax; gl += nsets)
 	{
 		const cd* w = y + (u_lo + in_step * gl + rq);
@@ -888,8 +1013,6 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* r
 		// the window in chunks of five taps, each chunk's reads issued one chunk ahead of its
 		// multiply-adds (two chunks of 16-byte values are live: the scheduler, left alone, reads all 25
 		// first -- 100 registers the prefetched samples of the next block then have to leave for)
-		constexpr int CH = T2 == 25 ? 5 : 3, NCH = T2 / CH;
-		static_assert(CH * NCH == T2, "chunks");
 		cd v[2][CH];
 #pragma unroll
 		for (int i = 0; i < CH; i++) v[0][i] = w[i];
@@ -914,6 +1037,11 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* r
 		}
 		const bool v0 = (gl > 0 || f0) && (gl < gmax || l0);
 		const bool v1 = (gl > 0 ? 2 * q + 1 < out_step : f1) && (gl < gmax || l1);
+		if constexpr ((R8B_ABL & 32) != 0)
+		{
+			// (timing ablation: the arithmetic without its stores)
+			if (a0[0] + a1[0] + b0[0] + b1[0] + a0[1] + a1[1] + b0[1] + b1[1] != 1.2345e300) continue;
+		}
 		if (linear)
 		{
 			// caller's buffer: row pointers once, a 32-bit index per output; the two phases of a
@@ -970,14 +1098,11 @@ struct ConvpItem
 	bool bvalid;
 };
 
-// PF (walker form, k_convpw): the samples of block cur.k already sit in st.pr / st.pi; those of block knext (if
-// knext >= 0) are fetched into them ahead of the last stage, whose length then covers their memory latency.
-template<int LN, int UL, int MODE, int FLENP, bool PF = false, class Exec>
-R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem& cur, long long knext = -1)
+template<int LN, int UL, int MODE, int FLENP, class Exec>
+R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem& cur)
 {
 	typedef ConvpGeom<LN, UL> G;
 	typedef ConvpState<LN, UL> St;
-	static_assert(!PF || G::SUB == 1, "walker form: one block pair per workgroup at a time");
 	// modes 6 / 7: modes 0 / 3 with a complex kernel spectrum
 	constexpr bool CX = MODE == 6 || MODE == 7;
 	constexpr int BM = MODE == 6 ? 0 : (MODE == 7 ? 3 : MODE);
@@ -1006,8 +1131,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	ex.phase([&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
-		if constexpr (!PF) cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
-		cp_first<LN, UL>(L, buf_of(tid), st, lt);
+		if constexpr (!(R8B_ABL & 8)) cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
+		ex.post_bits(tid, cp_nonzero_bits<LN, UL>(st));
+		if constexpr (!(R8B_ABL & 16)) cp_first<LN, UL>(L, buf_of(tid), st, lt);
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
 		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
 	});
@@ -1101,7 +1227,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	{
 		const int lt = lt_of(tid);
 		cp_middle_compute<LN, UL, CX>(buf_of(tid), st, lt);
-		if constexpr (G::B1) ptw_fetch<16, G::NT>(st.tw, L.ptw, 3, lt);
+		if constexpr (G::B1) ptw_fetch<16, G::NT, (16 < G::NT ? 16 : G::NT)>(st.tw, L.ptw, 3, lt);
 		else cp_back2_prefetch<LN, UL>(L, st, lt);
 	};
 	auto s_midw = [&](int tid, St& st) { cp_middle_write<LN, UL>(buf_of(tid), st, lt_of(tid)); };
@@ -1112,7 +1238,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		cp_back2_prefetch<LN, UL>(L, st, lt);
 	};
 	static_assert(G::NPRE >= 1 && G::NPRE <= 3, "pair kernel: one to three forward passes before the middle");
-	if constexpr (G::NPRE == 3) ex.wave_steps(s_pre1, s_pre2, s_midc, s_midw, s_b1);
+	if constexpr ((R8B_ABL & 2) != 0) ex.wave_steps([](int, St&) {});
+	else if constexpr (G::NPRE == 3) ex.wave_steps(s_pre1, s_pre2, s_midc, s_midw, s_b1);
 	else if constexpr (G::NPRE == 2 && G::B1) ex.wave_steps(s_pre1, s_midc, s_midw, s_b1);
 	else if constexpr (G::NPRE == 2) ex.wave_steps(s_pre1, s_midc, s_midw);
 	else if constexpr (G::B1) ex.wave_steps(s_midc, s_midw, s_b1);
@@ -1139,8 +1266,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
-			if constexpr (PF) if (knext >= 0) cp_load<LN, UL, BM>(L, st, knext, chA, chB, lt);
 			ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
+			cp_silence<LN, UL>(st, ex.collect_bits());
 			if (live(tid))
 			{
 				if constexpr (UL < 0) cp_store_conv_down<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
@@ -1153,8 +1280,16 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
-			if constexpr (PF) if (knext >= 0) cp_load<LN, UL, BM>(L, st, knext, chA, chB, lt);
 			cp_back2<LN, UL>(buf_of(tid), st, lt);
+			cp_silence<LN, UL>(st, ex.collect_bits());
+			if constexpr ((R8B_ABL & 64) != 0)
+			{
+				// (timing ablation: the transform without its stores)
+				double acc = 0.0;
+#pragma unroll
+				for (int p = 0; p < 16; p++) acc += st.vr[p] * st.vi[p];
+				if (acc != 1.2345e300) return;
+			}
 			if (live(tid)) cp_store_conv<LN, UL, BM>(L, st, k_of(tid), chA, chB, bvalid, lt);
 		});
 	}
@@ -1164,17 +1299,18 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		static_assert(UL >= 0, "the decimating form has no fused interpolator");
 		ex.phase([&](int tid, St& st)
 		{
-			if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
+			if constexpr ((R8B_ABL & 4) != 0) {}
+			else if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
 			else cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
 			cp_rows2_fetch<T2>(X, st.rows2, &st.pt, tid);
 		});
 		ex.phase([&](int tid, St& st)
 		{
+			cp_silence<LN, UL>(st, ex.collect_bits());
 			cp_final_store<LN, UL>(L, buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
-			if constexpr (PF) if (knext >= 0) cp_load<LN, UL, BM>(L, st, knext, chA, chB, lt_of(tid));
 		});
 		// the interpolator: all 256 threads over the run of one block pair after the other
-		ex.each([&](int, St& st)
+		if constexpr (!(R8B_ABL & 1)) ex.each([&](int, St& st)
 		{
 			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
 				cp_whole2_compute<T2>(X, buf + sb * G::NA, st.rows2, st.pt, cur.k + sb, chA, chB, bvalid);
@@ -1191,8 +1327,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		});
 		ex.phase([&](int tid, St& st)
 		{
+			cp_silence<LN, UL>(st, ex.collect_bits());
 			cp_final_store<LN, UL>(L, buf_of(tid), st, k_of(tid), lt_of(tid));
-			if constexpr (PF) if (knext >= 0) cp_load<LN, UL, BM>(L, st, knext, chA, chB, lt_of(tid));
 		});
 		ex.each([&](int tid, St& st)
 		{

@@ -6,6 +6,8 @@
 #include <climits>
 #include <cmath>
 #include <complex>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -717,31 +719,62 @@ void Engine::prepare_two_phase(size_t s)
 	for (int q = 0; 2 * q + 1 < Out; q++) maxdl = std::max(maxdl, r_of(2 * q + 1) - r_of(2 * q));
 	if (maxdl > 3) return;
 	const int T2 = maxdl <= 1 ? 25 : 27;
-	// deal the phase pairs to service groups such that the window starts inside a group fall into
-	// different 16-byte bank groups (start mod 16) wherever the counts allow
-	std::vector<std::vector<int>> grp((size_t) nsg);
-	std::vector<std::vector<int>> cls(16);
-	for (int q = 0; q < NP; q++) cls[(size_t) (r_of(2 * q) & 15)].push_back(q);
-	for (int r = 0; r < 16; r++)
-		for (int q : cls[(size_t) r])
+	// Phase pairs go to lanes in QUADS: the four lanes of an aligned lane quad own four consecutive phase pairs, i.e.
+	// store 64 consecutive bytes of a channel's output per group (one L2 write request per quad; assigned pair by
+	// pair, the 16-byte pieces of a store instruction were scattered over the whole group: 19 bytes per request
+	// measured).  The quads are dealt to the 16-lane LDS service groups (four lane quads each) such that the window
+	// starts inside a group fall into different 16-byte bank groups (start mod 16) as far as the counts allow: a
+	// deterministic local search over quad swaps between groups (cfg2: 5 clashes among 80 windows -- dealing single
+	// pairs reaches 4, the residues are not evenly populated).
+	const int NQ = (NP + 3) / 4;
+	std::vector<std::vector<int>> grp((size_t) nsg); // data quads of each service group, in lane-quad order
+	auto quad_cost = [&](const std::vector<int>& g)
+	{
+		int cnt[16] = { 0 }, c = 0;
+		for (int dq : g)
+			for (int i = 0; i < 4 && 4 * dq + i < NP; i++)
+				if (cnt[r_of(2 * (4 * dq + i)) & 15]++) c++;
+		return c;
+	};
+	{
+		// (several deterministic starts -- quad dq to group (dq * mul + rot) mod nsg --, each improved by swaps)
+		int best_cost = -1;
+		std::vector<std::vector<int>> cur((size_t) nsg);
+		for (int start = 0; start < 4 * nsg && best_cost != 0; start++)
 		{
-			int best = -1;
-			bool best_clash = true;
-			for (int g = 0; g < nsg; g++)
+			for (auto& g : cur) g.clear();
+			const int mul = 1 + start / nsg, rot = start % nsg;
+			std::vector<int> fill((size_t) nsg, 0);
+			for (int dq = 0; dq < NQ; dq++)
 			{
-				if (grp[(size_t) g].size() >= 16) continue;
-				bool clash = false;
-				for (int o : grp[(size_t) g]) clash = clash || (r_of(2 * o) & 15) == r;
-				if (best < 0 || (best_clash && !clash) ||
-					(best_clash == clash && grp[(size_t) g].size() < grp[(size_t) best].size()))
-				{
-					best = g;
-					best_clash = clash;
-				}
+				int g = (dq * mul + rot) % nsg;
+				while ((int) cur[(size_t) g].size() >= 4) g = (g + 1) % nsg;
+				cur[(size_t) g].push_back(dq);
 			}
-			if (best < 0) return;
-			grp[(size_t) best].push_back(q);
+			for (bool improved = true; improved;)
+			{
+				improved = false;
+				for (int a = 0; a < nsg; a++)
+					for (int b = a + 1; b < nsg; b++)
+						for (size_t i = 0; i < cur[(size_t) a].size(); i++)
+							for (size_t j = 0; j < cur[(size_t) b].size(); j++)
+							{
+								const int before = quad_cost(cur[(size_t) a]) + quad_cost(cur[(size_t) b]);
+								std::swap(cur[(size_t) a][i], cur[(size_t) b][j]);
+								if (quad_cost(cur[(size_t) a]) + quad_cost(cur[(size_t) b]) < before) improved = true;
+								else std::swap(cur[(size_t) a][i], cur[(size_t) b][j]);
+							}
+			}
+			int c = 0;
+			for (const auto& g : cur) c += quad_cost(g);
+			if (best_cost < 0 || c < best_cost)
+			{
+				best_cost = c;
+				grp = cur;
+			}
 		}
+		if (std::getenv("R8B_DEBUG_TWO")) fprintf(stderr, "two-phase tables: %d phase pairs in %d quads, %d service groups x %d sets, %d bank clashes\n", NP, NQ, nsg, nsets, best_cost);
+	}
 	// lanes LDS serves together for 16-byte reads (MI355X_MICROARCH.md, LDS): within each half of a
 	// wave the quads {0, 3, 5, 6} and {1, 2, 4, 7}
 	std::vector<int> pt(256, -1);
@@ -752,10 +785,10 @@ void Engine::prepare_two_phase(size_t s)
 		const int wave = t >> 6, lane = t & 63, half = lane >> 5, quad = (lane & 31) >> 2;
 		static const int cls_of[8] = { 0, 1, 1, 0, 1, 0, 0, 1 }, rank_of[8] = { 0, 0, 1, 1, 2, 2, 3, 3 };
 		const int sg = 4 * wave + 2 * half + cls_of[quad];
-		const int pos = 4 * rank_of[quad] + (lane & 3);
 		const int set = sg / nsg, g = sg % nsg;
-		if (set >= nsets || pos >= (int) grp[(size_t) g].size()) continue;
-		const int q = grp[(size_t) g][(size_t) pos];
+		if (set >= nsets || rank_of[quad] >= (int) grp[(size_t) g].size()) continue;
+		const int q = 4 * grp[(size_t) g][(size_t) rank_of[quad]] + (lane & 3);
+		if (q >= NP) continue;
 		pt[(size_t) t] = q | (set << 8) | (r_of(2 * q) << 12);
 		const int p0 = 2 * q, p1 = 2 * q + 1;
 		const int row0 = (int) (((long long) p0 * In) % Out);

@@ -502,11 +502,41 @@ __global__ __launch_bounds__(kConvxThreads, (LOGN + (UPLOG > 0 ? UPLOG : 0) >= 1
 }
 
 // ------------------------------------------------------------------ fast path, pair form (r8b_convp.h)
+#ifdef R8B_CP_STAMPS
+__device__ long long g_cp_stamps[8 * 8 * 32];
+} // namespace
+} // namespace r8bhip
+// (development builds: the stamps of workgroups R8B_CP_STAMPS .. + 7 of the last launch; tools/stamps_probe.py)
+extern "C" __attribute__((visibility("default"))) void r8b_dev_stamps(long long* out)
+{
+	(void) hipDeviceSynchronize();
+	(void) hipMemcpyFromSymbol(out, HIP_SYMBOL(r8bhip::g_cp_stamps), sizeof(long long) * 8 * 8 * 32);
+}
+namespace r8bhip {
+namespace {
+#endif
 template<int LN, int UL>
 struct GpuExecP
 {
 	ConvpState<LN, UL> st;
-	int tid_ = (int) threadIdx.x; // (the walker form re-launders it per block: see k_convpw)
+	int tid_ = (int) threadIdx.x;
+	unsigned* flags_; // one word per wave behind the array (r8b_convp.h kConvpFlagBytes)
+	__device__ __forceinline__ explicit GpuExecP(unsigned char* smem)
+		: flags_(reinterpret_cast<unsigned*>(smem + convp_array_bytes<LN, UL>())) {}
+	// workgroup-wide OR of a small bit set: every thread posts before a barrier, anybody collects after it
+	__device__ __forceinline__ void post_bits(int, unsigned v)
+	{
+		const unsigned w = (__builtin_amdgcn_ballot_w64((v & 1u) != 0) != 0 ? 1u : 0u) |
+			(__builtin_amdgcn_ballot_w64((v & 2u) != 0) != 0 ? 2u : 0u);
+		if ((threadIdx.x & 63u) == 0) flags_[threadIdx.x >> 6] = w;
+	}
+	__device__ __forceinline__ unsigned collect_bits() const
+	{
+		unsigned r = 0;
+#pragma unroll
+		for (int w = 0; w < ConvpGeom<LN, UL>::WT / 64; w++) r |= flags_[w];
+		return (unsigned) __builtin_amdgcn_readfirstlane((int) r);
+	}
 	// steps that exchange data between the lanes of ONE wave only (r8b_convp.h: forward passes 1..,
 	// middle pass, first backward pass): LDS serves a wave's accesses in issue order, so between the
 	// steps only the compiler must be kept from reordering them; a workgroup barrier ends the sequence
@@ -516,23 +546,47 @@ struct GpuExecP
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 	}
+#ifdef R8B_CP_STAMPS
+	// (development: cycle stamps of eight workgroups' phases -- before / after each barrier; written straight to
+	// global memory so that the stamped workgroups keep their registers and the others pay one scalar branch)
+	int nts_ = 0;
+	__device__ __forceinline__ void stamp()
+	{
+		if (blockIdx.x >= R8B_CP_STAMPS && blockIdx.x < R8B_CP_STAMPS + 8 && (threadIdx.x & 63) == 0)
+		{
+			long long* o = g_cp_stamps + ((blockIdx.x - R8B_CP_STAMPS) * 8 + (threadIdx.x >> 6)) * 32;
+			nts_++;
+			o[nts_] = clock64();
+			o[0] = nts_;
+		}
+	}
+	__device__ void dump() const {}
+#else
+	__device__ __forceinline__ void stamp() {}
+	__device__ __forceinline__ void dump() const {}
+#endif
 	template<class F0, class... F>
 	__device__ __forceinline__ void wave_steps(F0 f0, F... f)
 	{
 		f0(tid_, st);
 		((wave_sync(), f(tid_, st)), ...);
+		stamp();
 		lds_barrier();
+		stamp();
 	}
 	template<class F>
 	__device__ __forceinline__ void each(F f) // no barrier
 	{
 		f(tid_, st);
+		stamp();
 	}
 	template<class F>
 	__device__ __forceinline__ void phase(F f)
 	{
 		f(tid_, st);
+		stamp();
 		lds_barrier();
+		stamp();
 	}
 };
 
@@ -566,7 +620,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
 	const int chA = (int) (2u * pr);
 	const bool bvalid = chA + 1 < X.c.nch;
-	GpuExecP<LN, UL> ex;
+	GpuExecP<LN, UL> ex(smem);
 	ConvpItem cur;
 	const int b0 = (int) bg * SUB;
 	cur.k = X.c.k0 + b0;
@@ -574,123 +628,14 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	cur.chA = chA;
 	cur.chB = bvalid ? chA + 1 : chA;
 	cur.bvalid = bvalid;
+	ex.stamp();
 	convp_body<LN, UL, MODE, FLENP>(ex, X, reinterpret_cast<cd*>(smem), cur);
-}
-
-// Walker form (geometries with one block pair per workgroup): a workgroup walks a run of consecutive blocks
-// of ITS channel pair instead of ending after one.  What a fresh workgroup pays per block -- dispatch, LDS
-// allocation, the scalar loads of the kernel arguments, and above all the memory latency of its first
-// samples, during which its half of the CU idles -- is paid once per run: the samples of block k + 1 are
-// requested before the last stage of block k and arrive while it computes.  With one run per channel pair and
-// 512 pairs (BASELINE configs 2 / 3) the grid is exactly two workgroups per CU, all ending together: no
-// partly filled last round.  Shorter runs (launch_convp_t) keep the chip full when there are fewer pairs.
-template<int LN, int UL, int MODE, int FLENP>
-__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) > 256 ? 1 : 2)) void k_convpw(const ConvxLaunch X)
-{
-	extern __shared__ __align__(16) unsigned char smem[];
-	static_assert(ConvpGeom<LN, UL>::SUB == 1, "walker form: one block pair per workgroup");
-	constexpr int BM = MODE == 6 ? 0 : (MODE == 7 ? 3 : MODE);
-	const unsigned w = blockIdx.x;
-	unsigned pr = w, seg = 0;
-	if (X.nseg > 1)
-	{
-		pr = convp_div(w, X.nseg_magic);
-		seg = w - pr * (unsigned) X.nseg;
-	}
-	pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
-	seg = (unsigned) __builtin_amdgcn_readfirstlane((int) seg);
-	const int chA = (int) (2u * pr);
-	const bool bvalid = chA + 1 < X.c.nch;
-	const int b0 = (int) seg * X.seg_len;
-	const int b1 = X.c.nblk - b0 < X.seg_len ? X.c.nblk : b0 + X.seg_len;
-	GpuExecP<LN, UL> ex;
-	ConvpItem cur;
-	cur.nvalid = 1;
-	cur.chA = chA;
-	cur.chB = bvalid ? chA + 1 : chA;
-	cur.bvalid = bvalid;
-	cur.k = X.c.k0 + b0;
-#ifndef R8B_WALK_NOPF
-	cp_load<LN, UL, BM>(X.c, ex.st, cur.k, cur.chA, cur.chB, (int) threadIdx.x);
-#endif
-#pragma unroll 1
-	for (int b = b0; b < b1; b++)
-	{
-		// (the table fetches of a block are loop invariant: hoisted out of the loop they would occupy
-		// every register the transforms need; a compiler-level memory barrier keeps them per block)
-		asm volatile("" ::: "memory");
-		// (... and so is everything derived from the thread index -- a hundred LDS addresses)
-		asm volatile("" : "+v"(ex.tid_));
-		__builtin_assume(ex.tid_ >= 0 && ex.tid_ < ConvpGeom<LN, UL>::WT);
-		cur.k = X.c.k0 + b;
-#ifndef R8B_WALK_NOPF
-		convp_body<LN, UL, MODE, FLENP, true>(ex, X, reinterpret_cast<cd*>(smem), cur,
-			b + 1 < b1 ? cur.k + 1 : -1);
-#else
-		convp_body<LN, UL, MODE, FLENP, false>(ex, X, reinterpret_cast<cd*>(smem), cur);
-#endif
-		// (the last stage reads the array the next block's first pass writes)
-		lds_barrier();
-	}
-}
-
-// run length of the walker form: the grid is pairs x ceil(nblk / len) workgroups, `slots` of which are
-// resident at a time; a workgroup costs its blocks plus a fixed start-up share
-inline int convpw_seg_len(int npair, int nblk, int slots)
-{
-	int best = 1;
-	double best_cost = 1e300;
-	for (int len = 1; len <= nblk; len++)
-	{
-		const long long wgs = (long long) npair * ((nblk + len - 1) / len);
-		const double cost = (double) ((wgs + slots - 1) / slots) * (len + 0.35);
-		if (cost < best_cost - 1e-9 || (cost < best_cost + 1e-9 && len > best))
-		{
-			best = len;
-			best_cost = cost;
-		}
-	}
-	return best;
-}
-
-template<int LN, int UL, int MODE, int FLENP>
-void launch_convpw_t(const ConvxLaunch& X0, hipStream_t stream)
-{
-	ConvxLaunch X = X0;
-	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
-	int dev = 0, cus = 256;
-	check(hipGetDevice(&dev), "hipGetDevice");
-	static int cus_of[64] = { 0 };
-	if (dev < 64 && cus_of[dev] == 0)
-	{
-		check(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute");
-		cus_of[dev] = cus;
-	}
-	if (dev < 64) cus = cus_of[dev];
-	const int per_cu = ConvpGeom<LN, UL>::WT > 256 ? 1 : 2;
-	X.seg_len = convpw_seg_len((int) npair, X.c.nblk, cus * per_cu);
-	X.nseg = (X.c.nblk + X.seg_len - 1) / X.seg_len;
-	X.nseg_magic = X.nseg > 1 ? (unsigned) (0x100000000ull / (unsigned) X.nseg) + 1u : 0u;
-	if ((unsigned long long) npair * (unsigned) X.nseg * (unsigned) X.nseg >= 0x100000000ull)
-		throw std::runtime_error("launch_convpw: grid too large");
-	auto kern = k_convpw<LN, UL, MODE, FLENP>;
-	const size_t lds = (size_t) convp_lds_bytes<LN, UL>();
-	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convpw)");
-	hipLaunchKernelGGL(kern, dim3(npair * (unsigned) X.nseg), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
-	check(hipGetLastError(), "launch k_convpw");
+	ex.dump();
 }
 
 template<int LN, int UL, int MODE, int FLENP>
 void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 {
-#ifndef R8B_NO_WALKER
-	if constexpr (ConvpGeom<LN, UL>::SUB == 1)
-	{
-		launch_convpw_t<LN, UL, MODE, FLENP>(X0, stream);
-		return;
-	}
-	else
-#endif
 	{
 	ConvxLaunch X = X0;
 	// (one block group: floor(2^32 / 1) + 1 does not fit; 0 makes convp_div return 0, handled by the kernel)
@@ -698,7 +643,11 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	const unsigned nbg = ((unsigned) X.c.nblk + SUB - 1u) / SUB;
 	X.nblk_magic = nbg > 1 ? (unsigned) (0x100000000ull / nbg) + 1u : 0u;
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
-	const size_t lds = (size_t) convp_lds_bytes<LN, UL>();
+	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
+#ifdef R8B_DEV_ONLY_MODE
+	// (development builds: occupancy experiments with a truncated array -- timing only, results are wrong)
+	if (const char* e = getenv("R8B_FAKE_LDS")) lds = (size_t) atoi(e);
+#endif
 	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
 	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
 	hipLaunchKernelGGL(kern, dim3(nbg * npair), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);

@@ -228,10 +228,6 @@ struct ConvxLaunch
 	const double* ctab;
 	int nsets;
 	unsigned nblk_magic; // floor(2^32 / c.nblk) + 1 (filled in by the launcher; r8b_convp.h convp_div)
-	// walker form (k_convpw): a workgroup takes segment seg of nseg of its channel pair's blocks,
-	// blocks [seg * seg_len, min(nblk, (seg + 1) * seg_len)); workgroup w = pair * nseg + seg
-	int nseg, seg_len;
-	unsigned nseg_magic; // floor(2^32 / nseg) + 1 (0: nseg = 1)
 };
 
 // geometries the fast path is instantiated for: (log2 of the forward complex length, up shift), and

@@ -120,8 +120,9 @@ class BatchResampler(_Base):
             raise ValueError("tensors on cuda:%s, the resampler lives on cuda:%d" % (x.device.index, dev))
         l = x.shape[1]
         if out is None:
-            out = torch.empty((self.nch, max(self.max_out_len, 1)), dtype=torch.float64,
-                              device=x.device)
+            # (rows on a 64-byte pitch: aligned rows let the kernels store output pairs as 16 bytes)
+            cap = max(self.max_out_len, 1)
+            out = torch.empty((self.nch, (cap + 7) // 8 * 8), dtype=torch.float64, device=x.device)[:, :cap]
         assert out.is_cuda and out.dtype == torch.float64 and out.stride(1) == 1
         assert out.shape[0] == self.nch and out.shape[1] >= self.max_out_len
         stream = torch.cuda.current_stream(x.device).cuda_stream

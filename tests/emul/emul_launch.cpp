@@ -227,7 +227,10 @@ struct EmulExecP
 {
 	static constexpr int WT = ConvpGeom<LN, UL>::WT;
 	std::vector<ConvpState<LN, UL>> st;
+	unsigned bits = 0;
 	EmulExecP() : st((size_t) WT) {}
+	void post_bits(int, unsigned v) { bits |= v; }
+	unsigned collect_bits() const { return bits; }
 	template<class F>
 	void phase(F f)
 	{

@@ -8,7 +8,7 @@ R=$PWD
 out=$R/gpurun_out/pmc_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-GROUPS=(
+PGRPS=(
  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"
  "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_SENDMSG"
  "SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_MFMA"
@@ -18,7 +18,7 @@ GROUPS=(
  "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA_RDREQ_sum TCC_EA_WRREQ_sum"
 )
 i=0
-for grp in "${GROUPS[@]}"; do
+for grp in "${PGRPS[@]}"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/p$i -- python $R/bench.py --steps 4 --warmup 2 --no-cpu "$@" > $out/p$i.log 2>&1
   if [ -x $R/tools/ubench/_build/pmc_calib ] && [ $i -le 3 ]; then
