@@ -2,8 +2,8 @@
 // of libr8bsrc_hip.so.  Same class names, constructor arguments and member functions as
 // r8b::CDSPResampler and its presets (reference CDSPResampler.h:117-120, 406-421, 476-519,
 // 521-529, 559-575, 592-651, 729-810), so code written against the reference compiles against
-// this header and runs on the GPU.  Linear phase only (the reference's default and the only mode
-// of its DLL, DLL/r8bsrc.h:52).
+// this header and runs on the GPU.  Both phase responses of the reference's constructor (fprLinearPhase, the
+// default and the only mode of its DLL, DLL/r8bsrc.h:52; fprMinPhase through r8b_batch_create_ex).
 //
 // process() keeps the reference's host-pointer contract: `op0` receives a pointer to a buffer
 // owned by the object (valid until the next call), or `ip0` itself when Src == Dst

@@ -73,7 +73,18 @@ typedef void* CR8BBatch;
 
 /* Creates `nch` independent linear-phase resamplers that share one schedule, on HIP device
  * `device` (-1 = current).  ReqAtten is the reference constructor's ReqAtten in dB
- * (CDSPResampler.h:117-120).  NULL + message in r8b_last_error() on failure. */
+ * (CDSPResampler.h:117-120).  NULL + message in r8b_last_error() on failure.
+ *
+ * Channel independence and accuracy.  The output of every channel equals the reference's for that channel's
+ * samples within RMS 1e-15 / peak 1e-13 of FULL SCALE (+-1.0), and is bitwise independent of how the stream is cut
+ * into calls.  Channels 2c and 2c+1 are convolved as the real and imaginary part of one complex transform
+ * (the filter kernels are real), so the rounding error of a channel is of the order of 1e-16 of the LOUDER of
+ * the two: a channel at -120 dBFS beside a full-scale partner still meets the absolute bound, i.e. 1e-9 of its
+ * own level.  A channel whose samples are all zero comes out as exact zeros whatever its partner carries
+ * (silence is detected per transform block).  Callers that need rounding errors scaled to each channel's own
+ * level -- e.g. impulse responses of very different magnitude in one batch -- put channels of similar level
+ * into a pair, leave the partner silent, or select the one-channel kernels (r8b_batch_set_option "pair_conv" = 0
+ * before the first sample; slower). */
 R8BSRC_DECL CR8BBatch r8b_batch_create(double SrcSampleRate, double DstSampleRate, int MaxInLen,
 	double ReqTransBand, double ReqAtten, int nch, int device);
 
@@ -96,6 +107,8 @@ R8BSRC_DECL int r8b_batch_inlen_before_outpos(CR8BBatch b, int OutPos);
  * channel c's samples start at d_in + c*in_stride (doubles), l <= MaxInLen samples each;
  * channel c's output is written at d_out + c*out_stride (out_stride >= r8b_batch_max_out_len).
  * `stream` is a hipStream_t (NULL = default stream); the call only enqueues work on it.
+ * Any 8-byte aligned rows work; rows that start on 16-byte boundaries (even strides, better multiples of 8
+ * samples = 64 bytes) let the last stage store pairs of outputs as 16 bytes.
  * Returns the number of output samples produced per channel (identical for all channels and equal
  * to what the reference's process() returns for the same call sequence), or -1 on error. */
 R8BSRC_DECL int r8b_batch_process(CR8BBatch b, const double* d_in, long long in_stride, int l,
@@ -141,8 +154,12 @@ R8BSRC_DECL int r8b_batch_state_load(CR8BBatch b, const void* buf, long long siz
 
 /* The same with the phase response of the low-pass filters selectable (reference CDSPResampler.h:117-120,
  * EDSPFilterPhaseResponse CDSPFIRFilter.h:28-45): ReqPhase 0 = fprLinearPhase, 1 = fprMinPhase.  A
- * minimum-phase chain carries fractional latencies from stage to stage like the reference does; it runs
- * on the generic (unfused) kernels. */
+ * minimum-phase chain carries fractional latencies from stage to stage like the reference does; its convolvers
+ * run on the pair kernel with a complex kernel spectrum, the interpolator behind them unfused.  Samples agree
+ * with the reference's to 1e-15 when both use the same taps (tests feed the reference's through
+ * r8b_design_set_lp_provider); with the taps of THIS library's designer the streams differ by 3e-7 ... 6e-5 RMS
+ * (-48 dB for 1/3-band filters at 180 dB), because the cepstral transform's result depends on the rounding noise
+ * of the FFT that computes it. */
 R8BSRC_DECL CR8BBatch r8b_batch_create_ex(double SrcSampleRate, double DstSampleRate, int MaxInLen,
 	double ReqTransBand, double ReqAtten, int ReqPhase, int nch, int device);
 
@@ -195,6 +212,18 @@ R8BSRC_DECL int r8b_design_lpfilter(double ReqNormFreq, double ReqTransBand, dou
 R8BSRC_DECL int r8b_design_lpfilter_ex(double ReqNormFreq, double ReqTransBand, double ReqAtten,
 	double ReqGain, int ReqPhase, int* BlockLenBits, int* Latency, double* LatencyFrac, double* taps,
 	int cap);
+
+/* PARITY-TEST HOOK (no product code path installs one).  A provider may supply the taps of a low-pass filter in
+ * place of the designer: it is asked on every designer cache miss with the filter's parameters and returns the
+ * number of taps it wrote (<= cap; 0 = "not mine", the designer runs), their group-delay split *Latency /
+ * *LatencyFrac and *BlockLenBits.  tests/ use it to feed the REFERENCE's own minimum-phase taps (recovered from
+ * CDSPFIRFilter::getKernelBlock) through the kernels, which separates kernel parity (1e-15) from the conditioning
+ * of the cepstral minimum-phase transform (CDSPRealFFT.h:681-785), whose output depends on the rounding noise of
+ * the particular FFT used.  Filters obtained under a provider are cached apart from designed ones; NULL removes it.
+ * Not thread safe against concurrent object creation. */
+typedef int (*r8b_lp_provider)(double ReqNormFreq, double ReqTransBand, double ReqAtten, double ReqGain,
+	int ReqPhase, double* taps, int cap, int* Latency, double* LatencyFrac, int* BlockLenBits);
+R8BSRC_DECL void r8b_design_set_lp_provider(r8b_lp_provider provider);
 
 /* Fractional-delay bank (CDSPFracDelayFilterBank): rows 0..FilterFracs, FilterLen*ElementSize
  * doubles each, natural (unshuffled) element order.  FilterFracs = -1 selects the default

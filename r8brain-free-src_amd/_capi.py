@@ -56,6 +56,7 @@ PROTOTYPES = [
     ("r8b_design_lpfilter_ex", C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                        C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double), C.c_int]),
+    ("r8b_design_set_lp_provider", None, [C.c_void_p]),
     ("r8b_design_fracbank", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, ip, ip, dp,
                                       C.c_int]),
     ("r8b_design_hbfilter", C.c_int, [C.c_double, C.c_int, C.c_int, dp, dp]),
@@ -70,6 +71,11 @@ PROTOTYPES = [
     ("r8b_plan_describe", C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     ("r8b_version", C.c_char_p, []),
 ]
+
+
+# parity-test hook (include/r8bsrc.h r8b_lp_provider)
+LP_PROVIDER = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double),
+                          C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int))
 
 
 def bind(path):

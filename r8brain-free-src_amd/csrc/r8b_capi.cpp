@@ -443,6 +443,11 @@ R8BSRC_DECL int r8b_design_lpfilter_ex(double ReqNormFreq, double ReqTransBand, 
 	return f.kernel_len;
 }
 
+R8BSRC_DECL void r8b_design_set_lp_provider(r8b_lp_provider provider)
+{
+	set_lp_provider(reinterpret_cast<LpProvider>(provider));
+}
+
 R8BSRC_DECL int r8b_design_fracbank(int FilterFracs, int ElementSize, int InterpPoints,
 	double ReqAtten, int IsThird, int* FilterLen, int* Fracs, double* table, int cap)
 {

@@ -244,14 +244,47 @@ std::vector<double> min_phase_transform(const std::vector<double>& kernel)
 
 } // namespace
 
+namespace {
+LpProvider g_lp_provider = nullptr;
+int g_lp_provider_gen = 0; // filters made under a provider are cached apart from the designer's own
+}
+
+void set_lp_provider(LpProvider p)
+{
+	std::lock_guard<std::mutex> lock(g_cache_mutex);
+	static int installs = 0;
+	g_lp_provider = p;
+	g_lp_provider_gen = p != nullptr ? ++installs : 0;
+}
+
 const LpFilter& design_lp(double norm_freq, double trans_band, double atten, double gain, bool min_phase)
 {
-	typedef std::tuple<double, double, double, double, bool> Key;
+	typedef std::tuple<double, double, double, double, bool, int> Key;
 	static std::map<Key, LpFilter> cache;
 	std::lock_guard<std::mutex> lock(g_cache_mutex);
-	const Key key(norm_freq, trans_band, atten, gain, min_phase);
+	const Key key(norm_freq, trans_band, atten, gain, min_phase, g_lp_provider != nullptr ? g_lp_provider_gen : 0);
 	auto it = cache.find(key);
 	if (it != cache.end()) return it->second;
+	if (g_lp_provider != nullptr)
+	{
+		// (parity tests only, r8b_design.h)
+		std::vector<double> t((size_t) 1 << 18);
+		int lat = 0, bits = 0;
+		double lf = 0.0;
+		const int n = g_lp_provider(norm_freq, trans_band, atten, gain, min_phase ? 1 : 0, t.data(), (int) t.size(),
+			&lat, &lf, &bits);
+		if (n > 0)
+		{
+			LpFilter f;
+			f.taps.assign(t.begin(), t.begin() + n);
+			f.kernel_len = n;
+			f.fl2 = lat;
+			f.lat_frac = lf;
+			f.zero_phase = !min_phase;
+			f.block_len_bits = bits;
+			return cache.emplace(key, std::move(f)).first->second;
+		}
+	}
 
 	double pwr, hl, fo1;
 	lp_fit(trans_band, atten, &pwr, &hl, &fo1);

@@ -560,7 +560,7 @@ static long long pow2_at_least(long long v)
 }
 
 Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int device)
-	: nch_(nch), device_(dev_resolve(device))
+	: nch_(nch), nchw_(nch), device_(dev_resolve(device))
 {
 	if (nch < 1) throw std::runtime_error("channel count must be >= 1");
 	if (nch > 65535) throw std::runtime_error("channel count must be <= 65535 per batch object "
@@ -580,6 +580,10 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["fuse"] = 1;      // ... with the whole-step interpolator behind it fused in
 	opt_["fuse_hb"] = 1;   // runs of half-band up-samplers as one kernel
 	opt_["poly_tiled"] = 1; // polynomial interpolator: 16 channels share each coefficient fetch
+	// convolver + polynomial interpolator walked in channel groups (1: 96 MB between them; n > 1: n KB; 0: off).  Off:
+	// measured on MI355X (profiles/r03_poly_groups.txt) the interpolator gains 2 % from reading the stream out of the
+	// Infinity Cache and the convolver loses 8 % to its smaller launches (44100 -> 44101 x 1024 ch: 0.285 vs 0.280 ms)
+	opt_["poly_groups"] = 0;
 	// two channels per workgroup as one complex transform (r8b_convp.h) where the geometry allows
 	opt_["pair_conv"] = 1;
 	// ... with two adjacent phases per thread in the fused interpolator when it up-samples (In <= Out:
@@ -1178,7 +1182,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 				L.tile /= 2;
 				L.span_max = (int) ((long long) L.tile * sp.in_step / sp.out_step) + sp.flen + 4 + 32;
 			}
-			L.nch = nch_;
+			L.nch = nchw_;
 			L.src = src; L.dst = dst;
 			launch_whole(L, stream);
 		}
@@ -1190,7 +1194,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			L.ssr = sp.ssr; L.dsr = sp.dsr;
 			L.rpos0 = ps.rpos; L.fpos0 = ps.pos_frac;
 			L.counter0 = ps.in_counter; L.pos_int0 = ps.in_pos_int; L.shift = ps.pos_shift;
-			L.a = a; L.b = b; L.nch = nch_;
+			L.a = a; L.b = b; L.nch = nchw_;
 			// tile of 64 outputs spans at most 64*Src/Dst + taps input samples (+ slack for the
 			// counter's rounding)
 			L.span_max = opt_.at("poly_tiled") ?
@@ -1210,7 +1214,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		for (int i = 0; i < 16; i++) L.taps[i] = i < sp.hb_n ? sp.hb_taps[i] : 0.0;
 		L.a = a; L.b = b;
 		L.tile = opt_.at("hb_tile");
-		L.nch = nch_;
+		L.nch = nchw_;
 		L.src = src; L.dst = dst;
 		if (sp.desc.kind == kHBUp) launch_hbup(L, stream);
 		else launch_hbdown(L, stream);
@@ -1279,38 +1283,57 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 		launch_tail(T, stream);
 		return l;
 	}
+	// Pass 1 (host only): advance the plan, stage group by stage group; what each launch has to produce.
+	struct Rec
+	{
+		size_t s;
+		int glen;
+		long long m_prev, a, b, wa, wb;
+		PolyState ps;
+		bool fused, work;
+	};
+	std::vector<Rec> recs;
 	int n = l;
 	for (size_t s = 0; s < ns; s++)
 	{
 		StagePlan& sp = plan_.stages[s];
-		const long long m_prev = sp.m;
-		long long a, b;
-		PolyState ps;
-		sp.step(n, &a, &b, &ps);
+		Rec r;
+		r.s = s;
+		r.m_prev = sp.m;
+		sp.step(n, &r.a, &r.b, &r.ps);
 		// stages [s, s+glen) are executed by one launch: convolver + whole-step interpolator, or a
 		// run of half-band up-samplers
-		const int glen = group_len(s);
-		const bool fused = glen > 1;
-		long long wa = a, wb = b;
-		for (int g = 1; g < glen; g++)
+		r.glen = group_len(s);
+		r.fused = r.glen > 1;
+		r.wa = r.a;
+		r.wb = r.b;
+		for (int g = 1; g < r.glen; g++)
 		{
 			long long ga, gb;
-			plan_.stages[s + g].step((int) (wb - wa), &ga, &gb, nullptr);
-			wa = ga;
-			wb = gb;
+			plan_.stages[s + g].step((int) (r.wb - r.wa), &ga, &gb, nullptr);
+			r.wa = ga;
+			r.wb = gb;
 		}
-		const size_t last = s + glen - 1; // stage whose output this launch produces
-		ensure_ring(s);
-		if (last + 1 < ns) ensure_ring(last + 1);
+		r.work = r.fused ? r.wb > r.wa : r.b > r.a;
+		n = (int) (r.fused ? r.wb - r.wa : r.b - r.a);
+		recs.push_back(r);
+		s += r.glen - 1;
+	}
+	// Pass 2: the launches, for the channel window [ch0_, ch0_ + nchw_).
+	auto launch_rec = [&](const Rec& r)
+	{
+		const size_t s = r.s;
+		const StagePlan& sp = plan_.stages[s];
+		const size_t last = s + r.glen - 1; // stage whose output this launch produces
 		SrcView src;
-		src.ring = dev_[s].ring;
+		src.ring = dev_[s].ring + (long long) ch0_ * dev_[s].ring_size;
 		src.ring_stride = dev_[s].ring_size;
 		src.ring_mask = dev_[s].ring_size - 1;
 		if (s == 0)
 		{
-			src.cur = d_in;
+			src.cur = d_in + (long long) ch0_ * in_stride; // (windows are used with fp64 buffers only)
 			src.cur_stride = in_stride;
-			src.cur_base = m_prev;
+			src.cur_base = r.m_prev;
 			src.cur_fmt = io_in_fmt_;
 		}
 		else
@@ -1323,23 +1346,22 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 		DstView dst;
 		if (last + 1 == ns)
 		{
-			dst.p = d_out;
+			dst.p = d_out + (long long) ch0_ * out_stride;
 			dst.stride = out_stride;
 			dst.mask = -1;
-			dst.off = -(fused ? wa : a);
+			dst.off = -(r.fused ? r.wa : r.a);
 			dst.fmt = io_out_fmt_;
 		}
 		else
 		{
-			dst.p = dev_[last + 1].ring;
+			dst.p = dev_[last + 1].ring + (long long) ch0_ * dev_[last + 1].ring_size;
 			dst.stride = dev_[last + 1].ring_size;
 			dst.mask = dev_[last + 1].ring_size - 1;
 			dst.off = 0;
 			dst.fmt = kPcmF64;
 		}
-		const bool work = fused ? wb > wa : b > a;
 		if (s == 0) tail_done_ = false;
-		if (work)
+		if (r.work)
 		{
 			const bool timing = opt_.at("timing") != 0;
 			void *e0 = nullptr, *e1 = nullptr;
@@ -1349,41 +1371,85 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 				e1 = get_event(dev_[s]);
 				dev_event_record(e0, stream);
 			}
-			if (fused && sp.desc.kind == kConv) launch_fused(s, wa, wb, src, dst, stream);
-			else if (fused && sp.desc.kind == kHBDown) launch_dcascade(s, glen, wa, wb, src, dst, stream);
-			else if (fused) launch_cascade(s, glen, wa, wb, src, dst, stream);
-			else launch_stage(s, m_prev, a, b, ps, src, dst, stream);
+			if (r.fused && sp.desc.kind == kConv) launch_fused(s, r.wa, r.wb, src, dst, stream);
+			else if (r.fused && sp.desc.kind == kHBDown) launch_dcascade(s, r.glen, r.wa, r.wb, src, dst, stream);
+			else if (r.fused) launch_cascade(s, r.glen, r.wa, r.wb, src, dst, stream);
+			else launch_stage(s, r.m_prev, r.a, r.b, r.ps, src, dst, stream);
 			if (timing)
 			{
 				dev_event_record(e1, stream);
 				dev_[s].pending.emplace_back(e0, e1);
-				dev_[s].t_in += n;
-				dev_[s].t_out += fused ? wb - wa : b - a;
+				// (one (in, out) count per call, however many channel windows it is launched in)
+				if (ch0_ == 0)
+				{
+					dev_[s].t_in += (long long) (sp.m - r.m_prev);
+					dev_[s].t_out += r.fused ? r.wb - r.wa : r.b - r.a;
+				}
 			}
 		}
-		if (s == 0)
+		if (s == 0 && !tail_done_)
 		{
 			// History for the next call: the last history() samples of the stream go into the
 			// OTHER ring (this call's kernels may still be reading the current one).  The fast
 			// convolver does the copy itself (tail_done_); otherwise a copy kernel.
-			if (!tail_done_)
-			{
-				TailLaunch T;
-				T.src = src;
-				T.p1 = sp.m;
-				T.p0 = sp.m - stage_history(0);
-				if (T.p0 < 0) T.p0 = 0;
-				T.ring = dev_[0].ring_alt;
-				T.ring_stride = dev_[0].ring_size;
-				T.ring_mask = dev_[0].ring_size - 1;
-				T.nch = nch_;
-				launch_tail(T, stream);
-			}
-			std::swap(dev_[0].ring, dev_[0].ring_alt);
+			TailLaunch T;
+			T.src = src;
+			T.p1 = sp.m;
+			T.p0 = sp.m - stage_history(0);
+			if (T.p0 < 0) T.p0 = 0;
+			T.ring = dev_[0].ring_alt + (long long) ch0_ * dev_[0].ring_size;
+			T.ring_stride = dev_[0].ring_size;
+			T.ring_mask = dev_[0].ring_size - 1;
+			T.nch = nchw_;
+			launch_tail(T, stream);
 		}
-		n = (int) (fused ? wb - wa : b - a);
-		s += glen - 1;
+	};
+	for (const Rec& r : recs)
+	{
+		ensure_ring(r.s);
+		if (r.s + r.glen < ns) ensure_ring(r.s + r.glen);
 	}
+	ch0_ = 0;
+	nchw_ = nch_;
+	for (size_t i = 0; i < recs.size(); i++)
+	{
+		// A convolver followed by the polynomial interpolator (non-whole-step ratios, 44100 -> 44101): two launches
+		// with the convolver's whole 2x stream between them -- 268 MB for BASELINE's batch, written to HBM and read
+		// back.  Walked in channel groups whose stream (<= ~96 MB) stays in the 256 MB Infinity Cache between the
+		// two launches, the interpolator reads it from there (reference CDSPFracInterpolator.h:1069-1179 behind
+		// CDSPBlockConvolver.h:252-354).  Channels are independent, so results do not change.
+		const Rec& r = recs[i];
+		int groups = 1;
+		if (i + 1 < recs.size() && opt_.at("poly_groups") && !r.fused && !recs[i + 1].fused && r.work && recs[i + 1].work &&
+			plan_.stages[r.s].desc.kind == kConv && plan_.stages[recs[i + 1].s].desc.kind == kFrac &&
+			!plan_.stages[recs[i + 1].s].whole && io_in_fmt_ == kPcmF64 && io_out_fmt_ == kPcmF64)
+		{
+			const double between = 8.0 * (double) nch_ * (double) (r.b - r.a);
+			const double cap = opt_.at("poly_groups") > 1 ? 1024.0 * opt_.at("poly_groups") : 96.0 * 1048576.0;
+			groups = (int) std::ceil(between / cap);
+			// (whole channel pairs per group, at least 256 pairs each: smaller launches do not fill the chip)
+			// (an explicit cap -- tests -- may cut down to single pairs)
+			const int min_per = opt_.at("poly_groups") > 1 ? 2 : 512;
+			while (groups > 1 && (nch_ / groups) < min_per) groups--;
+		}
+		if (groups <= 1)
+		{
+			launch_rec(r);
+			continue;
+		}
+		const int per = ((nch_ + groups - 1) / groups + 1) & ~1;
+		for (int c0 = 0; c0 < nch_; c0 += per)
+		{
+			ch0_ = c0;
+			nchw_ = std::min(per, nch_ - c0);
+			launch_rec(r);
+			launch_rec(recs[i + 1]);
+		}
+		ch0_ = 0;
+		nchw_ = nch_;
+		i++;
+	}
+	if (ns > 0) std::swap(dev_[0].ring, dev_[0].ring_alt);
 	return n;
 }
 
@@ -1463,7 +1529,7 @@ void Engine::launch_dcascade(size_t s, int glen, long long fa, long long fb, con
 	L.buf2 = (int) odd + 8;
 	L.pair_ok = 0;
 	L.in_end = plan_.stages[s].m;
-	L.nch = nch_;
+	L.nch = nchw_;
 	L.src = src; L.dst = dst;
 	launch_hbdcascade(L, stream);
 }
@@ -1499,7 +1565,7 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 	L.tile = tile;
 	L.buf = tile / 2 + 96;  // largest intermediate stream of a tile (input of the last stage)
 	L.buf2 = tile / 4 + 96; // the one before it (the buffers alternate)
-	L.nch = nch_;
+	L.nch = nchw_;
 	L.src = src; L.dst = dst;
 	L.in_end = plan_.stages[s].m;
 	// 16-byte stores of output pairs: output q is even for the first of an (even, odd) pair, whose element
@@ -1585,7 +1651,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	for (int i = 0; i < L.n_fwd; i++) L.fwd_radix[i] = d.fwd_radix[(size_t) i];
 	for (int i = 0; i < L.n_inv; i++) L.inv_radix[i] = d.inv_radix[(size_t) i];
 	L.H = d.H; L.Hc = d.Hc; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.spec2 = d.spec2; L.hp = d.hp; L.ptw = d.ptw;
-	L.nch = nch_;
+	L.nch = nchw_;
 	// (short transforms: fewer threads per block -- a 64-point transform on 256 threads is four waves
 	// meeting at barriers with nothing to do)
 	{
@@ -1599,7 +1665,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	{
 		// stage 0 on the fast path: let the kernel keep the history (see process())
 		const StagePlan& sp0 = plan_.stages[0];
-		L.tail_ring = dev_[0].ring_alt;
+		L.tail_ring = dev_[0].ring_alt + (long long) ch0_ * dev_[0].ring_size;
 		L.tail_p1 = sp0.m;
 		L.tail_p0 = sp0.m - stage_history(0);
 		if (L.tail_p0 < 0) L.tail_p0 = 0;

@@ -114,6 +114,9 @@ private:
 
 	ChainPlan plan_;
 	int nch_;
+	// channel window of the launches being issued (process() walks a convolver + polynomial-interpolator pair in
+	// channel groups so that the stream between them stays in the 256 MB Infinity Cache; [0, nch_) otherwise)
+	int ch0_ = 0, nchw_ = 0;
 	int device_;
 	std::vector<StageDev> dev_;
 	std::map<std::string, int> opt_;

@@ -17,3 +17,8 @@ run --src 48000 --dst 32000
 run --src 176400 --dst 44100
 run --src 44100 --dst 96000 --atten 109.56
 tail -5 $out/pytest.log; tail -1 $out/smoke.log; cat $out/bench_default_20.json; cat $out/bench.txt
+for ch in 256 1024 2048; do
+  run --src 44100 --dst 44101 --channels $ch
+  run --src 44100 --dst 44101 --channels $ch --opt poly_groups=0
+done
+tail -8 $out/bench.txt
