@@ -157,6 +157,9 @@ template<int LN, int UL> constexpr int convp_lds_bytes() { return convp_array_by
 template<int LN, int UL>
 R8B_HD unsigned cp_nonzero_bits(const ConvpState<LN, UL>& st)
 {
+#ifdef R8B_NO_SILENCE
+	return 3u; // (development: timing without the detection)
+#endif
 	bool a = false, b = false;
 #pragma unroll
 	for (int p = 0; p < ConvpGeom<LN, UL>::E1; p++)
@@ -348,8 +351,7 @@ R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st,
 {
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int R = G::E1, q = G::N / R;
-	cd loc[6];
-	ptw_fetch<R, G::NT>(loc, L.ptw, 0, lt);
+	const cd* const loc = st.tw; // (fetched by the caller ahead of the samples)
 	double vr[R], vi[R];
 #pragma unroll
 	for (int p = 0; p < R; p++)
@@ -840,12 +842,10 @@ R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 R8B_HD int cp_whole_phase(const ConvxLaunch& X, int tid) { return tid % X.out_step; }
 
 template<int FLEN>
-R8B_HD void cp_whole_compute(const ConvxLaunch& X, const cd* y, double* row, int* row_t, long long k,
+R8B_HD void cp_whole_compute(const ConvxLaunch& X, const SpanInfo& B, const cd* y, double* row, int* row_t,
 	int chA, int chB, bool bvalid, int tid, int wt)
 {
 	// *row_t: the phase whose row `row` holds
-	const ConvLaunch& L = X.c;
-	const SpanInfo& B = X.blk[k - L.k0];
 	const long long jhi = B.jhi;
 	const int nsets = wt >= X.out_step ? wt / X.out_step : 1;
 	const int set = wt >= X.out_step ? tid / X.out_step : 0;
@@ -933,14 +933,13 @@ R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int* pt, int tid)
 }
 
 template<int T2>
-R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const cd* y, const double* rows, int pt, long long k,
+R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const SpanInfo& Bm, const cd* y, const double* rows, int pt,
 	int chA, int chB, bool bvalid)
 {
 	// pt: phase pair q (bits 0-7), group set (8-11), window start floor(2 q In / Out) (12-)
 	if (pt < 0) return;
 	const int q = pt & 0xff, set = (pt >> 8) & 15, rq = pt >> 12;
 	// (block constants into registers once: the kernel arguments live in memory)
-	const SpanInfo& Bm = X.blk[k - X.c.k0];
 	const int hi_mod = Bm.pad, gmax = Bm.ph_lo, lo_mod = Bm.jlo_mod, u_lo = Bm.u_lo;
 	if (hi_mod == 0) return;
 	const int in_step = X.in_step, out_step = X.out_step, nsets = X.nsets;
@@ -1098,8 +1097,11 @@ struct ConvpItem
 	bool bvalid;
 };
 
+
+// X: the launch descriptor as the phases read it -- on the GPU a copy whose hot scalars k_convp has pinned in
+// scalar registers (see there); XM: the descriptor in kernel-argument memory, for its per-block array only.
 template<int LN, int UL, int MODE, int FLENP, class Exec>
-R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem& cur)
+R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd* buf, const ConvpItem& cur)
 {
 	typedef ConvpGeom<LN, UL> G;
 	typedef ConvpState<LN, UL> St;
@@ -1131,8 +1133,13 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	ex.phase([&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
+		// (the first pass's twiddles -- L2 -- requested ahead of the samples -- HBM --, not behind their wait)
+		ptw_fetch<G::E1, G::NT>(st.tw, L.ptw, 0, lt);
+		ex.stamp2();
 		if constexpr (!(R8B_ABL & 8)) cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
+		ex.stamp2();
 		ex.post_bits(tid, cp_nonzero_bits<LN, UL>(st));
+		ex.stamp2();
 		if constexpr (!(R8B_ABL & 16)) cp_first<LN, UL>(L, buf_of(tid), st, lt);
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
 		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
@@ -1247,7 +1254,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 	}
 	// history for the next call (stage 0 only): the first block's workgroup copies the tail of
 	// the caller's buffers into the other history ring; the stores need no wait
-	if (L.tail_ring != nullptr && cur.k == L.k0)
+	if (cur.k == L.k0 && L.tail_ring != nullptr)
 	{
 		ex.each([&](int tid, St&)
 		{
@@ -1313,7 +1320,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		if constexpr (!(R8B_ABL & 1)) ex.each([&](int, St& st)
 		{
 			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
-				cp_whole2_compute<T2>(X, buf + sb * G::NA, st.rows2, st.pt, cur.k + sb, chA, chB, bvalid);
+				cp_whole2_compute<T2>(X, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
 		});
 	}
 	else
@@ -1334,9 +1341,15 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 		{
 			int row_t = cp_whole_phase(X, tid); // (what cx_whole_row fetched ahead)
 			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
-				cp_whole_compute<FLENP>(X, buf + sb * G::NA, st.row, &row_t, cur.k + sb, chA, chB, bvalid, tid, G::WT);
+				cp_whole_compute<FLENP>(X, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.row, &row_t, chA, chB, bvalid, tid, G::WT);
 		});
 	}
+}
+
+template<int LN, int UL, int MODE, int FLENP, class Exec>
+R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem& cur)
+{
+	convp_body<LN, UL, MODE, FLENP>(ex, X, X, buf, cur);
 }
 
 // workgroup i of a launch, pair major: the block groups of one channel pair are consecutive

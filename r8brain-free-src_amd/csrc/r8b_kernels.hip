@@ -561,7 +561,9 @@ struct GpuExecP
 		}
 	}
 	__device__ void dump() const {}
+	__device__ __forceinline__ void stamp2() { stamp(); }
 #else
+	__device__ __forceinline__ void stamp2() {}
 	__device__ __forceinline__ void stamp() {}
 	__device__ __forceinline__ void dump() const {}
 #endif
@@ -620,6 +622,12 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
 	const int chA = (int) (2u * pr);
 	const bool bvalid = chA + 1 < X.c.nch;
+	if constexpr ((R8B_ABL & 2048) != 0)
+	{
+		// (timing ablation, bit 11: what dispatching the grid costs -- every workgroup ends at once)
+		if (X.c.nch < 0) smem[threadIdx.x] = 1;
+		return;
+	}
 	GpuExecP<LN, UL> ex(smem);
 	ConvpItem cur;
 	const int b0 = (int) bg * SUB;
@@ -628,8 +636,40 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	cur.chA = chA;
 	cur.chB = bvalid ? chA + 1 : chA;
 	cur.bvalid = bvalid;
+	// Kernel arguments live in memory: left to itself the compiler fetches each one where it is first needed --
+	// chains of dependent scalar loads at the start of the workgroup (measured: 3 300 cycles before the first sample
+	// load is issued) and one more load in front of most phases, whose wait is a wait on the LDS counter too, i.e. a
+	// full drain of the phase's LDS traffic.  The scalars the phases use are therefore copied into a local descriptor
+	// and pinned in scalar registers HERE, all loads in flight together and one wait; the phases read the copy.
+	// (Pointers to rarely used data -- the history ring of a call's first blocks -- stay in memory.)
+	ConvxLaunch H;
+	H.c = X.c;
+	H.in_step = X.in_step; H.out_step = X.out_step; H.flen = X.flen; H.fl2w = X.fl2w; H.fllw = X.fllw;
+	H.table = X.table; H.wtab = X.wtab; H.wa = X.wa; H.wb = X.wb; H.wdst = X.wdst;
+	H.run_off = X.run_off; H.ptab = X.ptab; H.ctab = X.ctab; H.nsets = X.nsets;
+	H.nblk_magic = X.nblk_magic;
+	// (integers are made opaque -- "+s" --, pointers are only USED here -- "s" --: a pointer that went through an asm
+	// output loses its kernel-argument provenance and would be dereferenced with flat instructions)
+	asm volatile("" : "+s"(H.c.k0), "+s"(H.c.blk_stride), "+s"(H.c.blk_offset), "+s"(H.c.in_len), "+s"(H.c.fl2),
+		"+s"(H.c.up_pow2), "+s"(H.c.src.cur_stride), "+s"(H.c.src.cur_base), "+s"(H.c.src.cur_fmt)
+		: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
+	if constexpr (MODE == 4 || MODE == 5)
+		asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),
+			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt) : "s"(H.ptab), "s"(H.ctab), "s"(H.wdst.p));
+	else if constexpr (MODE == 1) {}
+	else
+		asm volatile("" : "+s"(H.c.a), "+s"(H.c.b), "+s"(H.c.dst.stride), "+s"(H.c.dst.mask), "+s"(H.c.dst.off),
+			"+s"(H.c.dst.fmt), "+s"(H.c.down), "+s"(H.c.down_pow2), "+s"(H.c.up) : "s"(H.c.dst.p));
 	ex.stamp();
-	convp_body<LN, UL, MODE, FLENP>(ex, X, reinterpret_cast<cd*>(smem), cur);
+	// (MODE 1 -- one phase per thread -- already fills the scalar file with its span bookkeeping: it reads the
+	// arguments where it needs them, as before)
+	if constexpr (MODE == 1) convp_body<LN, UL, MODE, FLENP>(ex, X, X, reinterpret_cast<cd*>(smem), cur);
+	else convp_body<LN, UL, MODE, FLENP>(ex, H, X, reinterpret_cast<cd*>(smem), cur);
+#ifdef R8B_CP_STAMPS
+	// (how long the workgroup's last stores take to be acknowledged: the slot stays occupied until then)
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	ex.stamp();
+#endif
 	ex.dump();
 }
 

@@ -229,6 +229,7 @@ struct EmulExecP
 	std::vector<ConvpState<LN, UL>> st;
 	unsigned bits = 0;
 	EmulExecP() : st((size_t) WT) {}
+	void stamp2() {}
 	void post_bits(int, unsigned v) { bits |= v; }
 	unsigned collect_bits() const { return bits; }
 	template<class F>

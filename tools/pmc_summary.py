@@ -72,8 +72,8 @@ for k in sorted(acc):
             d.append(("units of 4 cycles per VALU instruction", g("SQ_ACTIVE_INST_VALU") / g("SQ_INSTS_VALU"),
                       "SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU"))
     if kc and g("SQ_BUSY_CU_CYCLES"):
-        d.append(("CUs with a wave resident", 4.0 * g("SQ_BUSY_CU_CYCLES") / (256.0 * kc),
-                  "4 * SQ_BUSY_CU_CYCLES / (256 * kernel cycles)"))
+        d.append(("CU time with a wave resident", g("SQ_BUSY_CU_CYCLES") / (256.0 * kc),
+                  "SQ_BUSY_CU_CYCLES / (256 * kernel cycles)  [this one counts cycles: 0.98 for the calibration kernels]"))
     if kc and g("SQ_LDS_IDX_ACTIVE"):
         d.append(("LDS busy (all 256 CUs)", g("SQ_LDS_IDX_ACTIVE") / (256.0 * kc),
                   "SQ_LDS_IDX_ACTIVE / (256 * kernel cycles)"))

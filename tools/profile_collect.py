@@ -18,7 +18,7 @@ for cfg in sorted(os.listdir(src)):
     d = os.path.join(src, cfg)
     if not os.path.isdir(d):
         continue
-    for f in ("kernel_stats.csv", "pmc_summary.txt", "bench_20.json", "bench_400.json"):
+    for f in ("kernel_stats.csv", "pmc_summary.txt", "bench_20.json", "bench_400.json", "rates.txt"):
         if os.path.exists(os.path.join(d, f)):
             shutil.copy(os.path.join(d, f), os.path.join(dst, "%s_%s_%s" % (prefix, cfg, f)))
     try:
