@@ -130,6 +130,66 @@ R8B_HD int bslot(int p)
 	else return pswz((p / G::BW) * G::FW + (p & (G::BW - 1)));
 }
 
+// The swizzle is linear over XOR and the wave maps only move bits, so for an element e0 | d whose offset d (a
+// compile-time constant: p times a power-of-two stride) has no bit in common with e0 the slot is
+//   slot(e0 | d) = (slot(e0) ^ xc) + hi,   xc = (m ^ (m >> 4)) & 15, hi = m & ~15, m = map(d):
+// one address register per pass (the slot of e0, as a BYTE offset), one XOR per access when xc != 0 and the rest in
+// the LDS instruction's immediate offset -- instead of a full swizzle (4 ... 7 integer instructions) per access.
+R8B_HD constexpr int sw_xc(int m) { return (m ^ (m >> 4)) & 15; }
+R8B_HD constexpr int sw_hi(int m) { return m & ~15; }
+template<int LN, int UL>
+R8B_HD constexpr int fmap_c(int d)
+{
+	typedef ConvpGeom<LN, UL> G;
+	return (UL <= 0 || G::NW == 1) ? d : (d / G::FW) * G::BW + (d & (G::FW - 1));
+}
+template<int LN, int UL>
+R8B_HD constexpr int bmap_c(int d)
+{
+	typedef ConvpGeom<LN, UL> G;
+	return (UL >= 0 || G::NW == 1) ? d : (d / G::BW) * G::FW + (d & (G::BW - 1));
+}
+// SwBase: the per-pass address register.  On the GPU it is the ABSOLUTE LDS byte address of slot(e0): the XOR
+// constants live in address bits 4-7 and every block pair's array starts on a multiple of 256 bytes (the dynamic LDS
+// segment starts at 0, an array is NA * 16 bytes), so the XOR may be applied to the address itself -- which also keeps
+// the compiler from adding the segment's base (a late constant it does not fold) to every access.  The host emulation
+// (tests/emul) has no such alignment and XORs the offset.
+#ifdef R8B_LDS_ABS
+typedef __attribute__((address_space(3))) cd lds_cd_t;
+struct SwBase { unsigned a; };
+R8B_HD SwBase sw_base(const cd* buf, int slot0)
+{
+	SwBase b;
+	b.a = (unsigned) (size_t) (const lds_cd_t*) buf + ((unsigned) slot0 << 4);
+	return b;
+}
+R8B_HD cd sw_ld(SwBase b, int m)
+{
+	return *(const lds_cd_t*) (size_t) ((b.a ^ (unsigned) (sw_xc(m) << 4)) + (unsigned) (sw_hi(m) << 4));
+}
+R8B_HD void sw_st(SwBase b, int m, cd v)
+{
+	*(lds_cd_t*) (size_t) ((b.a ^ (unsigned) (sw_xc(m) << 4)) + (unsigned) (sw_hi(m) << 4)) = v;
+}
+#else
+struct SwBase { char* p; int bb; };
+R8B_HD SwBase sw_base(const cd* buf, int slot0)
+{
+	SwBase b;
+	b.p = reinterpret_cast<char*>(const_cast<cd*>(buf));
+	b.bb = slot0 << 4;
+	return b;
+}
+R8B_HD cd sw_ld(SwBase b, int m)
+{
+	return *reinterpret_cast<const cd*>(b.p + ((b.bb ^ (sw_xc(m) << 4)) + (sw_hi(m) << 4)));
+}
+R8B_HD void sw_st(SwBase b, int m, cd v)
+{
+	*reinterpret_cast<cd*>(b.p + ((b.bb ^ (sw_xc(m) << 4)) + (sw_hi(m) << 4))) = v;
+}
+#endif
+
 template<int LN, int UL>
 struct ConvpState
 {
@@ -160,14 +220,19 @@ R8B_HD unsigned cp_nonzero_bits(const ConvpState<LN, UL>& st)
 #ifdef R8B_NO_SILENCE
 	return 3u; // (development: timing without the detection)
 #endif
-	bool a = false, b = false;
+	// (integer form: a double is +-0 exactly when its low word and its high word without the sign are both zero --
+	// three cheap integer instructions per two samples instead of a 64-bit compare and a mask merge per sample)
+	unsigned a = 0, b = 0;
 #pragma unroll
 	for (int p = 0; p < ConvpGeom<LN, UL>::E1; p++)
 	{
-		a = a || st.pr[p] != 0.0;
-		b = b || st.pi[p] != 0.0;
+		unsigned long long ua, ub;
+		__builtin_memcpy(&ua, &st.pr[p], 8);
+		__builtin_memcpy(&ub, &st.pi[p], 8);
+		a |= (unsigned) ua | ((unsigned) (ua >> 32) << 1);
+		b |= (unsigned) ub | ((unsigned) (ub >> 32) << 1);
 	}
-	return (a ? 1u : 0u) | (b ? 2u : 0u);
+	return (a != 0 ? 1u : 0u) | (b != 0 ? 2u : 0u);
 }
 
 template<int LN, int UL>
@@ -221,11 +286,12 @@ R8B_HD void pdif(cd* buf, int n, int b, const cd* twr)
 	const int q = n / R;
 	const int blk = b / q, j = b - blk * q;
 	const int e0 = blk * n + j;
+	const SwBase bb = sw_base(buf, fslot<LN, UL>(e0));
 	double vr[R], vi[R];
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
-		const cd v = buf[fslot<LN, UL>(e0 + p * q)];
+		const cd v = sw_ld(bb, fmap_c<LN, UL>(p * q));
 		vr[p] = v.re;
 		vi[p] = v.im;
 	}
@@ -248,7 +314,7 @@ R8B_HD void pdif(cd* buf, int n, int b, const cd* twr)
 		cd v;
 		v.re = vr[p];
 		v.im = vi[p];
-		buf[fslot<LN, UL>(e0 + p * q)] = v;
+		sw_st(bb, fmap_c<LN, UL>(p * q), v);
 	}
 }
 
@@ -258,10 +324,11 @@ R8B_HD void pdit_regs(const cd* buf, int n, int b, const cd* twr, double* vr, do
 	const int q = n / R;
 	const int blk = b / q, j = b - blk * q;
 	const int e0 = blk * n + j;
+	const SwBase bb = sw_base(buf, pswz(e0));
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
-		const cd v = buf[pswz(e0 + p * q)];
+		const cd v = sw_ld(bb, p * q);
 		vr[p] = v.re;
 		vi[p] = v.im;
 	}
@@ -317,20 +384,25 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 	constexpr int US = UL > 0 ? UL : 0; // (L.up == 1 << US)
 	const int iln = L.in_len >> US;
 	const long long base = (k * (long long) L.blk_stride + L.blk_offset) >> US; // (>= 0, even)
+	// Element i of the circular array holds sample base + rel((i + rot) mod N), rel(j) = j < iln ? j : j - N: the N
+	// CONSECUTIVE samples base - (N - iln) ... base + iln - 1, sample w of that window at element (w - wr) mod N,
+	// wr = (rot + N - iln) mod N.
+	const int wr = (L.rot + G::N - iln) & (G::N - 1);
 	// most blocks of a call lie entirely inside the caller's buffer: one uniform row pointer per channel
 	// and a 32-bit offset per load (the general form selects ring / buffer / zero per sample: ~12
 	// vector instructions per load)
 	if (L.src.cur_fmt == kPcmF64 && base - (G::N - iln) >= L.src.cur_base && base - (G::N - iln) >= 0)
 	{
-		const double* const pa = L.src.cur + ((long long) chA * L.src.cur_stride + (base - L.src.cur_base));
-		const double* const pb = L.src.cur + ((long long) chB * L.src.cur_stride + (base - L.src.cur_base));
+		const long long w0 = base - (G::N - iln) - L.src.cur_base;
+		const double* const pa = L.src.cur + ((long long) chA * L.src.cur_stride + w0);
+		const double* const pb = L.src.cur + ((long long) chB * L.src.cur_stride + w0);
+		const unsigned l0 = (unsigned) (lt + wr);
 #pragma unroll
 		for (int p = 0; p < R; p++)
 		{
-			const int i = lt + p * q;
-			const int rel = i < iln ? i : i - G::N;
-			st.pr[p] = pa[rel];
-			st.pi[p] = pb[rel];
+			const unsigned w = (l0 + (unsigned) (p * q)) & (unsigned) (G::N - 1);
+			st.pr[p] = pa[w];
+			st.pi[p] = pb[w];
 		}
 		return;
 	}
@@ -338,7 +410,7 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
-		const int i = lt + p * q;
+		const int i = (lt + p * q + L.rot) & (G::N - 1);
 		const int rel = i < iln ? i : i - G::N;
 		st.pr[p] = src_block_load1(sa, rel);
 		st.pi[p] = src_block_load1(sb, rel);
@@ -369,13 +441,14 @@ R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st,
 		vr[p] = tr;
 		vi[p] = ti;
 	}
+	const SwBase bb = sw_base(buf, fslot<LN, UL>(lt));
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
 		cd v;
 		v.re = vr[p];
 		v.im = vi[p];
-		buf[fslot<LN, UL>(lt + p * q)] = v;
+		sw_st(bb, fmap_c<LN, UL>(p * q), v);
 	}
 }
 
@@ -424,10 +497,11 @@ R8B_HD void cp_middle_compute(const cd* buf, ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
 	double zr[G::E1], zi[G::E1];
+	const SwBase bbf = sw_base(buf, fslot<LN, UL>(G::E1 * lt));
 #pragma unroll
 	for (int c = 0; c < G::E1; c++)
 	{
-		const cd v = buf[fslot<LN, UL>(G::E1 * lt + c)];
+		const cd v = sw_ld(bbf, fmap_c<LN, UL>(c));
 		zr[c] = v.re;
 		zi[c] = v.im;
 	}
@@ -492,13 +566,14 @@ R8B_HD void cp_middle_compute(const cd* buf, ConvpState<LN, UL>& st, int lt)
 template<int LN, int UL>
 R8B_HD void cp_middle_write(cd* buf, const ConvpState<LN, UL>& st, int lt)
 {
+	const SwBase bb = sw_base(buf, pswz(16 * lt));
 #pragma unroll
 	for (int p = 0; p < 16; p++)
 	{
 		cd v;
 		v.re = st.vr[p];
 		v.im = st.vi[p];
-		buf[pswz(16 * lt + p)] = v;
+		sw_st(bb, p, v);
 	}
 }
 
@@ -514,13 +589,14 @@ R8B_HD void cp_back1(cd* buf, ConvpState<LN, UL>& st, int lt)
 		double vr[16], vi[16];
 		pdit_regs<16, true>(buf, 256, lt, st.tw, vr, vi);
 		const int e0 = (lt >> 4) * 256 + (lt & 15);
+		const SwBase bb = sw_base(buf, pswz(e0));
 #pragma unroll
 		for (int p = 0; p < 16; p++)
 		{
 			cd v;
 			v.re = vr[p];
 			v.im = vi[p];
-			buf[pswz(e0 + p * 16)] = v;
+			sw_st(bb, p * 16, v);
 		}
 	}
 }
@@ -544,10 +620,11 @@ R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 	else if constexpr (G::R2 > 1)
 	{
 		constexpr int R = G::R2, NB = G::NB2;
+		const SwBase bb = sw_base(buf, pswz(lt));
 #pragma unroll
 		for (int i = 0; i < 16; i++)
 		{
-			const cd v = buf[pswz(lt + G::NT * i)];
+			const cd v = sw_ld(bb, G::NT * i);
 			st.vr[i] = v.re;
 			st.vi[i] = v.im;
 		}
@@ -591,10 +668,11 @@ R8B_HD void cp_middle_compute_down(const cd* buf, ConvpState<LN, UL>& st, int lt
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int D = 1 << G::DL;
 	double zr[16], zi[16];
+	const SwBase bbf = sw_base(buf, pswz(16 * lt));
 #pragma unroll
 	for (int c = 0; c < 16; c++)
 	{
-		const cd v = buf[pswz(16 * lt + c)];
+		const cd v = sw_ld(bbf, c);
 		zr[c] = v.re;
 		zi[c] = v.im;
 	}
@@ -650,13 +728,14 @@ template<int LN, int UL>
 R8B_HD void cp_middle_write_down(cd* buf, const ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
+	const SwBase bb = sw_base(buf, bslot<LN, UL>(G::E2 * lt));
 #pragma unroll
 	for (int p = 0; p < G::E2; p++)
 	{
 		cd v;
 		v.re = st.vr[p];
 		v.im = st.vi[p];
-		buf[bslot<LN, UL>(G::E2 * lt + p)] = v;
+		sw_st(bb, bmap_c<LN, UL>(p), v);
 	}
 }
 
@@ -677,11 +756,12 @@ struct ConvpPost
 		constexpr int R = G::E2, q = n / R;
 		const int blk = lt / q, j = lt - blk * q;
 		const int e0 = blk * n + j;
+		const SwBase bb = sw_base(buf, bslot<LN, UL>(e0));
 		double vr[R], vi[R];
 #pragma unroll
 		for (int p = 0; p < R; p++)
 		{
-			const cd v = buf[bslot<LN, UL>(e0 + p * q)];
+			const cd v = sw_ld(bb, bmap_c<LN, UL>(p * q));
 			vr[p] = v.re;
 			vi[p] = v.im;
 		}
@@ -708,7 +788,7 @@ struct ConvpPost
 				cd v;
 				v.re = vr[p];
 				v.im = vi[p];
-				buf[bslot<LN, UL>(e0 + p * q)] = v;
+				sw_st(bb, bmap_c<LN, UL>(p * q), v);
 			}
 		}
 	}
@@ -740,16 +820,42 @@ R8B_HD void cp_store_conv_down(const ConvLaunch& L, const ConvpState<LN, UL>& st
 
 // MODE 1: the block's valid outputs as one linear run of (A, B) pairs, y[u] = outputs at time t0 + u
 template<int LN, int UL>
-R8B_HD void cp_final_store(const ConvLaunch& L, cd* y, const ConvpState<LN, UL>& st, long long k, int lt)
+R8B_HD void cp_final_store(const ConvLaunch& L, cd* ybase, cd* y, const ConvpState<LN, UL>& st, long long k, int lt)
 {
-	// (y already points at the run: the pair's array + run_off)
+	// (ybase: the pair's array; y: the run inside it, ybase + run_off)
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int mask = G::N2 - 1;
 	const long long t0 = cx_block_t0(L, k);
 	// a stage's stream starts at t = 0: earlier outputs do not exist for the interpolator
 	// (reference CDSPFracInterpolator.h:834-859)
 	const int nzero = t0 >= 0 ? 0 : (-t0 > L.in_len ? L.in_len : (int) -t0);
-	const int in_len = L.in_len, u0 = (lt + L.fl2) & mask;
+	const int in_len = L.in_len, u0 = (lt + L.fl2r) & mask;
+	if (nzero == 0 && L.fl2r + (int) (y - ybase) <= G::NT)
+	{
+		// (every block but the first ones of a stream, in the rotated layout of convp_prepare: fl2r = 0 or 1)
+		// The thread's element p is y[lt + fl2r + NT p]: one address register, no index arithmetic, and nothing
+		// to mask for p < 15 -- slots in_len ... of the run are only ever multiplied by the zero taps of the
+		// padded rows or belong to masked outputs, and what lands there is finite transform data; the slots up to
+		// fl2r + 16 NT - 1 lie inside the array.  The last element may wrap or leave the array: the general form.
+		cd* const yl = y + (lt + L.fl2r);
+#pragma unroll
+		for (int p = 0; p < 15; p++)
+		{
+			cd v;
+			v.re = st.vr[p];
+			v.im = st.vi[p];
+			yl[G::NT * p] = v;
+		}
+		const int u = (u0 + G::NT * 15) & mask;
+		if (u < in_len)
+		{
+			cd v;
+			v.re = st.vr[15];
+			v.im = st.vi[15];
+			y[u] = v;
+		}
+		return;
+	}
 	if (nzero == 0)
 	{
 		// (every block but the first ones of a stream)
@@ -770,7 +876,7 @@ R8B_HD void cp_final_store(const ConvLaunch& L, cd* y, const ConvpState<LN, UL>&
 #pragma unroll
 	for (int p = 0; p < 16; p++)
 	{
-		const int u = (lt + G::NT * p + L.fl2) & mask;
+		const int u = (lt + G::NT * p + L.fl2r) & mask;
 		if (u < L.in_len)
 		{
 			cd v;
@@ -808,7 +914,7 @@ R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 #pragma unroll
 			for (int p = 0; p < 16; p++)
 			{
-				const int u = (lt + G::NT * p + L.fl2) & mask;
+				const int u = (lt + G::NT * p + L.fl2r) & mask;
 				const unsigned w = r0 + (unsigned) u;
 				const unsigned wq = down == 3 ? w / 3u : w / (unsigned) down;
 				const long long q = qf + wq;
@@ -824,7 +930,7 @@ R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 #pragma unroll
 	for (int p = 0; p < 16; p++)
 	{
-		const int u = (lt + G::NT * p + L.fl2) & mask;
+		const int u = (lt + G::NT * p + L.fl2r) & mask;
 		const long long q = t0 + u;
 		if (u < L.in_len && q >= L.a && q < L.b)
 		{
@@ -1314,7 +1420,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.phase([&](int tid, St& st)
 		{
 			cp_silence<LN, UL>(st, ex.collect_bits());
-			cp_final_store<LN, UL>(L, buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
+			cp_final_store<LN, UL>(L, buf_of(tid), buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
 		});
 		// the interpolator: all 256 threads over the run of one block pair after the other
 		if constexpr (!(R8B_ABL & 1)) ex.each([&](int, St& st)
@@ -1335,7 +1441,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.phase([&](int tid, St& st)
 		{
 			cp_silence<LN, UL>(st, ex.collect_bits());
-			cp_final_store<LN, UL>(L, buf_of(tid), st, k_of(tid), lt_of(tid));
+			cp_final_store<LN, UL>(L, buf_of(tid), buf_of(tid), st, k_of(tid), lt_of(tid));
 		});
 		ex.each([&](int tid, St& st)
 		{
@@ -1350,6 +1456,27 @@ template<int LN, int UL, int MODE, int FLENP, class Exec>
 R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem& cur)
 {
 	convp_body<LN, UL, MODE, FLENP>(ex, X, X, buf, cur);
+}
+
+// What a launcher (r8b_kernels.hip, tests/emul) sets in its copy of the descriptor before the kernel runs: the
+// rotation of the block inside the circular array (ConvLaunch::rot / fl2r).  Rotating the input by rot samples
+// rotates the circular convolution's output by up * rot, so with rot = -(fl2 / up) mod N the valid outputs start at
+// circular position fl2 mod up instead of fl2.  Power-of-two zero stuffing only (the 3x forms and the decimating
+// form keep rot = 0, fl2r = fl2).
+template<int LN, int UL>
+inline void convp_prepare(ConvxLaunch& X)
+{
+	X.c.rot = 0;
+	X.c.fl2r = X.c.fl2;
+	if constexpr (UL >= 0)
+	{
+		if (X.c.up_pow2 && X.c.up == (1 << (UL > 0 ? UL : 0)))
+		{
+			constexpr int N = ConvpGeom<LN, UL>::N;
+			X.c.rot = (N - ((X.c.fl2 / X.c.up) & (N - 1))) & (N - 1);
+			X.c.fl2r = X.c.fl2 % X.c.up;
+		}
+	}
 }
 
 // workgroup i of a launch, pair major: the block groups of one channel pair are consecutive

@@ -1634,6 +1634,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	const StageDev& d = dev_[s];
 	const ConvGeom& g = sp.cg;
 	L.up = g.up; L.down = g.down; L.fl2 = g.fl2; L.bl2 = g.bl2; L.in_len = g.in_len;
+	L.rot = 0; L.fl2r = g.fl2;
 	L.n_in = g.n_in; L.n_out = g.n_out;
 	L.blk_stride = g.in_len;
 	L.blk_offset = 0;

@@ -28,6 +28,8 @@
 #endif
 
 #define R8B_HD __device__ __forceinline__
+// r8b_convp.h: pass addresses as absolute LDS byte addresses (its arrays start on multiples of 256 bytes)
+#define R8B_LDS_ABS 1
 // 8 consecutive doubles from LDS as 8 separate ds_read_b64 (the compiler would pair them into
 // ds_read2_b64, half the LDS rate); completion is awaited by the wait statement naming the
 // registers (cdna_hip_programming.md 5.7, form ii)
@@ -596,7 +598,7 @@ struct GpuExecP
 template<int LN, int UL, int MODE, int FLENP>
 __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) > 256 ? 1 : 2)) void k_convp(const ConvxLaunch X)
 {
-	extern __shared__ __align__(16) unsigned char smem[];
+	extern __shared__ __align__(256) unsigned char smem[];
 	// XCD-aware mapping as in k_convx, over channel PAIRS and groups of SUB consecutive blocks
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
 	const unsigned w = blockIdx.x, npair = ((unsigned) X.c.nch + 1u) >> 1;
@@ -682,6 +684,7 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	constexpr unsigned SUB = ConvpGeom<LN, UL>::SUB;
 	const unsigned nbg = ((unsigned) X.c.nblk + SUB - 1u) / SUB;
 	X.nblk_magic = nbg > 1 ? (unsigned) (0x100000000ull / nbg) + 1u : 0u;
+	convp_prepare<LN, UL>(X);
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
 #ifdef R8B_DEV_ONLY_MODE

@@ -47,6 +47,11 @@ struct ConvLaunch
 {
 	// geometry (r8b_plan.h ConvGeom)
 	int up, down, fl2, bl2, in_len, n_in, n_out;
+	// pair form (r8b_convp.h convp_prepare): the block sits in the transform's circular array rotated by `rot`
+	// input samples, chosen so that the valid outputs come out at circular positions fl2r, fl2r + 1, ... with
+	// fl2r = fl2 mod up (0 or 1) instead of fl2: the run needs no index rotation when it is written out.
+	// (0 / fl2 elsewhere.)
+	int rot, fl2r;
 	// virtual samples between the starts of consecutive blocks: in_len (the reference's own block
 	// anchoring, reference CDSPBlockConvolver.h:283-305) except in the fused fast path
 	int blk_stride;
