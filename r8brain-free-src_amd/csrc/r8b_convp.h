@@ -154,7 +154,7 @@ R8B_HD constexpr int bmap_c(int d)
 // segment starts at 0, an array is NA * 16 bytes), so the XOR may be applied to the address itself -- which also keeps
 // the compiler from adding the segment's base (a late constant it does not fold) to every access.  The host emulation
 // (tests/emul) has no such alignment and XORs the offset.
-#ifdef R8B_LDS_ABS
+#if defined(R8B_LDS_ABS) && defined(__HIP_DEVICE_COMPILE__) // (the host pass of hipcc compiles the other form, never runs it)
 typedef __attribute__((address_space(3))) cd lds_cd_t;
 struct SwBase { unsigned a; };
 R8B_HD SwBase sw_base(const cd* buf, int slot0)
@@ -1090,8 +1090,10 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const SpanInfo& Bm, const cd
 						else v[(c + 1) & 1][i] = w[CH * (c + 1) + i];
 					}
 				}
+				// (last pair of the chunk first: LDS returns in order, so the wait in front of its multiply-adds covers
+				// the whole chunk -- one wait instruction per chunk instead of one per pair)
 #pragma unroll
-				for (int i = 0; i < CH; i++)
+				for (int i = CH - 1; i >= 0; i--)
 				{
 					const int t = CH * c + i;
 					a0[t & 1] += rows[t] * v[c & 1][i].re;
@@ -1100,14 +1102,15 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const SpanInfo& Bm, const cd
 					b1[t & 1] += rows[T2 + t] * v[c & 1][i].im;
 				}
 			}
-			const int o = out_step * gl;
+			// (uniform row pointer + one 32-bit index: no 64-bit address arithmetic per store)
+			const unsigned o = (unsigned) (out_step * gl + 2 * q);
 			cd va, vb;
 			va.re = a0[0] + a0[1];
 			va.im = a1[0] + a1[1];
 			vb.re = b0[0] + b0[1];
 			vb.im = b1[0] + b1[1];
-			*reinterpret_cast<cd*>(pa + o) = va;
-			if (bvalid) *reinterpret_cast<cd*>(pb + o) = vb;
+			*reinterpret_cast<cd*>(pa0 + o) = va;
+			if (bvalid) *reinterpret_cast<cd*>(pb0 + o) = vb;
 		}
 		return;
 	}

@@ -599,31 +599,33 @@ template<int LN, int UL, int MODE, int FLENP>
 __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) > 256 ? 1 : 2)) void k_convp(const ConvxLaunch X)
 {
 	extern __shared__ __align__(256) unsigned char smem[];
-	// XCD-aware mapping as in k_convx, over channel PAIRS and groups of SUB consecutive blocks
+	// XCD-aware mapping as in k_convx, over channel PAIRS and groups of SUB consecutive blocks: item w of a launch
+	// is block group bg of channel pair pr
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
-	const unsigned w = blockIdx.x, npair = ((unsigned) X.c.nch + 1u) >> 1;
+	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
 	const unsigned nbg = ((unsigned) X.c.nblk + SUB - 1u) / SUB;
-	unsigned bg, pr;
-	if (nbg == 1)
+	unsigned w = blockIdx.x;
+	auto decode = [&](unsigned wi, unsigned& bg, unsigned& pr)
 	{
-		bg = 0;
-		pr = w;
-	}
-	else if ((npair & 7u) == 0)
-	{
-		const unsigned i = w >> 3, qd = convp_div(i, X.nblk_magic);
-		bg = i - qd * nbg;
-		pr = (qd << 3) + (w & 7u);
-	}
-	else
-	{
-		pr = convp_div(w, X.nblk_magic);
-		bg = w - pr * nbg;
-	}
-	bg = (unsigned) __builtin_amdgcn_readfirstlane((int) bg);
-	pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
-	const int chA = (int) (2u * pr);
-	const bool bvalid = chA + 1 < X.c.nch;
+		if (nbg == 1)
+		{
+			bg = 0;
+			pr = wi;
+		}
+		else if ((npair & 7u) == 0)
+		{
+			const unsigned i = wi >> 3, qd = convp_div(i, X.nblk_magic);
+			bg = i - qd * nbg;
+			pr = (qd << 3) + (wi & 7u);
+		}
+		else
+		{
+			pr = convp_div(wi, X.nblk_magic);
+			bg = wi - pr * nbg;
+		}
+		bg = (unsigned) __builtin_amdgcn_readfirstlane((int) bg);
+		pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
+	};
 	if constexpr ((R8B_ABL & 2048) != 0)
 	{
 		// (timing ablation, bit 11: what dispatching the grid costs -- every workgroup ends at once)
@@ -631,13 +633,6 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 		return;
 	}
 	GpuExecP<LN, UL> ex(smem);
-	ConvpItem cur;
-	const int b0 = (int) bg * SUB;
-	cur.k = X.c.k0 + b0;
-	cur.nvalid = X.c.nblk - b0 < SUB ? X.c.nblk - b0 : SUB;
-	cur.chA = chA;
-	cur.chB = bvalid ? chA + 1 : chA;
-	cur.bvalid = bvalid;
 	// Kernel arguments live in memory: left to itself the compiler fetches each one where it is first needed --
 	// chains of dependent scalar loads at the start of the workgroup (measured: 3 300 cycles before the first sample
 	// load is issued) and one more load in front of most phases, whose wait is a wait on the LDS counter too, i.e. a
@@ -650,29 +645,100 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	H.table = X.table; H.wtab = X.wtab; H.wa = X.wa; H.wb = X.wb; H.wdst = X.wdst;
 	H.run_off = X.run_off; H.ptab = X.ptab; H.ctab = X.ctab; H.nsets = X.nsets;
 	H.nblk_magic = X.nblk_magic;
-	// (integers are made opaque -- "+s" --, pointers are only USED here -- "s" --: a pointer that went through an asm
-	// output loses its kernel-argument provenance and would be dereferenced with flat instructions)
-	asm volatile("" : "+s"(H.c.k0), "+s"(H.c.blk_stride), "+s"(H.c.blk_offset), "+s"(H.c.in_len), "+s"(H.c.fl2),
-		"+s"(H.c.up_pow2), "+s"(H.c.src.cur_stride), "+s"(H.c.src.cur_base), "+s"(H.c.src.cur_fmt)
-		: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
-	if constexpr (MODE == 4 || MODE == 5)
-		asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),
-			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt) : "s"(H.ptab), "s"(H.ctab), "s"(H.wdst.p));
-	else if constexpr (MODE == 1) {}
-	else
-		asm volatile("" : "+s"(H.c.a), "+s"(H.c.b), "+s"(H.c.dst.stride), "+s"(H.c.dst.mask), "+s"(H.c.dst.off),
-			"+s"(H.c.dst.fmt), "+s"(H.c.down), "+s"(H.c.down_pow2), "+s"(H.c.up) : "s"(H.c.dst.p));
 	ex.stamp();
-	// (MODE 1 -- one phase per thread -- already fills the scalar file with its span bookkeeping: it reads the
-	// arguments where it needs them, as before)
-	if constexpr (MODE == 1) convp_body<LN, UL, MODE, FLENP>(ex, X, X, reinterpret_cast<cd*>(smem), cur);
-	else convp_body<LN, UL, MODE, FLENP>(ex, H, X, reinterpret_cast<cd*>(smem), cur);
+	// Persistent form (X.qcnt != null; launch_convp_t): the grid is what the chip holds at once and a workgroup that has
+	// finished an item takes the next one from the work queue of its XCD -- items 8 j + x, j = 0, 1, ..., for the
+	// workgroups with blockIdx mod 8 = x (the dispatcher deals workgroups to the XCDs round robin; the blocks of a channel
+	// pair stay on one XCD's L2 as in the one-item form) -- and, once that is empty, from the other XCDs' queues.  No
+	// workgroup start-up between items (arguments, descriptors, LDS allocation: the slot of a finished workgroup stays
+	// empty for thousands of cycles), and the load balances itself.  The request for the next item goes out before the
+	// current one is processed; the last workgroup to leave zeroes the counters for the next launch.
+	unsigned* const qc = X.qcnt;
+	const unsigned total = nbg * npair;
+	const unsigned xq = blockIdx.x & 7u, nper = gridDim.x >> 3;
+	for (;;)
+	{
+		// (the thread index is made opaque per item: nothing derived from it -- LDS addresses, table offsets -- is
+		// carried around the loop in registers the phases need)
+		{
+			int t = (int) threadIdx.x;
+			asm volatile("" : "+v"(t));
+			ex.tid_ = t;
+		}
+		// (per item, so that nothing derived from them is carried around the loop either; integers are made opaque -- "+s" --, pointers are only USED here -- "s" --: a pointer that went through an asm
+		// output loses its kernel-argument provenance and would be dereferenced with flat instructions)
+		asm volatile("" : "+s"(H.c.k0), "+s"(H.c.blk_stride), "+s"(H.c.blk_offset), "+s"(H.c.in_len), "+s"(H.c.fl2),
+			"+s"(H.c.up_pow2), "+s"(H.c.src.cur_stride), "+s"(H.c.src.cur_base), "+s"(H.c.src.cur_fmt), "+s"(H.c.rot),
+			"+s"(H.c.fl2r)
+			: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
+		if constexpr (MODE == 4 || MODE == 5)
+			asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),
+				"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt) : "s"(H.ptab), "s"(H.ctab), "s"(H.wdst.p));
+		else if constexpr (MODE == 1) {}
+		else
+			asm volatile("" : "+s"(H.c.a), "+s"(H.c.b), "+s"(H.c.dst.stride), "+s"(H.c.dst.mask), "+s"(H.c.dst.off),
+				"+s"(H.c.dst.fmt), "+s"(H.c.down), "+s"(H.c.down_pow2), "+s"(H.c.up) : "s"(H.c.dst.p));
+		unsigned bg, pr;
+		decode(w, bg, pr);
+		unsigned nxt = 0;
+		if (qc != nullptr && threadIdx.x == 0) nxt = atomicAdd(qc + xq, 1u);
+		const int chA = (int) (2u * pr);
+		const bool bvalid = chA + 1 < X.c.nch;
+		ConvpItem cur;
+		const int b0 = (int) bg * SUB;
+		cur.k = X.c.k0 + b0;
+		cur.nvalid = X.c.nblk - b0 < SUB ? X.c.nblk - b0 : SUB;
+		cur.chA = chA;
+		cur.chB = bvalid ? chA + 1 : chA;
+		cur.bvalid = bvalid;
+		// (MODE 1 -- one phase per thread -- already fills the scalar file with its span bookkeeping: it reads the
+		// arguments where it needs them, as before)
+		if constexpr (MODE == 1) convp_body<LN, UL, MODE, FLENP>(ex, X, X, reinterpret_cast<cd*>(smem), cur);
+		else convp_body<LN, UL, MODE, FLENP>(ex, H, X, reinterpret_cast<cd*>(smem), cur);
+		if (qc == nullptr) break;
+		if (threadIdx.x == 0)
+		{
+			unsigned wn = ((nxt + nper) << 3) + xq;
+			// own queue empty: the others', one after the other (each hands out an index past its end at most
+			// once per workgroup)
+			for (unsigned d = 1; wn >= total && d < 8u; d++)
+			{
+				const unsigned x2 = (xq + d) & 7u;
+				wn = ((atomicAdd(qc + x2, 1u) + nper) << 3) + x2;
+			}
+			ex.flags_[8] = wn;
+		}
+		// (also: every wave has left the item's last LDS reads behind before the next item's first pass writes)
+		lds_barrier();
+		w = (unsigned) __builtin_amdgcn_readfirstlane((int) ex.flags_[8]);
+		if (w >= total) break;
+	}
+	if (qc != nullptr && threadIdx.x == 0)
+	{
+		if (atomicAdd(qc + 8, 1u) == gridDim.x - 1u)
+		{
+#pragma unroll
+			for (int i = 0; i < 9; i++) atomicExch(qc + i, 0u);
+		}
+	}
 #ifdef R8B_CP_STAMPS
 	// (how long the workgroup's last stores take to be acknowledged: the slot stays occupied until then)
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	ex.stamp();
 #endif
 	ex.dump();
+}
+
+// workgroups of a pair kernel the device holds at once, rounded down to a multiple of 8 (0: unknown)
+unsigned convp_capacity(const void* kern, int threads, size_t lds)
+{
+	int dev = 0, cus = 0, per = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return 0;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, threads, lds) != hipSuccess) return 0;
+	if (const char* e = getenv("R8B_PERSIST_PER_CU")) per = atoi(e); // (development: occupancy experiments)
+	const long long n = (long long) cus * per;
+	return n > 0 ? (unsigned) (n & ~7ll) : 0u;
 }
 
 template<int LN, int UL, int MODE, int FLENP>
@@ -693,7 +759,13 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 #endif
 	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
 	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
-	hipLaunchKernelGGL(kern, dim3(nbg * npair), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
+	unsigned grid = nbg * npair;
+	// persistent form: as many workgroups as the chip holds at once (a multiple of 8, the XCDs), when the launch has
+	// at least twice as many items; the shorter ones keep one workgroup per item
+	static const unsigned capacity = convp_capacity(reinterpret_cast<const void*>(kern), ConvpGeom<LN, UL>::WT, lds);
+	if (X.qcnt != nullptr && capacity >= 8u && grid >= 2u * capacity) grid = capacity;
+	else X.qcnt = nullptr;
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
 	}
 }
