@@ -202,6 +202,12 @@ def main():
                          "same JSON line (with its own roofline block) for each")
     ap.add_argument("--tb", type=float, default=2.0, help="transition band, percent (side runs)")
     ap.add_argument("--atten", type=float, default=180.15, help="stop-band attenuation (side runs)")
+    ap.add_argument("--settle", type=int, default=60,
+                    help="untimed calls between the first timed window and the reported one (0: report the first window). "
+                         "After an idle gap the board's power controller answers the load step with a clock dip that lasts "
+                         "about 40 calls of this batch (DESIGN.md section 5): a 5 + 20 call window lies inside it. The line "
+                         "reports the K steps timed after the clock has settled as `value` and the K steps timed straight "
+                         "after the W warm-up calls as `first_window`, both bracketed the same way")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--e2e", action="store_true",
                     help="side measurement (SURVEY.md 8e): the whole batch lives on rank 0; every step "
@@ -331,20 +337,33 @@ def main():
                "out_samples_per_step": int(got[-1].shape[1]) if rank == 0 and got else None}
         del got
 
+    def timed(k0):
+        barrier()
+        t0 = time.perf_counter()
+        n = run(k0, args.steps)
+        barrier()
+        d = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([d], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        return n, d
+
     run(0, args.warmup, capture=not args.pcm and not args.no_cpu and world == 1)
-    barrier()
-    t0 = time.perf_counter()
-    n_out = run(args.warmup, args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    n_out, dt = timed(args.warmup)
+    first_window = None
+    if args.settle > 0:
+        # the same K steps once more after `settle` further untimed calls (the stream simply continues)
+        first_window = {"ms_per_step": round(dt / args.steps * 1e3, 4),
+                        "value": round(C * L * args.steps * world / dt / 1e6, 3),
+                        "what": "the %d steps timed straight after the %d warm-up calls (inside the power "
+                                "controller's response to the load step when the GPU was idle before)" % (args.steps, args.warmup)}
+        run(args.warmup + args.steps, args.settle)
+        n_out, dt = timed(args.warmup + args.steps + args.settle)
 
     # second pass, same steps, with per-kernel HIP events (kept out of the headline timing)
     rs.set_option("timing", 1)
-    run(args.warmup + args.steps, args.steps)
+    run(args.warmup + 2 * args.steps + args.settle, args.steps)
     torch.cuda.synchronize()
     timings = rs.stage_timings()
     rs.set_option("timing", 0)
@@ -389,6 +408,9 @@ def main():
                          "path_frac": round(path_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                                             4)},
         }
+        if first_window is not None:
+            res["settle_calls"] = args.settle
+            res["first_window"] = first_window
         if e2e is not None:
             # (kernel-only = the line's own `value`: shards at rest; end-to-end beside it)
             res["e2e"] = e2e

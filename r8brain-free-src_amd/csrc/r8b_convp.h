@@ -40,6 +40,7 @@
 #ifndef R8B_CONVP_H
 #define R8B_CONVP_H
 
+#include <cstdlib>
 #include "r8b_convx.h"
 
 // R8B_ABL (development builds only, tools/variant.sh: timing ablations, results are wrong): bit 0 no interpolator,
@@ -48,6 +49,16 @@
 // bit 6 convolver-only modes without their stores, bit 7 twiddles / bit 8 kernel constants / bit 9 interpolator rows without table fetches
 #ifndef R8B_ABL
 #define R8B_ABL 0
+#endif
+
+// R8B_PRIO(i) (development: -DR8B_PRIOS=abc sets the wave priority to a / b / c at the start of an item / before the
+// last backward pass / before the interpolator; nothing otherwise)
+#ifndef R8B_PRIO
+#define R8B_PRIO(i)
+#endif
+// R8B_FORCE4: the four values are computed HERE (device: an empty asm statement that reads them)
+#ifndef R8B_FORCE4
+#define R8B_FORCE4(a, b, c, d)
 #endif
 
 namespace r8bhip {
@@ -1010,29 +1021,31 @@ R8B_HD void cp_whole_compute(const ConvxLaunch& X, const SpanInfo& B, const cd* 
 // computed whole and masked at the store (slots outside the run hold finite transform data).
 // MODE 5: the same with In > Out (down-sampling interpolators, cfg3: 320 / 147): the windows of adjacent
 // phases start 2 or 3 samples apart, the rows have 27 entries, 27 reads feed four outputs.
-template<int T2>
-R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int* pt, int tid)
+R8B_HD int cp_ptab_fetch(const ConvxLaunch& X, int tid)
 {
-	// (the tables are laid out for 256 lanes: in a 512-thread workgroup the upper half sits this phase out)
-	if (tid >= kConvpThreads)
-	{
-		*pt = -1;
-		return;
-	}
-	*pt = X.ptab[tid];
+	// (the tables are laid out for 256 lanes: in a 512-thread workgroup the upper half sits the interpolator out)
+	return tid < kConvpThreads ? X.ptab[tid] : -1;
+}
+
+template<int T2>
+R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int pt)
+{
 	if constexpr ((R8B_ABL & 512) != 0)
 	{
 #pragma unroll
-		for (int i = 0; i < 2 * T2; i++) rows[i] = 0.01 * i + 1e-3 * tid;
+		for (int i = 0; i < 2 * T2; i++) rows[i] = 0.01 * i + 1e-3 * pt;
 		return;
 	}
-	// X.ctab holds the 2 T2 values of a thread as T2 pairs, pair i of thread t at [(i * 256 + t) * 2]: a
-	// wave reads 64 consecutive 16-byte entries per load
-	const cd* ct = reinterpret_cast<const cd*>(X.ctab) + tid;
+	// X.ctab holds the 2 T2 values of a phase pair as T2 pairs, pair i of phase pair q at [(i * ctp + q) * 2], ctp = the
+	// number of phase pairs rounded up to whole quads: a lane quad reads 64 consecutive bytes, and the lanes of other
+	// sets with the same phase pairs find them in the CU's cache (idle lanes read pair 0)
+	const int q = pt < 0 ? 0 : pt & 0xff;
+	const int ctp = (((X.out_step + 1) >> 1) + 3) & ~3;
+	const cd* ct = reinterpret_cast<const cd*>(X.ctab) + q;
 #pragma unroll
 	for (int i = 0; i < T2; i++)
 	{
-		const cd v = ct[i * kConvpThreads];
+		const cd v = ct[i * ctp];
 		rows[2 * i] = v.re;
 		rows[2 * i + 1] = v.im;
 	}
@@ -1102,6 +1115,9 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const SpanInfo& Bm, const cd
 					b1[t & 1] += rows[T2 + t] * v[c & 1][i].im;
 				}
 			}
+			// (channel B's sums are only stored under a uniform condition: without this the compiler moves their
+			// multiply-adds behind it, away from the LDS reads they should overlap, and keeps the whole window live)
+			R8B_FORCE4(b0[0], b0[1], b1[0], b1[1]);
 			// (uniform row pointer + one 32-bit index: no 64-bit address arithmetic per store)
 			const unsigned o = (unsigned) (out_step * gl + 2 * q);
 			cd va, vb;
@@ -1133,8 +1149,9 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const SpanInfo& Bm, const cd
 #pragma unroll
 				for (int i = 0; i < CH; i++) v[(c + 1) & 1][i] = w[CH * (c + 1) + i];
 			}
+			// (the same order of additions as the loop above: an output must not depend on which loop produced it)
 #pragma unroll
-			for (int i = 0; i < CH; i++)
+			for (int i = CH - 1; i >= 0; i--)
 			{
 				const int t = CH * c + i;
 				a0[t & 1] += rows[t] * v[c & 1][i].re;
@@ -1241,6 +1258,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	};
 	ex.phase([&](int tid, St& st)
 	{
+		R8B_PRIO(0);
 		const int lt = lt_of(tid);
 		// (the first pass's twiddles -- L2 -- requested ahead of the samples -- HBM --, not behind their wait)
 		ptw_fetch<G::E1, G::NT>(st.tw, L.ptw, 0, lt);
@@ -1250,6 +1268,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.post_bits(tid, cp_nonzero_bits<LN, UL>(st));
 		ex.stamp2();
 		if constexpr (!(R8B_ABL & 16)) cp_first<LN, UL>(L, buf_of(tid), st, lt);
+		// (modes 4 / 5: the thread's entry of the interpolator's lane table, long before its rows are addressed with it)
+		if constexpr (MODE == 4 || MODE == 5) st.pt = cp_ptab_fetch(X, tid);
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
 		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
 	});
@@ -1415,10 +1435,11 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		static_assert(UL >= 0, "the decimating form has no fused interpolator");
 		ex.phase([&](int tid, St& st)
 		{
+			R8B_PRIO(1);
 			if constexpr ((R8B_ABL & 4) != 0) {}
 			else if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
 			else cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
-			cp_rows2_fetch<T2>(X, st.rows2, &st.pt, tid);
+			cp_rows2_fetch<T2>(X, st.rows2, st.pt);
 		});
 		ex.phase([&](int tid, St& st)
 		{
@@ -1428,6 +1449,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		// the interpolator: all 256 threads over the run of one block pair after the other
 		if constexpr (!(R8B_ABL & 1)) ex.each([&](int, St& st)
 		{
+			R8B_PRIO(2);
 			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
 				cp_whole2_compute<T2>(X, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
 		});
@@ -1473,7 +1495,7 @@ inline void convp_prepare(ConvxLaunch& X)
 	X.c.fl2r = X.c.fl2;
 	if constexpr (UL >= 0)
 	{
-		if (X.c.up_pow2 && X.c.up == (1 << (UL > 0 ? UL : 0)))
+		if (X.c.up_pow2 && X.c.up == (1 << (UL > 0 ? UL : 0)) && getenv("R8B_NO_ROT") == nullptr)
 		{
 			constexpr int N = ConvpGeom<LN, UL>::N;
 			X.c.rot = (N - ((X.c.fl2 / X.c.up) & (N - 1))) & (N - 1);

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <mutex>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
@@ -589,7 +590,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// ... with two adjacent phases per thread in the fused interpolator when it up-samples (In <= Out:
 	// half the LDS reads per output, nearly all lanes busy)
 	opt_["pair_two"] = 1;
-	opt_["persist"] = 1; // pair kernel: launches with more items than the chip holds at once run as persistent workgroups on work queues
+	opt_["persist"] = 0; // pair kernel: launches with more items than the chip holds at once as persistent workgroups on work queues (needs a build with -DR8B_PERSIST_LOOP; measured slower)
 	opt_["align_groups"] = 1; // ... with whole output groups per block (launch_fused)
 	opt_["fold_tail"] = 1; // fast convolver at stage 0 keeps the input history itself
 	// a constructor that throws half way must not leak what it has already put on the device
@@ -724,82 +725,125 @@ void Engine::prepare_two_phase(size_t s)
 	for (int q = 0; 2 * q + 1 < Out; q++) maxdl = std::max(maxdl, r_of(2 * q + 1) - r_of(2 * q));
 	if (maxdl > 3) return;
 	const int T2 = maxdl <= 1 ? 25 : 27;
-	// Phase pairs go to lanes in QUADS: the four lanes of an aligned lane quad own four consecutive phase pairs, i.e.
-	// store 64 consecutive bytes of a channel's output per group (one L2 write request per quad; assigned pair by
-	// pair, the 16-byte pieces of a store instruction were scattered over the whole group: 19 bytes per request
-	// measured).  The quads are dealt to the 16-lane LDS service groups (four lane quads each) such that the window
-	// starts inside a group fall into different 16-byte bank groups (start mod 16) as far as the counts allow: a
-	// deterministic local search over quad swaps between groups (cfg2: 5 clashes among 80 windows -- dealing single
-	// pairs reaches 4, the residues are not evenly populated).
-	const int NQ = (NP + 3) / 4;
-	std::vector<std::vector<int>> grp((size_t) nsg); // data quads of each service group, in lane-quad order
-	auto quad_cost = [&](const std::vector<int>& g)
+	// Phase pairs go to lanes in QUADS: the four lanes of an aligned lane quad own four consecutive phase pairs of one
+	// group set, i.e. store 64 consecutive bytes of a channel's output per group (one L2 write request per quad;
+	// assigned pair by pair, the 16-byte pieces of a store instruction were scattered over the whole group: 19 bytes
+	// per request measured).  A workgroup has 16 LDS service groups of four lane quads each (the 16 lanes LDS serves
+	// in one cycle of a 16-byte read), and a service group takes as many cycles as its most crowded 16-byte bank
+	// group: ONE pair of windows starting in the same bank group (start mod 16) doubles the time of all its reads.
+	// The (data quad, set) items -- NQ x nsets <= 64 -- are therefore dealt to the 64 (service group, lane quad)
+	// slots such that as few service groups as possible hold a clash.  Items of DIFFERENT sets may share a service
+	// group (a set shifts the window starts by In mod 16), and slots may stay empty: with both freedoms cfg2 comes to
+	// 2 clashing service groups of 16, where set-by-set dealing left one clash in every group (7.5 LDS cycles per read
+	// instead of 4; counters: bank conflicts 30 % of the LDS cycles).  Deterministic annealing over slot swaps (fixed
+	// seed: the same tables for the same ratio, always).
+	const int NQ = (NP + 3) / 4, NI = NQ * nsets;
+	std::vector<int> slot_item(64, -1); // [service group * 4 + rank] -> item = set * NQ + data quad
+	// (the table depends on the ratio alone: searched once per process and ratio)
+	static std::mutex cache_mutex;
+	static std::map<std::pair<int, int>, std::vector<int>> cache;
+	bool cached = false;
 	{
-		int cnt[16] = { 0 }, c = 0;
-		for (int dq : g)
-			for (int i = 0; i < 4 && 4 * dq + i < NP; i++)
-				if (cnt[r_of(2 * (4 * dq + i)) & 15]++) c++;
-		return c;
-	};
-	{
-		// (several deterministic starts -- quad dq to group (dq * mul + rot) mod nsg --, each improved by swaps)
-		int best_cost = -1;
-		std::vector<std::vector<int>> cur((size_t) nsg);
-		for (int start = 0; start < 4 * nsg && best_cost != 0; start++)
+		std::lock_guard<std::mutex> lock(cache_mutex);
+		auto it = cache.find(std::make_pair(In, Out));
+		if (it != cache.end())
 		{
-			for (auto& g : cur) g.clear();
-			const int mul = 1 + start / nsg, rot = start % nsg;
-			std::vector<int> fill((size_t) nsg, 0);
-			for (int dq = 0; dq < NQ; dq++)
-			{
-				int g = (dq * mul + rot) % nsg;
-				while ((int) cur[(size_t) g].size() >= 4) g = (g + 1) % nsg;
-				cur[(size_t) g].push_back(dq);
-			}
-			for (bool improved = true; improved;)
-			{
-				improved = false;
-				for (int a = 0; a < nsg; a++)
-					for (int b = a + 1; b < nsg; b++)
-						for (size_t i = 0; i < cur[(size_t) a].size(); i++)
-							for (size_t j = 0; j < cur[(size_t) b].size(); j++)
-							{
-								const int before = quad_cost(cur[(size_t) a]) + quad_cost(cur[(size_t) b]);
-								std::swap(cur[(size_t) a][i], cur[(size_t) b][j]);
-								if (quad_cost(cur[(size_t) a]) + quad_cost(cur[(size_t) b]) < before) improved = true;
-								else std::swap(cur[(size_t) a][i], cur[(size_t) b][j]);
-							}
-			}
-			int c = 0;
-			for (const auto& g : cur) c += quad_cost(g);
-			if (best_cost < 0 || c < best_cost)
-			{
-				best_cost = c;
-				grp = cur;
-			}
+			slot_item = it->second;
+			cached = true;
 		}
-		if (std::getenv("R8B_DEBUG_TWO")) fprintf(stderr, "two-phase tables: %d phase pairs in %d quads, %d service groups x %d sets, %d bank clashes\n", NP, NQ, nsg, nsets, best_cost);
+	}
+	if (!cached)
+	{
+		auto res_of = [&](int item, int j) // bank group of the window start of pair j of the item (-1: no such pair)
+		{
+			const int dq = item % NQ, set = item / NQ, q = 4 * dq + j;
+			return q < NP ? (int) ((r_of(2 * q) + (long long) In * set) & 15) : -1;
+		};
+		auto sg_cost = [&](const int* sl) // clashes of one service group
+		{
+			int cnt[16] = { 0 }, c = 0;
+			for (int k = 0; k < 4; k++)
+				if (sl[k] >= 0)
+					for (int j = 0; j < 4; j++)
+					{
+						const int r = res_of(sl[k], j);
+						if (r >= 0 && cnt[r]++) c++;
+					}
+			return c;
+		};
+		// start: set by set, data quads in order
+		for (int i = 0; i < NI; i++)
+		{
+			const int set = i / NQ, dq = i % NQ;
+			slot_item[(size_t) ((set * nsg + dq / 4) * 4 + dq % 4)] = i;
+		}
+		auto total = [&]()
+		{
+			int c = 0;
+			for (int g = 0; g < 16; g++) c += sg_cost(&slot_item[(size_t) g * 4]);
+			return c;
+		};
+		std::vector<int> best = slot_item;
+		int cur = total(), best_cost = cur;
+		unsigned long long rng = 0x9E3779B97F4A7C15ull;
+		auto next = [&]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (unsigned) (rng >> 33); };
+		double temp = 1.0;
+		for (int it = 0; it < 250000 && best_cost > 0; it++)
+		{
+			const int a = (int) (next() % 64u), b = (int) (next() % 64u);
+			if (a / 4 == b / 4 || (slot_item[(size_t) a] < 0 && slot_item[(size_t) b] < 0)) continue;
+			int* ga = &slot_item[(size_t) (a / 4) * 4];
+			int* gb = &slot_item[(size_t) (b / 4) * 4];
+			const int before = sg_cost(ga) + sg_cost(gb);
+			std::swap(slot_item[(size_t) a], slot_item[(size_t) b]);
+			const int after = sg_cost(ga) + sg_cost(gb);
+			bool keep = after <= before;
+			if (!keep)
+			{
+				// (accept a worse state with probability exp(-(after - before) / temp))
+				const double u = (next() & 0xffffff) / 16777216.0;
+				keep = u < std::exp(-(after - before) / temp);
+			}
+			if (keep) cur += after - before;
+			else std::swap(slot_item[(size_t) a], slot_item[(size_t) b]);
+			if (cur < best_cost)
+			{
+				best_cost = cur;
+				best = slot_item;
+			}
+			temp = std::max(0.05, temp * 0.99998);
+		}
+		slot_item = best;
+		{
+			std::lock_guard<std::mutex> lock(cache_mutex);
+			cache[std::make_pair(In, Out)] = slot_item;
+		}
+		if (std::getenv("R8B_DEBUG_TWO")) fprintf(stderr, "two-phase tables: %d phase pairs in %d quads x %d sets, %d bank clashes over the 16 service groups\n", NP, NQ, nsets, best_cost);
 	}
 	// lanes LDS serves together for 16-byte reads (MI355X_MICROARCH.md, LDS): within each half of a
 	// wave the quads {0, 3, 5, 6} and {1, 2, 4, 7}
 	std::vector<int> pt(256, -1);
-	std::vector<double> ct((size_t) 2 * T2 * 256, 0.0);
+	const int ctp = (NP + 3) & ~3;
+	std::vector<double> ct((size_t) 2 * T2 * ctp, 0.0);
 	const std::vector<double>& T = w.bank->table;
 	for (int t = 0; t < 256; t++)
 	{
 		const int wave = t >> 6, lane = t & 63, half = lane >> 5, quad = (lane & 31) >> 2;
 		static const int cls_of[8] = { 0, 1, 1, 0, 1, 0, 0, 1 }, rank_of[8] = { 0, 0, 1, 1, 2, 2, 3, 3 };
 		const int sg = 4 * wave + 2 * half + cls_of[quad];
-		const int set = sg / nsg, g = sg % nsg;
-		if (set >= nsets || rank_of[quad] >= (int) grp[(size_t) g].size()) continue;
-		const int q = 4 * grp[(size_t) g][(size_t) rank_of[quad]] + (lane & 3);
+		const int item = slot_item[(size_t) (sg * 4 + rank_of[quad])];
+		if (item < 0) continue;
+		const int set = item / NQ;
+		const int q = 4 * (item % NQ) + (lane & 3);
 		if (q >= NP) continue;
 		pt[(size_t) t] = q | (set << 8) | (r_of(2 * q) << 12);
 		const int p0 = 2 * q, p1 = 2 * q + 1;
 		const int row0 = (int) (((long long) p0 * In) % Out);
-		// value v (0 .. 2 T2 - 1: the T2 taps of phase p0, then of p1 shifted by its window offset) of thread t
-		// sits in pair v / 2: ct[((v / 2) * 256 + t) * 2 + v % 2]
-		auto put = [&](int v, double x) { ct[((size_t) (v / 2) * 256 + t) * 2 + (v & 1)] = x; };
+		// value v (0 .. 2 T2 - 1: the T2 taps of phase p0, then of p1 shifted by its window offset) of phase PAIR q
+		// sits in pair v / 2: ct[((v / 2) * ctp + q) * 2 + v % 2], ctp = NP rounded up to whole quads.  Indexed by the
+		// pair, not by the thread: the lanes of the nsets sets that own the same pair read the same entries, and a
+		// workgroup pulls every row through L2 once instead of nsets times (cfg2: 34 KB instead of 102 KB per block).
+		auto put = [&](int v, double x) { ct[((size_t) (v / 2) * ctp + q) * 2 + (v & 1)] = x; };
 		for (int i = 0; i < w.flen; i++) put(i, T[(size_t) row0 * w.flen + i]);
 		if (p1 < Out)
 		{

@@ -76,6 +76,10 @@
 			"+v"(v[(N) - 2]), "+v"(v[(N) - 1])); \
 	}
 #endif
+#ifdef R8B_PRIOS
+#define R8B_PRIO(i) __builtin_amdgcn_s_setprio((i) == 0 ? (R8B_PRIOS / 100) % 10 : ((i) == 1 ? (R8B_PRIOS / 10) % 10 : R8B_PRIOS % 10))
+#endif
+#define R8B_FORCE4(a, b, c, d) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d))
 // nothing is scheduled across this point (no instruction is emitted)
 #ifndef R8B_NO_SCHED_FENCE
 #define R8B_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -653,9 +657,20 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	// workgroup start-up between items (arguments, descriptors, LDS allocation: the slot of a finished workgroup stays
 	// empty for thousands of cycles), and the load balances itself.  The request for the next item goes out before the
 	// current one is processed; the last workgroup to leave zeroes the counters for the next launch.
+#ifdef R8B_PERSIST_LOOP
 	unsigned* const qc = X.qcnt;
+#else
+	// (measured slower -- DESIGN.md section 5 --: compiled in by -DR8B_PERSIST_LOOP only; the loop runs once)
+	unsigned* const qc = nullptr;
+#endif
 	const unsigned total = nbg * npair;
 	const unsigned xq = blockIdx.x & 7u, nper = gridDim.x >> 3;
+	// Two workgroups share a CU (the dispatcher fills an XCD's CUs round robin: workgroups j and j + CUs-per-XCD of an
+	// XCD, j = blockIdx / 8).  Started together and given items of equal length they would stay in the SAME phase for
+	// the whole launch -- both in their memory phase, then both in their arithmetic --; the second one starts half an
+	// item late instead, so that one computes while the other waits.
+	if (qc != nullptr && (blockIdx.x >> 3) >= (nper >> 1))
+		for (unsigned i = 0, n = qc[9]; i < n; i++) __builtin_amdgcn_s_sleep(127); // (qc[9]: sleep periods of ~8 000 cycles, set by the launcher)
 	for (;;)
 	{
 		// (the thread index is made opaque per item: nothing derived from it -- LDS addresses, table offsets -- is
@@ -763,6 +778,14 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	// persistent form: as many workgroups as the chip holds at once (a multiple of 8, the XCDs), when the launch has
 	// at least twice as many items; the shorter ones keep one workgroup per item
 	static const unsigned capacity = convp_capacity(reinterpret_cast<const void*>(kern), ConvpGeom<LN, UL>::WT, lds);
+#ifndef R8B_PERSIST_LOOP
+	X.qcnt = nullptr;
+#endif
+	if (X.qcnt != nullptr)
+	{
+		static unsigned stagger = getenv("R8B_STAGGER") ? (unsigned) atoi(getenv("R8B_STAGGER")) : 2u;
+		check(hipMemcpyAsync(X.qcnt + 9, &stagger, sizeof(unsigned), hipMemcpyHostToDevice, stream), "stagger");
+	}
 	if (X.qcnt != nullptr && capacity >= 8u && grid >= 2u * capacity) grid = capacity;
 	else X.qcnt = nullptr;
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);

@@ -445,3 +445,23 @@ def test_emulated_process_rejects_overlapping_rows_and_null_pointers(emul):
         assert emul.r8b_last_error()
     with pytest.raises(Exception):
         r8b.BatchResampler(0, 0, 1024, nch=1, lib=emul, stage=(7, 0.0, 0.0, 0.0, 0.0, 0, 0))
+
+
+def test_emulated_paired_rows_equal_the_unpaired_row_bitwise(emul):
+    """identical data in every channel: the even rows of a batch (real halves of the pair kernel's transforms) equal
+    the row of a one-channel object BIT FOR BIT across calls -- whichever of the interpolator's loops (whole groups /
+    masked groups) and of the loaders (caller's buffer / history ring) produced an output.  (What
+    tests/cxx_batch.cpp checks on the GPU; an order of additions that differs between the two loops shows here.)"""
+    L = 2000
+    b5 = r8b.BatchResampler(44100.0, 96000.0, L, 2.0, 180.15, nch=5, lib=emul)
+    b1 = r8b.BatchResampler(44100.0, 96000.0, L, 2.0, 180.15, nch=1, lib=emul)
+    rng = np.random.default_rng(3)
+    for c in range(6):
+        x = rng.uniform(-1.0, 1.0, L)
+        y5 = b5.process_host(np.ascontiguousarray(np.tile(x, (5, 1))))
+        y1 = b1.process_host(x[None, :].copy())
+        assert y5.shape[1] == y1.shape[1]
+        for ch in (0, 2, 4):
+            assert np.array_equal(y5[ch], y1[0]), (c, ch)
+        for ch in (1, 3):
+            assert np.abs(y5[ch] - y1[0]).max() <= 4e-15, (c, ch)
