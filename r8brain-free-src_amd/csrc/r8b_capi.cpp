@@ -112,7 +112,9 @@ int batch_process_pcm(Batch* h, const void* d_in, int in_fmt, int in_interleaved
 	if (l == 0) return 0;
 	// Src == Dst has no stage to fuse into: both sides staged
 	const bool pass = e.plan().stages.empty();
-	const bool stage_in = in_interleaved || pass, stage_out = out_interleaved || pass;
+	// ... and so has a planar PCM side whose first / last stage is a compile-time-sized convolver (fp64 views only)
+	const bool stage_in = in_interleaved || pass || (in_fmt != kPcmF64 && !e.pcm_fused_in());
+	const bool stage_out = out_interleaved || pass || (out_fmt != kPcmF64 && !e.pcm_fused_out());
 	if (stage_in || stage_out) h->need_staging();
 	PcmLaunch P;
 	P.nch = e.channels();

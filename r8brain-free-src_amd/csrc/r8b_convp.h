@@ -1447,6 +1447,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_final_store<LN, UL>(L, buf_of(tid), buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
 		});
 		// the interpolator: all 256 threads over the run of one block pair after the other
+		ex.before_last_phase();
 		if constexpr (!(R8B_ABL & 1)) ex.each([&](int, St& st)
 		{
 			R8B_PRIO(2);

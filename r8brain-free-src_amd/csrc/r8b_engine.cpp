@@ -1668,6 +1668,25 @@ bool Engine::latency_chain() const
 	return false;
 }
 
+// PCM at the edges (Engine::process_planar): a streaming kernel or the generic convolver decodes / encodes planar PCM
+// caller buffers in place; the compile-time-sized convolvers (r8b_convx.h, r8b_convp.h) exist for fp64 views only --
+// r8b_kernels.hip, top -- and have the samples brought to them through the staging rows (r8b_capi.cpp).
+bool Engine::pcm_fused_in() const
+{
+	if (plan_.stages.empty()) return false;
+	const StagePlan& sp = plan_.stages[0];
+	return !(sp.desc.kind == kConv && conv_path(sp.cg) != kPathGeneric);
+}
+
+bool Engine::pcm_fused_out() const
+{
+	const size_t ns = plan_.stages.size();
+	if (ns == 0) return false;
+	if (ns >= 2 && fuse_with_next(ns - 2)) return false; // (convolver + whole-step interpolator as one fast-path kernel)
+	const StagePlan& sp = plan_.stages[ns - 1];
+	return !(sp.desc.kind == kConv && conv_path(sp.cg) != kPathGeneric);
+}
+
 bool Engine::fuse_with_next(size_t s) const
 {
 	if (latency_chain()) return false;

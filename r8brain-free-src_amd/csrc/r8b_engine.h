@@ -32,6 +32,9 @@ public:
 		long long out_stride, void* stream);
 	// the same with PLANAR buffers of PCM samples (PcmFormat; strides in samples), converted by
 	// the first stage's loads and the last stage's stores; needs at least one stage (Src != Dst)
+	// can the first / last stage of the chain take planar PCM caller buffers itself?
+	bool pcm_fused_in() const;
+	bool pcm_fused_out() const;
 	int process_planar(const void* d_in, int in_fmt, long long in_stride, int l, void* d_out,
 		int out_fmt, long long out_stride, void* stream);
 	void clear();

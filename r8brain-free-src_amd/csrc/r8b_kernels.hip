@@ -26,6 +26,29 @@
 #define R8B_LAUNCH(name) name##_f64
 #define R8B_NO_PCM_FUSE
 #endif
+// ... and, for the build's sake, in parts (Makefile: six compilations side by side instead of one of six minutes):
+//   -DR8B_TU_PAIR=k  the pair kernels (r8b_convp.h) of part k only -- the geometry lists R8B_CONVP_GEOMS* come from the
+//                    command line (with -DR8B_DEV_GEOMS) -- and their dispatcher launch_convp_part<k>_f64
+//   -DR8B_TU_NOPAIR=n everything else; launch_convp_f64 tries the n part dispatchers
+//   neither          one object with everything (development builds: tools/variant.sh, tools/isa_dev.sh)
+// The PCM twin carries the streaming kernels and the generic convolver only: a fast-path convolver at a PCM edge is
+// fed through the staging rows (r8b_capi.cpp batch_process_pcm, Engine::pcm_fused_in / _out), so the hundreds of
+// fast-path instantiations exist once.
+#if defined(R8B_TU_PAIR)
+#define R8B_HAS_REST 0
+#define R8B_HAS_PAIR 1
+#elif defined(R8B_TU_NOPAIR)
+#define R8B_HAS_REST 1
+#define R8B_HAS_PAIR 0
+#else
+#define R8B_HAS_REST 1
+#define R8B_HAS_PAIR 1
+#endif
+#ifdef R8B_PCM_VARIANT
+#define R8B_HAS_FAST 0
+#else
+#define R8B_HAS_FAST 1
+#endif
 
 #define R8B_HD __device__ __forceinline__
 // r8b_convp.h: pass addresses as absolute LDS byte addresses (its arrays start on multiples of 256 bytes)
@@ -113,6 +136,7 @@ void lds_opt_in(const void* fn, const char* what)
 	done.insert(std::make_pair(fn, dev));
 }
 
+#if R8B_HAS_REST
 // ------------------------------------------------------------------ overlap-save block convolver
 // one workgroup = one FFT block of one channel, everything between the global load of the input
 // samples and the global store of the valid outputs stays in LDS
@@ -426,6 +450,8 @@ __global__ __launch_bounds__(256) void k_pcm_out(const PcmLaunch L)
 }
 #endif
 
+#endif // R8B_HAS_REST
+
 // ------------------------------------------------------------------ fast path (r8b_convx.h)
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory,
 // i.e. drains vmcnt before every barrier; the phases exchange data through LDS exclusively, and
@@ -437,6 +463,7 @@ __device__ __forceinline__ void lds_barrier()
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+#if R8B_HAS_REST && R8B_HAS_FAST
 template<int LOGN, int UPLOG>
 struct GpuExec
 {
@@ -507,6 +534,9 @@ __global__ __launch_bounds__(kConvxThreads, (LOGN + (UPLOG > 0 ? UPLOG : 0) >= 1
 	convx_body<LOGN, UPLOG, MODE, FLENP>(ex, X, reinterpret_cast<double*>(smem), X.c.k0 + blk, (int) ch);
 }
 
+#endif // R8B_HAS_REST && R8B_HAS_FAST
+
+#if R8B_HAS_PAIR && R8B_HAS_FAST
 // ------------------------------------------------------------------ fast path, pair form (r8b_convp.h)
 #ifdef R8B_CP_STAMPS
 __device__ long long g_cp_stamps[8 * 8 * 32];
@@ -527,6 +557,15 @@ struct GpuExecP
 	ConvpState<LN, UL> st;
 	int tid_ = (int) threadIdx.x;
 	unsigned* flags_; // one word per wave behind the array (r8b_convp.h kConvpFlagBytes)
+	// persistent form: the request for the next item (an atomic on a queue counter in device memory, microseconds of
+	// round trip) goes out in front of the item's last phase, which issues no loads: requested at the start of an item
+	// it sits in front of the sample loads in the in-order return queue and the first pass waits for it
+	unsigned* qreq_ = nullptr;
+	unsigned nxt_ = 0;
+	__device__ __forceinline__ void before_last_phase()
+	{
+		if (qreq_ != nullptr && threadIdx.x == 0) nxt_ = atomicAdd(qreq_, 1u);
+	}
 	__device__ __forceinline__ explicit GpuExecP(unsigned char* smem)
 		: flags_(reinterpret_cast<unsigned*>(smem + convp_array_bytes<LN, UL>())) {}
 	// workgroup-wide OR of a small bit set: every thread posts before a barrier, anybody collects after it
@@ -664,13 +703,46 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	unsigned* const qc = nullptr;
 #endif
 	const unsigned total = nbg * npair;
-	const unsigned xq = blockIdx.x & 7u, nper = gridDim.x >> 3;
-	// Two workgroups share a CU (the dispatcher fills an XCD's CUs round robin: workgroups j and j + CUs-per-XCD of an
-	// XCD, j = blockIdx / 8).  Started together and given items of equal length they would stay in the SAME phase for
-	// the whole launch -- both in their memory phase, then both in their arithmetic --; the second one starts half an
-	// item late instead, so that one computes while the other waits.
-	if (qc != nullptr && (blockIdx.x >> 3) >= (nper >> 1))
-		for (unsigned i = 0, n = qc[9]; i < n; i++) __builtin_amdgcn_s_sleep(127); // (qc[9]: sleep periods of ~8 000 cycles, set by the launcher)
+	// the XCD this workgroup runs on, from the hardware (the round-robin rule blockIdx mod 8 is the dispatcher's habit,
+	// not a guarantee); qc[10] counts the workgroups for which the rule did not hold (development statistics)
+	unsigned xq = blockIdx.x & 7u;
+	if (qc != nullptr)
+	{
+		unsigned xcc;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+		xcc &= 7u;
+		if (threadIdx.x == 0 && xcc != xq) atomicAdd(qc + 10, 1u);
+		xq = xcc;
+		// every item comes from the queues, the first one too
+		unsigned wn = 0xffffffffu;
+		if (threadIdx.x == 0)
+		{
+			wn = (atomicAdd(qc + xq, 1u) << 3) + xq;
+			for (unsigned d = 1; wn >= nbg * npair && d < 8u; d++)
+			{
+				const unsigned x2 = (xq + d) & 7u;
+				wn = (atomicAdd(qc + x2, 1u) << 3) + x2;
+			}
+		}
+		if (threadIdx.x == 0) ex.flags_[8] = wn;
+		lds_barrier();
+		w = (unsigned) __builtin_amdgcn_readfirstlane((int) ex.flags_[8]);
+		lds_barrier();
+		// (w < items: the launcher's grid is at most half the items, and an empty queue sends a workgroup to the others)
+	}
+	const unsigned nper = 0;
+#ifdef R8B_PERSIST_SPREAD
+	// Started together, given items of equal length, the workgroups of the whole CHIP stay in the same phase: every one
+	// loads its samples at the same moment, then none does -- the memory system sees bursts at a fraction of the duty
+	// cycle.  Start offsets spread evenly over one item's duration (R8B_PERSIST_SPREAD periods of 512 cycles at most).
+	if (qc != nullptr)
+		for (unsigned i = 0, n = ((blockIdx.x * 2654435761u) >> 16) % (unsigned) (R8B_PERSIST_SPREAD); i < n; i++)
+			__builtin_amdgcn_s_sleep(8);
+#endif
+#ifdef R8B_PERSIST_PRIO
+	// (development: one of the two workgroups of a CU always wins the issue arbitration)
+	if (qc != nullptr && (blockIdx.x >> 3) >= (gridDim.x >> 4)) __builtin_amdgcn_s_setprio(R8B_PERSIST_PRIO);
+#endif
 	for (;;)
 	{
 		// (the thread index is made opaque per item: nothing derived from it -- LDS addresses, table offsets -- is
@@ -695,8 +767,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 				"+s"(H.c.dst.fmt), "+s"(H.c.down), "+s"(H.c.down_pow2), "+s"(H.c.up) : "s"(H.c.dst.p));
 		unsigned bg, pr;
 		decode(w, bg, pr);
-		unsigned nxt = 0;
-		if (qc != nullptr && threadIdx.x == 0) nxt = atomicAdd(qc + xq, 1u);
+		if (qc != nullptr) ex.qreq_ = qc + xq;
 		const int chA = (int) (2u * pr);
 		const bool bvalid = chA + 1 < X.c.nch;
 		ConvpItem cur;
@@ -713,7 +784,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 		if (qc == nullptr) break;
 		if (threadIdx.x == 0)
 		{
-			unsigned wn = ((nxt + nper) << 3) + xq;
+			unsigned wn = ((ex.nxt_ + nper) << 3) + xq;
 			// own queue empty: the others', one after the other (each hands out an index past its end at most
 			// once per workgroup)
 			for (unsigned d = 1; wn >= total && d < 8u; d++)
@@ -783,8 +854,13 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 #endif
 	if (X.qcnt != nullptr)
 	{
-		static unsigned stagger = getenv("R8B_STAGGER") ? (unsigned) atoi(getenv("R8B_STAGGER")) : 2u;
-		check(hipMemcpyAsync(X.qcnt + 9, &stagger, sizeof(unsigned), hipMemcpyHostToDevice, stream), "stagger");
+		if (getenv("R8B_PERSIST_STATS"))
+		{
+			// (development: workgroups of the earlier launches whose XCD was not blockIdx mod 8)
+			unsigned v = 0;
+			check(hipMemcpy(&v, X.qcnt + 10, sizeof(unsigned), hipMemcpyDeviceToHost), "stats");
+			fprintf(stderr, "k_convp persistent: %u workgroups so far ran on an XCD other than blockIdx mod 8\n", v);
+		}
 	}
 	if (X.qcnt != nullptr && capacity >= 8u && grid >= 2u * capacity) grid = capacity;
 	else X.qcnt = nullptr;
@@ -793,6 +869,9 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	}
 }
 
+#endif // R8B_HAS_PAIR && R8B_HAS_FAST
+
+#if R8B_HAS_REST && R8B_HAS_FAST
 template<int LOGN, int UPLOG, int MODE, int FLENP>
 void launch_convx_t(const ConvxLaunch& X, hipStream_t stream)
 {
@@ -805,15 +884,20 @@ void launch_convx_t(const ConvxLaunch& X, hipStream_t stream)
 	check(hipGetLastError(), "launch k_convx");
 }
 
+#endif // R8B_HAS_REST && R8B_HAS_FAST
+
+#if R8B_HAS_REST
 void set_lds_attrs()
 {
 	lds_opt_in(reinterpret_cast<const void*>(k_conv), "hipFuncSetAttribute(k_conv)");
 	lds_opt_in(reinterpret_cast<const void*>(k_whole), "hipFuncSetAttribute(k_whole)");
 	lds_opt_in(reinterpret_cast<const void*>(k_hbdcascade), "hipFuncSetAttribute(k_hbdcascade)");
 }
+#endif // R8B_HAS_REST
 
 } // namespace
 
+#if R8B_HAS_REST
 void R8B_LAUNCH(launch_conv)(const ConvLaunch& L, void* stream)
 {
 	set_lds_attrs();
@@ -868,6 +952,17 @@ void R8B_LAUNCH(launch_hbdown)(const HBLaunch& L, void* stream)
 	check(hipGetLastError(), "launch k_hbdown");
 }
 
+#if !R8B_HAS_FAST
+// (the PCM twin has no fast-path convolvers: see the top of the file)
+void R8B_LAUNCH(launch_convx)(const ConvxLaunch&, int, void*)
+{
+	throw std::logic_error("launch_convx: a PCM view reached a fast-path convolver (it is fed through the staging rows)");
+}
+void R8B_LAUNCH(launch_convp)(const ConvxLaunch&, int, void*)
+{
+	throw std::logic_error("launch_convp: a PCM view reached a fast-path convolver (it is fed through the staging rows)");
+}
+#else
 void R8B_LAUNCH(launch_convx)(const ConvxLaunch& X, int mode, void* stream)
 {
 	int logn = 0;
@@ -900,8 +995,24 @@ void R8B_LAUNCH(launch_convx)(const ConvxLaunch& X, int mode, void* stream)
 #undef R8B_CONVX_DISPATCH
 	throw std::runtime_error("launch_convx: geometry not instantiated");
 }
+#endif // R8B_HAS_FAST
+#endif // R8B_HAS_REST
 
+#if R8B_HAS_FAST
+#if R8B_HAS_PAIR
+// the dispatcher over the pair kernels of this object: the whole set (one-object builds: throws when the geometry is
+// not among them), or part R8B_TU_PAIR of it (returns false then)
+#ifdef R8B_TU_PAIR
+#define R8B_PAIR_CAT2(a, b) a##b
+#define R8B_PAIR_CAT(a, b) R8B_PAIR_CAT2(a, b)
+#define R8B_PAIR_RET bool
+#define R8B_PAIR_DONE return true
+bool R8B_PAIR_CAT(launch_convp_part, R8B_TU_PAIR)(const ConvxLaunch& X, int mode, void* stream)
+#else
+#define R8B_PAIR_RET void
+#define R8B_PAIR_DONE return
 void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
+#endif
 {
 	int ln = 0;
 	while ((1 << ln) < X.c.n_in) ln++;
@@ -913,7 +1024,7 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 	if (ln == LN && up == (1 << UL) && mode == R8B_DEV_ONLY_MODE) \
 	{ \
 		launch_convp_t<LN, UL, R8B_DEV_ONLY_MODE, 24>(X, (hipStream_t) stream); \
-		return; \
+		R8B_PAIR_DONE; \
 	}
 #else
 #define R8B_CONVP_DISPATCH(LN, UL) \
@@ -927,7 +1038,7 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 		else if (mode == 5) launch_convp_t<LN, UL, 5, 24>(X, (hipStream_t) stream); \
 		else if (wide) launch_convp_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
 		else launch_convp_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
-		return; \
+		R8B_PAIR_DONE; \
 	}
 #endif
 	if (X.c.down_pow2 && X.c.down > 1)
@@ -939,11 +1050,15 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 			else if (mode == 6) launch_convp_t<LN, -DL, 6, 24>(X, (hipStream_t) stream); \
 			else if (mode == 7) launch_convp_t<LN, -DL, 7, 24>(X, (hipStream_t) stream); \
 			else launch_convp_t<LN, -DL, 0, 24>(X, (hipStream_t) stream); \
-			return; \
+			R8B_PAIR_DONE; \
 		}
 		R8B_CONVP_GEOMS_DOWN(R8B_CONVP_DISPATCH_DOWN)
 #undef R8B_CONVP_DISPATCH_DOWN
+#ifdef R8B_TU_PAIR
+		return false;
+#else
 		throw std::runtime_error("launch_convp: decimating geometry not instantiated");
+#endif
 	}
 #define R8B_CONVP_DISPATCH_BIG(LN, UL) \
 	if (ln == LN && up == (1 << UL)) \
@@ -956,14 +1071,33 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 		else if (mode == 5) launch_convp_t<LN, UL, 5, 24>(X, (hipStream_t) stream); \
 		else if (wide) launch_convp_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
 		else launch_convp_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
-		return; \
+		R8B_PAIR_DONE; \
 	}
 	R8B_CONVP_GEOMS_BIG(R8B_CONVP_DISPATCH_BIG)
 #undef R8B_CONVP_DISPATCH_BIG
 	R8B_CONVP_GEOMS(R8B_CONVP_DISPATCH)
 #undef R8B_CONVP_DISPATCH
+#ifdef R8B_TU_PAIR
+	return false;
+#else
+	throw std::runtime_error("launch_convp: geometry not instantiated");
+#endif
+}
+#else // !R8B_HAS_PAIR: the pair kernels live in R8B_TU_NOPAIR part objects
+#define R8B_PAIR_DECL(k) bool launch_convp_part##k(const ConvxLaunch& X, int mode, void* stream);
+R8B_PAIR_DECL(1) R8B_PAIR_DECL(2) R8B_PAIR_DECL(3) R8B_PAIR_DECL(4)
+#undef R8B_PAIR_DECL
+void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
+{
+	static_assert(R8B_TU_NOPAIR == 4, "the Makefile builds four pair-kernel parts");
+	if (launch_convp_part1(X, mode, stream) || launch_convp_part2(X, mode, stream) ||
+		launch_convp_part3(X, mode, stream) || launch_convp_part4(X, mode, stream)) return;
 	throw std::runtime_error("launch_convp: geometry not instantiated");
 }
+#endif // R8B_HAS_PAIR
+#endif // R8B_HAS_FAST
+
+#if R8B_HAS_REST
 
 void R8B_LAUNCH(launch_hbcascade)(const HBCascadeLaunch& L, void* stream)
 {
@@ -1145,5 +1279,6 @@ float dev_event_elapsed_ms(void* start, void* stop)
 	return ms;
 }
 #endif // !R8B_PCM_VARIANT
+#endif // R8B_HAS_REST
 
 } // namespace r8bhip

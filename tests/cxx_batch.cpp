@@ -80,7 +80,12 @@ int main()
 			for (int i = 0; i < n; i++)
 			{
 				const double d = out[(size_t) (ch * out_stride + i)] - ref[i];
-				if ((ch & 1) == 0 ? d != 0.0 : (d > 4e-15 || d < -4e-15)) return 5;
+				if ((ch & 1) == 0 ? d != 0.0 : (d > 4e-15 || d < -4e-15))
+				{
+					fprintf(stderr, "call %d, channel %d, output %d of %d: batch %.17g, single stream %.17g (difference %.3g)\n",
+						c, ch, i, n, out[(size_t) (ch * out_stride + i)], ref[i], d);
+					return 5;
+				}
 			}
 		printf("call %d: %d samples x %d channels equal\n", c, n, nch);
 	}
