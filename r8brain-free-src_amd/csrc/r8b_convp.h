@@ -51,11 +51,6 @@
 #define R8B_ABL 0
 #endif
 
-// R8B_PRIO(i) (development: -DR8B_PRIOS=abc sets the wave priority to a / b / c at the start of an item / before the
-// last backward pass / before the interpolator; nothing otherwise)
-#ifndef R8B_PRIO
-#define R8B_PRIO(i)
-#endif
 // R8B_FORCE4: the four values are computed HERE (device: an empty asm statement that reads them)
 #ifndef R8B_FORCE4
 #define R8B_FORCE4(a, b, c, d)
@@ -1258,7 +1253,6 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	};
 	ex.phase([&](int tid, St& st)
 	{
-		R8B_PRIO(0);
 		const int lt = lt_of(tid);
 		// (the first pass's twiddles -- L2 -- requested ahead of the samples -- HBM --, not behind their wait)
 		ptw_fetch<G::E1, G::NT>(st.tw, L.ptw, 0, lt);
@@ -1435,7 +1429,6 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		static_assert(UL >= 0, "the decimating form has no fused interpolator");
 		ex.phase([&](int tid, St& st)
 		{
-			R8B_PRIO(1);
 			if constexpr ((R8B_ABL & 4) != 0) {}
 			else if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
 			else cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
@@ -1450,7 +1443,6 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.before_last_phase();
 		if constexpr (!(R8B_ABL & 1)) ex.each([&](int, St& st)
 		{
-			R8B_PRIO(2);
 			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
 				cp_whole2_compute<T2>(X, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
 		});

@@ -99,9 +99,6 @@
 			"+v"(v[(N) - 2]), "+v"(v[(N) - 1])); \
 	}
 #endif
-#ifdef R8B_PRIOS
-#define R8B_PRIO(i) __builtin_amdgcn_s_setprio((i) == 0 ? (R8B_PRIOS / 100) % 10 : ((i) == 1 ? (R8B_PRIOS / 10) % 10 : R8B_PRIOS % 10))
-#endif
 #define R8B_FORCE4(a, b, c, d) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d))
 // nothing is scheduled across this point (no instruction is emitted)
 #ifndef R8B_NO_SCHED_FENCE
@@ -738,10 +735,6 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	if (qc != nullptr)
 		for (unsigned i = 0, n = ((blockIdx.x * 2654435761u) >> 16) % (unsigned) (R8B_PERSIST_SPREAD); i < n; i++)
 			__builtin_amdgcn_s_sleep(8);
-#endif
-#ifdef R8B_PERSIST_PRIO
-	// (development: one of the two workgroups of a CU always wins the issue arbitration)
-	if (qc != nullptr && (blockIdx.x >> 3) >= (gridDim.x >> 4)) __builtin_amdgcn_s_setprio(R8B_PERSIST_PRIO);
 #endif
 	for (;;)
 	{
