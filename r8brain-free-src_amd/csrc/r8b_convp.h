@@ -1488,7 +1488,7 @@ inline void convp_prepare(ConvxLaunch& X)
 	X.c.fl2r = X.c.fl2;
 	if constexpr (UL >= 0)
 	{
-		if (X.c.up_pow2 && X.c.up == (1 << (UL > 0 ? UL : 0)) && getenv("R8B_NO_ROT") == nullptr)
+		if (X.c.up_pow2 && X.c.up == (1 << (UL > 0 ? UL : 0)))
 		{
 			constexpr int N = ConvpGeom<LN, UL>::N;
 			X.c.rot = (N - ((X.c.fl2 / X.c.up) & (N - 1))) & (N - 1);

@@ -445,6 +445,17 @@ __global__ __launch_bounds__(256) void k_pcm_out(const PcmLaunch L)
 	__syncthreads();
 	pcm_out_scatter(L, tile, f0, c0, threadIdx.x, 256);
 }
+
+// planar buffers: a workgroup per (chunk of a row, channel)
+__global__ __launch_bounds__(256) void k_pcm_rows_in(const PcmLaunch L)
+{
+	pcm_row_in(L, (long long) blockIdx.x * kPcmRowChunk, (int) blockIdx.y, threadIdx.x, 256);
+}
+
+__global__ __launch_bounds__(256) void k_pcm_rows_out(const PcmLaunch L)
+{
+	pcm_row_out(L, (long long) blockIdx.x * kPcmRowChunk, (int) blockIdx.y, threadIdx.x, 256);
+}
 #endif
 
 #endif // R8B_HAS_REST
@@ -808,6 +819,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	ex.dump();
 }
 
+#ifdef R8B_PERSIST_LOOP
 // workgroups of a pair kernel the device holds at once, rounded down to a multiple of 8 (0: unknown)
 unsigned convp_capacity(const void* kern, int threads, size_t lds)
 {
@@ -819,6 +831,7 @@ unsigned convp_capacity(const void* kern, int threads, size_t lds)
 	const long long n = (long long) cus * per;
 	return n > 0 ? (unsigned) (n & ~7ll) : 0u;
 }
+#endif
 
 template<int LN, int UL, int MODE, int FLENP>
 void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
@@ -839,24 +852,22 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
 	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
 	unsigned grid = nbg * npair;
+#ifdef R8B_PERSIST_LOOP
 	// persistent form: as many workgroups as the chip holds at once (a multiple of 8, the XCDs), when the launch has
 	// at least twice as many items; the shorter ones keep one workgroup per item
 	static const unsigned capacity = convp_capacity(reinterpret_cast<const void*>(kern), ConvpGeom<LN, UL>::WT, lds);
-#ifndef R8B_PERSIST_LOOP
-	X.qcnt = nullptr;
-#endif
-	if (X.qcnt != nullptr)
+	if (X.qcnt != nullptr && getenv("R8B_PERSIST_STATS"))
 	{
-		if (getenv("R8B_PERSIST_STATS"))
-		{
-			// (development: workgroups of the earlier launches whose XCD was not blockIdx mod 8)
-			unsigned v = 0;
-			check(hipMemcpy(&v, X.qcnt + 10, sizeof(unsigned), hipMemcpyDeviceToHost), "stats");
-			fprintf(stderr, "k_convp persistent: %u workgroups so far ran on an XCD other than blockIdx mod 8\n", v);
-		}
+		// (development: workgroups of the earlier launches whose XCD was not blockIdx mod 8)
+		unsigned v = 0;
+		check(hipMemcpy(&v, X.qcnt + 10, sizeof(unsigned), hipMemcpyDeviceToHost), "stats");
+		fprintf(stderr, "k_convp persistent: %u workgroups so far ran on an XCD other than blockIdx mod 8\n", v);
 	}
 	if (X.qcnt != nullptr && capacity >= 8u && grid >= 2u * capacity) grid = capacity;
 	else X.qcnt = nullptr;
+#else
+	X.qcnt = nullptr; // (the persistent form is compiled out: DESIGN.md section 5)
+#endif
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
 	}
@@ -1171,6 +1182,14 @@ void launch_tail(const TailLaunch& L, void* stream)
 static void launch_pcm(const PcmLaunch& L, bool in, void* stream)
 {
 	if (L.n <= 0 || L.nch <= 0) return;
+	if (!L.interleaved)
+	{
+		const dim3 rows((unsigned) ((L.n + kPcmRowChunk - 1) / kPcmRowChunk), (unsigned) L.nch);
+		if (in) hipLaunchKernelGGL(k_pcm_rows_in, rows, dim3(256), 0, (hipStream_t) stream, L);
+		else hipLaunchKernelGGL(k_pcm_rows_out, rows, dim3(256), 0, (hipStream_t) stream, L);
+		check(hipGetLastError(), in ? "launch k_pcm_rows_in" : "launch k_pcm_rows_out");
+		return;
+	}
 	const dim3 grid((unsigned) ((L.n + kPcmTile - 1) / kPcmTile),
 		(unsigned) ((L.nch + kPcmTile - 1) / kPcmTile));
 	if (in) hipLaunchKernelGGL(k_pcm_in, grid, dim3(256), 0, (hipStream_t) stream, L);

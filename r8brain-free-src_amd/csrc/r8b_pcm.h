@@ -104,6 +104,62 @@ R8B_HD void pcm_out_direct(const PcmLaunch& L, long long f0, int c0, int tid, in
 	}
 }
 
+// Planar PCM <-> planar rows, row by row (no transposition): a workgroup converts kPcmRowChunk consecutive frames
+// of ONE channel, thread tid the frames tid, tid + nthr, ... of the chunk -- consecutive lanes on consecutive
+// samples, eight independent loads in flight per thread, the format switch outside the loop.  (The tile form
+// above moves 64 frames of a row per instruction and decides the format per sample: 2.2 TB/s on the staging
+// passes in front of / behind a fast-path convolver, where this streams.)
+static const int kPcmRowChunk = 2048;
+
+template<int FMT>
+R8B_HD void pcm_row_in_t(const PcmLaunch& L, long long f0, int c, int tid, int nthr)
+{
+	const unsigned char* src = static_cast<const unsigned char*>(L.pcm) +
+		(long long) c * L.pcm_stride * pcm_bytes(FMT);
+	double* dst = L.planar + (long long) c * L.planar_stride;
+	long long f1 = f0 + kPcmRowChunk;
+	if (f1 > L.n) f1 = L.n;
+	constexpr int B = FMT == kPcmF64 ? 8 : (FMT == kPcmS16 ? 2 : (FMT == kPcmS24 ? 3 : 4));
+#pragma unroll 8
+	for (long long f = f0 + tid; f < f1; f += nthr) dst[f] = pcm_decode(src + f * B, FMT);
+}
+
+template<int FMT>
+R8B_HD void pcm_row_out_t(const PcmLaunch& L, long long f0, int c, int tid, int nthr)
+{
+	unsigned char* dst = static_cast<unsigned char*>(L.pcm) + (long long) c * L.pcm_stride * pcm_bytes(FMT);
+	const double* src = L.planar + (long long) c * L.planar_stride;
+	long long f1 = f0 + kPcmRowChunk;
+	if (f1 > L.n) f1 = L.n;
+	constexpr int B = FMT == kPcmF64 ? 8 : (FMT == kPcmS16 ? 2 : (FMT == kPcmS24 ? 3 : 4));
+#pragma unroll 8
+	for (long long f = f0 + tid; f < f1; f += nthr) pcm_encode(dst + f * B, FMT, src[f]);
+}
+
+R8B_HD void pcm_row_in(const PcmLaunch& L, long long f0, int c, int tid, int nthr)
+{
+	switch (L.fmt)
+	{
+	case kPcmF64: pcm_row_in_t<kPcmF64>(L, f0, c, tid, nthr); break;
+	case kPcmF32: pcm_row_in_t<kPcmF32>(L, f0, c, tid, nthr); break;
+	case kPcmS16: pcm_row_in_t<kPcmS16>(L, f0, c, tid, nthr); break;
+	case kPcmS24: pcm_row_in_t<kPcmS24>(L, f0, c, tid, nthr); break;
+	case kPcmS32: pcm_row_in_t<kPcmS32>(L, f0, c, tid, nthr); break;
+	}
+}
+
+R8B_HD void pcm_row_out(const PcmLaunch& L, long long f0, int c, int tid, int nthr)
+{
+	switch (L.fmt)
+	{
+	case kPcmF64: pcm_row_out_t<kPcmF64>(L, f0, c, tid, nthr); break;
+	case kPcmF32: pcm_row_out_t<kPcmF32>(L, f0, c, tid, nthr); break;
+	case kPcmS16: pcm_row_out_t<kPcmS16>(L, f0, c, tid, nthr); break;
+	case kPcmS24: pcm_row_out_t<kPcmS24>(L, f0, c, tid, nthr); break;
+	case kPcmS32: pcm_row_out_t<kPcmS32>(L, f0, c, tid, nthr); break;
+	}
+}
+
 } // namespace r8bhip
 
 #endif

@@ -446,6 +446,18 @@ void launch_tail(const TailLaunch& L, void*)
 
 static void emul_pcm(const PcmLaunch& L, bool in)
 {
+	if (!L.interleaved)
+	{
+		// planar buffers: the row kernels (r8b_pcm.h pcm_row_in / _out)
+		for (int c = 0; c < L.nch; c++)
+			for (long long f0 = 0; f0 < L.n; f0 += kPcmRowChunk)
+				for (int t = 0; t < 256; t++)
+				{
+					if (in) pcm_row_in(L, f0, c, t, 256);
+					else pcm_row_out(L, f0, c, t, 256);
+				}
+		return;
+	}
 	std::vector<double> tile((size_t) kPcmTile * kPcmPitch);
 	const int nthr = 256;
 	for (int c0 = 0; c0 < L.nch; c0 += kPcmTile)

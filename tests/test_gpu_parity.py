@@ -418,6 +418,10 @@ def test_bench_contract(tmp_path):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["achieved"] > 0
     assert d["value"] > 0 and abs(d["value"] - 1024 * 16384 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
+    # the window straight after the warm-up calls is reported beside the settled one (bench.py --settle)
+    fw = d["first_window"]
+    assert d["settle_calls"] == 60 and fw["value"] > 0
+    assert abs(fw["value"] - 1024 * 16384 / fw["ms_per_step"] / 1e3) / fw["value"] < 0.01
 
 
 @pytest.mark.gpu

@@ -30,6 +30,8 @@ prof() {
   i=0
   for grp in "${PGRPS[@]}"; do
     i=$((i+1))
+    # PROF_LIGHT="name ...": those configurations collect the HBM byte counters only (groups 6 and 7)
+    if [ -n "$PROF_LIGHT" ] && echo " $PROF_LIGHT " | grep -q " $name " && [ $i -ne 6 ] && [ $i -ne 7 ]; then continue; fi
     timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$name/p$i -- python $R/bench.py --steps 4 --warmup 2 --no-cpu "$@" > $out/$name/p$i.log 2>&1
   done
   (cd $R && python tools/pmc_summary.py $out/$name > $out/$name/pmc_summary.txt 2>&1)
