@@ -208,6 +208,9 @@ def main():
                          "about 40 calls of this batch (DESIGN.md section 5): a 5 + 20 call window lies inside it. The line "
                          "reports the K steps timed after the clock has settled as `value` and the K steps timed straight "
                          "after the W warm-up calls as `first_window`, both bracketed the same way")
+    ap.add_argument("--align-out", type=int, default=1,
+                    help="1 (default): a call's outputs go to column (outputs so far) mod 8 of 64-byte-aligned rows; "
+                         "0: every call writes from column 0")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--e2e", action="store_true",
                     help="side measurement (SURVEY.md 8e): the whole batch lives on rank 0; every step "
@@ -267,8 +270,17 @@ def main():
     g.manual_seed(1234 + rank)
     # (output rows on a 64-byte pitch: the interpolator stores pairs of outputs as 16 bytes when both rows of a
     # channel pair are 16-byte aligned; max_out_len itself is odd for this conversion)
-    pitch = (rs.max_out_len + 7) // 8 * 8
-    outs = [torch.empty((C, pitch), dtype=torch.float64, device=dev)[:, :rs.max_out_len] for _ in range(2)]
+    # ... and the caller -- this script -- places a call's outputs at column (outputs produced so far) mod 8 of those
+    # rows (--align-out, default): output j of the STREAM then always sits at a column congruent to j mod 8, so the
+    # 64-byte pieces the kernel stores (four adjacent phase pairs) are whole aligned 64-byte segments in every call,
+    # not only in the calls whose first output index happens to be a multiple of 8
+    pitch = (rs.max_out_len + 7) // 8 * 8 + 8
+    outs_full = [torch.empty((C, pitch), dtype=torch.float64, device=dev) for _ in range(2)]
+    produced = [0]
+
+    def out_view(i):
+        off = produced[0] % 8 if args.align_out else 0
+        return outs_full[i % 2][:, off:off + rs.max_out_len]
 
     def barrier():
         torch.cuda.synchronize()
@@ -300,7 +312,8 @@ def main():
                 n_out += rs.process_pcm(pin[i % nbuf], out_format=fmt, out=pouts[i % 2],
                                         planar=args.planar).shape[1 if args.planar else 0]
             else:
-                y = rs.process(xin[i % nbuf], out=outs[i % 2])
+                y = rs.process(xin[i % nbuf], out=out_view(i))
+                produced[0] += y.shape[1]
                 n_out += y.shape[1]
                 if capture and i < nbuf:
                     captured.append(y[chk_rows].clone())
@@ -393,7 +406,9 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: CDSPResampler24 %g->%g, %d channels/GPU x %d-sample blocks, "
                                    "fp64 splitmix64 noise (seed 1 + channel), inputs and outputs "
-                                   "resident in HBM" % (cfg_name, args.src, args.dst, C, L),
+                                   "resident in HBM%s" % (cfg_name, args.src, args.dst, C, L,
+                                                         ", output rows 64-byte aligned with a call's outputs at column "
+                                                         "(outputs so far) mod 8" if args.align_out and not args.pcm else ""),
                        "channels_per_gpu": C, "block": L, "io": ((args.pcm + (" planar" if args.planar else " interleaved"))
                                                    if args.pcm else "f64 planar"),
                        "out_msamples_per_s":

@@ -76,6 +76,7 @@ class BatchResampler(_Base):
 
     def clear(self):
         self._lib.r8b_batch_clear(self._h)
+        self._produced = 0
 
     def describe(self):
         n = self._lib.r8b_batch_describe(self._h, None, 0)
@@ -120,13 +121,17 @@ class BatchResampler(_Base):
             raise ValueError("tensors on cuda:%s, the resampler lives on cuda:%d" % (x.device.index, dev))
         l = x.shape[1]
         if out is None:
-            # (rows on a 64-byte pitch: aligned rows let the kernels store output pairs as 16 bytes)
+            # rows on a 64-byte pitch, this call's outputs at column (outputs produced so far) mod 8: output j of
+            # the stream always sits at a column congruent to j mod 8, so the 64-byte pieces the fused kernels store
+            # (four adjacent phase pairs of a group) are whole aligned segments in every call
             cap = max(self.max_out_len, 1)
-            out = torch.empty((self.nch, (cap + 7) // 8 * 8), dtype=torch.float64, device=x.device)[:, :cap]
+            off = getattr(self, "_produced", 0) % 8
+            out = torch.empty((self.nch, (cap + 7) // 8 * 8 + 8), dtype=torch.float64, device=x.device)[:, off:off + cap]
         assert out.is_cuda and out.dtype == torch.float64 and out.stride(1) == 1
         assert out.shape[0] == self.nch and out.shape[1] >= self.max_out_len
         stream = torch.cuda.current_stream(x.device).cuda_stream
         n = self.process_ptr(x.data_ptr(), x.stride(0), l, out.data_ptr(), out.stride(0), stream)
+        self._produced = getattr(self, "_produced", 0) + n
         return out[:, :n]
 
     def state_dict(self, stream=0):
