@@ -202,10 +202,10 @@ def main():
                          "same JSON line (with its own roofline block) for each")
     ap.add_argument("--tb", type=float, default=2.0, help="transition band, percent (side runs)")
     ap.add_argument("--atten", type=float, default=180.15, help="stop-band attenuation (side runs)")
-    ap.add_argument("--settle", type=int, default=60,
+    ap.add_argument("--settle", type=int, default=150,
                     help="untimed calls between the first timed window and the reported one (0: report the first window). "
                          "After an idle gap the board's power controller answers the load step with a clock dip that lasts "
-                         "about 40 calls of this batch (DESIGN.md section 5): a 5 + 20 call window lies inside it. The line "
+                         "about 40 calls of this batch, and the clock has fully recovered after about 150 (DESIGN.md section 5): a 5 + 20 call window lies inside it. The line "
                          "reports the K steps timed after the clock has settled as `value` and the K steps timed straight "
                          "after the W warm-up calls as `first_window`, both bracketed the same way")
     ap.add_argument("--align-out", type=int, default=1,
