@@ -41,7 +41,6 @@
 #define R8B_CONVP_H
 
 #include <cstdlib>
-#include <type_traits>
 #include "r8b_convx.h"
 
 // R8B_ABL (development builds only, tools/variant.sh: timing ablations, results are wrong): bit 0 no interpolator,
@@ -1079,17 +1078,10 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const SpanInfo& Bm, const cd
 	const bool pair16 = (((size_t) pa0 | (size_t) pb0) & 15) == 0 && (out_step & 1) == 0;
 	constexpr int CH = T2 == 25 ? 5 : 3, NCH = T2 / CH;
 	static_assert(CH * NCH == T2, "chunks");
-	// Whole groups only (every block of a call but those cut by its ends, when the blocks are aligned to groups --
-	// Engine::launch_fused): nothing to mask.  EVEN (Out even, both rows 16-byte aligned at the block's first group):
-	// every output pair is one 16-byte store.  Otherwise (Out odd: cfg3's 147; or rows at odd columns) a group's
-	// pairs are 16-byte aligned in every second group / in one of the two rows: decided per group and row, the
-	// other ones go out as two 8-byte stores; the last phase of an odd Out has no partner.
-	auto whole_groups = [&](auto even_tag)
+	if (lo_mod == 0 && hi_mod == out_step && linear && pair16 && (R8B_ABL & 32) == 0)
 	{
-		constexpr bool EVEN = decltype(even_tag)::value;
-		const unsigned parA = (unsigned) ((size_t) pa0 >> 3) & 1u, parB = (unsigned) ((size_t) pb0 >> 3) & 1u;
-		const unsigned godd = (unsigned) out_step & 1u;
-		const bool has1 = 2 * q + 1 < out_step;
+		// Whole groups only (every block of a call but those cut by its ends, when the blocks are aligned to
+		// groups -- Engine::launch_fused): nothing to mask, every output pair is one 16-byte store.
 		for (int gl = set; gl <= gmax; gl += nsets)
 		{
 			const cd* w = y + (u_lo + in_step * gl + rq);
@@ -1136,36 +1128,9 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const SpanInfo& Bm, const cd
 			va.im = a1[0] + a1[1];
 			vb.re = b0[0] + b0[1];
 			vb.im = b1[0] + b1[1];
-			if constexpr (EVEN)
-			{
-				*reinterpret_cast<cd*>(pa0 + o) = va;
-				if (bvalid) *reinterpret_cast<cd*>(pb0 + o) = vb;
-			}
-			else
-			{
-				const unsigned gp = godd & (unsigned) gl;
-				if (has1 && ((parA + gp) & 1u) == 0) *reinterpret_cast<cd*>(pa0 + o) = va;
-				else
-				{
-					pa0[o] = va.re;
-					if (has1) pa0[o + 1] = va.im;
-				}
-				if (bvalid)
-				{
-					if (has1 && ((parB + gp) & 1u) == 0) *reinterpret_cast<cd*>(pb0 + o) = vb;
-					else
-					{
-						pb0[o] = vb.re;
-						if (has1) pb0[o + 1] = vb.im;
-					}
-				}
-			}
+			*reinterpret_cast<cd*>(pa0 + o) = va;
+			if (bvalid) *reinterpret_cast<cd*>(pb0 + o) = vb;
 		}
-	};
-	if (lo_mod == 0 && hi_mod == out_step && linear && (R8B_ABL & 32) == 0)
-	{
-		if (pair16) whole_groups(std::true_type());
-		else whole_groups(std::false_type());
 		return;
 	}
 	for (int gl = set; gl <= gmax; gl += nsets)
