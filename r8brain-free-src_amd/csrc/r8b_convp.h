@@ -1383,19 +1383,41 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	else if constexpr (G::B1) ex.wave_steps(s_midc, s_midw, s_b1);
 	else ex.wave_steps(s_midc, s_midw);
 	}
-	// history for the next call (stage 0 only): the first block's workgroup copies the tail of
-	// the caller's buffers into the other history ring; the stores need no wait
-	if (cur.k == L.k0 && L.tail_ring != nullptr)
+	// History for the next call (stage 0 only): the tail of the caller's buffers goes into the other history ring, every
+	// workgroup of a channel pair copying its share of it (block b of the launch's nblk the b-th slice), eight
+	// samples per channel in flight per thread.  (One workgroup -- the first block's -- copying the whole tail with
+	// one load in flight per thread took 40 000 cycles on top of its 31 000: tools/timeline_probe.py, 8 % of the
+	// workgroups at 2.2x the lifetime of the others.)  The stores need no wait.
+	if (L.tail_ring != nullptr)
 	{
+		const unsigned tn = (unsigned) (L.tail_p1 - L.tail_p0), nb = (unsigned) L.nblk;
+		const unsigned bi = (unsigned) (cur.k - L.k0), be = bi + (unsigned) (G::SUB == 1 ? 1 : cur.nvalid);
+		// (tn * nblk < 2^32: the tail is a few thousand samples, a launch at most kConvxMaxBlocks blocks)
+		const long long s0 = L.tail_p0 + (long long) (tn * bi / nb), s1 = L.tail_p0 + (long long) (tn * be / nb);
 		ex.each([&](int tid, St&)
 		{
-			for (long long i = L.tail_p0 + tid; i < L.tail_p1; i += G::WT)
+			constexpr int TB = 8;
+			for (long long i0 = s0 + tid; i0 < s1; i0 += (long long) TB * G::WT)
 			{
-				L.tail_ring[(long long) chA * L.src.ring_stride + (i & L.src.ring_mask)] =
-					src_load(L.src, chA, i);
-				if (bvalid)
-					L.tail_ring[(long long) chB * L.src.ring_stride + (i & L.src.ring_mask)] =
-						src_load(L.src, chB, i);
+				double va[TB], vb[TB];
+#pragma unroll
+				for (int j = 0; j < TB; j++)
+				{
+					const long long i = i0 + (long long) j * G::WT;
+					const long long ic = i < s1 ? i : s1 - 1; // (clamped: a load that is not used)
+					va[j] = src_load(L.src, chA, ic);
+					vb[j] = bvalid ? src_load(L.src, chB, ic) : 0.0;
+				}
+#pragma unroll
+				for (int j = 0; j < TB; j++)
+				{
+					const long long i = i0 + (long long) j * G::WT;
+					if (i < s1)
+					{
+						L.tail_ring[(long long) chA * L.src.ring_stride + (i & L.src.ring_mask)] = va[j];
+						if (bvalid) L.tail_ring[(long long) chB * L.src.ring_stride + (i & L.src.ring_mask)] = vb[j];
+					}
+				}
 			}
 		});
 	}

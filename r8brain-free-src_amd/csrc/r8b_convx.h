@@ -962,16 +962,32 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 		cx_final_store<LOGN, UPLOG, MODE == 1>(L, rbuf, st, k, tid);
 		if constexpr (MODE == 1) cx_whole_row<FLENP>(X, st.row, tid);
 	});
-	// history for the next call (stage 0 only): the first block's workgroup copies the tail of
-	// the caller's buffer into the other history ring; issued before the output phase, the
-	// stores need no wait
-	if (L.tail_ring != nullptr && k == L.k0)
+	// history for the next call (stage 0 only): the tail of the caller's buffer goes into the other history ring, every
+	// workgroup of a channel copying its share (block b of the launch's nblk the b-th slice), eight samples in
+	// flight per thread (cf. r8b_convp.h); issued before the output phase, the stores need no wait
+	if (L.tail_ring != nullptr)
 	{
+		const unsigned tn = (unsigned) (L.tail_p1 - L.tail_p0), nb = (unsigned) L.nblk, bi = (unsigned) (k - L.k0);
+		const long long s0 = L.tail_p0 + (long long) (tn * bi / nb), s1 = L.tail_p0 + (long long) (tn * (bi + 1u) / nb);
 		ex.each([&](int tid, St&)
 		{
-			for (long long i = L.tail_p0 + tid; i < L.tail_p1; i += kConvxThreads)
-				L.tail_ring[(long long) ch * L.src.ring_stride + (i & L.src.ring_mask)] =
-					src_load(L.src, ch, i);
+			constexpr int TB = 8;
+			for (long long i0 = s0 + tid; i0 < s1; i0 += (long long) TB * kConvxThreads)
+			{
+				double v[TB];
+#pragma unroll
+				for (int j = 0; j < TB; j++)
+				{
+					const long long i = i0 + (long long) j * kConvxThreads;
+					v[j] = src_load(L.src, ch, i < s1 ? i : s1 - 1);
+				}
+#pragma unroll
+				for (int j = 0; j < TB; j++)
+				{
+					const long long i = i0 + (long long) j * kConvxThreads;
+					if (i < s1) L.tail_ring[(long long) ch * L.src.ring_stride + (i & L.src.ring_mask)] = v[j];
+				}
+			}
 		});
 	}
 	ex.phase([&](int tid, St& st)

@@ -559,6 +559,20 @@ extern "C" __attribute__((visibility("default"))) void r8b_dev_stamps(long long*
 namespace r8bhip {
 namespace {
 #endif
+#ifdef R8B_TIMELINE
+// (development, tools/timeline_probe.py: every workgroup of the last pair-kernel launch leaves where and when it ran --
+// hardware id, cycle counter at its first instruction, at the arrival of its samples and at its last store's issue)
+__device__ long long g_timeline[16384 * 4];
+} // namespace
+} // namespace r8bhip
+extern "C" __attribute__((visibility("default"))) void r8b_dev_timeline(long long* out, int n)
+{
+	(void) hipDeviceSynchronize();
+	(void) hipMemcpyFromSymbol(out, HIP_SYMBOL(r8bhip::g_timeline), sizeof(long long) * 4 * (size_t) n);
+}
+namespace r8bhip {
+namespace {
+#endif
 template<int LN, int UL>
 struct GpuExecP
 {
@@ -650,6 +664,9 @@ template<int LN, int UL, int MODE, int FLENP>
 __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) > 256 ? 1 : 2)) void k_convp(const ConvxLaunch X)
 {
 	extern __shared__ __align__(256) unsigned char smem[];
+#ifdef R8B_TIMELINE
+	const long long tl_t0 = (long long) __builtin_readcyclecounter();
+#endif
 	// XCD-aware mapping as in k_convx, over channel PAIRS and groups of SUB consecutive blocks: item w of a launch
 	// is block group bg of channel pair pr
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
@@ -811,6 +828,19 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 			for (int i = 0; i < 9; i++) atomicExch(qc + i, 0u);
 		}
 	}
+#ifdef R8B_TIMELINE
+	if (threadIdx.x == 0 && blockIdx.x < 16384)
+	{
+		unsigned hwid, xcc;
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+		long long* o = g_timeline + 4 * (size_t) blockIdx.x;
+		o[0] = tl_t0;
+		o[1] = (long long) __builtin_readcyclecounter();
+		o[2] = (long long) hwid | ((long long) xcc << 32);
+		o[3] = X.c.k0; // (first block of the launch: tells the launches apart)
+	}
+#endif
 #ifdef R8B_CP_STAMPS
 	// (how long the workgroup's last stores take to be acknowledged: the slot stays occupied until then)
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
