@@ -1387,7 +1387,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	// workgroup of a channel pair copying its share of it (block b of the launch's nblk the b-th slice), eight
 	// samples per channel in flight per thread.  (One workgroup -- the first block's -- copying the whole tail with
 	// one load in flight per thread took 40 000 cycles on top of its 31 000: tools/timeline_probe.py, 8 % of the
-	// workgroups at 2.2x the lifetime of the others.)  The stores need no wait.
+	// workgroups at 2.2x the lifetime of the others; cfg3 -18 %.  Issued here, behind the wave-local passes: with
+	// the first phase's sample loads -- one wait for both -- it measured 1.5 % / 5 % slower on cfg2 / cfg3.)  The
+	// stores need no wait.
 	if (L.tail_ring != nullptr)
 	{
 		const unsigned tn = (unsigned) (L.tail_p1 - L.tail_p0), nb = (unsigned) L.nblk;
@@ -1404,9 +1406,12 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				for (int j = 0; j < TB; j++)
 				{
 					const long long i = i0 + (long long) j * G::WT;
-					const long long ic = i < s1 ? i : s1 - 1; // (clamped: a load that is not used)
-					va[j] = src_load(L.src, chA, ic);
-					vb[j] = bvalid ? src_load(L.src, chB, ic) : 0.0;
+					va[j] = vb[j] = 0.0;
+					if (i < s1)
+					{
+						va[j] = src_load(L.src, chA, i);
+						if (bvalid) vb[j] = src_load(L.src, chB, i);
+					}
 				}
 #pragma unroll
 				for (int j = 0; j < TB; j++)

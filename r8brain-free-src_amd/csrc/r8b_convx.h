@@ -979,7 +979,8 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 				for (int j = 0; j < TB; j++)
 				{
 					const long long i = i0 + (long long) j * kConvxThreads;
-					v[j] = src_load(L.src, ch, i < s1 ? i : s1 - 1);
+					v[j] = 0.0;
+					if (i < s1) v[j] = src_load(L.src, ch, i);
 				}
 #pragma unroll
 				for (int j = 0; j < TB; j++)
