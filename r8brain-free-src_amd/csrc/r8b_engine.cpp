@@ -883,7 +883,11 @@ unsigned* Engine::queue_counters()
 void Engine::release()
 {
 	if (dev_.empty()) return;
-	DevGuard guard(device_);
+	// (called from the destructor: a device that cannot be made current any more -- runtime unloaded at interpreter
+	// exit, sticky error -- must not throw here; the frees below then fail silently)
+	int prev = -1;
+	try { prev = dev_swap(device_); } catch (...) { prev = -1; }
+	struct Restore { int prev; ~Restore() { if (prev >= 0) dev_restore(prev); } } restore{prev};
 	for (StageDev& d : dev_)
 	{
 		for (auto& pr : d.pending)

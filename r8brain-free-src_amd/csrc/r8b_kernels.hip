@@ -872,6 +872,15 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	constexpr unsigned SUB = ConvpGeom<LN, UL>::SUB;
 	const unsigned nbg = ((unsigned) X.c.nblk + SUB - 1u) / SUB;
 	X.nblk_magic = nbg > 1 ? (unsigned) (0x100000000ull / nbg) + 1u : 0u;
+	{
+		// convp_div(i, magic) is floor(i / nbg) only while i * nbg < 2^32; i runs up to the grid size (an eighth of
+		// it in the XCD-interleaved mapping).  Far out of reach of audio batches -- tens of millions of input
+		// samples per call and channel pair --, refused rather than mapped wrongly
+		const unsigned long long np = ((unsigned long long) X.c.nch + 1ull) >> 1;
+		const unsigned long long imax = (np & 7ull) == 0 ? (np >> 3) * nbg : np * nbg;
+		if (nbg > 1 && imax * nbg >= 0x100000000ull)
+			throw std::runtime_error("launch_convp: too many blocks per call for the workgroup map (split the call)");
+	}
 	convp_prepare<LN, UL>(X);
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
@@ -1247,6 +1256,14 @@ int dev_swap(int device)
 	check(hipGetDevice(&cur), "hipGetDevice");
 	if (cur != device) check(hipSetDevice(device), "hipSetDevice");
 	return cur;
+}
+
+void dev_restore(int device) noexcept
+{
+	// (a failure here -- the runtime already unloaded at interpreter exit, a device lost to an earlier sticky error --
+	// must not turn a destructor into std::terminate or mask the exception being unwound)
+	int cur = -1;
+	if (hipGetDevice(&cur) == hipSuccess && cur != device) (void) hipSetDevice(device);
 }
 
 void* dev_alloc(size_t bytes)

@@ -342,11 +342,12 @@ void launch_convp(const ConvxLaunch& X, int mode, void* stream);
 // (or torch) considers current.
 int dev_resolve(int device);
 int dev_swap(int device);              // makes `device` current, returns the previous one
+void dev_restore(int device) noexcept; // makes `device` current again; never throws (destructors, unwinding)
 struct DevGuard
 {
 	int prev;
 	explicit DevGuard(int device) : prev(dev_swap(device)) {}
-	~DevGuard() { if (prev >= 0) (void) dev_swap(prev); }
+	~DevGuard() { if (prev >= 0) dev_restore(prev); }
 	DevGuard(const DevGuard&) = delete;
 	DevGuard& operator=(const DevGuard&) = delete;
 };

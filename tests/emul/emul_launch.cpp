@@ -491,6 +491,7 @@ void launch_pcm_out(const PcmLaunch& L, void*) { emul_pcm(L, false); }
 
 int dev_resolve(int device) { return device < 0 ? 0 : device; }
 int dev_swap(int) { return -1; }
+void dev_restore(int) noexcept {}
 
 void* dev_alloc(size_t bytes)
 {
