@@ -76,13 +76,7 @@ struct ConvpGeom
 		"pair kernel: transforms of 64 ... 8192 points");
 	static constexpr int NA = N > N2 ? N : N2;        // a block pair's part of the array (complex elements)
 	static constexpr int NT = NA / 16;                // threads per block pair
-#ifdef R8B_TWIN
-	// (development: 4096-point block pairs two to a 512-thread workgroup -- the halves run in step, so their table
-	// fetches meet in the L1)
-	static constexpr int WT = NT > kConvpThreads ? NT : (NT == kConvpThreads ? 2 * kConvpThreads : kConvpThreads);
-#else
 	static constexpr int WT = NT > kConvpThreads ? NT : kConvpThreads; // threads per workgroup (512 for 8192 points)
-#endif
 	static constexpr int SUB = WT / NT;               // block pairs per workgroup
 	static constexpr int E1 = N / NT, E2 = N2 / NT;    // elements per thread, forward / backward
 	static constexpr int EB1 = UL == 1 ? 3 : 4;
@@ -1022,12 +1016,10 @@ R8B_HD void cp_whole_compute(const ConvxLaunch& X, const SpanInfo& B, const cd* 
 // computed whole and masked at the store (slots outside the run hold finite transform data).
 // MODE 5: the same with In > Out (down-sampling interpolators, cfg3: 320 / 147): the windows of adjacent
 // phases start 2 or 3 samples apart, the rows have 27 entries, 27 reads feed four outputs.
-template<bool TWIN>
 R8B_HD int cp_ptab_fetch(const ConvxLaunch& X, int tid)
 {
 	// (the tables are laid out for 256 lanes: in a 512-thread workgroup the upper half sits the interpolator out)
-	// (... unless each 256-thread half owns a block pair of its own: R8B_TWIN)
-	return tid < kConvpThreads ? X.ptab[tid] : (TWIN ? X.ptab[tid - kConvpThreads] : -1);
+	return tid < kConvpThreads ? X.ptab[tid] : -1;
 }
 
 template<int T2>
@@ -1271,7 +1263,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.stamp2();
 		if constexpr (!(R8B_ABL & 16)) cp_first<LN, UL>(L, buf_of(tid), st, lt);
 		// (modes 4 / 5: the thread's entry of the interpolator's lane table, long before its rows are addressed with it)
-		if constexpr (MODE == 4 || MODE == 5) st.pt = cp_ptab_fetch<(G::SUB * kConvpThreads == G::WT && G::SUB > 1)>(X, tid);
+		if constexpr (MODE == 4 || MODE == 5) st.pt = cp_ptab_fetch(X, tid);
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
 		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
 	});
@@ -1475,17 +1467,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_final_store<LN, UL>(L, buf_of(tid), buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
 		});
 		// the interpolator: all 256 threads over the run of one block pair after the other
-		ex.before_last_phase();
-		if constexpr (!(R8B_ABL & 1)) ex.each([&](int tid, St& st)
+		if constexpr (!(R8B_ABL & 1)) ex.each([&](int, St& st)
 		{
-			if constexpr (G::SUB > 1 && G::SUB * kConvpThreads == G::WT)
-			{
-				// (each 256-thread part of the workgroup on the run of its own block pair)
-				const int sb = tid / kConvpThreads;
-				if (sb < cur.nvalid)
-					cp_whole2_compute<T2>(X, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
-			}
-			else
 			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
 				cp_whole2_compute<T2>(X, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
 		});

@@ -590,7 +590,6 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// ... with two adjacent phases per thread in the fused interpolator when it up-samples (In <= Out:
 	// half the LDS reads per output, nearly all lanes busy)
 	opt_["pair_two"] = 1;
-	opt_["persist"] = 0; // pair kernel: launches with more items than the chip holds at once as persistent workgroups on work queues (needs a build with -DR8B_PERSIST_LOOP; measured slower)
 	opt_["align_groups"] = 1; // ... with whole output groups per block (launch_fused)
 	opt_["fold_tail"] = 1; // fast convolver at stage 0 keeps the input history itself
 	// a constructor that throws half way must not leak what it has already put on the device
@@ -873,13 +872,6 @@ bool Engine::use_pair_two(size_t s, int* run_off) const
 
 Engine::~Engine() { release(); }
 
-unsigned* Engine::queue_counters()
-{
-	if (!opt_.at("persist")) return nullptr;
-	if (qcnt_ == nullptr) qcnt_ = (unsigned*) dev_alloc(16 * sizeof(unsigned));
-	return qcnt_;
-}
-
 void Engine::release()
 {
 	if (dev_.empty()) return;
@@ -910,8 +902,6 @@ void Engine::release()
 		dev_free(d.ptab);
 		dev_free(d.ctab);
 	}
-	dev_free(qcnt_);
-	qcnt_ = nullptr;
 	dev_.clear();
 }
 
@@ -1197,7 +1187,6 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0; X.run_off = 0;
 			X.ptab = nullptr; X.ctab = nullptr; X.nsets = 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
-			X.qcnt = queue_counters();
 			if (path == kPathPair3) launch_convp(X, g.complex_h ? 7 : 3, stream);
 			else if (path == kPathConvx3) launch_convx(X, 3, stream);
 			else if (path == kPathPair) launch_convp(X, g.complex_h ? 6 : 0, stream);
@@ -1776,7 +1765,6 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	const bool pair_two = use_pair_two(s, &run_off);
 	X.run_off = run_off;
 	X.ptab = dw.ptab; X.ctab = dw.ctab; X.nsets = dw.nsets;
-	X.qcnt = queue_counters();
 	// Blocks start S virtual samples apart with S = in_len - (interpolator taps, rounded up to
 	// the up factor): the valid ranges [k*S - fl2, k*S - fl2 + in_len) of consecutive blocks
 	// overlap by at least flen-1 convolver outputs, so each interpolator tap window lies inside

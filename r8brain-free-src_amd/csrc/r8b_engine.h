@@ -89,7 +89,6 @@ private:
 	};
 	void* get_event(StageDev& d);
 	void release();
-	unsigned* queue_counters();
 	unsigned long long config_hash() const;
 	bool stage_owns_ring(size_t s) const;
 
@@ -126,7 +125,6 @@ private:
 	std::map<std::string, int> opt_;
 	int io_in_fmt_ = kPcmF64, io_out_fmt_ = kPcmF64; // formats of the current call's buffers
 	bool tail_done_ = false; // stage-0 history already written by the convolver kernel
-	unsigned* qcnt_ = nullptr; // work-queue counters of the pair kernel's persistent launches (ConvxLaunch::qcnt)
 };
 
 // complex twiddle table exp(-2 pi i e / len), exact on the axes; interleaved (re, im)

@@ -579,15 +579,6 @@ struct GpuExecP
 	ConvpState<LN, UL> st;
 	int tid_ = (int) threadIdx.x;
 	unsigned* flags_; // one word per wave behind the array (r8b_convp.h kConvpFlagBytes)
-	// persistent form: the request for the next item (an atomic on a queue counter in device memory, microseconds of
-	// round trip) goes out in front of the item's last phase, which issues no loads: requested at the start of an item
-	// it sits in front of the sample loads in the in-order return queue and the first pass waits for it
-	unsigned* qreq_ = nullptr;
-	unsigned nxt_ = 0;
-	__device__ __forceinline__ void before_last_phase()
-	{
-		if (qreq_ != nullptr && threadIdx.x == 0) nxt_ = atomicAdd(qreq_, 1u);
-	}
 	__device__ __forceinline__ explicit GpuExecP(unsigned char* smem)
 		: flags_(reinterpret_cast<unsigned*>(smem + convp_array_bytes<LN, UL>())) {}
 	// workgroup-wide OR of a small bit set: every thread posts before a barrier, anybody collects after it
@@ -672,7 +663,6 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
 	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
 	const unsigned nbg = ((unsigned) X.c.nblk + SUB - 1u) / SUB;
-	unsigned w = blockIdx.x;
 	auto decode = [&](unsigned wi, unsigned& bg, unsigned& pr)
 	{
 		if (nbg == 1)
@@ -714,120 +704,37 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	H.run_off = X.run_off; H.ptab = X.ptab; H.ctab = X.ctab; H.nsets = X.nsets;
 	H.nblk_magic = X.nblk_magic;
 	ex.stamp();
-	// Persistent form (X.qcnt != null; launch_convp_t): the grid is what the chip holds at once and a workgroup that has
-	// finished an item takes the next one from the work queue of its XCD -- items 8 j + x, j = 0, 1, ..., for the
-	// workgroups with blockIdx mod 8 = x (the dispatcher deals workgroups to the XCDs round robin; the blocks of a channel
-	// pair stay on one XCD's L2 as in the one-item form) -- and, once that is empty, from the other XCDs' queues.  No
-	// workgroup start-up between items (arguments, descriptors, LDS allocation: the slot of a finished workgroup stays
-	// empty for thousands of cycles), and the load balances itself.  The request for the next item goes out before the
-	// current one is processed; the last workgroup to leave zeroes the counters for the next launch.
-#ifdef R8B_PERSIST_LOOP
-	unsigned* const qc = X.qcnt;
-#else
-	// (measured slower -- DESIGN.md section 5 --: compiled in by -DR8B_PERSIST_LOOP only; the loop runs once)
-	unsigned* const qc = nullptr;
-#endif
-	const unsigned total = nbg * npair;
-	// the XCD this workgroup runs on, from the hardware (the round-robin rule blockIdx mod 8 is the dispatcher's habit,
-	// not a guarantee); qc[10] counts the workgroups for which the rule did not hold (development statistics)
-	unsigned xq = blockIdx.x & 7u;
-	if (qc != nullptr)
-	{
-		unsigned xcc;
-		asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-		xcc &= 7u;
-		if (threadIdx.x == 0 && xcc != xq) atomicAdd(qc + 10, 1u);
-		xq = xcc;
-		// every item comes from the queues, the first one too
-		unsigned wn = 0xffffffffu;
-		if (threadIdx.x == 0)
-		{
-			wn = (atomicAdd(qc + xq, 1u) << 3) + xq;
-			for (unsigned d = 1; wn >= nbg * npair && d < 8u; d++)
-			{
-				const unsigned x2 = (xq + d) & 7u;
-				wn = (atomicAdd(qc + x2, 1u) << 3) + x2;
-			}
-		}
-		if (threadIdx.x == 0) ex.flags_[8] = wn;
-		lds_barrier();
-		w = (unsigned) __builtin_amdgcn_readfirstlane((int) ex.flags_[8]);
-		lds_barrier();
-		// (w < items: the launcher's grid is at most half the items, and an empty queue sends a workgroup to the others)
-	}
-	const unsigned nper = 0;
-#ifdef R8B_PERSIST_SPREAD
-	// Started together, given items of equal length, the workgroups of the whole CHIP stay in the same phase: every one
-	// loads its samples at the same moment, then none does -- the memory system sees bursts at a fraction of the duty
-	// cycle.  Start offsets spread evenly over one item's duration (R8B_PERSIST_SPREAD periods of 512 cycles at most).
-	if (qc != nullptr)
-		for (unsigned i = 0, n = ((blockIdx.x * 2654435761u) >> 16) % (unsigned) (R8B_PERSIST_SPREAD); i < n; i++)
-			__builtin_amdgcn_s_sleep(8);
-#endif
-	for (;;)
-	{
-		// (the thread index is made opaque per item: nothing derived from it -- LDS addresses, table offsets -- is
-		// carried around the loop in registers the phases need)
-		{
-			int t = (int) threadIdx.x;
-			asm volatile("" : "+v"(t));
-			ex.tid_ = t;
-		}
-		// (per item, so that nothing derived from them is carried around the loop either; integers are made opaque -- "+s" --, pointers are only USED here -- "s" --: a pointer that went through an asm
-		// output loses its kernel-argument provenance and would be dereferenced with flat instructions)
-		asm volatile("" : "+s"(H.c.k0), "+s"(H.c.blk_stride), "+s"(H.c.blk_offset), "+s"(H.c.in_len), "+s"(H.c.fl2),
-			"+s"(H.c.up_pow2), "+s"(H.c.src.cur_stride), "+s"(H.c.src.cur_base), "+s"(H.c.src.cur_fmt), "+s"(H.c.rot),
-			"+s"(H.c.fl2r)
-			: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
-		if constexpr (MODE == 4 || MODE == 5)
-			asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),
-				"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt) : "s"(H.ptab), "s"(H.ctab), "s"(H.wdst.p));
-		else if constexpr (MODE == 1) {}
-		else
-			asm volatile("" : "+s"(H.c.a), "+s"(H.c.b), "+s"(H.c.dst.stride), "+s"(H.c.dst.mask), "+s"(H.c.dst.off),
-				"+s"(H.c.dst.fmt), "+s"(H.c.down), "+s"(H.c.down_pow2), "+s"(H.c.up) : "s"(H.c.dst.p));
-		unsigned bg, pr;
-		decode(w, bg, pr);
-		if (qc != nullptr) ex.qreq_ = qc + xq;
-		const int chA = (int) (2u * pr);
-		const bool bvalid = chA + 1 < X.c.nch;
-		ConvpItem cur;
-		const int b0 = (int) bg * SUB;
-		cur.k = X.c.k0 + b0;
-		cur.nvalid = X.c.nblk - b0 < SUB ? X.c.nblk - b0 : SUB;
-		cur.chA = chA;
-		cur.chB = bvalid ? chA + 1 : chA;
-		cur.bvalid = bvalid;
-		// (MODE 1 -- one phase per thread -- already fills the scalar file with its span bookkeeping: it reads the
-		// arguments where it needs them, as before)
-		if constexpr (MODE == 1) convp_body<LN, UL, MODE, FLENP>(ex, X, X, reinterpret_cast<cd*>(smem), cur);
-		else convp_body<LN, UL, MODE, FLENP>(ex, H, X, reinterpret_cast<cd*>(smem), cur);
-		if (qc == nullptr) break;
-		if (threadIdx.x == 0)
-		{
-			unsigned wn = ((ex.nxt_ + nper) << 3) + xq;
-			// own queue empty: the others', one after the other (each hands out an index past its end at most
-			// once per workgroup)
-			for (unsigned d = 1; wn >= total && d < 8u; d++)
-			{
-				const unsigned x2 = (xq + d) & 7u;
-				wn = ((atomicAdd(qc + x2, 1u) + nper) << 3) + x2;
-			}
-			ex.flags_[8] = wn;
-		}
-		// (also: every wave has left the item's last LDS reads behind before the next item's first pass writes)
-		lds_barrier();
-		w = (unsigned) __builtin_amdgcn_readfirstlane((int) ex.flags_[8]);
-		if (w >= total) break;
-	}
-	if (qc != nullptr && threadIdx.x == 0)
-	{
-		if (atomicAdd(qc + 8, 1u) == gridDim.x - 1u)
-		{
-#pragma unroll
-			for (int i = 0; i < 9; i++) atomicExch(qc + i, 0u);
-		}
-	}
+	// (integers are made opaque -- "+s" --, pointers are only USED here -- "s" --: a pointer that went through an asm
+	// output loses its kernel-argument provenance and would be dereferenced with flat instructions)
+	asm volatile("" : "+s"(H.c.k0), "+s"(H.c.blk_stride), "+s"(H.c.blk_offset), "+s"(H.c.in_len), "+s"(H.c.fl2),
+		"+s"(H.c.up_pow2), "+s"(H.c.src.cur_stride), "+s"(H.c.src.cur_base), "+s"(H.c.src.cur_fmt), "+s"(H.c.rot),
+		"+s"(H.c.fl2r)
+		: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
+	if constexpr (MODE == 4 || MODE == 5)
+		asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),
+			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt) : "s"(H.ptab), "s"(H.ctab), "s"(H.wdst.p));
+	else if constexpr (MODE == 1) {}
+	else
+		asm volatile("" : "+s"(H.c.a), "+s"(H.c.b), "+s"(H.c.dst.stride), "+s"(H.c.dst.mask), "+s"(H.c.dst.off),
+			"+s"(H.c.dst.fmt), "+s"(H.c.down), "+s"(H.c.down_pow2), "+s"(H.c.up) : "s"(H.c.dst.p));
+	// (One workgroup per item.  Persistent workgroups that take their items from per-XCD work queues -- no start-up
+	// between items -- were built and measured 25-30 % SLOWER, as was a 512-thread workgroup carrying two block pairs
+	// in step: DESIGN.md section 5; the code is in the history of this file, the round-3 commits "Pair kernel: persistent workgroups on per-XCD work queues" ... "twin-block experiment".)
+	unsigned bg, pr;
+	decode(blockIdx.x, bg, pr);
+	const int chA = (int) (2u * pr);
+	const bool bvalid = chA + 1 < X.c.nch;
+	ConvpItem cur;
+	const int b0 = (int) bg * SUB;
+	cur.k = X.c.k0 + b0;
+	cur.nvalid = X.c.nblk - b0 < SUB ? X.c.nblk - b0 : SUB;
+	cur.chA = chA;
+	cur.chB = bvalid ? chA + 1 : chA;
+	cur.bvalid = bvalid;
+	// (MODE 1 -- one phase per thread -- already fills the scalar file with its span bookkeeping: it reads the
+	// arguments where it needs them, as before)
+	if constexpr (MODE == 1) convp_body<LN, UL, MODE, FLENP>(ex, X, X, reinterpret_cast<cd*>(smem), cur);
+	else convp_body<LN, UL, MODE, FLENP>(ex, H, X, reinterpret_cast<cd*>(smem), cur);
 #ifdef R8B_TIMELINE
 	if (threadIdx.x == 0 && blockIdx.x < 16384)
 	{
@@ -848,20 +755,6 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 #endif
 	ex.dump();
 }
-
-#ifdef R8B_PERSIST_LOOP
-// workgroups of a pair kernel the device holds at once, rounded down to a multiple of 8 (0: unknown)
-unsigned convp_capacity(const void* kern, int threads, size_t lds)
-{
-	int dev = 0, cus = 0, per = 0;
-	if (hipGetDevice(&dev) != hipSuccess) return 0;
-	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, kern, threads, lds) != hipSuccess) return 0;
-	if (const char* e = getenv("R8B_PERSIST_PER_CU")) per = atoi(e); // (development: occupancy experiments)
-	const long long n = (long long) cus * per;
-	return n > 0 ? (unsigned) (n & ~7ll) : 0u;
-}
-#endif
 
 template<int LN, int UL, int MODE, int FLENP>
 void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
@@ -891,22 +784,6 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
 	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
 	unsigned grid = nbg * npair;
-#ifdef R8B_PERSIST_LOOP
-	// persistent form: as many workgroups as the chip holds at once (a multiple of 8, the XCDs), when the launch has
-	// at least twice as many items; the shorter ones keep one workgroup per item
-	static const unsigned capacity = convp_capacity(reinterpret_cast<const void*>(kern), ConvpGeom<LN, UL>::WT, lds);
-	if (X.qcnt != nullptr && getenv("R8B_PERSIST_STATS"))
-	{
-		// (development: workgroups of the earlier launches whose XCD was not blockIdx mod 8)
-		unsigned v = 0;
-		check(hipMemcpy(&v, X.qcnt + 10, sizeof(unsigned), hipMemcpyDeviceToHost), "stats");
-		fprintf(stderr, "k_convp persistent: %u workgroups so far ran on an XCD other than blockIdx mod 8\n", v);
-	}
-	if (X.qcnt != nullptr && capacity >= 8u && grid >= 2u * capacity) grid = capacity;
-	else X.qcnt = nullptr;
-#else
-	X.qcnt = nullptr; // (the persistent form is compiled out: DESIGN.md section 5)
-#endif
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
 	}

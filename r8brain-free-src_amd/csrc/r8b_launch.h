@@ -233,9 +233,6 @@ struct ConvxLaunch
 	const double* ctab;
 	int nsets;
 	unsigned nblk_magic; // floor(2^32 / c.nblk) + 1 (filled in by the launcher; r8b_convp.h convp_div)
-	// pair form, persistent launches (r8b_kernels.hip k_convp): 8 work-queue counters (one per XCD) + 1 exit counter,
-	// all zero between launches; null: one workgroup per item
-	unsigned* qcnt;
 };
 
 // geometries the fast path is instantiated for: (log2 of the forward complex length, up shift), and

@@ -230,7 +230,6 @@ struct EmulExecP
 	unsigned bits = 0;
 	EmulExecP() : st((size_t) WT) {}
 	void stamp2() {}
-	void before_last_phase() {}
 	void post_bits(int, unsigned v) { bits |= v; }
 	unsigned collect_bits() const { return bits; }
 	template<class F>
