@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical record of a round-3 experiment: it ran against the build of its own commit; variants, macros and the
+# engine option "persist" it names were removed again -- DESIGN.md section 5, profiles/r03_experiments.txt)
 # tools/r3_p.sh -- round 3, second session: GPU tier on the new build, then A/B of the headline configuration:
 # variants/base.so (build of commit 1ef1b84), the new library with one workgroup per item (persist=0) and with
 # persistent workgroups on work queues (default)

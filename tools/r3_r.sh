@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical record of a round-3 experiment: it ran against the build of its own commit; variants, macros and the
+# engine option "persist" it names were removed again -- DESIGN.md section 5, profiles/r03_experiments.txt)
 # tools/r3_r.sh -- lane assignment of the interpolator with fewer LDS bank clashes (lean), LDS reads pair by pair
 # between the multiply-adds (pipe5 / pipe8: 5 / 8 pairs ahead); counters of lean and pipe5
 out=gpurun_out/r3r; mkdir -p $out; rm -f $out/*

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical record of a round-3 experiment: it ran against the build of its own commit; variants, macros and the
+# engine option "persist" it names were removed again -- DESIGN.md section 5, profiles/r03_experiments.txt)
 # tools/r3_t.sh -- persistent workgroups with the second workgroup of every CU started late (R8B_STAGGER sleep periods)
 out=gpurun_out/r3t; mkdir -p $out; rm -f $out/*
 line() { python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('%-40s' % sys.argv[1], d['value'], d['ms_per_step'], d['roofline']['kernels_ms_per_step'])" "$1"; }

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical record of a round-3 experiment: it ran against the build of its own commit; variants, macros and the
+# engine option "persist" it names were removed again -- DESIGN.md section 5, profiles/r03_experiments.txt)
 # tools/r3_u.sh -- wave priority by phase (s_setprio at the start of an item / before the last backward pass / before
 # the interpolator): does asymmetry between the two workgroups of a CU matter?
 out=gpurun_out/r3u; mkdir -p $out; rm -f $out/*

@@ -1,4 +1,6 @@
 #!/bin/bash
+# (historical record of a round-3 experiment: it ran against the build of its own commit; variants, macros and the
+# engine option "persist" it names were removed again -- DESIGN.md section 5, profiles/r03_experiments.txt)
 # tools/r3_w.sh -- persistent form with the work queue chosen by the hardware's XCC id (and the statistics of how often
 # blockIdx mod 8 is NOT the XCD)
 out=gpurun_out/r3w; mkdir -p $out; rm -f $out/*
