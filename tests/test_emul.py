@@ -465,3 +465,32 @@ def test_emulated_paired_rows_equal_the_unpaired_row_bitwise(emul):
             assert np.array_equal(y5[ch], y1[0]), (c, ch)
         for ch in (1, 3):
             assert np.abs(y5[ch] - y1[0]).max() <= 4e-15, (c, ch)
+
+
+@pytest.mark.parametrize("src,dst,att", [(44100.0, 1411200.0, 49.5), (44100.0, 2822400.0, 50.38), (11025.0, 384000.0, 50.38)])
+def test_one_tap_halfband_start_of_stream(emul, refwrap, src, dst, att):
+    """Chains that contain a ONE-tap half-band up-sampler (attenuations below ~55 dB with four or more doubling stages).
+    The reference's CDSPHBUpsampler reads rp[1] of its ring's overrun area for the stream's first odd output, a slot its
+    constructor neither mirrors nor clears when the filter has one tap (CDSPHBUpsampler.h:606-607 flo = fll + fl2 = 1,
+    :668-671 nothing cleared, :688-693 one sample mirrored; `double Buf[BufLen + 27]` is an uninitialised member) -- the
+    reference's value there is indeterminate.  This library computes the stated filter (= the numpy restatement) for every
+    sample; it must agree with the reference everywhere else.  (Found by tools/wide_fuzz.py, round 3.)"""
+    maxin, tb = 1024, 1.49
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=1, lib=emul)
+    assert "taps=1 " in b.describe(), b.describe()
+    ref = refwrap.RefResampler(src, dst, maxin, tb, att)
+    orc = O.OracleResampler(src, dst, maxin, tb, att)
+    x = O.splitmix_uniform(48, 1500)
+    pos, seen = 0, 0
+    for l in (300, 400, 200, 600):
+        y = b.process_host(x[None, pos:pos + l])[0]
+        yr, yo = ref.process(x[pos:pos + l]), orc.process(x[pos:pos + l])
+        assert len(y) == len(yr) == len(yo)
+        if len(y):
+            assert np.abs(y - yo).max() <= PEAK_TOL
+            bad = np.nonzero(np.abs(y - yr) > PEAK_TOL)[0] + seen
+            # (only among the first outputs of the stream: one per one-tap stage, spread by the stages behind it)
+            assert len(bad) <= 4 and (len(bad) == 0 or bad.max() < 8), bad
+        seen += len(y)
+        pos += l
+    assert seen > 100
