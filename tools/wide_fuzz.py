@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 rng = np.random.default_rng(seed)
 emul = T.r8b.bind(os.path.join(ROOT, "tests", "emul", "_build", "libr8bsrc_emul.so"))
-bad = skipped = 0
+bad = skipped = known = 0
 geoms = {}
 for i, c in enumerate(T._cases(n, seed)):
     src, dst, maxin, _, _, s = c
@@ -23,7 +23,12 @@ for i, c in enumerate(T._cases(n, seed)):
     except pytest.skip.Exception:
         skipped += 1
     except AssertionError as e:
-        bad += 1; print("FAIL", case, str(e)[:300], flush=True)
+        # (the one known difference: the reference's indeterminate start-of-stream sample behind a one-tap half-band
+        # up-sampler -- DESIGN.md section 6, tests/test_emul.py test_one_tap_halfband_start_of_stream)
+        if "taps=1 " in T.r8b.BatchResampler(src, dst, maxin, tb, att, nch=1, lib=emul).describe():
+            known += 1
+        else:
+            bad += 1; print("FAIL", case, str(e)[:300], flush=True)
     except Exception as e:
         bad += 1; print("ERR", case, repr(e)[:300], flush=True)
-print("wide fuzz done", n, "bad", bad, "skipped", skipped)
+print("wide fuzz done", n, "bad", bad, "skipped", skipped, "one-tap half-band chains (reference indeterminate)", known)
