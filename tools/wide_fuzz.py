@@ -11,7 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 rng = np.random.default_rng(seed)
 emul = T.r8b.bind(os.path.join(ROOT, "tests", "emul", "_build", "libr8bsrc_emul.so"))
-bad = skipped = known = 0
+bad = skipped = known = known32 = 0
 geoms = {}
 for i, c in enumerate(T._cases(n, seed)):
     src, dst, maxin, _, _, s = c
@@ -25,10 +25,17 @@ for i, c in enumerate(T._cases(n, seed)):
     except AssertionError as e:
         # (the one known difference: the reference's indeterminate start-of-stream sample behind a one-tap half-band
         # up-sampler -- DESIGN.md section 6, tests/test_emul.py test_one_tap_halfband_start_of_stream)
-        if "taps=1 " in T.r8b.BatchResampler(src, dst, maxin, tb, att, nch=1, lib=emul).describe():
+        desc = T.r8b.BatchResampler(src, dst, maxin, tb, att, nch=1, lib=emul).describe()
+        a = e.args[0] if e.args and isinstance(e.args[0], tuple) and len(e.args[0]) == 3 else None
+        if "taps=1 " in desc:
             known += 1
+        elif "fft=32768/" in desc and a is not None and a[1] <= 1e-10 and a[2] <= 5e-10:
+            # (the stated exception of tests/cases.py REBLOCK_CASES: a 32768-point reference block whose spectrum the
+            # reference truncates -- ratios 3/2 and 3/4 --, run here on 16384-point blocks of the same filter)
+            known32 += 1
         else:
             bad += 1; print("FAIL", case, str(e)[:300], flush=True)
     except Exception as e:
         bad += 1; print("ERR", case, repr(e)[:300], flush=True)
-print("wide fuzz done", n, "bad", bad, "skipped", skipped, "one-tap half-band chains (reference indeterminate)", known)
+print("wide fuzz done", n, "bad", bad, "skipped", skipped, "one-tap half-band chains (reference indeterminate)", known,
+      "truncated 32768-point reference blocks within 1e-10", known32)
