@@ -1811,6 +1811,18 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 		return v < 0 ? 0 : v / S + 1;
 	};
 	const long long kfirst = owner(wa), klast = owner(wb - 1);
+	if (X.c.tail_ring != nullptr && pair_two && c.cg.up_pow2)
+	{
+		// History for the next call, exactly: its first block is owner(wb) -- the first block whose outputs this call
+		// has not produced --, and no later block reads further back than that block's window (r8b_convp.h cp_load:
+		// n_in input samples ending in_len / up behind the block's start).  fill_conv asked for history(), the bound
+		// over every way of cutting the stream into calls: about twice what a call of MaxInLen samples needs.
+		const long long kn = owner(wb);
+		const long long wstart = ((kn * S + off) >> (up > 1 ? 1 : 0)) - ((long long) c.cg.n_in - in_len / up);
+		const long long p0 = std::min(std::max(X.c.tail_p0, wstart - 8), X.c.tail_p1);
+		X.c.tail_p0 = p0 & ~1LL; // (even: pairs of samples)
+		if (X.c.tail_p0 < 0) X.c.tail_p0 = 0;
+	}
 	for (long long k0 = kfirst; k0 <= klast; k0 += kConvxMaxBlocks)
 	{
 		const long long k1 = std::min(klast, k0 + kConvxMaxBlocks - 1);
