@@ -1187,6 +1187,16 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0; X.run_off = 0;
 			X.ptab = nullptr; X.ctab = nullptr; X.nsets = 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
+			if (path == kPathPair && L.tail_ring != nullptr && g.up_pow2)
+			{
+				// (history for the next call, exactly -- cf. launch_fused: the next call's first block is the one that
+				// holds output b, blocks sit at multiples of in_len, a block's window is n_in input samples ending
+				// in_len / up behind its start)
+				const long long kn = ((long long) g.down * b + g.fl2) / g.in_len;
+				const long long wstart = ((kn * g.in_len) >> (g.up > 1 ? 1 : 0)) - ((long long) g.n_in - g.in_len / g.up);
+				const long long p0 = std::min(std::max(L.tail_p0, wstart - 8), L.tail_p1);
+				L.tail_p0 = p0 < 0 ? 0 : (p0 & ~1LL);
+			}
 			if (path == kPathPair3) launch_convp(X, g.complex_h ? 7 : 3, stream);
 			else if (path == kPathConvx3) launch_convx(X, 3, stream);
 			else if (path == kPathPair) launch_convp(X, g.complex_h ? 6 : 0, stream);
