@@ -423,6 +423,79 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 	}
 }
 
+// History for the next call out of the registers cp_load() filled (convp_tail_owners): the block's own part of the
+// tail -- positions base(k) .. base(k + 1) - 1 of its window, clipped to [tail_c0, tail_c1) -- goes to the other
+// history ring as it arrives; no load, no wait.
+template<int LN, int UL>
+R8B_HD void cp_tail_owned(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int chA, int chB, bool bvalid, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int R = G::E1, q = G::N / R;
+	constexpr int US = UL > 0 ? UL : 0;
+	if (k < L.k0 + L.tail_bf) return;
+	const int iln = L.in_len >> US;
+	const long long base = (k * (long long) L.blk_stride + L.blk_offset) >> US;
+	const long long nbase = ((k + 1) * (long long) L.blk_stride + L.blk_offset) >> US;
+	const long long lo = k == L.k0 + L.tail_bf || base < L.tail_c0 ? L.tail_c0 : base;
+	const long long hi = k == L.k0 + L.nblk - 1 || nbase > L.tail_c1 ? L.tail_c1 : nbase;
+	if (lo >= hi) return;
+	const long long w0 = base - (G::N - iln);
+	// (0 <= lo - w0 < hi - w0 <= N: both inside the window)
+	const unsigned lo_r = (unsigned) (lo - w0), n_r = (unsigned) (hi - lo);
+	const unsigned m = (unsigned) L.src.ring_mask, w0m = (unsigned) (w0 & L.src.ring_mask);
+	double* const ra = L.tail_ring + (long long) chA * L.src.ring_stride;
+	double* const rb = L.tail_ring + (long long) chB * L.src.ring_stride;
+	const unsigned l0 = (unsigned) (lt + ((L.rot + G::N - iln) & (G::N - 1)));
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		const unsigned w = (l0 + (unsigned) (p * q)) & (unsigned) (G::N - 1);
+		if (w - lo_r < n_r)
+		{
+			const unsigned e = (w0m + w) & m;
+			ra[e] = st.pr[p];
+			if (bvalid) rb[e] = st.pi[p];
+		}
+	}
+}
+
+// positions [s0, s1) of the caller's fp64 buffer to the other history ring, by the WT threads of a workgroup, eight
+// samples per channel in flight per thread
+template<int WT>
+R8B_HD void cp_tail_rest(const ConvLaunch& L, long long s0, long long s1, int chA, int chB, bool bvalid, int tid)
+{
+	constexpr int TB = 8;
+	const double* const pa = L.src.cur + ((long long) chA * L.src.cur_stride - L.src.cur_base);
+	const double* const pb = L.src.cur + ((long long) chB * L.src.cur_stride - L.src.cur_base);
+	double* const ra = L.tail_ring + (long long) chA * L.src.ring_stride;
+	double* const rb = L.tail_ring + (long long) chB * L.src.ring_stride;
+	for (long long i0 = s0 + tid; i0 < s1; i0 += (long long) TB * WT)
+	{
+		double va[TB], vb[TB];
+#pragma unroll
+		for (int j = 0; j < TB; j++)
+		{
+			const long long i = i0 + (long long) j * WT;
+			va[j] = vb[j] = 0.0;
+			if (i < s1)
+			{
+				va[j] = pa[i];
+				if (bvalid) vb[j] = pb[i];
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < TB; j++)
+		{
+			const long long i = i0 + (long long) j * WT;
+			if (i < s1)
+			{
+				ra[i & L.src.ring_mask] = va[j];
+				if (bvalid) rb[i & L.src.ring_mask] = vb[j];
+			}
+		}
+	}
+}
+
 // first forward pass, from the registers cp_load() filled
 template<int LN, int UL>
 R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st, int lt)
@@ -1258,6 +1331,18 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ptw_fetch<G::E1, G::NT>(st.tw, L.ptw, 0, lt);
 		ex.stamp2();
 		if constexpr (!(R8B_ABL & 8)) cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
+		if constexpr (UL >= 0)
+		{
+			if ((L.tail_flags & 2) != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) > L.k0 + L.tail_bf)
+			{
+				// (the launch's last block: the samples behind its window -- read by no block of this call -- requested
+				// beside its own, one wait for both; all of them in the caller's fp64 buffer: convp_tail_owners)
+				if (cur.k + (G::SUB == 1 ? 1 : cur.nvalid) == L.k0 + L.nblk)
+					cp_tail_rest<G::WT>(L, L.tail_c1, L.tail_p1, chA, chB, bvalid, tid);
+				ex.stamp2();
+				if (live(tid)) cp_tail_owned<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
+			}
+		}
 		ex.stamp2();
 		ex.post_bits(tid, cp_nonzero_bits<LN, UL>(st));
 		ex.stamp2();
@@ -1375,19 +1460,32 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	else if constexpr (G::B1) ex.wave_steps(s_midc, s_midw, s_b1);
 	else ex.wave_steps(s_midc, s_midw);
 	}
-	// History for the next call (stage 0 only): the tail of the caller's buffers goes into the other history ring, every
-	// workgroup of a channel pair copying its share of it (block b of the launch's nblk the b-th slice), eight
-	// samples per channel in flight per thread.  (One workgroup -- the first block's -- copying the whole tail with
-	// one load in flight per thread took 40 000 cycles on top of its 31 000: tools/timeline_probe.py, 8 % of the
-	// workgroups at 2.2x the lifetime of the others; cfg3 -18 %.  Issued here, behind the wave-local passes: with
-	// the first phase's sample loads -- one wait for both -- it measured 1.5 % / 5 % slower on cfg2 / cfg3.)  The
-	// stores need no wait.
-	if (L.tail_ring != nullptr)
+	// History for the next call (stage 0 only): the tail of the caller's buffers goes into the other history ring.
+	// Calls whose blocks read the caller's fp64 buffer (tail_flags & 2, convp_tail_owners): the blocks that hold the tail
+	// in registers stored it in the first phase (cp_tail_owned: no load at all), the launch's last block fetched what lies
+	// behind its window beside its samples (cp_tail_rest); left for this place is only history older than the caller's
+	// buffer -- short calls --, with the first block.  Otherwise (tail_flags & 1: PCM input, 3x zero stuffing, calls
+	// shorter than a window) every workgroup of a channel pair copies its share of the tail here, block b of the
+	// launch's nblk the b-th slice, eight samples per channel in flight per thread.  (History of this code, all
+	// measured, DESIGN.md section 5: the first block copying the whole tail with one load in flight per thread took
+	// 40 000 cycles on top of its 31 000 -- tools/timeline_probe.py --; slices for every block, here: cfg3 -18 %, but
+	// a round trip of 3 500-5 500 cycles per workgroup wherever the loads were put; from the registers: cfg2 -3.5 %,
+	// cfg3 -6 % again, the last block 5 000 cycles longer than the others -- the samples it fetches for the ring miss
+	// the caches like its own, and a CU's L1 keeps only so many misses in flight.)
+	if ((L.tail_flags & 5) != 0)
 	{
 		const unsigned tn = (unsigned) (L.tail_p1 - L.tail_p0), nb = (unsigned) L.nblk;
 		const unsigned bi = (unsigned) (cur.k - L.k0), be = bi + (unsigned) (G::SUB == 1 ? 1 : cur.nvalid);
 		// (tn * nblk < 2^32: the tail is a few thousand samples, a launch at most kConvxMaxBlocks blocks)
-		const long long s0 = L.tail_p0 + (long long) (tn * bi / nb), s1 = L.tail_p0 + (long long) (tn * be / nb);
+		long long s0 = L.tail_p0 + (long long) (tn * bi / nb), s1 = L.tail_p0 + (long long) (tn * be / nb);
+		if ((L.tail_flags & 2) != 0)
+		{
+			// (what the blocks' registers did not hold -- cp_tail_owned -- and the last block did not fetch beside its
+			// samples: history older than the caller's buffer, with the launch's first block)
+			const bool first = bi == 0;
+			s0 = L.tail_p0;
+			s1 = first ? L.tail_c0 : L.tail_p0;
+		}
 		ex.each([&](int tid, St&)
 		{
 			constexpr int TB = 8;
@@ -1507,11 +1605,42 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 // rotates the circular convolution's output by up * rot, so with rot = -(fl2 / up) mod N the valid outputs start at
 // circular position fl2 mod up instead of fl2.  Power-of-two zero stuffing only (the 3x forms and the decimating
 // form keep rot = 0, fl2r = fl2).
+// History tail from the registers (cp_tail_owned): which blocks of the launch put which part of [tail_p0, tail_p1)
+// into the ring.  Block k's window is the N samples ending at base(k) + iln (cp_load); blocks kf .. read it from the
+// caller's fp64 buffer alone, and consecutive windows start at most iln apart, so position i of
+// [max(tail_p0, window start of kf), min(tail_p1, window end of the last block)) lies in the window of the block with
+// base(k) <= i < base(k + 1) (kf below its base, the last block above the next base).
+template<int N, int US>
+inline void convp_tail_owners(ConvLaunch& L)
+{
+	if (L.tail_ring == nullptr || L.src.cur_fmt != kPcmF64 || L.blk_stride > L.in_len || L.tail_p1 <= L.tail_p0) return;
+	const long long iln = L.in_len >> US, hist = N - iln;
+	auto base = [&](long long k) { return (k * (long long) L.blk_stride + L.blk_offset) >> US; };
+	const long long klast = L.k0 + L.nblk - 1;
+	const long long floor0 = L.src.cur_base > 0 ? L.src.cur_base : 0;
+	long long kf = L.k0;
+	while (kf <= klast && base(kf) - hist < floor0) kf++;
+	if (kf > klast) return;
+	long long c0 = base(kf) - hist, c1 = base(klast) + iln;
+	c0 = c0 < L.tail_p0 ? L.tail_p0 : (c0 > L.tail_p1 ? L.tail_p1 : c0);
+	c1 = c1 > L.tail_p1 ? L.tail_p1 : (c1 < c0 ? c0 : c1);
+	// (the first block that has something to do: the one whose part of the stream reaches past c0, at the latest the
+	// last one -- it fetches what lies behind c1)
+	while (kf < klast && base(kf + 1) <= c0) kf++;
+	L.tail_flags = 2 | (L.tail_p0 < c0 ? 4 : 0);
+	L.tail_bf = (int) (kf - L.k0);
+	L.tail_c0 = c0;
+	L.tail_c1 = c1;
+}
+
 template<int LN, int UL>
 inline void convp_prepare(ConvxLaunch& X)
 {
 	X.c.rot = 0;
 	X.c.fl2r = X.c.fl2;
+	X.c.tail_flags = X.c.tail_ring != nullptr ? 1 : 0;
+	X.c.tail_bf = 0;
+	X.c.tail_c0 = X.c.tail_c1 = 0;
 	if constexpr (UL >= 0)
 	{
 		if (X.c.up_pow2 && X.c.up == (1 << (UL > 0 ? UL : 0)))
@@ -1519,6 +1648,7 @@ inline void convp_prepare(ConvxLaunch& X)
 			constexpr int N = ConvpGeom<LN, UL>::N;
 			X.c.rot = (N - ((X.c.fl2 / X.c.up) & (N - 1))) & (N - 1);
 			X.c.fl2r = X.c.fl2 % X.c.up;
+			convp_tail_owners<N, (UL > 0 ? UL : 0)>(X.c);
 		}
 	}
 }

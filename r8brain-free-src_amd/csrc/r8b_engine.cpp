@@ -1739,6 +1739,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	}
 	L.src = src;
 	L.tail_ring = nullptr; L.tail_p0 = L.tail_p1 = 0;
+	L.tail_flags = 0; L.tail_bf = 0; L.tail_c0 = L.tail_c1 = 0;
 	if (s == 0 && opt_.at("fold_tail"))
 	{
 		// stage 0 on the fast path: let the kernel keep the history (see process())
@@ -1833,9 +1834,12 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 		X.c.tail_p0 = p0 & ~1LL; // (even: pairs of samples)
 		if (X.c.tail_p0 < 0) X.c.tail_p0 = 0;
 	}
+	double* const tail_ring = X.c.tail_ring;
 	for (long long k0 = kfirst; k0 <= klast; k0 += kConvxMaxBlocks)
 	{
 		const long long k1 = std::min(klast, k0 + kConvxMaxBlocks - 1);
+		// (the history with the call's LAST launch: its blocks are the ones that hold the tail in registers)
+		X.c.tail_ring = k1 == klast ? tail_ring : nullptr;
 		X.c.k0 = k0;
 		X.c.nblk = (int) (k1 - k0 + 1);
 		for (int i = 0; i < X.c.nblk; i++)
@@ -1874,7 +1878,6 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 		else if (use_pair_fused(c.cg)) launch_convp(X, 1, stream);
 		else launch_convx(X, 1, stream);
 		if (X.c.tail_ring != nullptr) tail_done_ = true;
-		X.c.tail_ring = nullptr; // once per call
 	}
 }
 

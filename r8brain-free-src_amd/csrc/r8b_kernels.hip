@@ -708,7 +708,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	// output loses its kernel-argument provenance and would be dereferenced with flat instructions)
 	asm volatile("" : "+s"(H.c.k0), "+s"(H.c.blk_stride), "+s"(H.c.blk_offset), "+s"(H.c.in_len), "+s"(H.c.fl2),
 		"+s"(H.c.up_pow2), "+s"(H.c.src.cur_stride), "+s"(H.c.src.cur_base), "+s"(H.c.src.cur_fmt), "+s"(H.c.rot),
-		"+s"(H.c.fl2r)
+		"+s"(H.c.fl2r), "+s"(H.c.tail_flags), "+s"(H.c.tail_bf)
 		: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
 	if constexpr (MODE == 4 || MODE == 5)
 		asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),

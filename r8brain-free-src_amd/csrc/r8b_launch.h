@@ -63,6 +63,14 @@ struct ConvLaunch
 	// [tail_p0, tail_p1) into the history ring the NEXT call reads (null: nothing to copy)
 	double* tail_ring;
 	long long tail_p0, tail_p1;
+	// pair form (r8b_convp.h convp_prepare / cp_tail_owned), tail_flags: 1 -- every block copies a slice of the tail;
+	// 2 -- positions [tail_c0, tail_c1) of the tail go to the ring from the registers of the blocks that load them
+	// anyway (blocks k0 + tail_bf ..: the ones that read the caller's buffer alone and hold a part of it), the launch's
+	// last block fetches [tail_c1, tail_p1) beside its samples; 4 (with 2) -- the first block copies [tail_p0, tail_c0).
+	// 0: nothing to do (tail_ring == nullptr).  (Two integers the kernel keeps in scalar registers: a block with
+	// nothing to do finds that out without a load.)
+	int tail_flags, tail_bf;
+	long long tail_c0, tail_c1;
 	int up_pow2, down_pow2;
 	// transform plan: radices of the forward passes in execution order (sub-length N, N/r0, ...)
 	// and of the backward passes in execution order (sub-length grows to N2)

@@ -13,7 +13,7 @@ if len(sys.argv) > 2:
 rs = r8b.BatchResampler(src, dst, L, 2.0, 180.15, nch=nch, device=0)
 x = torch.rand((nch, L), dtype=torch.float64, device="cuda:0") * 2 - 1
 out = torch.empty((nch, rs.max_out_len), dtype=torch.float64, device="cuda:0")
-for i in range(30):
+for i in range(int(os.environ.get("NCALLS", "30"))):
     rs.process(x, out=out)
 torch.cuda.synchronize()
 lib = ctypes.CDLL(os.environ["R8B_HIP_LIB"])

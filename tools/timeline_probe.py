@@ -12,6 +12,8 @@ src, dst, nch, L = 44100.0, 96000.0, 1024, 16384
 if len(sys.argv) > 2:
     src, dst = float(sys.argv[1]), float(sys.argv[2])
 rs = r8b.BatchResampler(src, dst, L, 2.0, 180.15, nch=nch, device=0)
+for o in os.environ.get("R8B_OPTS", "").split():  # (engine options, "name=value ...")
+    rs.set_option(o.split("=")[0], int(o.split("=")[1]))
 x = torch.rand((nch, L), dtype=torch.float64, device="cuda:0") * 2 - 1
 out = torch.empty((nch, rs.max_out_len + 8), dtype=torch.float64, device="cuda:0")
 for i in range(200):
@@ -67,3 +69,15 @@ first = np.sort(t0)[:512] - kstart
 print("start of the first 512 workgroups after the launch's first: p50 %.0f p90 %.0f max %.0f" % (*np.percentile(first, [50, 90]), first.max()))
 last_start = np.sort(t0)[-1] - kstart
 print("last workgroup starts at %.0f, launch ends at %.0f" % (last_start, kend - kstart))
+# lifetime by the block's place in its channel pair's run (k_convp's mapping: workgroup w -> block group (w >> 3) % nbg
+# when the pair count is a multiple of 8); the tail of the history goes with the last ones
+idx = np.nonzero(np.array(buf[:], dtype=np.int64).reshape(N, 4)[:, 1] > 0)[0]
+idx = idx[np.array(buf[:], dtype=np.int64).reshape(N, 4)[idx, 3] == a[:, 3].max()]
+npair = (nch + 1) // 2
+if len(idx) == len(a) and len(a) % npair == 0 and npair % 8 == 0:
+    nbg = len(a) // npair
+    bg = (idx >> 3) % nbg
+    print("blocks per pair", nbg, "- lifetime by block (mean / p50 / p90):")
+    for b in range(nbg):
+        m = bg == b
+        print("  block %2d: %6.0f %6.0f %6.0f" % (b, life[m].mean(), *np.percentile(life[m], [50, 90])))
