@@ -1331,17 +1331,14 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ptw_fetch<G::E1, G::NT>(st.tw, L.ptw, 0, lt);
 		ex.stamp2();
 		if constexpr (!(R8B_ABL & 8)) cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
-		if constexpr (UL >= 0)
+		if ((L.tail_flags & 2) != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) > L.k0 + L.tail_bf)
 		{
-			if ((L.tail_flags & 2) != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) > L.k0 + L.tail_bf)
-			{
-				// (the launch's last block: the samples behind its window -- read by no block of this call -- requested
-				// beside its own, one wait for both; all of them in the caller's fp64 buffer: convp_tail_owners)
-				if (cur.k + (G::SUB == 1 ? 1 : cur.nvalid) == L.k0 + L.nblk)
-					cp_tail_rest<G::WT>(L, L.tail_c1, L.tail_p1, chA, chB, bvalid, tid);
-				ex.stamp2();
-				if (live(tid)) cp_tail_owned<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
-			}
+			// (the launch's last block: the samples behind its window -- read by no block of this call -- requested
+			// beside its own, one wait for both; all of them in the caller's fp64 buffer: convp_tail_owners)
+			if (cur.k + (G::SUB == 1 ? 1 : cur.nvalid) == L.k0 + L.nblk)
+				cp_tail_rest<G::WT>(L, L.tail_c1, L.tail_p1, chA, chB, bvalid, tid);
+			ex.stamp2();
+			if (live(tid)) cp_tail_owned<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
 		}
 		ex.stamp2();
 		ex.post_bits(tid, cp_nonzero_bits<LN, UL>(st));
@@ -1650,6 +1647,11 @@ inline void convp_prepare(ConvxLaunch& X)
 			X.c.fl2r = X.c.fl2 % X.c.up;
 			convp_tail_owners<N, (UL > 0 ? UL : 0)>(X.c);
 		}
+	}
+	else
+	{
+		// (decimation in the spectrum: the block is loaded as in the 1:1 form)
+		if (X.c.up == 1) convp_tail_owners<ConvpGeom<LN, UL>::N, 0>(X.c);
 	}
 }
 
