@@ -494,3 +494,24 @@ def test_one_tap_halfband_start_of_stream(emul, refwrap, src, dst, att):
         seen += len(y)
         pos += l
     assert seen > 100
+
+
+TAIL_TOPOLOGIES = [(44100.0, 96000.0, 8192), (96000.0, 44100.0, 16384), (88200.0, 44100.0, 12000), (44100.0, 88200.0, 6000),
+                   (48000.0, 32000.0, 16384)]
+
+
+@pytest.mark.parametrize("src,dst,maxin", TAIL_TOPOLOGIES)
+def test_emulated_history_from_registers_equals_the_copy_kernel(emul, src, dst, maxin):
+    """the stream's history for the next call, three ways: stored by the blocks that hold it in registers plus the last
+    block's fetch (long calls, r8b_convp.h convp_tail_owners), copied in slices by every block (calls shorter than a
+    window) and by a kernel of its own (option fold_tail = 0) -- the outputs are the same BIT FOR BIT, with an odd channel
+    count (a block pair without a partner) and calls of every length in between"""
+    lens = [maxin, maxin, maxin // 3, 300, maxin, 17, 1, maxin - 5, 2500, maxin]
+    a = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=3, lib=emul)
+    b = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=3, lib=emul)
+    b.set_option("fold_tail", 0)
+    rng = np.random.default_rng(5)
+    for i, l in enumerate(lens):
+        x = rng.uniform(-1.0, 1.0, (3, l))
+        ya, yb = a.process_host(x), b.process_host(x)
+        assert ya.shape == yb.shape and np.array_equal(ya, yb), (i, l)

@@ -467,3 +467,20 @@ def test_cxx_batch_device(tmp_path):
                     "-L" + libdir, "-lr8bsrc_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.returncode, out.stdout)
+
+
+@pytest.mark.parametrize("src,dst,maxin", [(44100.0, 96000.0, 16384), (96000.0, 44100.0, 16384), (88200.0, 44100.0, 12000),
+                                           (44100.0, 88200.0, 6000), (48000.0, 32000.0, 16384)])
+def test_hip_history_from_registers_equals_the_copy_kernel(torch, src, dst, maxin):
+    """the GPU twin of tests/test_emul.py test_emulated_history_from_registers_equals_the_copy_kernel: the next call's
+    history stored from the blocks' registers / copied in slices / copied by a kernel of its own -- same stream bit for
+    bit, odd channel count, ragged calls"""
+    lens = [maxin, maxin, maxin // 3, 300, maxin, 17, 1, maxin - 5, 2500, maxin]
+    a = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=5, device=0)
+    b = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=5, device=0)
+    b.set_option("fold_tail", 0)
+    rng = np.random.default_rng(5)
+    for i, l in enumerate(lens):
+        x = rng.uniform(-1.0, 1.0, (5, l))
+        ya, yb = a.process_host(x), b.process_host(x)
+        assert ya.shape == yb.shape and np.array_equal(ya, yb), (i, l)
