@@ -284,6 +284,59 @@ R8B_HD void ptw_fetch(cd* twr, const cd* ptw, int slot, int lt)
 	for (int c = 0; c < NB; c++) twr[c] = p[c * NT];
 }
 
+// First forward / last backward pass: every thread has twiddles of its own (NT distinct rows: 16 KB ... 24 KB per pass and
+// block from L2, and the L1's miss queue is what the kernel waits for -- DESIGN.md section 5), so only the powers that
+// cannot be had from others are fetched -- w (and w^4 for radix 16) -- and the rest of the base set comes from
+// products: w^2 = w w, w^3 = w^2 w, (radix 8: w^4 = w^2 w^2,) w^8 = w^4 w^4, w^12 = w^8 w^4.  A twiddle of a butterfly
+// is then the product of at most three rounded products instead of one (tw_get); the stream's distance from the
+// reference stays where it was (tests: RMS 3e-16).  R8B_TW_DERIVE = 0: every base power fetched, as before.
+#ifndef R8B_TW_DERIVE
+#define R8B_TW_DERIVE 1
+#endif
+template<int R, int NT>
+R8B_HD void ptw_fetch_lean(cd* twr, const cd* ptw, int slot, int lt)
+{
+	constexpr int NB = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
+	if constexpr (!R8B_TW_DERIVE || (R8B_ABL & 128) != 0) ptw_fetch<R, NT>(twr, ptw, slot, lt);
+	else
+	{
+		const cd* p = ptw + (slot * 6 * NT + lt);
+		twr[0] = p[0];
+		if constexpr (NB == 6) twr[3] = p[3 * NT];
+	}
+}
+R8B_HD cd tw_sq(cd a)
+{
+	cd r;
+	r.re = a.re * a.re - a.im * a.im;
+	r.im = 2.0 * (a.re * a.im);
+	return r;
+}
+R8B_HD cd tw_mul(cd a, cd b)
+{
+	cd r;
+	r.re = a.re * b.re - a.im * b.im;
+	r.im = a.re * b.im + a.im * b.re;
+	return r;
+}
+// the base set of tw_get (w, w^2, w^3, w^4, w^8, w^12) completed from what ptw_fetch_lean fetched
+template<int R>
+R8B_HD void tw_expand(cd* twr)
+{
+	constexpr int NB = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
+	if constexpr (R8B_TW_DERIVE && (R8B_ABL & 128) == 0 && NB >= 3)
+	{
+		twr[1] = tw_sq(twr[0]);
+		twr[2] = tw_mul(twr[1], twr[0]);
+		if constexpr (NB == 4) twr[3] = tw_sq(twr[1]);
+		if constexpr (NB == 6)
+		{
+			twr[4] = tw_sq(twr[3]);
+			twr[5] = tw_mul(twr[4], twr[3]);
+		}
+	}
+}
+
 // ---- passes over the swizzled array ---------------------------------------------------------------
 
 template<int LN, int UL, int R, bool TW>
@@ -502,7 +555,12 @@ R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st,
 {
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int R = G::E1, q = G::N / R;
-	const cd* const loc = st.tw; // (fetched by the caller ahead of the samples)
+	// (fetched by the caller ahead of the samples -- ptw_fetch_lean --, completed here)
+	constexpr int NBW = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
+	cd loc[NBW];
+#pragma unroll
+	for (int c = 0; c < NBW; c++) loc[c] = st.tw[c];
+	tw_expand<R>(loc);
 	double vr[R], vi[R];
 #pragma unroll
 	for (int p = 0; p < R; p++)
@@ -686,7 +744,7 @@ R8B_HD void cp_back2_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int l
 {
 	typedef ConvpGeom<LN, UL> G;
 #pragma unroll
-	for (int m = 0; m < G::NB2; m++) ptw_fetch<G::R2, G::NT>(st.tw + m * G::NBASE2, L.ptw, 4 + m, lt);
+	for (int m = 0; m < G::NB2; m++) ptw_fetch_lean<G::R2, G::NT>(st.tw + m * G::NBASE2, L.ptw, 4 + m, lt);
 }
 
 // last backward pass (sub-length N2, radix R2 = N2 / 256): the thread's elements lt + NT i, i = 0 .. 15,
@@ -695,6 +753,11 @@ template<int LN, int UL>
 R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
+	if constexpr (G::R2 > 1)
+	{
+#pragma unroll
+		for (int m = 0; m < G::NB2; m++) tw_expand<G::R2>(st.tw + m * G::NBASE2);
+	}
 	if constexpr (G::R2 == 16) pdit_regs<16, true>(buf, G::N2, lt, st.tw, st.vr, st.vi);
 	else if constexpr (G::R2 > 1)
 	{
@@ -1328,7 +1391,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	{
 		const int lt = lt_of(tid);
 		// (the first pass's twiddles -- L2 -- requested ahead of the samples -- HBM --, not behind their wait)
-		ptw_fetch<G::E1, G::NT>(st.tw, L.ptw, 0, lt);
+		ptw_fetch_lean<G::E1, G::NT>(st.tw, L.ptw, 0, lt);
 		ex.stamp2();
 		if constexpr (!(R8B_ABL & 8)) cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
 		if ((L.tail_flags & 2) != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) > L.k0 + L.tail_bf)

@@ -1,12 +1,9 @@
 #!/bin/bash
-# tools/r3_y.sh -- A/B of history-tail variants (b2 / b3: the tree before; q2 / q3: tail from the blocks' registers, the
-# rest fetched beside the last block's samples; r2 / r3: the same with the blocks' "anything to do" test on two
-# scalars pinned at kernel entry; development builds of cfg2 / cfg3)
-for r in 1 2; do
-AB_ARGS="" bash tools/ab2.sh r3y_c2_$r b2 q2 r2 >/dev/null
-AB_ARGS="--config cfg3" bash tools/ab2.sh r3y_c3_$r b3 q3 r3 >/dev/null
+# tools/r3_y.sh -- A/B of one-kernel development builds (tools/variant.sh) on one box, alternating:
+# w0 / x0: cfg2 / cfg3 with every twiddle base power fetched (-DR8B_TW_DERIVE=0); w1 / x1: first / last pass powers derived
+for r in 1 2 3; do
+AB_ARGS="" bash tools/ab2.sh r3y_c2_$r w0 w1 >/dev/null
+AB_ARGS="--config cfg3" bash tools/ab2.sh r3y_c3_$r x0 x1 >/dev/null
 done
-for r in 1 2; do cat gpurun_out/r3y_c2_$r/bench.txt; done
-for r in 1 2; do cat gpurun_out/r3y_c3_$r/bench.txt; done
-R8B_HIP_LIB=$PWD/variants/tr2.so timeout 100 python tools/timeline_probe.py 2>&1 | grep -E "^lifetime|  block"
-timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -2
+for r in 1 2 3; do cat gpurun_out/r3y_c2_$r/bench.txt; done
+for r in 1 2 3; do cat gpurun_out/r3y_c3_$r/bench.txt; done
