@@ -191,6 +191,11 @@ R8BSRC_DECL int r8b_batch_set_option(CR8BBatch b, const char* name, int value);
  * the per-channel input/output sample counts those launches covered, and the kernel's name.
  * 0 on success. */
 R8BSRC_DECL int r8b_batch_stage_count(CR8BBatch b);
+/* Instrumentation: a counter of the engine since creation (-1: unknown name).  "conv_blocks": overlap-save blocks
+ * per channel the compile-time-sized convolver kernels were launched for (the reference computes every block once,
+ * CDSPBlockConvolver.h:283-350; so does this library where a call's last block parks what it holds of the next
+ * call); "park_calls": calls that took outputs from the park buffer; "park_only_calls": calls served from it alone. */
+R8BSRC_DECL long long r8b_batch_stat(CR8BBatch b, const char* name);
 R8BSRC_DECL int r8b_batch_stage_timing(CR8BBatch b, int stage, double* ms_sum, int* launches,
 	long long* in_samples, long long* out_samples, char* kernel, int cap);
 

@@ -341,6 +341,11 @@ R8BSRC_DECL int r8b_batch_set_option(CR8BBatch b, const char* name, int value)
 	return ((Batch*) b)->eng->set_option(name, value) ? 0 : -1;
 }
 
+R8BSRC_DECL long long r8b_batch_stat(CR8BBatch b, const char* name)
+{
+	return name != nullptr ? ((Batch*) b)->eng->stat(name) : -1;
+}
+
 R8BSRC_DECL int r8b_batch_stage_count(CR8BBatch b)
 {
 	return (int) ((Batch*) b)->eng->plan().stages.size();

@@ -549,6 +549,44 @@ R8B_HD void cp_tail_rest(const ConvLaunch& L, long long s0, long long s1, int ch
 	}
 }
 
+// Parked outputs of the previous call (ConvxLaunch::park_src) to the caller's rows: outputs [park_j0, park_j0 + park_n) of
+// both channels by the WT threads of the launch's first workgroup of the pair, eight per channel in flight per thread,
+// issued beside the block's sample loads (one wait for both)
+template<int WT>
+R8B_HD void cp_park_back(const ConvxLaunch& XM, const DstView& wd, int chA, int chB, bool bvalid, int tid)
+{
+	constexpr int TB = 8;
+	const double* const sa = XM.park_src + (long long) chA * XM.park_stride;
+	const double* const sb = XM.park_src + (long long) chB * XM.park_stride;
+	const int n = XM.park_n;
+	const long long j0 = XM.park_j0;
+	for (int i0 = tid; i0 < n; i0 += TB * WT)
+	{
+		double va[TB], vb[TB];
+#pragma unroll
+		for (int j = 0; j < TB; j++)
+		{
+			const int i = i0 + j * WT;
+			va[j] = vb[j] = 0.0;
+			if (i < n)
+			{
+				va[j] = sa[i];
+				if (bvalid) vb[j] = sb[i];
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < TB; j++)
+		{
+			const int i = i0 + j * WT;
+			if (i < n)
+			{
+				dst_store(wd, chA, j0 + i, va[j]);
+				if (bvalid) dst_store(wd, chB, j0 + i, vb[j]);
+			}
+		}
+	}
+}
+
 // first forward pass, from the registers cp_load() filled
 template<int LN, int UL>
 R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st, int lt)
@@ -1182,9 +1220,11 @@ R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int pt)
 	}
 }
 
+// (wd: where the outputs go -- the launch's X.wdst, or the park buffer for the part of the call's last block that
+// belongs to the next call, ConvxLaunch::park_dst)
 template<int T2>
-R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const SpanInfo& Bm, const cd* y, const double* rows, int pt,
-	int chA, int chB, bool bvalid)
+R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const SpanInfo& Bm, const cd* y, const double* rows,
+	int pt, int chA, int chB, bool bvalid)
 {
 	// pt: phase pair q (bits 0-7), group set (8-11), window start floor(2 q In / Out) (12-)
 	if (pt < 0) return;
@@ -1197,10 +1237,10 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const SpanInfo& Bm, const cd
 	// group 0 starts at the block's first output (phase lo_mod), the last group ends before phase hi_mod
 	const bool f0 = 2 * q >= lo_mod, f1 = 2 * q + 1 >= lo_mod && 2 * q + 1 < out_step;
 	const bool l0 = 2 * q < hi_mod, l1 = 2 * q + 1 < hi_mod && 2 * q + 1 < out_step;
-	const bool linear = X.wdst.mask == -1 && X.wdst.fmt == kPcmF64;
+	const bool linear = wd.mask == -1 && wd.fmt == kPcmF64;
 	// (row pointers of the block's first group: uniform over the workgroup, so is the alignment test)
-	double* const pa0 = X.wdst.p + ((long long) chA * X.wdst.stride + (jg0 + X.wdst.off));
-	double* const pb0 = X.wdst.p + ((long long) chB * X.wdst.stride + (jg0 + X.wdst.off));
+	double* const pa0 = wd.p + ((long long) chA * wd.stride + (jg0 + wd.off));
+	double* const pb0 = wd.p + ((long long) chB * wd.stride + (jg0 + wd.off));
 	double* const pa = pa0 + 2 * q;
 	double* const pb = pb0 + 2 * q;
 	const bool pair16 = (((size_t) pa0 | (size_t) pb0) & 15) == 0 && (out_step & 1) == 0;
@@ -1330,13 +1370,13 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const SpanInfo& Bm, const cd
 		const long long j = jg + (long long) out_step * gl;
 		if (v0)
 		{
-			dst_store(X.wdst, chA, j, a0[0] + a0[1]);
-			if (bvalid) dst_store(X.wdst, chB, j, b0[0] + b0[1]);
+			dst_store(wd, chA, j, a0[0] + a0[1]);
+			if (bvalid) dst_store(wd, chB, j, b0[0] + b0[1]);
 		}
 		if (v1)
 		{
-			dst_store(X.wdst, chA, j + 1, a1[0] + a1[1]);
-			if (bvalid) dst_store(X.wdst, chB, j + 1, b1[0] + b1[1]);
+			dst_store(wd, chA, j + 1, a1[0] + a1[1]);
+			if (bvalid) dst_store(wd, chB, j + 1, b1[0] + b1[1]);
 		}
 	}
 }
@@ -1402,6 +1442,11 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				cp_tail_rest<G::WT>(L, L.tail_c1, L.tail_p1, chA, chB, bvalid, tid);
 			ex.stamp2();
 			if (live(tid)) cp_tail_owned<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
+		}
+		if constexpr (MODE == 4 || MODE == 5)
+		{
+			// (the previous call's parked outputs, with the launch's first block of the pair)
+			if (X.park_n > 0 && cur.k == L.k0) cp_park_back<G::WT>(XM, X.wdst, chA, chB, bvalid, tid);
 		}
 		ex.stamp2();
 		ex.post_bits(tid, cp_nonzero_bits<LN, UL>(st));
@@ -1627,8 +1672,21 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		// the interpolator: all 256 threads over the run of one block pair after the other
 		if constexpr (!(R8B_ABL & 1)) ex.each([&](int, St& st)
 		{
-			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
-				cp_whole2_compute<T2>(X, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
+			const int nv = G::SUB == 1 ? 1 : cur.nvalid;
+			for (int sb = 0; sb < nv; sb++)
+				cp_whole2_compute<T2>(X, X.wdst, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
+			if (X.park_out != 0 && cur.k + nv == L.k0 + L.nblk)
+			{
+				// (the call's last block: its outputs behind the call's range belong to the next call -- parked, not
+				// computed again there)
+				DstView pd;
+				pd.p = XM.park_dst;
+				pd.stride = XM.park_stride;
+				pd.mask = -1;
+				pd.off = -XM.wb;
+				pd.fmt = kPcmF64;
+				cp_whole2_compute<T2>(X, pd, XM.park_blk, buf + (nv - 1) * G::NA, st.rows2, st.pt, chA, chB, bvalid);
+			}
 		});
 	}
 	else

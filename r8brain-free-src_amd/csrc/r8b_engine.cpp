@@ -592,6 +592,12 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["pair_two"] = 1;
 	opt_["align_groups"] = 1; // ... with whole output groups per block (launch_fused)
 	opt_["fold_tail"] = 1; // fast convolver at stage 0 keeps the input history itself
+	// the call's last block of a fused pair at the end of the chain is computed once: what it holds beyond the call
+	// is parked for the next one (launch_fused)
+	opt_["park"] = 1;
+	stat_["conv_blocks"] = 0;
+	stat_["park_calls"] = 0;
+	stat_["park_only_calls"] = 0;
 	// a constructor that throws half way must not leak what it has already put on the device
 	try
 	{
@@ -870,6 +876,35 @@ bool Engine::use_pair_two(size_t s, int* run_off) const
 	return true;
 }
 
+// Does the fused pair (convolver s, whole-step interpolator s + 1) park the outputs its last block holds beyond a
+// call (launch_fused)?  Only at the end of the chain -- the caller's rows are the one destination that cannot take
+// outputs ahead of their call -- and only in the two-phase pair form.  A constant of the object and its options.
+bool Engine::stage_parks(size_t s) const
+{
+	if (!opt_.at("park") || s + 2 != plan_.stages.size() || !fuse_with_next(s)) return false;
+	return use_pair_two(s, nullptr);
+}
+
+// doubles per channel of a park buffer: what one block can hold, rounded up to whole 64-byte lines
+long long Engine::park_row_len(size_t s) const
+{
+	long long S = 0, off = 0;
+	fused_blocking(s, &S, &off);
+	const StagePlan& w = plan_.stages[s + 1];
+	const long long n = (S * w.out_step + w.in_step - 1) / w.in_step + 2;
+	return (n + 7) / 8 * 8 + 8;
+}
+
+void Engine::ensure_park(size_t s)
+{
+	StageDev& d = dev_[s];
+	if (d.park[0] != nullptr) return;
+	d.park_stride = park_row_len(s);
+	const size_t bytes = (size_t) d.park_stride * (size_t) nch_ * sizeof(double);
+	d.park[0] = (double*) dev_alloc(bytes);
+	d.park[1] = (double*) dev_alloc(bytes);
+}
+
 Engine::~Engine() { release(); }
 
 void Engine::release()
@@ -901,6 +936,8 @@ void Engine::release()
 		dev_free(d.wtab);
 		dev_free(d.ptab);
 		dev_free(d.ctab);
+		dev_free(d.park[0]);
+		dev_free(d.park[1]);
 	}
 	dev_.clear();
 }
@@ -926,7 +963,7 @@ bool Engine::set_option(const std::string& name, int value)
 	// (unfused stages keep it in rings the fused kernels never write): once a stream has started they
 	// may only change after clear().
 	static const char* const structural[] = { "fuse", "fuse_hb", "fuse_hbd", "fold_tail", "fast_conv",
-		"pair_conv", "pair_two", "align_groups" };
+		"pair_conv", "pair_two", "align_groups", "park" };
 	bool started = false;
 	for (const StagePlan& sp : plan_.stages) started = started || sp.m != 0;
 	for (const char* n : structural)
@@ -934,6 +971,12 @@ bool Engine::set_option(const std::string& name, int value)
 	it->second = value;
 	plan_transforms();
 	return true;
+}
+
+long long Engine::stat(const std::string& name) const
+{
+	auto it = stat_.find(name);
+	return it == stat_.end() ? -1 : it->second;
 }
 
 void Engine::ensure_ring(size_t s)
@@ -1000,6 +1043,7 @@ void Engine::clear()
 	// ring contents need no reset: positions restart at 0 and every position >= 0 is rewritten
 	// before it is read again, positions < 0 read as zero by construction
 	plan_.clear();
+	for (StageDev& d : dev_) d.park_base = d.park_end = 0;
 }
 
 // ---- checkpoint -------------------------------------------------------------------------------
@@ -1017,6 +1061,9 @@ struct StageState
 	long long m, done, rpos, ring_size, has_ring;
 	double pos_frac, pos_shift;
 	long long in_counter, in_pos_int;
+	// parked outputs (Engine::stage_parks): doubles per channel (0: the stage does not park), the stream positions the
+	// buffer holds; the buffer itself (nch x park_len doubles) follows the ring
+	long long park_len, park_base, park_end;
 };
 }
 
@@ -1058,6 +1105,7 @@ size_t Engine::state_size() const
 	{
 		n += sizeof(StageState);
 		if (stage_owns_ring(s)) n += (size_t) dev_[s].ring_size * (size_t) nch_ * sizeof(double);
+		if (stage_parks(s)) n += (size_t) park_row_len(s) * (size_t) nch_ * sizeof(double);
 	}
 	return n;
 }
@@ -1068,11 +1116,14 @@ size_t Engine::save_state(void* buf, size_t cap, void* stream)
 	if (cap < need) throw std::runtime_error("state buffer too small");
 	DevGuard guard(device_);
 	for (size_t s = 0; s < dev_.size(); s++)
+	{
 		if (stage_owns_ring(s)) ensure_ring(s);
+		if (stage_parks(s)) ensure_park(s);
+	}
 	dev_sync(stream);
 	unsigned char* p = static_cast<unsigned char*>(buf);
 	StateHeader h;
-	std::memcpy(h.magic, "R8BHIPS1", 8);
+	std::memcpy(h.magic, "R8BHIPS2", 8);
 	h.config = config_hash();
 	h.nstages = (long long) dev_.size();
 	h.nch = nch_;
@@ -1088,12 +1139,20 @@ size_t Engine::save_state(void* buf, size_t cap, void* stream)
 		st.in_counter = sp.poly.in_counter; st.in_pos_int = sp.poly.in_pos_int;
 		st.ring_size = d.ring_size;
 		st.has_ring = stage_owns_ring(s) ? 1 : 0;
+		st.park_len = stage_parks(s) ? d.park_stride : 0;
+		st.park_base = d.park_base; st.park_end = d.park_end;
 		std::memcpy(p, &st, sizeof(st));
 		p += sizeof(st);
 		if (st.has_ring)
 		{
 			const size_t bytes = (size_t) d.ring_size * (size_t) nch_ * sizeof(double);
 			dev_download(p, d.ring, bytes, stream);
+			p += bytes;
+		}
+		if (st.park_len > 0)
+		{
+			const size_t bytes = (size_t) d.park_stride * (size_t) nch_ * sizeof(double);
+			dev_download(p, d.park[d.park_cur], bytes, stream);
 			p += bytes;
 		}
 	}
@@ -1108,14 +1167,14 @@ void Engine::load_state(const void* buf, size_t size, void* stream)
 	if (size < sizeof(h)) throw std::runtime_error("state blob truncated");
 	std::memcpy(&h, p, sizeof(h));
 	p += sizeof(h);
-	if (std::memcmp(h.magic, "R8BHIPS1", 8) != 0) throw std::runtime_error("not a state blob");
+	if (std::memcmp(h.magic, "R8BHIPS2", 8) != 0) throw std::runtime_error("not a state blob");
 	if (h.config != config_hash() || h.nstages != (long long) dev_.size() || h.nch != nch_)
 		throw std::runtime_error("state blob was saved by a differently configured resampler");
 	// pass 1: the whole blob against this object, nothing touched yet (a truncated or foreign blob
 	// must not leave a half-restored stream behind)
 	if (size != state_size()) throw std::runtime_error("state blob has the wrong size");
 	std::vector<StageState> sts(dev_.size());
-	std::vector<const unsigned char*> rings(dev_.size(), nullptr);
+	std::vector<const unsigned char*> rings(dev_.size(), nullptr), parks(dev_.size(), nullptr);
 	for (size_t s = 0; s < dev_.size(); s++)
 	{
 		const StageDev& d = dev_[s];
@@ -1136,6 +1195,17 @@ void Engine::load_state(const void* buf, size_t size, void* stream)
 			rings[s] = p;
 			p += bytes;
 		}
+		if (st.park_len != (stage_parks(s) ? park_row_len(s) : 0))
+			throw std::runtime_error("state blob park layout mismatch");
+		if (st.park_base < 0 || st.park_end < st.park_base || st.park_end - st.park_base > st.park_len)
+			throw std::runtime_error("state blob holds impossible counters");
+		if (st.park_len > 0)
+		{
+			const size_t bytes = (size_t) st.park_len * (size_t) nch_ * sizeof(double);
+			if ((size_t) (end - p) < bytes) throw std::runtime_error("state blob truncated");
+			parks[s] = p;
+			p += bytes;
+		}
 	}
 	if (p != end) throw std::runtime_error("state blob has trailing bytes");
 	// pass 2: commit
@@ -1152,6 +1222,12 @@ void Engine::load_state(const void* buf, size_t size, void* stream)
 		{
 			ensure_ring(s);
 			dev_upload(dev_[s].ring, rings[s], (size_t) dev_[s].ring_size * (size_t) nch_ * sizeof(double));
+		}
+		dev_[s].park_base = st.park_base; dev_[s].park_end = st.park_end;
+		if (parks[s] != nullptr)
+		{
+			ensure_park(s);
+			dev_upload(dev_[s].park[dev_[s].park_cur], parks[s], (size_t) dev_[s].park_stride * (size_t) nch_ * sizeof(double));
 		}
 	}
 }
@@ -1187,6 +1263,9 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0; X.run_off = 0;
 			X.ptab = nullptr; X.ctab = nullptr; X.nsets = 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
+			X.park_n = 0; X.park_out = 0; X.park_j0 = 0; X.park_stride = 0;
+			X.park_src = nullptr; X.park_dst = nullptr;
+			X.park_blk = SpanInfo();
 			if (path == kPathPair && L.tail_ring != nullptr && g.up_pow2)
 			{
 				// (history for the next call, exactly -- cf. launch_fused: the next call's first block is the one that
@@ -1197,6 +1276,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 				const long long p0 = std::min(std::max(L.tail_p0, wstart - 8), L.tail_p1);
 				L.tail_p0 = p0 < 0 ? 0 : (p0 & ~1LL);
 			}
+			if (ch0_ == 0) stat_["conv_blocks"] += L.nblk;
 			if (path == kPathPair3) launch_convp(X, g.complex_h ? 7 : 3, stream);
 			else if (path == kPathConvx3) launch_convx(X, 3, stream);
 			else if (path == kPathPair) launch_convp(X, g.complex_h ? 6 : 0, stream);
@@ -1751,31 +1831,16 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	}
 }
 
-static long long ceil_div_nonneg(long long a, long long b) { return a <= 0 ? 0 : (a + b - 1) / b; }
-
-void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& src,
-	const DstView& dst, void* stream)
+// Block anchoring of a fused pair (convolver s, whole-step interpolator s + 1): blocks start S virtual samples apart,
+// block 0's first fresh sample sits at virtual position off.  Constants of the object (its options included).
+void Engine::fused_blocking(size_t s, long long* S_out, long long* off_out) const
 {
 	const StagePlan& c = plan_.stages[s];
 	const StagePlan& w = plan_.stages[s + 1];
-	ConvxLaunch X;
-	fill_conv(s, X.c, src);
-	X.c.a = 0; X.c.b = 0;
-	X.c.dst = dst; // unused in fused mode
-	X.in_step = w.in_step; X.out_step = w.out_step; X.flen = w.flen;
-	X.fl2w = w.fl2; X.fllw = w.fll;
-	X.table = dev_[s + 1].table;
-	X.wtab = dev_[s + 1].wtab;
-	X.wa = wa; X.wb = wb;
-	X.wdst = dst;
-	const int in_len = c.cg.in_len, fl2c = c.cg.fl2, up = c.cg.up;
-	const long long In = w.in_step, Out = w.out_step;
-	X.c.blk_offset = 0;
 	const StageDev& dw = dev_[s + 1];
-	int run_off = 0;
-	const bool pair_two = use_pair_two(s, &run_off);
-	X.run_off = run_off;
-	X.ptab = dw.ptab; X.ctab = dw.ctab; X.nsets = dw.nsets;
+	const int in_len = c.cg.in_len, fl2c = c.cg.fl2, up = c.cg.up;
+	const long long In = w.in_step;
+	const bool pair_two = use_pair_two(s, nullptr);
 	// Blocks start S virtual samples apart with S = in_len - (interpolator taps, rounded up to
 	// the up factor): the valid ranges [k*S - fl2, k*S - fl2 + in_len) of consecutive blocks
 	// overlap by at least flen-1 convolver outputs, so each interpolator tap window lies inside
@@ -1813,6 +1878,37 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			}
 		}
 	}
+	*S_out = S;
+	*off_out = off;
+}
+
+static long long ceil_div_nonneg(long long a, long long b) { return a <= 0 ? 0 : (a + b - 1) / b; }
+
+void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& src,
+	const DstView& dst, void* stream)
+{
+	const StagePlan& c = plan_.stages[s];
+	const StagePlan& w = plan_.stages[s + 1];
+	ConvxLaunch X;
+	fill_conv(s, X.c, src);
+	X.c.a = 0; X.c.b = 0;
+	X.c.dst = dst; // unused in fused mode
+	X.in_step = w.in_step; X.out_step = w.out_step; X.flen = w.flen;
+	X.fl2w = w.fl2; X.fllw = w.fll;
+	X.table = dev_[s + 1].table;
+	X.wtab = dev_[s + 1].wtab;
+	X.wa = wa; X.wb = wb;
+	X.wdst = dst;
+	const int in_len = c.cg.in_len, fl2c = c.cg.fl2, up = c.cg.up;
+	const long long In = w.in_step, Out = w.out_step;
+	X.c.blk_offset = 0;
+	const StageDev& dw = dev_[s + 1];
+	int run_off = 0;
+	const bool pair_two = use_pair_two(s, &run_off);
+	X.run_off = run_off;
+	X.ptab = dw.ptab; X.ctab = dw.ctab; X.nsets = dw.nsets;
+	long long S = 0, off = 0;
+	fused_blocking(s, &S, &off);
 	X.c.blk_stride = (int) S;
 	X.c.blk_offset = (int) off;
 	if (((S / up) & 1) != 0 || ((off / up) & 1) != 0) X.c.vec_ok = 0;
@@ -1821,37 +1917,88 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 		const long long v = j * In / Out + w.fl2 + fl2c - in_len - off;
 		return v < 0 ? 0 : v / S + 1;
 	};
-	const long long kfirst = owner(wa), klast = owner(wb - 1);
+	// outputs of block k, not clipped to the call: [first output whose window block k - 1 does not hold, first one
+	// block k does not hold either)
+	auto block_jlo = [&](long long k)
+	{
+		return k == 0 ? 0 : ceil_div_nonneg(((k - 1) * S + off - fl2c + in_len - w.fl2) * Out, In);
+	};
+	auto block_jhi = [&](long long k) { return ceil_div_nonneg((k * S + off - fl2c + in_len - w.fl2) * Out, In); };
+	X.park_n = 0; X.park_out = 0; X.park_j0 = 0; X.park_stride = 0;
+	X.park_src = nullptr; X.park_dst = nullptr;
+	X.park_blk = SpanInfo();
+	// Parked outputs (ConvxLaunch::park_*): the block that holds the call's last output is computed ONCE -- what it
+	// holds beyond wb waits in the park buffer for the next call(s) instead of being computed again there (one block
+	// in 13.4 for BASELINE's cfg2 call, one in 7.5 for cfg3).  ja: the first output this call has to compute.
+	StageDev& dp = dev_[s];
+	const bool parks = stage_parks(s) && dst.mask == -1 && dst.fmt == kPcmF64;
+	if (parks) ensure_park(s);
+	long long ja = wa;
+	if (parks && dp.park_end > wa)
+	{
+		if (dp.park_base > wa) throw std::logic_error("parked outputs start behind the call's first output");
+		ja = std::min(dp.park_end, wb);
+		X.park_src = dp.park[dp.park_cur] + (long long) ch0_ * dp.park_stride + (wa - dp.park_base);
+		X.park_stride = dp.park_stride;
+		X.park_j0 = wa;
+		X.park_n = (int) (ja - wa);
+		if (ch0_ == 0) stat_["park_calls"]++;
+	}
+	if (ja >= wb)
+	{
+		// the whole call comes out of the park buffer (a short call): a plain copy; the stream's history is kept by
+		// process() (tail_done_ stays false)
+		TailLaunch T;
+		T.src.ring = X.park_src; T.src.ring_stride = 0; T.src.ring_mask = 0;
+		T.src.cur = X.park_src; T.src.cur_stride = X.park_stride; T.src.cur_base = wa;
+		T.src.cur_fmt = kPcmF64;
+		T.p0 = wa; T.p1 = wb;
+		T.ring = dst.p + dst.off; T.ring_stride = dst.stride; T.ring_mask = -1;
+		T.nch = nchw_;
+		launch_tail(T, stream);
+		if (ch0_ == 0) stat_["park_only_calls"]++;
+		return;
+	}
+	const long long kfirst = owner(ja), klast = owner(wb - 1);
+	// (with parked outputs the next call's first block is the one behind this call's last: whatever that one holds
+	// beyond wb is parked below)
+	const long long knext = parks ? klast + 1 : owner(wb);
 	if (X.c.tail_ring != nullptr && pair_two && c.cg.up_pow2)
 	{
-		// History for the next call, exactly: its first block is owner(wb) -- the first block whose outputs this call
+		// History for the next call, exactly: its first block is knext -- the first block whose outputs this call
 		// has not produced --, and no later block reads further back than that block's window (r8b_convp.h cp_load:
 		// n_in input samples ending in_len / up behind the block's start).  fill_conv asked for history(), the bound
 		// over every way of cutting the stream into calls: about twice what a call of MaxInLen samples needs.
-		const long long kn = owner(wb);
-		const long long wstart = ((kn * S + off) >> (up > 1 ? 1 : 0)) - ((long long) c.cg.n_in - in_len / up);
+		// (up is 1 or 2 here: use_pair_fused)
+		if (up > 2) throw std::logic_error("fused pair kernel: up-sampling factor");
+		const long long wstart = ((knext * S + off) >> (up > 1 ? 1 : 0)) - ((long long) c.cg.n_in - in_len / up);
 		const long long p0 = std::min(std::max(X.c.tail_p0, wstart - 8), X.c.tail_p1);
 		X.c.tail_p0 = p0 & ~1LL; // (even: pairs of samples)
 		if (X.c.tail_p0 < 0) X.c.tail_p0 = 0;
 	}
 	double* const tail_ring = X.c.tail_ring;
+	const double* const park_src = X.park_src;
+	const int park_n = X.park_n;
+	long long park_b = wb; // end of what the call's last block holds
 	for (long long k0 = kfirst; k0 <= klast; k0 += kConvxMaxBlocks)
 	{
 		const long long k1 = std::min(klast, k0 + kConvxMaxBlocks - 1);
 		// (the history with the call's LAST launch: its blocks are the ones that hold the tail in registers)
 		X.c.tail_ring = k1 == klast ? tail_ring : nullptr;
+		// (the parked outputs of the previous call with the FIRST launch)
+		X.park_src = k0 == kfirst ? park_src : nullptr;
+		X.park_n = k0 == kfirst ? park_n : 0;
 		X.c.k0 = k0;
 		X.c.nblk = (int) (k1 - k0 + 1);
+		if (ch0_ == 0) stat_["conv_blocks"] += X.c.nblk;
 		for (int i = 0; i < X.c.nblk; i++)
 		{
 			const long long k = k0 + i;
 			const long long t0 = k * S + off - fl2c;    // first valid time of block k
-			const long long e_prev = t0 - S + in_len;   // end of block k-1's valid range
-			const long long e_this = t0 + in_len;
 			SpanInfo& B = X.blk[i];
-			long long jlo = k == 0 ? 0 : ceil_div_nonneg((e_prev - w.fl2) * Out, In);
-			long long jhi = ceil_div_nonneg((e_this - w.fl2) * Out, In);
-			if (jlo < wa) jlo = wa;
+			long long jlo = block_jlo(k);
+			long long jhi = block_jhi(k);
+			if (jlo < ja) jlo = ja;
 			if (jhi > wb) jhi = wb;
 			if (jhi < jlo) jhi = jlo;
 			B.jlo = jlo; B.jhi = jhi;
@@ -1862,22 +2009,43 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 		}
 		if (pair_two)
 		{
-			for (int i = 0; i < X.c.nblk; i++)
+			auto two_phase_span = [&](SpanInfo& B, long long k)
 			{
-				SpanInfo& B = X.blk[i];
 				B.pad = 0;
-				if (B.jhi <= B.jlo) continue;
-				const long long t0 = (k0 + i) * S + off - fl2c;
+				if (B.jhi <= B.jlo) return;
+				const long long t0 = k * S + off - fl2c;
 				const long long g0 = B.jlo / Out, glast = (B.jhi - 1) / Out;
 				B.ph_lo = (int) (glast - g0);
 				B.pad = (int) (B.jhi - glast * Out); // the phase the block's last group ends before
 				B.u_lo = (int) (In * g0 - w.fll - t0) + run_off;
+			};
+			for (int i = 0; i < X.c.nblk; i++) two_phase_span(X.blk[i], k0 + i);
+			if (parks && k1 == klast && block_jhi(klast) > wb)
+			{
+				// what the call's last block holds beyond the call: [wb, end of the block) into the other park buffer
+				park_b = block_jhi(klast);
+				if (park_b - wb > dp.park_stride) throw std::logic_error("park buffer too small");
+				SpanInfo& P = X.park_blk;
+				P.jlo = wb; P.jhi = park_b;
+				P.jlo_mod = (int) (wb % Out);
+				P.ph_lo = 0; P.u_lo = 0;
+				two_phase_span(P, klast);
+				X.park_out = 1;
+				X.park_dst = dp.park[dp.park_cur ^ 1] + (long long) ch0_ * dp.park_stride;
+				X.park_stride = dp.park_stride;
 			}
 			launch_convp(X, dw.taps2 == 27 ? 5 : 4, stream);
 		}
 		else if (use_pair_fused(c.cg)) launch_convp(X, 1, stream);
 		else launch_convx(X, 1, stream);
 		if (X.c.tail_ring != nullptr) tail_done_ = true;
+	}
+	if (parks && ch0_ + nchw_ >= nch_)
+	{
+		// (the counters once per call, after its last channel window)
+		if (park_b > wb) dp.park_cur ^= 1;
+		dp.park_base = wb;
+		dp.park_end = park_b;
 	}
 }
 

@@ -39,6 +39,8 @@ public:
 		int out_fmt, long long out_stride, void* stream);
 	void clear();
 	bool set_option(const std::string& name, int value);
+	// counters since creation ("conv_blocks", "park_calls", "park_only_calls"); -1: unknown name
+	long long stat(const std::string& name) const;
 
 	// per-stage kernel time accumulated since the last call (only while option "timing" is 1):
 	// resolves pending events, returns total milliseconds and the number of launches
@@ -80,6 +82,13 @@ private:
 		double* ctab = nullptr;
 		int nsets = 0;
 		int taps2 = 25; // entries per row: 25 (In <= Out) or 27
+		// parked outputs of a fused pair at the end of the chain (launch_fused, ConvxLaunch::park_*): two buffers of
+		// nch x park_stride doubles used in turn (a call reads the one the previous call filled while its own last block
+		// fills the other); outputs [park_base, park_end) of the stream sit at indices 0 .. of buffer park_cur
+		double* park[2] = { nullptr, nullptr };
+		long long park_stride = 0;
+		long long park_base = 0, park_end = 0;
+		int park_cur = 0;
 		std::vector<int> fwd_radix, inv_radix;
 		std::vector<std::pair<void*, void*>> pending; // (start, stop) events not yet read
 		std::vector<void*> free_events;
@@ -102,6 +111,10 @@ private:
 	int conv_path(const ConvGeom& g) const;
 	bool latency_chain() const; // some stage carries fractional-latency state (minimum phase): no fusing
 	bool use_pair_two(size_t s, int* run_off) const;
+	void fused_blocking(size_t s, long long* S, long long* off) const;
+	bool stage_parks(size_t s) const;
+	long long park_row_len(size_t s) const;
+	void ensure_park(size_t s);
 	void prepare_two_phase(size_t s);
 	int group_len(size_t s) const;
 	void launch_cascade(size_t s, int glen, long long fa, long long fb, const SrcView& src,
@@ -123,6 +136,7 @@ private:
 	int device_;
 	std::vector<StageDev> dev_;
 	std::map<std::string, int> opt_;
+	std::map<std::string, long long> stat_;
 	int io_in_fmt_ = kPcmF64, io_out_fmt_ = kPcmF64; // formats of the current call's buffers
 	bool tail_done_ = false; // stage-0 history already written by the convolver kernel
 };

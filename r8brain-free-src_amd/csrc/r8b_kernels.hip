@@ -703,6 +703,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	H.table = X.table; H.wtab = X.wtab; H.wa = X.wa; H.wb = X.wb; H.wdst = X.wdst;
 	H.run_off = X.run_off; H.ptab = X.ptab; H.ctab = X.ctab; H.nsets = X.nsets;
 	H.nblk_magic = X.nblk_magic;
+	H.park_n = X.park_n; H.park_out = X.park_out;
 	ex.stamp();
 	// (integers are made opaque -- "+s" --, pointers are only USED here -- "s" --: a pointer that went through an asm
 	// output loses its kernel-argument provenance and would be dereferenced with flat instructions)
@@ -712,7 +713,8 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 		: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
 	if constexpr (MODE == 4 || MODE == 5)
 		asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),
-			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt) : "s"(H.ptab), "s"(H.ctab), "s"(H.wdst.p));
+			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt), "+s"(H.park_n), "+s"(H.park_out)
+			: "s"(H.ptab), "s"(H.ctab), "s"(H.wdst.p));
 	else if constexpr (MODE == 1) {}
 	else
 		asm volatile("" : "+s"(H.c.a), "+s"(H.c.b), "+s"(H.c.dst.stride), "+s"(H.c.dst.mask), "+s"(H.c.dst.off),

@@ -241,6 +241,18 @@ struct ConvxLaunch
 	const double* ctab;
 	int nsets;
 	unsigned nblk_magic; // floor(2^32 / c.nblk) + 1 (filled in by the launcher; r8b_convp.h convp_div)
+	// Parked outputs (pair form, modes 4 / 5 at the chain's last stage; r8b_engine.cpp launch_fused): the block that
+	// holds a call's last output usually holds outputs of the NEXT call too (the reference answers one block late,
+	// reference CDSPBlockConvolver.h:94-101, 283-305, so a call's outputs end in the middle of a block).  Instead of
+	// computing that block again in the next call, the launch's last block leaves its outputs [wb, park_blk.jhi) in a
+	// small per-channel buffer (park_dst: row ch at park_dst + ch * park_stride, output j at index j - wb), and the next
+	// call's first workgroup of each channel pair copies them to the caller's rows beside its sample loads (park_src:
+	// outputs [park_j0, park_j0 + park_n) at indices 0 ..).  park_n = 0 / park_out = 0: nothing to do.
+	int park_n, park_out;
+	long long park_j0, park_stride;
+	const double* park_src;
+	double* park_dst;
+	SpanInfo park_blk;
 };
 
 // geometries the fast path is instantiated for: (log2 of the forward complex length, up shift), and

@@ -88,6 +88,13 @@ class BatchResampler(_Base):
         if self._lib.r8b_batch_set_option(self._h, name.encode(), int(value)) != 0:
             raise KeyError(name)
 
+    def stat(self, name):
+        """a counter of the engine since creation (include/r8bsrc.h r8b_batch_stat)"""
+        v = self._lib.r8b_batch_stat(self._h, name.encode())
+        if v < 0:
+            raise KeyError(name)
+        return v
+
     def stage_timings(self):
         """[(kernel name, total ms, launches, samples in, samples out)] per stage since the last
         query (needs set_option("timing", 1)); sample counts are per channel; waits for the

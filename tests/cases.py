@@ -229,3 +229,47 @@ def check_pair_scales(batch, case):
     # that end before it are exact -- the first eighth of the stream is well clear of it)
     assert not y[6, :int(n // 8 * dst / src)].any() and not yo[6, :int(n // 8 * dst / src)].any()
     return float(rms.max()), float(pk.max())
+
+
+# Parked outputs (Engine::launch_fused, ConvxLaunch::park_*): the block that holds a call's last output is computed
+# once; what it holds of the next call(s) waits in a park buffer.  (src, dst, maxin, tb, atten): cfg2 and cfg3
+# topologies, a short filter (several blocks per workgroup), the 16IR preset, an interpolator with more phases than
+# threads stays on the one-phase form (no parking: counted blocks equal with and without)
+PARK_CASES = [
+    (44100.0, 96000.0, 8192, 2.0, 180.15),
+    (96000.0, 44100.0, 16384, 2.0, 180.15),
+    (44100.0, 96000.0, 4096, 2.0, 109.56),      # 16IR preset: two blocks per workgroup
+    (48000.0, 44100.0, 6000, 2.0, 109.56),
+    (44100.0, 48000.0, 5000, 2.0, 180.15),
+    (44100.0, 96000.0, 4096, 10.0, 109.56),     # 512-point blocks, one phase per thread: does not park
+]
+PARK_CASES_THAT_PARK = PARK_CASES[:5]
+
+
+def check_parked_outputs(make, case):
+    """`make(park)` builds a 3-channel batch object (odd: a block pair without a partner) with option park = 1 / 0.
+    Calls of every length -- MaxInLen, a third, a few samples, one sample (served from the park buffer alone) -- give
+    the same outputs BIT FOR BIT with parked outputs and with the call's last block computed again by the next call,
+    across clear(); with parking every block of the stream is computed exactly once."""
+    src, dst, maxin, tb, att = case
+    lens = [maxin, maxin, maxin // 3, 300, 1, 1, 2, maxin, 17, 1, maxin - 5, 2500 % maxin + 1, maxin, 40, maxin]
+    a, b = make(1), make(0)
+    rng = np.random.default_rng(7)
+    for rep in range(2):
+        for i, l in enumerate(lens):
+            x = rng.uniform(-1.0, 1.0, (3, l))
+            ya, yb = a.process_host(x), b.process_host(x)
+            assert ya.shape == yb.shape and np.array_equal(ya, yb), (rep, i, l)
+        if rep == 0:
+            na, nb = a.stat("conv_blocks"), b.stat("conv_blocks")
+            a.clear()
+            b.clear()
+    parked = a.stat("park_calls")
+    if parked == 0:
+        assert na == nb           # (a topology that does not park)
+        return 0, na, nb
+    # without parking nearly every call with work computes one block twice; with it the blocks of the stream are
+    # consecutive: their number is (index of the last one + 1), which the run without parking reaches as well
+    assert a.stat("park_only_calls") > 0
+    assert na < nb, (na, nb)
+    return parked, na, nb

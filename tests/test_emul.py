@@ -10,8 +10,8 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, RMS_TOL, PEAK_TOL,
-                   compare_stream, make_input, check_pair_scales)
+from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES, PARK_CASES_THAT_PARK, RMS_TOL,
+                   PEAK_TOL, compare_stream, make_input, check_pair_scales, check_parked_outputs)
 from conftest import ROOT
 
 r8b = importlib.import_module("r8brain-free-src_amd")
@@ -515,3 +515,31 @@ def test_emulated_history_from_registers_equals_the_copy_kernel(emul, src, dst, 
         x = rng.uniform(-1.0, 1.0, (3, l))
         ya, yb = a.process_host(x), b.process_host(x)
         assert ya.shape == yb.shape and np.array_equal(ya, yb), (i, l)
+
+
+@pytest.mark.parametrize("case", PARK_CASES)
+def test_emulated_parked_outputs_equal_recomputation(emul, case):
+    """cases.check_parked_outputs on the emulated engine"""
+    src, dst, maxin, tb, att = case
+
+    def make(park):
+        r = r8b.BatchResampler(src, dst, maxin, tb, att, nch=3, lib=emul)
+        r.set_option("park", park)
+        return r
+
+    parked, na, nb = check_parked_outputs(make, case)
+    assert (parked > 0) == (case in PARK_CASES_THAT_PARK), (case, parked, na, nb)
+
+
+def test_emulated_every_block_once_with_parked_outputs(emul):
+    """BASELINE's cfg2 / cfg3 call size: 13.4 / 7.5 blocks per call with the last block computed twice, 12.4 / 6.5
+    with its outputs parked (one block per call less)"""
+    for src, dst, per_call in ((44100.0, 96000.0, 32768.0 / 2646.0), (96000.0, 44100.0, 16384.0 / 2530.0)):
+        r = r8b.BatchResampler(src, dst, 16384, 2.0, 180.15, nch=1, lib=emul)
+        x = make_input(1, 16384, 3)
+        calls = 12
+        for _ in range(calls):
+            r.process_host(x)
+        nblk = r.stat("conv_blocks")
+        assert abs(nblk / calls - per_call) < 0.6 / calls + 0.25, (src, dst, nblk / calls, per_call)
+        assert nblk / calls < per_call + 0.35

@@ -12,8 +12,9 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, RMS_TOL, PEAK_TOL,
-                   compare_stream, make_input, check_pair_scales)
+from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES,
+                   PARK_CASES_THAT_PARK, RMS_TOL, PEAK_TOL, compare_stream, make_input, check_pair_scales,
+                   check_parked_outputs)
 from conftest import rms, peak
 
 pytestmark = pytest.mark.gpu
@@ -484,3 +485,19 @@ def test_hip_history_from_registers_equals_the_copy_kernel(torch, src, dst, maxi
         x = rng.uniform(-1.0, 1.0, (5, l))
         ya, yb = a.process_host(x), b.process_host(x)
         assert ya.shape == yb.shape and np.array_equal(ya, yb), (i, l)
+
+
+@pytest.mark.parametrize("case", PARK_CASES)
+def test_hip_parked_outputs_equal_recomputation(torch, case):
+    """the call's last block computed once, its outputs of the next call parked (r8b_convp.h cp_park_back, the second
+    cp_whole2_compute of the last block) == the block computed again by the next call, bit for bit, on the real
+    kernels (cases.check_parked_outputs)"""
+    src, dst, maxin, tb, att = case
+
+    def make(park):
+        r = r8b.BatchResampler(src, dst, maxin, tb, att, nch=3, device=0)
+        r.set_option("park", park)
+        return r
+
+    parked, na, nb = check_parked_outputs(make, case)
+    assert (parked > 0) == (case in PARK_CASES_THAT_PARK), (case, parked, na, nb)
