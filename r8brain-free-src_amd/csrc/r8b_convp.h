@@ -206,6 +206,9 @@ struct ConvpState
 	double row[32];
 	double rows2[2 * 27]; // modes 4 / 5: the two rows of the thread's phase pair (25 or 27 entries each)
 	int pt;               // ... and its entry of X.ptab
+	double pk[2];         // ... the thread's element of the previous call's parked outputs and where it goes (cp_park_slice_*)
+	double* pka;
+	int pf;               // ... and whether the workgroup holds the call's last block and parks what lies beyond the call
 };
 
 // (+ 64 bytes behind the array: one word per wave for the workgroup-wide "channel has a non-zero sample" bits)
@@ -584,6 +587,33 @@ R8B_HD void cp_park_back(const ConvxLaunch& XM, const DstView& wd, int chA, int 
 				if (bvalid) dst_store(wd, chB, j0 + i, vb[j]);
 			}
 		}
+	}
+}
+
+// The same copy shared by the workgroups of the pair's blocks (ConvxLaunch::park_slices): workgroup bgi of the launch
+// takes elements [bgi WT, (bgi + 1) WT), one per thread and channel -- requested at entry behind the block's samples (the
+// kernel arguments it needs arrive with all the others), stored when the interpolator starts: no workgroup waits for
+// it and no phase reads an argument from memory for it (the destination is the caller's fp64 rows: Engine::launch_fused)
+template<int WT, class St>
+R8B_HD void cp_park_slice_load(const ConvxLaunch& XM, const DstView& wd, St& st, int bgi, int chA, int chB, int tid)
+{
+	const int i = bgi * WT + tid;
+	st.pk[0] = st.pk[1] = 0.0;
+	st.pka = nullptr;
+	if (i < XM.park_n)
+	{
+		st.pk[0] = XM.park_src[(long long) chA * XM.park_stride + i];
+		st.pk[1] = XM.park_src[(long long) chB * XM.park_stride + i];
+		st.pka = wd.p + ((long long) chA * wd.stride + (XM.park_j0 + i + wd.off));
+	}
+}
+template<class St>
+R8B_HD void cp_park_slice_store(const DstView& wd, const St& st, int chA, int chB, bool bvalid)
+{
+	if (st.pka != nullptr)
+	{
+		st.pka[0] = st.pk[0];
+		if (bvalid) st.pka[(long long) (chB - chA) * wd.stride] = st.pk[1];
 	}
 }
 
@@ -1446,7 +1476,14 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		if constexpr (MODE == 4 || MODE == 5)
 		{
 			// (the previous call's parked outputs, with the launch's first block of the pair)
-			if (X.park_n > 0 && cur.k == L.k0) cp_park_back<G::WT>(XM, X.wdst, chA, chB, bvalid, tid);
+			st.pf = X.park_out != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) == L.k0 + L.nblk ? 1 : 0;
+			st.pka = nullptr;
+			if (X.park_n > 0)
+			{
+				if (X.park_slices != 0)
+					cp_park_slice_load<G::WT>(XM, X.wdst, st, (int) (cur.k - L.k0) / G::SUB, chA, chB, tid);
+				else if (cur.k == L.k0) cp_park_back<G::WT>(XM, X.wdst, chA, chB, bvalid, tid);
+			}
 		}
 		ex.stamp2();
 		ex.post_bits(tid, cp_nonzero_bits<LN, UL>(st));
@@ -1670,12 +1707,13 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_final_store<LN, UL>(L, buf_of(tid), buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
 		});
 		// the interpolator: all 256 threads over the run of one block pair after the other
-		if constexpr (!(R8B_ABL & 1)) ex.each([&](int, St& st)
+		if constexpr (!(R8B_ABL & 1)) ex.each([&](int tid, St& st)
 		{
+			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
 			const int nv = G::SUB == 1 ? 1 : cur.nvalid;
 			for (int sb = 0; sb < nv; sb++)
 				cp_whole2_compute<T2>(X, X.wdst, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
-			if (X.park_out != 0 && cur.k + nv == L.k0 + L.nblk)
+			if (ex.uniform(st.pf) != 0)
 			{
 				// (the call's last block: its outputs behind the call's range belong to the next call -- parked, not
 				// computed again there)
@@ -1759,6 +1797,11 @@ inline void convp_prepare(ConvxLaunch& X)
 	X.c.tail_flags = X.c.tail_ring != nullptr ? 1 : 0;
 	X.c.tail_bf = 0;
 	X.c.tail_c0 = X.c.tail_c1 = 0;
+	{
+		typedef ConvpGeom<LN, UL> G;
+		const long long nwg = (X.c.nblk + G::SUB - 1) / G::SUB;
+		X.park_slices = X.park_n > 0 && X.park_n <= nwg * G::WT ? 1 : 0;
+	}
 	if constexpr (UL >= 0)
 	{
 		if (X.c.up_pow2 && X.c.up == (1 << (UL > 0 ? UL : 0)))

@@ -1263,7 +1263,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0; X.run_off = 0;
 			X.ptab = nullptr; X.ctab = nullptr; X.nsets = 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
-			X.park_n = 0; X.park_out = 0; X.park_j0 = 0; X.park_stride = 0;
+			X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
 			X.park_src = nullptr; X.park_dst = nullptr;
 			X.park_blk = SpanInfo();
 			if (path == kPathPair && L.tail_ring != nullptr && g.up_pow2)
@@ -1924,7 +1924,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 		return k == 0 ? 0 : ceil_div_nonneg(((k - 1) * S + off - fl2c + in_len - w.fl2) * Out, In);
 	};
 	auto block_jhi = [&](long long k) { return ceil_div_nonneg((k * S + off - fl2c + in_len - w.fl2) * Out, In); };
-	X.park_n = 0; X.park_out = 0; X.park_j0 = 0; X.park_stride = 0;
+	X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
 	X.park_src = nullptr; X.park_dst = nullptr;
 	X.park_blk = SpanInfo();
 	// Parked outputs (ConvxLaunch::park_*): the block that holds the call's last output is computed ONCE -- what it

@@ -595,6 +595,8 @@ struct GpuExecP
 		for (int w = 0; w < ConvpGeom<LN, UL>::WT / 64; w++) r |= flags_[w];
 		return (unsigned) __builtin_amdgcn_readfirstlane((int) r);
 	}
+	// a value that is the same in every lane, kept in a vector register across phases: back to the scalar unit
+	__device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
 	// steps that exchange data between the lanes of ONE wave only (r8b_convp.h: forward passes 1..,
 	// middle pass, first backward pass): LDS serves a wave's accesses in issue order, so between the
 	// steps only the compiler must be kept from reordering them; a workgroup barrier ends the sequence
@@ -703,7 +705,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	H.table = X.table; H.wtab = X.wtab; H.wa = X.wa; H.wb = X.wb; H.wdst = X.wdst;
 	H.run_off = X.run_off; H.ptab = X.ptab; H.ctab = X.ctab; H.nsets = X.nsets;
 	H.nblk_magic = X.nblk_magic;
-	H.park_n = X.park_n; H.park_out = X.park_out;
+	H.park_n = X.park_n; H.park_out = X.park_out; H.park_slices = X.park_slices;
 	ex.stamp();
 	// (integers are made opaque -- "+s" --, pointers are only USED here -- "s" --: a pointer that went through an asm
 	// output loses its kernel-argument provenance and would be dereferenced with flat instructions)
@@ -713,7 +715,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 		: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
 	if constexpr (MODE == 4 || MODE == 5)
 		asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),
-			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt), "+s"(H.park_n), "+s"(H.park_out)
+			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt), "+s"(H.park_n), "+s"(H.park_out), "+s"(H.park_slices)
 			: "s"(H.ptab), "s"(H.ctab), "s"(H.wdst.p));
 	else if constexpr (MODE == 1) {}
 	else

@@ -248,7 +248,10 @@ struct ConvxLaunch
 	// small per-channel buffer (park_dst: row ch at park_dst + ch * park_stride, output j at index j - wb), and the next
 	// call's first workgroup of each channel pair copies them to the caller's rows beside its sample loads (park_src:
 	// outputs [park_j0, park_j0 + park_n) at indices 0 ..).  park_n = 0 / park_out = 0: nothing to do.
-	int park_n, park_out;
+	// park_slices (set by convp_prepare): the copy is shared by the workgroups of the pair's blocks in this launch, one
+	// element per thread and channel, requested a phase ahead of the interpolator and stored at its start (no wait of
+	// its own); 0: the launch's first workgroup of the pair copies everything beside its sample loads (short calls)
+	int park_n, park_out, park_slices;
 	long long park_j0, park_stride;
 	const double* park_src;
 	double* park_dst;

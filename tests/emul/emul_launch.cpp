@@ -232,6 +232,7 @@ struct EmulExecP
 	void stamp2() {}
 	void post_bits(int, unsigned v) { bits |= v; }
 	unsigned collect_bits() const { return bits; }
+	int uniform(int v) const { return v; }
 	template<class F>
 	void phase(F f)
 	{
