@@ -203,14 +203,18 @@ def main():
     ap.add_argument("--tb", type=float, default=2.0, help="transition band, percent (side runs)")
     ap.add_argument("--atten", type=float, default=180.15, help="stop-band attenuation (side runs)")
     ap.add_argument("--settle", type=int, default=150,
-                    help="untimed calls between the first timed window and the reported one (0: report the first window). "
-                         "After an idle gap the board's power controller answers the load step with a clock dip that lasts "
-                         "about 40 calls of this batch, and the clock has fully recovered after about 150 (DESIGN.md section 5): a 5 + 20 call window lies inside it. The line "
-                         "reports the K steps timed after the clock has settled as `value` and the K steps timed straight "
-                         "after the W warm-up calls as `first_window`, both bracketed the same way")
-    ap.add_argument("--align-out", type=int, default=1,
-                    help="1 (default): a call's outputs go to column (outputs so far) mod 8 of 64-byte-aligned rows; "
-                         "0: every call writes from column 0")
+                    help="`value` is ALWAYS the K steps timed straight after the W warm-up calls (the driver's contract).  "
+                         "With --settle N > 0 the line also carries, as side fields, the same K steps timed again after N further "
+                         "untimed calls (`settled`: after an idle gap the board's power controller answers the load step with a "
+                         "clock dip that lasts about 40 calls of this batch and has fully recovered after about 150, DESIGN.md "
+                         "section 5 -- a 5 + 20 call window lies inside it) and once more with the other output placement "
+                         "(`other_placement`, see --align-out); 0: neither")
+    ap.add_argument("--align-out", type=int, default=0,
+                    help="where the caller (this script) puts a call's outputs.  0 (default, `placement` \"column 0\"): every "
+                         "call writes its rows from column 0 of the output buffer, as a caller of the reference's process() "
+                         "does; 1 (\"stream-aligned\"): at column (outputs so far) mod 8 of 64-byte-aligned rows, so that every "
+                         "64-byte piece the kernel stores is a whole aligned segment in every call (INTEGRATION.md section 5).  "
+                         "The line reports the other placement's rate beside the headline when --settle > 0")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--e2e", action="store_true",
                     help="side measurement (SURVEY.md 8e): the whole batch lives on rank 0; every step "
@@ -278,8 +282,10 @@ def main():
     outs_full = [torch.empty((C, pitch), dtype=torch.float64, device=dev) for _ in range(2)]
     produced = [0]
 
+    placement = [bool(args.align_out)]  # (switched for the `other_placement` window below)
+
     def out_view(i):
-        off = produced[0] % 8 if args.align_out else 0
+        off = produced[0] % 8 if placement[0] else 0
         return outs_full[i % 2][:, off:off + rs.max_out_len]
 
     def barrier():
@@ -362,21 +368,40 @@ def main():
             d = float(t.item())
         return n, d
 
+    def window(n, d, what):
+        return {"ms_per_step": round(d / args.steps * 1e3, 4),
+                "value": round(C * L * args.steps * world / d / 1e6, 3),
+                "out_msamples_per_s": round(n * C * world / d / 1e6, 3), "what": what}
+
+    # THE measurement: W untimed warm-up calls, then exactly K timed steps, barrier + synchronize on both sides
     run(0, args.warmup, capture=not args.pcm and not args.no_cpu and world == 1)
     n_out, dt = timed(args.warmup)
-    first_window = None
+    calls = args.warmup + args.steps
+    settled = other = None
     if args.settle > 0:
-        # the same K steps once more after `settle` further untimed calls (the stream simply continues)
-        first_window = {"ms_per_step": round(dt / args.steps * 1e3, 4),
-                        "value": round(C * L * args.steps * world / dt / 1e6, 3),
-                        "what": "the %d steps timed straight after the %d warm-up calls (inside the power "
-                                "controller's response to the load step when the GPU was idle before)" % (args.steps, args.warmup)}
-        run(args.warmup + args.steps, args.settle)
-        n_out, dt = timed(args.warmup + args.steps + args.settle)
+        # side fields: the same K steps once more after `settle` further untimed calls (the stream simply
+        # continues), and once more with the other output placement
+        run(calls, args.settle)
+        calls += args.settle
+        n2, dt2 = timed(calls)
+        calls += args.steps
+        settled = window(n2, dt2, "the same %d steps timed again after %d further untimed calls (clock settled; same "
+                                  "placement as `value`)" % (args.steps, args.settle))
+        if not args.pcm:
+            placement[0] = not placement[0]
+            run(calls, 8)
+            calls += 8
+            n3, dt3 = timed(calls)
+            calls += args.steps
+            other = window(n3, dt3, "the same %d steps, settled, with the caller's other output placement" % args.steps)
+            other["placement"] = "stream-aligned" if placement[0] else "column 0"
+            placement[0] = not placement[0]
+            run(calls, 8)
+            calls += 8
 
     # second pass, same steps, with per-kernel HIP events (kept out of the headline timing)
     rs.set_option("timing", 1)
-    run(args.warmup + 2 * args.steps + args.settle, args.steps)
+    run(calls, args.steps)
     torch.cuda.synchronize()
     timings = rs.stage_timings()
     rs.set_option("timing", 0)
@@ -408,7 +433,9 @@ def main():
                                    "fp64 splitmix64 noise (seed 1 + channel), inputs and outputs "
                                    "resident in HBM%s" % (cfg_name, args.src, args.dst, C, L,
                                                          ", output rows 64-byte aligned with a call's outputs at column "
-                                                         "(outputs so far) mod 8" if args.align_out and not args.pcm else ""),
+                                                         "(outputs so far) mod 8" if args.align_out and not args.pcm else
+                                                         ", a call's outputs from column 0 of 64-byte-aligned rows"),
+                       "placement": "stream-aligned" if args.align_out else "column 0",
                        "channels_per_gpu": C, "block": L, "io": ((args.pcm + (" planar" if args.planar else " interleaved"))
                                                    if args.pcm else "f64 planar"),
                        "out_msamples_per_s":
@@ -423,9 +450,12 @@ def main():
                          "path_frac": round(path_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                                             4)},
         }
-        if first_window is not None:
+        res["value_window"] = "the %d steps timed straight after the %d warm-up calls" % (args.steps, args.warmup)
+        if settled is not None:
             res["settle_calls"] = args.settle
-            res["first_window"] = first_window
+            res["settled"] = settled
+        if other is not None:
+            res["other_placement"] = other
         if e2e is not None:
             # (kernel-only = the line's own `value`: shards at rest; end-to-end beside it)
             res["e2e"] = e2e

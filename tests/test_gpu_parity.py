@@ -419,10 +419,13 @@ def test_bench_contract(tmp_path):
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["achieved"] > 0
     assert d["value"] > 0 and abs(d["value"] - 1024 * 16384 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
-    # the window straight after the warm-up calls is reported beside the settled one (bench.py --settle)
-    fw = d["first_window"]
-    assert d["settle_calls"] == 150 and fw["value"] > 0
-    assert abs(fw["value"] - 1024 * 16384 / fw["ms_per_step"] / 1e3) / fw["value"] < 0.01
+    # `value` is the window straight after the warm-up calls, from column 0 of the caller's rows; the settled window and
+    # the other output placement are side fields (bench.py --settle / --align-out)
+    assert d["config"]["placement"] == "column 0" and "straight after the 2 warm-up calls" in d["value_window"]
+    assert d["settle_calls"] == 150
+    for side in (d["settled"], d["other_placement"]):
+        assert side["value"] > 0 and abs(side["value"] - 1024 * 16384 / side["ms_per_step"] / 1e3) / side["value"] < 0.01
+    assert d["other_placement"]["placement"] == "stream-aligned"
 
 
 @pytest.mark.gpu

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarises rocprofv3 --pmc CSV passes (tools/pmc4.sh, pmc.sh): per kernel, the mean counter value per dispatch,
+"""Summarises rocprofv3 --pmc CSV passes (tools/pmc.sh, tools/profile_all.sh): per kernel, the mean counter value per dispatch,
 then -- where the counters needed are present -- derived ratios WITH their formulas, so that every percentage quoted
 in DESIGN.md can be recomputed from this file.
 

@@ -2,7 +2,7 @@
 # tools/profile_all.sh <tag> : rocprofv3 kernel stats + hardware counters for every hot kernel
 # (BASELINE configs 2, 3, 5 and the side topologies), on the GPU box.  Writes under
 # gpurun_out/prof_<tag>/<name>/; tools/profile_collect.py copies the summaries into profiles/.
-# Counter groups: tools/pmc4.sh (one rocprofv3 --pmc pass per group, kernel trace only), the
+# Counter groups: those of tools/pmc.sh core (one rocprofv3 --pmc pass per group, kernel trace only), the
 # calibration kernels of tools/ubench/pmc_calib.hip once (configuration "calib").
 tag=$1
 R=$PWD
@@ -26,13 +26,13 @@ prof() {
   # driver-style bench line (20 steps) and the long one, no profiler attached
   (cd $R && timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu "$@" > $out/$name/bench_20.json 2>/dev/null)
   (cd $R && timeout 300 python bench.py --steps 400 --warmup 40 --no-cpu "$@" > $out/$name/bench_400.json 2>/dev/null)
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name/stats -- python $R/bench.py --steps 50 --warmup 10 --no-cpu "$@" > $out/$name/stats.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name/stats -- python $R/bench.py --steps 200 --warmup 40 --settle 0 --no-cpu "$@" > $out/$name/stats.log 2>&1
   i=0
   for grp in "${PGRPS[@]}"; do
     i=$((i+1))
     # PROF_LIGHT="name ...": those configurations collect the HBM byte counters only (groups 6 and 7)
     if [ -n "$PROF_LIGHT" ] && echo " $PROF_LIGHT " | grep -q " $name " && [ $i -ne 6 ] && [ $i -ne 7 ]; then continue; fi
-    timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$name/p$i -- python $R/bench.py --steps 4 --warmup 2 --no-cpu "$@" > $out/$name/p$i.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $out/$name/p$i -- python $R/bench.py --steps 4 --warmup 2 --settle 0 --no-cpu "$@" > $out/$name/p$i.log 2>&1
   done
   (cd $R && python tools/pmc_summary.py $out/$name > $out/$name/pmc_summary.txt 2>&1)
   # keep only the summaries (the raw traces are large)
