@@ -160,7 +160,7 @@ R8BSRC_DECL int r8b_batch_state_load(CR8BBatch b, const void* buf, long long siz
  * minimum-phase chain carries fractional latencies from stage to stage like the reference does; its convolvers
  * run on the pair kernel with a complex kernel spectrum, the interpolator behind them unfused.  Samples agree
  * with the reference's to 1e-15 when both use the same taps (tests feed the reference's through
- * r8b_design_set_lp_provider); with the taps of THIS library's designer the streams differ by 3e-7 ... 6e-5 RMS
+ * r8b_design_set_lp_provider of a test build); with the taps of THIS library's designer the streams differ by 3e-7 ... 6e-5 RMS
  * (-48 dB for 1/3-band filters at 180 dB), because the cepstral transform's result depends on the rounding noise
  * of the FFT that computes it. */
 R8BSRC_DECL CR8BBatch r8b_batch_create_ex(double SrcSampleRate, double DstSampleRate, int MaxInLen,
@@ -221,17 +221,20 @@ R8BSRC_DECL int r8b_design_lpfilter_ex(double ReqNormFreq, double ReqTransBand, 
 	double ReqGain, int ReqPhase, int* BlockLenBits, int* Latency, double* LatencyFrac, double* taps,
 	int cap);
 
-/* PARITY-TEST HOOK (no product code path installs one).  A provider may supply the taps of a low-pass filter in
- * place of the designer: it is asked on every designer cache miss with the filter's parameters and returns the
- * number of taps it wrote (<= cap; 0 = "not mine", the designer runs), their group-delay split *Latency /
- * *LatencyFrac and *BlockLenBits.  tests/ use it to feed the REFERENCE's own minimum-phase taps (recovered from
- * CDSPFIRFilter::getKernelBlock) through the kernels, which separates kernel parity (1e-15) from the conditioning
- * of the cepstral minimum-phase transform (CDSPRealFFT.h:681-785), whose output depends on the rounding noise of
- * the particular FFT used.  Filters obtained under a provider are cached apart from designed ones; NULL removes it.
- * Not thread safe against concurrent object creation. */
+#ifdef R8B_TEST_HOOKS
+/* PARITY-TEST HOOK -- NOT part of the shipped library: libr8bsrc_hip.so neither exports this symbol nor contains its
+ * code; only builds made with -DR8B_TEST_HOOKS do (tests/emul, tests/_build/libr8bsrc_hip_testhooks.so).  A
+ * provider may supply the taps of a low-pass filter in place of the designer: it is asked on every designer cache miss
+ * (cache unlocked) with the filter's parameters and returns the number of taps it wrote (<= cap; 0 = "not mine", the
+ * designer runs), their group-delay split *Latency / *LatencyFrac and *BlockLenBits.  tests/ use it to feed the
+ * REFERENCE's own minimum-phase taps (recovered from CDSPFIRFilter::getKernelBlock) through the kernels, which
+ * separates kernel parity (1e-15) from the conditioning of the cepstral minimum-phase transform
+ * (CDSPRealFFT.h:681-785), whose output depends on the rounding noise of the particular FFT used.  Filters obtained
+ * under a provider are cached apart from designed ones; NULL removes it. */
 typedef int (*r8b_lp_provider)(double ReqNormFreq, double ReqTransBand, double ReqAtten, double ReqGain,
 	int ReqPhase, double* taps, int cap, int* Latency, double* LatencyFrac, int* BlockLenBits);
 R8BSRC_DECL void r8b_design_set_lp_provider(r8b_lp_provider provider);
+#endif
 
 /* Fractional-delay bank (CDSPFracDelayFilterBank): rows 0..FilterFracs, FilterLen*ElementSize
  * doubles each, natural (unshuffled) element order.  FilterFracs = -1 selects the default

@@ -57,7 +57,6 @@ PROTOTYPES = [
     ("r8b_design_lpfilter_ex", C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, C.c_int,
                                        C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                        C.POINTER(C.c_double), C.c_int]),
-    ("r8b_design_set_lp_provider", None, [C.c_void_p]),
     ("r8b_design_fracbank", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, ip, ip, dp,
                                       C.c_int]),
     ("r8b_design_hbfilter", C.c_int, [C.c_double, C.c_int, C.c_int, dp, dp]),
@@ -79,9 +78,15 @@ LP_PROVIDER = C.CFUNCTYPE(C.c_int, C.c_double, C.c_double, C.c_double, C.c_doubl
                           C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int))
 
 
-def bind(path):
+# ... which only TEST builds of the library export (-DR8B_TEST_HOOKS: tests/emul, tests/_build)
+TEST_HOOK_PROTOTYPES = [
+    ("r8b_design_set_lp_provider", None, [C.c_void_p]),
+]
+
+
+def bind(path, test_hooks=False):
     lib = C.CDLL(path)
-    for name, res, args in PROTOTYPES:
+    for name, res, args in PROTOTYPES + (TEST_HOOK_PROTOTYPES if test_hooks else []):
         f = getattr(lib, name)  # AttributeError if the library does not export it
         f.restype = res
         f.argtypes = args

@@ -450,10 +450,12 @@ R8BSRC_DECL int r8b_design_lpfilter_ex(double ReqNormFreq, double ReqTransBand, 
 	return f.kernel_len;
 }
 
+#ifdef R8B_TEST_HOOKS
 R8BSRC_DECL void r8b_design_set_lp_provider(r8b_lp_provider provider)
 {
 	set_lp_provider(reinterpret_cast<LpProvider>(provider));
 }
+#endif
 
 R8BSRC_DECL int r8b_design_fracbank(int FilterFracs, int ElementSize, int InterpPoints,
 	double ReqAtten, int IsThird, int* FilterLen, int* Fracs, double* table, int cap)

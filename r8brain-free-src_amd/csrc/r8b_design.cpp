@@ -244,6 +244,9 @@ std::vector<double> min_phase_transform(const std::vector<double>& kernel)
 
 } // namespace
 
+#ifdef R8B_TEST_HOOKS
+// (test builds only -- tests/emul and the GPU tier's libr8bsrc_hip_testhooks.so; the shipped library does not
+// contain the hook: r8b_design.h)
 namespace {
 LpProvider g_lp_provider = nullptr;
 int g_lp_provider_gen = 0; // filters made under a provider are cached apart from the designer's own
@@ -256,23 +259,35 @@ void set_lp_provider(LpProvider p)
 	g_lp_provider = p;
 	g_lp_provider_gen = p != nullptr ? ++installs : 0;
 }
+#endif
 
 const LpFilter& design_lp(double norm_freq, double trans_band, double atten, double gain, bool min_phase)
 {
 	typedef std::tuple<double, double, double, double, bool, int> Key;
 	static std::map<Key, LpFilter> cache;
-	std::lock_guard<std::mutex> lock(g_cache_mutex);
-	const Key key(norm_freq, trans_band, atten, gain, min_phase, g_lp_provider != nullptr ? g_lp_provider_gen : 0);
+	std::unique_lock<std::mutex> lock(g_cache_mutex);
+	int gen = 0;
+#ifdef R8B_TEST_HOOKS
+	const LpProvider provider = g_lp_provider;
+	gen = provider != nullptr ? g_lp_provider_gen : 0;
+#endif
+	const Key key(norm_freq, trans_band, atten, gain, min_phase, gen);
 	auto it = cache.find(key);
 	if (it != cache.end()) return it->second;
-	if (g_lp_provider != nullptr)
+#ifdef R8B_TEST_HOOKS
+	if (provider != nullptr)
 	{
-		// (parity tests only, r8b_design.h)
+		// the provider runs with the cache unlocked (it may call back into r8b_design_*); the cache is looked up
+		// again afterwards
+		lock.unlock();
 		std::vector<double> t((size_t) 1 << 18);
 		int lat = 0, bits = 0;
 		double lf = 0.0;
-		const int n = g_lp_provider(norm_freq, trans_band, atten, gain, min_phase ? 1 : 0, t.data(), (int) t.size(),
+		const int n = provider(norm_freq, trans_band, atten, gain, min_phase ? 1 : 0, t.data(), (int) t.size(),
 			&lat, &lf, &bits);
+		lock.lock();
+		it = cache.find(key);
+		if (it != cache.end()) return it->second;
 		if (n > 0)
 		{
 			LpFilter f;
@@ -285,6 +300,7 @@ const LpFilter& design_lp(double norm_freq, double trans_band, double atten, dou
 			return cache.emplace(key, std::move(f)).first->second;
 		}
 	}
+#endif
 
 	double pwr, hl, fo1;
 	lp_fit(trans_band, atten, &pwr, &hl, &fo1);

@@ -32,13 +32,17 @@ struct LpFilter
 	int block_len_bits = 0;   // CDSPFIRFilter::getBlockLenBits()
 };
 
-// Parity-test hook: a provider that may supply a low-pass filter's taps instead of the designer (e.g. the
-// REFERENCE's own minimum-phase taps, so that the kernels' parity can be checked apart from the conditioning of the
-// cepstral transform, whose result depends on the rounding noise of the FFT that computes it).  Called on a cache
-// miss; returns the number of taps written (<= cap), 0 to decline.  The product never installs one.
+#ifdef R8B_TEST_HOOKS
+// Parity-test hook, compiled into TEST builds only (tests/emul/Makefile, `make testhooks` in csrc/: -DR8B_TEST_HOOKS);
+// the shipped libr8bsrc_hip.so has neither the symbol nor the code.  A provider may supply a low-pass filter's taps
+// instead of the designer (e.g. the REFERENCE's own minimum-phase taps, so that the kernels' parity can be checked
+// apart from the conditioning of the cepstral transform, whose result depends on the rounding noise of the FFT that
+// computes it).  Called on a cache miss, with the cache unlocked; returns the number of taps written (<= cap), 0 to
+// decline.
 typedef int (*LpProvider)(double norm_freq, double trans_band, double atten, double gain, int phase,
 	double* taps, int cap, int* latency, double* lat_frac, int* block_len_bits);
 void set_lp_provider(LpProvider p);
+#endif
 
 // reference EDSPFilterPhaseResponse (CDSPFIRFilter.h:28-45)
 enum FilterPhase { kLinearPhase = 0, kMinPhase = 1 };

@@ -42,6 +42,20 @@ def refwrap():
     return R
 
 
+@pytest.fixture(scope="session")
+def hip_hooks():
+    """TEST build of the HIP library with the parity-test hooks compiled in (csrc/Makefile `testhooks`:
+    tests/_build/libr8bsrc_hip_testhooks.so -- same kernels, r8b_design_set_lp_provider added); the product library has
+    neither the symbol nor its code.  Built by __graft_entry__.build(); it travels to the GPU box with the snapshot."""
+    import importlib
+    path = os.path.join(ROOT, "tests", "_build", "libr8bsrc_hip_testhooks.so")
+    if not os.path.exists(path):
+        pytest.skip("tests/_build/libr8bsrc_hip_testhooks.so not built (python __graft_entry__.py)")
+    r8b = importlib.import_module("r8brain-free-src_amd")
+    r8b.load()   # (torch's HIP runtime first, then the product, then the test build: _capi.load)
+    return r8b.bind(path, test_hooks=True)
+
+
 def rms(a):
     a = np.asarray(a, dtype=np.float64)
     return float(np.sqrt(np.mean(a * a))) if a.size else 0.0

@@ -32,6 +32,13 @@ def lib():
 def test_exports_every_declared_symbol(lib):
     hdr = open(os.path.join(ROOT, "include", "r8bsrc.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    # what only TEST builds declare and export (-DR8B_TEST_HOOKS) must be absent from the shipped library
+    hooks = re.findall(r"#ifdef R8B_TEST_HOOKS(.*?)#endif", hdr, flags=re.S)
+    hook_names = set(re.findall(r"R8BSRC_DECL[^;(]*?\b(r8b_\w+)\s*\(", "".join(hooks)))
+    assert hook_names == {p[0] for p in r8b._capi.TEST_HOOK_PROTOTYPES} and hook_names
+    for n in hook_names:
+        assert not hasattr(lib, n), n + " is exported by the product library"
+    hdr = re.sub(r"#ifdef R8B_TEST_HOOKS.*?#endif", "", hdr, flags=re.S)
     names = set(re.findall(r"R8BSRC_DECL[^;(]*?\b(r8b_\w+)\s*\(", hdr))
     assert {"r8b_create", "r8b_delete", "r8b_inlen", "r8b_clear", "r8b_process"} <= names
     assert len(names) >= 30

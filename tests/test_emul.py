@@ -21,7 +21,7 @@ r8b = importlib.import_module("r8brain-free-src_amd")
 def emul():
     d = os.path.join(ROOT, "tests", "emul")
     subprocess.run(["make"], cwd=d, check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-    return r8b.bind(os.path.join(d, "_build", "libr8bsrc_emul.so"))
+    return r8b.bind(os.path.join(d, "_build", "libr8bsrc_emul.so"), test_hooks=True)
 
 
 @pytest.mark.parametrize("case", STREAM_CASES)

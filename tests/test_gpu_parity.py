@@ -296,12 +296,12 @@ def test_hip_minimum_phase_chains(torch, refwrap, case):
 
 
 @pytest.mark.parametrize("case", MINPHASE_CASES)
-def test_hip_minimum_phase_kernels_on_reference_taps(torch, refwrap, case):
+def test_hip_minimum_phase_kernels_on_reference_taps(torch, refwrap, hip_hooks, case):
     """the minimum-phase chains on the real kernels with the REFERENCE's own minimum-phase taps
-    (parity-test hook r8b_design_set_lp_provider): pair-kernel modes 6 / 7, k_whole / k_poly / half-band kernels with
+    (parity-test hook r8b_design_set_lp_provider of the test build, conftest.hip_hooks): pair-kernel modes 6 / 7, k_whole / k_poly / half-band kernels with
     fractional start positions -- RMS <= 1e-15 / peak <= 1e-13 against the reference stream"""
     from test_emul import run_minphase_reference_taps
-    run_minphase_reference_taps(r8b.load(), {"device": 0}, refwrap, case)
+    run_minphase_reference_taps(hip_hooks, {"device": 0, "lib": hip_hooks}, refwrap, case)
 
 
 def test_hip_poly_channel_groups(torch):
