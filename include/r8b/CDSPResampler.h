@@ -73,7 +73,8 @@ public:
 	}
 
 	int getLatency() const { return 0; }
-	double getLatencyFrac() const { return 0.0; }
+	// reference CDSPResampler.h:491-494: the fractional latency the last stage reports (0 for linear phase)
+	double getLatencyFrac() const { return r8b_batch_latency_frac(h); }
 	int getMaxOutLen(const int /*MaxInLen*/) const { return r8b_batch_max_out_len(h); }
 	void clear() { r8b_batch_clear(h); }
 

@@ -99,6 +99,10 @@ R8BSRC_DECL int r8b_batch_device(CR8BBatch b);
 /* CDSPResampler::getMaxOutLen(0) for the MaxInLen given at creation (CDSPResampler.h:502-519):
  * the minimum per-channel capacity of the output buffer. */
 R8BSRC_DECL int r8b_batch_max_out_len(CR8BBatch b);
+/* The chain's residual fractional latency in OUTPUT samples: r8b::CDSPResampler::getLatencyFrac() (reference
+ * CDSPResampler.h:491-494: the LatencyFrac the last stage reports, :688).  0.0 for linear-phase objects; for
+ * fprMinPhase (r8b_batch_create_ex) what a caller that compensates latency has to add to getLatency() = 0. */
+R8BSRC_DECL double r8b_batch_latency_frac(CR8BBatch b);
 /* CDSPResampler::getInputRequiredForOutput / getInLenBeforeOutPos (CDSPResampler.h:476-484,406) */
 R8BSRC_DECL int r8b_batch_inlen(CR8BBatch b, int ReqOutSamples);
 R8BSRC_DECL int r8b_batch_inlen_before_outpos(CR8BBatch b, int OutPos);

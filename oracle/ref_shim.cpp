@@ -89,6 +89,8 @@ REFX_API int refx_inlen_before_outstart(void* h, int pos)
 }
 
 REFX_API int refx_maxoutlen(void* h) { return ((CDSPResampler*) h)->getMaxOutLen(0); }
+// CDSPResampler::getLatencyFrac (CDSPResampler.h:491-494)
+REFX_API double refx_latency_frac(void* h) { return ((CDSPResampler*) h)->getLatencyFrac(); }
 
 REFX_API int refx_topology(double src, double dst, int maxin, double tb, double atten,
 	char* buf, int cap)

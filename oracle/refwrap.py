@@ -84,6 +84,8 @@ def _bind(lib):
     lib.refx_batch_check_ex.argtypes = [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
                                         C.c_int, C.c_int, _ip, _dp, C.c_longlong, _dp, C.c_longlong, _ip,
                                         C.c_int, _dp, _dp, C.POINTER(C.c_longlong)]
+    lib.refx_latency_frac.restype = C.c_double
+    lib.refx_latency_frac.argtypes = [C.c_void_p]
     lib.refx_version.restype = C.c_char_p
     return lib
 
@@ -176,6 +178,10 @@ class RefResampler:
 
     def inlen_before_outstart(self, p=0):
         return lib().refx_inlen_before_outstart(self.h, p)
+
+    def latency_frac(self):
+        """CDSPResampler::getLatencyFrac (CDSPResampler.h:491-494)"""
+        return lib().refx_latency_frac(self.h)
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -341,6 +341,13 @@ R8BSRC_DECL int r8b_batch_set_option(CR8BBatch b, const char* name, int value)
 	return ((Batch*) b)->eng->set_option(name, value) ? 0 : -1;
 }
 
+R8BSRC_DECL double r8b_batch_latency_frac(CR8BBatch b)
+{
+	// (what the last stage hands on: reference CDSPResampler.h:688, addProcessor)
+	const r8bhip::ChainPlan& pl = ((Batch*) b)->eng->plan();
+	return pl.stages.empty() ? 0.0 : pl.stages.back().lat_frac;
+}
+
 R8BSRC_DECL long long r8b_batch_stat(CR8BBatch b, const char* name)
 {
 	return name != nullptr ? ((Batch*) b)->eng->stat(name) : -1;

@@ -88,6 +88,10 @@ class BatchResampler(_Base):
         if self._lib.r8b_batch_set_option(self._h, name.encode(), int(value)) != 0:
             raise KeyError(name)
 
+    def getLatencyFrac(self):
+        """reference CDSPResampler.h:491-494: the chain's residual fractional latency (0.0 for linear phase)"""
+        return self._lib.r8b_batch_latency_frac(self._h)
+
     def stat(self, name):
         """a counter of the engine since creation (include/r8bsrc.h r8b_batch_stat)"""
         v = self._lib.r8b_batch_stat(self._h, name.encode())
@@ -264,6 +268,10 @@ class CDSPResampler(_Base):
 
     def getMaxOutLen(self, MaxInLen=0):
         return self._b.max_out_len
+
+    def getLatencyFrac(self):
+        """reference CDSPResampler.h:491-494"""
+        return self._b.getLatencyFrac()
 
     def getLatency(self):
         return 0

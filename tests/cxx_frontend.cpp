@@ -25,6 +25,17 @@ int main()
 	CR8BResampler dll = r8b_create(44100.0, 96000.0, L, 2.0, r8brr24);
 	if (dll == nullptr) return 2;
 	printf("inlen %d %d\n", rs.getInputRequiredForOutput(1), r8b_inlen(dll, 1));
+	// getLatencyFrac (reference CDSPResampler.h:491-494): 0 for linear phase, the last stage's residual for fprMinPhase
+	{
+		const double rates[8][2] = { { 44100.0, 88200.0 }, { 44100.0, 96000.0 }, { 96000.0, 44100.0 }, { 44100.0, 44101.0 },
+			{ 44100.0, 176400.0 }, { 176400.0, 44100.0 }, { 88200.0, 44100.0 }, { 48000.0, 32000.0 } };
+		for (int i = 0; i < 8; i++)
+		{
+			r8b::CDSPResampler lin(rates[i][0], rates[i][1], L, 2.0, 180.15, r8b::fprLinearPhase);
+			r8b::CDSPResampler mp(rates[i][0], rates[i][1], L, 2.0, 180.15, r8b::fprMinPhase);
+			printf("latfrac %.1f %.1f %a %a\n", rates[i][0], rates[i][1], lin.getLatencyFrac(), mp.getLatencyFrac());
+		}
+	}
 	for (int c = 0; c < calls; c++)
 	{
 		for (int i = 0; i < L; i++) in[(size_t) i] = splitmix(seed);

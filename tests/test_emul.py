@@ -237,6 +237,38 @@ def test_minimum_phase_latency_split_matches_reference(emul, refwrap):
         assert abs(lf.value - rlf) < 0.02, (nf, tb, att, lf.value, rlf)   # (1/3-band at 180 dB: 0.011 samples)
 
 
+LATFRAC_TOPOLOGIES = [(44100.0, 88200.0), (44100.0, 96000.0), (96000.0, 44100.0), (44100.0, 44101.0),
+                      (44100.0, 176400.0), (176400.0, 44100.0), (88200.0, 44100.0), (44100.0, 192000.0),
+                      (64000.0, 48000.0), (48000.0, 32000.0)]
+
+
+def check_latency_frac(lib, lib_kw, refwrap, provider):
+    """CDSPResampler::getLatencyFrac (reference CDSPResampler.h:491-494, 688: what the chain's LAST stage reports).
+    Linear phase: exactly 0.0, as the reference.  Minimum phase on the REFERENCE's own taps (test-build hook): the
+    chain's bookkeeping alone is compared -- equal to 1e-9; with this library's designer the filter's own group-delay
+    fraction differs by up to 0.011 samples (test_minimum_phase_latency_split_matches_reference), scaled by the
+    chain's rate ratio."""
+    for src, dst in LATFRAC_TOPOLOGIES:
+        lin = r8b.BatchResampler(src, dst, 1024, 2.0, 180.15, nch=1, **lib_kw)
+        assert lin.getLatencyFrac() == 0.0 == refwrap.RefResampler(src, dst, 1024, 2.0, 180.15).latency_frac()
+        want = refwrap.RefResampler(src, dst, 1024, 2.0, 180.15, phase=1).latency_frac()
+        own = r8b.BatchResampler(src, dst, 1024, 2.0, 180.15, nch=1, phase=1, **lib_kw).getLatencyFrac()
+        assert abs(own - want) < 0.02 * max(1.0, dst / src), (src, dst, own, want)
+        if provider is not None:
+            with provider as prov:
+                got = r8b.BatchResampler(src, dst, 1024, 2.0, 180.15, nch=1, phase=1, **lib_kw).getLatencyFrac()
+                assert prov.calls
+            assert abs(got - want) < 1e-9, (src, dst, got, want)
+    # the Python mirror of the front-end class
+    m = r8b.CDSPResampler(44100.0, 96000.0, 1024, 2.0, 180.15, ReqPhase=1, **lib_kw)
+    assert m.getLatencyFrac() == r8b.BatchResampler(44100.0, 96000.0, 1024, 2.0, 180.15, nch=1, phase=1,
+                                                    **lib_kw).getLatencyFrac() != 0.0
+
+
+def test_emulated_latency_frac_matches_reference(emul, refwrap):
+    check_latency_frac(emul, {"lib": emul}, refwrap, reference_minphase_taps(emul, refwrap))
+
+
 @pytest.mark.parametrize("case", MINPHASE_CASES)
 def test_emulated_minimum_phase_chains(emul, refwrap, case):
     """fprMinPhase: counts and latency bookkeeping equal the reference's, samples

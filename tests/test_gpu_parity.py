@@ -368,6 +368,26 @@ def test_cxx_frontend(torch, tmp_path):
     x = O.splitmix_uniform(7, 1024 * 6)
     yo = np.concatenate([o.process(x[i:i + 1024]) for i in range(0, len(x), 1024)])
     assert len(vals) == len(yo) and rms(vals - yo) <= RMS_TOL and peak(vals - yo) <= PEAK_TOL
+    # getLatencyFrac through the mirror header: 0.0 for linear phase as in the reference, the reference's value for
+    # fprMinPhase to what the designer's group-delay fraction allows (equality on the reference's own taps:
+    # test_hip_latency_frac_matches_reference)
+    lat = [l.split() for l in out if l.startswith("latfrac")]
+    assert len(lat) == 8
+    import refwrap as R
+    for _, a, b, lin, mp in lat:
+        a, b = float(a), float(b)
+        assert float.fromhex(lin) == 0.0
+        if R.available():
+            want = R.RefResampler(a, b, 1024, 2.0, 180.15, phase=1).latency_frac()
+            assert R.RefResampler(a, b, 1024, 2.0, 180.15).latency_frac() == 0.0
+            assert abs(float.fromhex(mp) - want) < 0.02 * max(1.0, b / a), (a, b, mp, want)
+
+
+def test_hip_latency_frac_matches_reference(torch, refwrap, hip_hooks):
+    """r8b_batch_latency_frac == CDSPResampler::getLatencyFrac of the compiled reference: 0.0 on linear phase, equal to
+    1e-9 on ten minimum-phase chains run on the reference's own taps (test build of the HIP library)"""
+    from test_emul import check_latency_frac, reference_minphase_taps
+    check_latency_frac(hip_hooks, {"lib": hip_hooks, "device": 0}, refwrap, reference_minphase_taps(hip_hooks, refwrap))
 
 
 @pytest.mark.parametrize("opts", [{"pair_two": 0}, {"fuse": 0}, {"fuse": 0, "fast_conv": 0},
