@@ -101,6 +101,25 @@ def lib():
     return _lib
 
 
+_pffft = None
+
+
+def pffft_lib():
+    """The reference built over its OTHER FFT back-end (oracle/Makefile libr8bref_pffft.so: -DR8B_PFFFT_DOUBLE=1, AVX);
+    None when it was not built or the host has no AVX.  Used only to measure the reference against itself."""
+    global _pffft
+    if _pffft is None:
+        p = os.path.join(_REFDIR, "libr8bref_pffft.so")
+        ok = False
+        try:
+            with open("/proc/cpuinfo") as f:
+                ok = any(line.startswith("flags") and " avx " in line + " " for line in f)
+        except OSError:
+            pass
+        _pffft = _bind(C.CDLL(p)) if ok and os.path.exists(p) else False
+    return _pffft or None
+
+
 def _cpu_has_avx2_fma():
     try:
         with open("/proc/cpuinfo") as f:
@@ -148,17 +167,19 @@ ATTEN = {"16": 136.45, "16IR": 109.56, "24": 180.15}
 class RefResampler:
     """r8b::CDSPResampler(src, dst, maxin, tb, atten, fprLinearPhase or fprMinPhase)."""
 
-    def __init__(self, src, dst, maxin, tb=2.0, atten=180.15, phase=0):
-        self.h = (lib().refx_create_ex(src, dst, maxin, tb, atten, int(phase)) if phase else
-                  lib().refx_create(src, dst, maxin, tb, atten))
+    def __init__(self, src, dst, maxin, tb=2.0, atten=180.15, phase=0, backend=None):
+        # (backend: another build of the same shim -- pffft_lib() --, default the Ooura build)
+        self._l = backend if backend is not None else lib()
+        self.h = (self._l.refx_create_ex(src, dst, maxin, tb, atten, int(phase)) if phase else
+                  self._l.refx_create(src, dst, maxin, tb, atten))
         self.maxin = maxin
-        self.maxout = lib().refx_maxoutlen(self.h) if src != dst else maxin
+        self.maxout = self._l.refx_maxoutlen(self.h) if src != dst else maxin
         self._buf = np.empty(self.maxout + 16, dtype=np.float64)
 
     def process(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         assert len(x) <= self.maxin
-        n = lib().refx_process(self.h, _ptr(x), len(x), _ptr(self._buf), len(self._buf))
+        n = self._l.refx_process(self.h, _ptr(x), len(x), _ptr(self._buf), len(self._buf))
         assert n <= len(self._buf)
         return self._buf[:n].copy()
 
@@ -168,24 +189,24 @@ class RefResampler:
         return np.concatenate(outs) if outs else np.zeros(0)
 
     def clear(self):
-        lib().refx_clear(self.h)
+        self._l.refx_clear(self.h)
 
     def input_required(self, n):
-        return lib().refx_input_required(self.h, n)
+        return self._l.refx_input_required(self.h, n)
 
     def inlen_before_outpos(self, p):
-        return lib().refx_inlen_before_outpos(self.h, p)
+        return self._l.refx_inlen_before_outpos(self.h, p)
 
     def inlen_before_outstart(self, p=0):
-        return lib().refx_inlen_before_outstart(self.h, p)
+        return self._l.refx_inlen_before_outstart(self.h, p)
 
     def latency_frac(self):
         """CDSPResampler::getLatencyFrac (CDSPResampler.h:491-494)"""
-        return lib().refx_latency_frac(self.h)
+        return self._l.refx_latency_frac(self.h)
 
     def __del__(self):
         if getattr(self, "h", None):
-            lib().refx_delete(self.h)
+            self._l.refx_delete(self.h)
             self.h = None
 
 

@@ -130,7 +130,18 @@ def test_emulated_minphase_pair_kernel_vs_generic(emul, topo):
     run_minphase_pair_vs_generic({"lib": emul}, topo)
 
 
+MINPHASE_NOISE_FACTOR = 3.0
+
+
 def run_minphase_case(lib_kw, refwrap, case):
+    """Minimum-phase chain with THIS library's designer against the compiled reference.  Per-call counts and the
+    latency queries must be equal.  Samples cannot be: the cepstral transform that derives the filter amplifies the
+    rounding noise of the FFT that computes it (reference CDSPRealFFT.h:681-785), so two correct builds of the
+    REFERENCE differ as well -- the bound is therefore the reference's own noise, measured in the same run: the
+    stream of the reference over its other FFT back-end (oracle/_ref/libr8bref_pffft.so, -DR8B_PFFFT_DOUBLE=1) against
+    the default (Ooura) build, times MINPHASE_NOISE_FACTOR.  Both sides are single draws of that noise: on the twelve
+    cases |ours - Ooura| / |PFFFT - Ooura| comes out between 0.41 and 2.64 (RMS and peak alike; 0.79 for most).
+    Without the PFFFT build (no AVX on the host) the hand-entered tolerances of cases.MINPHASE_CASES are used."""
     src, dst, maxin, chunk, n, tb, att, rtol, ptol = case
     b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, phase=1, **lib_kw)
     x = make_input(2, n, 5)
@@ -142,10 +153,21 @@ def run_minphase_case(lib_kw, refwrap, case):
         counts.append(y.shape[1])
         ys.append(y)
         pos += l
+    y = np.concatenate(ys, axis=1)
     # raises if any call's count differs from the reference's
-    r, p = refwrap.batch_check(src, dst, maxin, lens, x, np.concatenate(ys, axis=1), counts, tb, att,
-                               phase=1)
-    assert sum(counts) > 0 and r.max() <= rtol and p.max() <= ptol, (r.max(), p.max())
+    r, p = refwrap.batch_check(src, dst, maxin, lens, x, y, counts, tb, att, phase=1)
+    assert sum(counts) > 0
+    pf = refwrap.pffft_lib()
+    if pf is None:
+        assert r.max() <= rtol and p.max() <= ptol, (r.max(), p.max())
+    else:
+        for c in range(2):
+            yp = refwrap.RefResampler(src, dst, maxin, tb, att, phase=1, backend=pf).stream(x[c], chunk)
+            assert len(yp) == y.shape[1]
+            rn, pn = refwrap.batch_check(src, dst, maxin, lens, x[c:c + 1], yp[None, :], counts, tb, att, phase=1)
+            assert rn[0] > 0.0
+            assert r[c] <= MINPHASE_NOISE_FACTOR * rn[0] and p[c] <= MINPHASE_NOISE_FACTOR * pn[0], \
+                (c, r[c], rn[0], p[c], pn[0])
     # the reference's bookkeeping queries see the same latencies
     ref = refwrap.RefResampler(src, dst, maxin, tb, att, phase=1)
     for q in (0, 1, 17, 1000):
