@@ -524,3 +524,22 @@ def test_hip_parked_outputs_equal_recomputation(torch, case):
 
     parked, na, nb = check_parked_outputs(make, case)
     assert (parked > 0) == (case in PARK_CASES_THAT_PARK), (case, parked, na, nb)
+
+
+def test_root_pipeline_on_one_gpu_nccl(torch):
+    """sharding.RootPipeline's side stream, events and allocator registration are dead code under gloo;
+    here they run on the GPU through a world-size-1 NCCL (RCCL) process group on cuda:0 -- 56 pipelined steps, bitwise
+    equal to the unsharded object (tests/nccl_world1_worker.py, a process of its own)"""
+    import socket
+    import subprocess
+    import sys
+    from conftest import ROOT
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_world1_worker.py"), str(port)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [l for l in r.stdout.split("\n") if l.startswith("OK")]
+    assert last and int(last[-1].split()[1]) > 56 * 6000, r.stdout[-500:]
