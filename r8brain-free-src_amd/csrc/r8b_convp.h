@@ -1616,9 +1616,10 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	// the caches like its own, and a CU's L1 keeps only so many misses in flight.)
 	if ((L.tail_flags & 5) != 0)
 	{
-		const unsigned tn = (unsigned) (L.tail_p1 - L.tail_p0), nb = (unsigned) L.nblk;
-		const unsigned bi = (unsigned) (cur.k - L.k0), be = bi + (unsigned) (G::SUB == 1 ? 1 : cur.nvalid);
-		// (tn * nblk < 2^32: the tail is a few thousand samples, a launch at most kConvxMaxBlocks blocks)
+		const unsigned long long tn = (unsigned long long) (L.tail_p1 - L.tail_p0), nb = (unsigned long long) L.nblk;
+		const unsigned long long bi = (unsigned long long) (cur.k - L.k0), be = bi + (unsigned) (G::SUB == 1 ? 1 : cur.nvalid);
+		// (64-bit products: a fused launch has at most kConvxMaxBlocks blocks, an unfused one -- launch_stage -- as many
+		// as the call holds)
 		long long s0 = L.tail_p0 + (long long) (tn * bi / nb), s1 = L.tail_p0 + (long long) (tn * be / nb);
 		if ((L.tail_flags & 2) != 0)
 		{

@@ -967,7 +967,9 @@ R8B_HD void convx_body(Exec& ex, const ConvxLaunch& X, double* rbuf, long long k
 	// flight per thread (cf. r8b_convp.h); issued before the output phase, the stores need no wait
 	if (L.tail_ring != nullptr)
 	{
-		const unsigned tn = (unsigned) (L.tail_p1 - L.tail_p0), nb = (unsigned) L.nblk, bi = (unsigned) (k - L.k0);
+		// (64-bit products: an unfused launch -- launch_stage -- carries as many blocks as the call holds)
+		const unsigned long long tn = (unsigned long long) (L.tail_p1 - L.tail_p0), nb = (unsigned long long) L.nblk,
+			bi = (unsigned long long) (k - L.k0);
 		const long long s0 = L.tail_p0 + (long long) (tn * bi / nb), s1 = L.tail_p0 + (long long) (tn * (bi + 1u) / nb);
 		ex.each([&](int tid, St&)
 		{

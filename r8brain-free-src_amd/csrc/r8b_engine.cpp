@@ -1271,6 +1271,8 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 				// (history for the next call, exactly -- cf. launch_fused: the next call's first block is the one that
 				// holds output b, blocks sit at multiples of in_len, a block's window is n_in input samples ending
 				// in_len / up behind its start)
+				// (up is 1 or 2 on this path: convp_geometry_ok)
+				if (g.up > 2) throw std::logic_error("pair convolver: up-sampling factor");
 				const long long kn = ((long long) g.down * b + g.fl2) / g.in_len;
 				const long long wstart = ((kn * g.in_len) >> (g.up > 1 ? 1 : 0)) - ((long long) g.n_in - g.in_len / g.up);
 				const long long p0 = std::min(std::max(L.tail_p0, wstart - 8), L.tail_p1);
@@ -1364,8 +1366,18 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 int Engine::process_planar(const void* d_in, int in_fmt, long long in_stride, int l, void* d_out,
 	int out_fmt, long long out_stride, void* stream)
 {
-	// the first stage decodes the caller's samples as it loads them, the last one encodes as it
-	// stores (src_load / dst_store): no staging copy, 2-4 bytes per sample at the HBM edge
+	// The first stage decodes the caller's samples as it loads them, the last one encodes as it stores (src_load /
+	// dst_store: no staging copy, 2-4 bytes per sample at the HBM edge) -- WHERE that stage's kernel exists for PCM
+	// views: the streaming kernels and the generic convolver (pcm_fused_in / pcm_fused_out).  The compile-time-sized
+	// convolvers are built for fp64 views only; a PCM side in front of / behind one of them has to arrive as fp64 rows
+	// (r8b_capi.cpp batch_process_pcm decodes / encodes through the object's staging rows, one extra pass over that
+	// side).  Refused here, for every caller, instead of failing inside a launcher.
+	if (in_fmt != kPcmF64 && !pcm_fused_in())
+		throw std::runtime_error("planar PCM input in front of a compile-time-sized convolver: decode it into fp64 rows "
+			"first (r8b_batch_process_pcm does)");
+	if (out_fmt != kPcmF64 && !pcm_fused_out())
+		throw std::runtime_error("planar PCM output behind a compile-time-sized convolver: take fp64 rows and encode "
+			"them (r8b_batch_process_pcm does)");
 	struct Reset
 	{
 		Engine& e;

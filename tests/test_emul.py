@@ -597,3 +597,37 @@ def test_emulated_every_block_once_with_parked_outputs(emul):
         nblk = r.stat("conv_blocks")
         assert abs(nblk / calls - per_call) < 0.6 / calls + 0.25, (src, dst, nblk / calls, per_call)
         assert nblk / calls < per_call + 0.35
+
+
+def run_chunk_invariance_with_no_work_calls_and_checkpoints(lib_kw, src, dst, maxin):
+    """the history a call leaves is cut to what the NEXT call's first block reads back to (launch_fused /
+    launch_stage), older ring positions keep stale samples, calls served from the park buffer alone keep the history
+    with the copy kernel, and checkpoints carry rings and park buffer as they are (state blobs are not canonical:
+    bytes nobody reads again depend on how the stream was cut).  None of that may show: a stream cut into ragged
+    calls -- single samples and other calls without a block of their own among them -- and resumed from checkpoints
+    in fresh objects at those points equals the stream cut into MaxInLen calls bit for bit."""
+    n = maxin * 5 + 1234
+    x = make_input(3, n, 21)
+    a = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=3, **lib_kw)
+    ya = np.concatenate([a.process_host(x[:, i:i + maxin]) for i in range(0, n, maxin)], axis=1)
+    lens = [maxin, 1, 1, 3, maxin // 2 + 7, 1, maxin, 17, 2, 1, maxin - 9, 40, 5, maxin, 1, 1, maxin // 3]
+    b = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=3, **lib_kw)
+    ys, pos, k = [], 0, 0
+    while pos < n:
+        l = min(lens[k % len(lens)], n - pos)
+        ys.append(b.process_host(x[:, pos:pos + l]))
+        pos += l
+        k += 1
+        if k in (2, 3, 6, 9, 10, 15):
+            # (behind single-sample calls, behind a long call, behind a call served from the park buffer)
+            blob = b.state_dict()
+            b = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=3, **lib_kw)
+            b.process_host(x[:, :min(333, maxin)] * 0.25)   # unrelated history before the load
+            b.load_state_dict(blob)
+    yb = np.concatenate(ys, axis=1)
+    assert ya.shape == yb.shape and np.array_equal(ya, yb)
+
+
+@pytest.mark.parametrize("src,dst,maxin", TAIL_TOPOLOGIES)
+def test_emulated_chunk_invariance_with_no_work_calls_and_checkpoints(emul, src, dst, maxin):
+    run_chunk_invariance_with_no_work_calls_and_checkpoints({"lib": emul}, src, dst, maxin)

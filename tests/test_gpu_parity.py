@@ -543,3 +543,9 @@ def test_root_pipeline_on_one_gpu_nccl(torch):
     assert r.returncode == 0, r.stderr[-2000:]
     last = [l for l in r.stdout.split("\n") if l.startswith("OK")]
     assert last and int(last[-1].split()[1]) > 56 * 6000, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("src,dst,maxin", [(44100.0, 96000.0, 8192), (96000.0, 44100.0, 16384), (88200.0, 44100.0, 12000)])
+def test_hip_chunk_invariance_with_no_work_calls_and_checkpoints(torch, src, dst, maxin):
+    from test_emul import run_chunk_invariance_with_no_work_calls_and_checkpoints
+    run_chunk_invariance_with_no_work_calls_and_checkpoints({"device": 0}, src, dst, maxin)
