@@ -1007,14 +1007,37 @@ struct ConvpPost
 // K7 of the decimating form, from the registers: output q sits at virtual time q * down; the block's first
 // one is (block start) / down - floor(fl2 / down), in_len and the block starts being multiples of down
 // (reference CDSPBlockConvolver.h:150-165; cf. cx_store_conv)
+// (pd / pend: outputs [L.b, pend) of the call's last block belong to the next call and go to the park view pd --
+// ConvxLaunch::park_dst; pend = L.b for every other block)
 template<int LN, int UL>
 R8B_HD void cp_store_conv_down(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int chA,
-	int chB, bool bvalid, int lt)
+	int chB, bool bvalid, int lt, const DstView& pd, long long pend)
 {
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int mask = G::N2 - 1;
 	const int fl2 = L.fl2 >> G::DL, n = L.in_len >> G::DL;
 	const long long q0 = ((k * (long long) L.blk_stride + L.blk_offset) >> G::DL) - fl2;
+	if (pend > L.b)
+	{
+		// (the call's last block: what lies behind the call's range goes to the park view)
+#pragma unroll
+		for (int p = 0; p < G::E2; p++)
+		{
+			const int u = (lt + G::NT * p + fl2) & mask;
+			const long long q = q0 + u;
+			if (u < n && q >= L.a && q < L.b)
+			{
+				dst_store(L.dst, chA, q, st.vr[p]);
+				if (bvalid) dst_store(L.dst, chB, q, st.vi[p]);
+			}
+			else if (u < n && q >= L.b && q < pend)
+			{
+				dst_store(pd, chA, q, st.vr[p]);
+				if (bvalid) dst_store(pd, chB, q, st.vi[p]);
+			}
+		}
+		return;
+	}
 #pragma unroll
 	for (int p = 0; p < G::E2; p++)
 	{
@@ -1107,7 +1130,7 @@ R8B_HD void cp_final_store(const ConvLaunch& L, cd* ybase, cd* y, const ConvpSta
 // MODE 0 / 3: K7 straight from the registers
 template<int LN, int UL, int MODE = 0>
 R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int chA,
-	int chB, bool bvalid, int lt)
+	int chB, bool bvalid, int lt, const DstView& pd, long long pend)
 {
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int mask = G::N2 - 1;
@@ -1133,9 +1156,35 @@ R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 					dst_store(L.dst, chA, q, st.vr[p]);
 					if (bvalid) dst_store(L.dst, chB, q, st.vi[p]);
 				}
+				else if (pend > L.b && u < L.in_len && wq * (unsigned) down == w && q >= L.b && q < pend)
+				{
+					dst_store(pd, chA, q, st.vr[p]);
+					if (bvalid) dst_store(pd, chB, q, st.vi[p]);
+				}
 			}
 			return;
 		}
+	}
+	if (pend > L.b)
+	{
+		// (the call's last block: what lies behind the call's range goes to the park view)
+#pragma unroll
+		for (int p = 0; p < 16; p++)
+		{
+			const int u = (lt + G::NT * p + L.fl2r) & mask;
+			const long long q = t0 + u;
+			if (u < L.in_len && q >= L.a && q < L.b)
+			{
+				dst_store(L.dst, chA, q, st.vr[p]);
+				if (bvalid) dst_store(L.dst, chB, q, st.vi[p]);
+			}
+			else if (u < L.in_len && q >= L.b && q < pend)
+			{
+				dst_store(pd, chA, q, st.vr[p]);
+				if (bvalid) dst_store(pd, chB, q, st.vi[p]);
+			}
+		}
+		return;
 	}
 #pragma unroll
 	for (int p = 0; p < 16; p++)
@@ -1411,6 +1460,24 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 	}
 }
 
+// convolver-only modes: the park view of the call's LAST block (st.pf: this workgroup holds it; in a workgroup that
+// carries several blocks only the last of them parks) -- outputs [L.b, park_blk.jhi) at index q - L.b of park_dst
+template<class Exec, class St, class Item>
+R8B_HD void cp_park_view(const Exec& ex, const ConvxLaunch& XM, const St& st, long long k, const Item& cur, DstView& pd,
+	long long& pend)
+{
+	if (ex.uniform(st.pf) != 0 && k == XM.c.k0 + XM.c.nblk - 1)
+	{
+		pd.p = XM.park_dst;
+		pd.stride = XM.park_stride;
+		pd.mask = -1;
+		pd.off = -XM.c.b;
+		pd.fmt = kPcmF64;
+		pend = XM.park_blk.jhi;
+	}
+	(void) cur;
+}
+
 // ---- the kernel body ---------------------------------------------------------------------------------
 
 // one workgroup's work: blocks k0 .. k0 + nvalid - 1 (nvalid <= SUB) of the channel pair (chA, chB);
@@ -1473,9 +1540,12 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			ex.stamp2();
 			if (live(tid)) cp_tail_owned<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
 		}
-		if constexpr (MODE == 4 || MODE == 5)
+		if constexpr (MODE != 1)
 		{
-			// (the previous call's parked outputs, with the launch's first block of the pair)
+			// Parked outputs (ConvxLaunch::park_*): does this workgroup hold the call's last block (whose outputs behind
+			// the call's range are parked, not computed again by the next call)?  The previous call's parked outputs:
+			// this thread's element requested here, behind the samples, and stored in the workgroup's last phase --
+			// or all of them by the launch's first workgroup of the pair (short calls).
 			st.pf = X.park_out != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) == L.k0 + L.nblk ? 1 : 0;
 			st.pka = nullptr;
 			if (X.park_n > 0)
@@ -1664,12 +1734,16 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
+			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
 			ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
 			cp_silence<LN, UL>(st, ex.collect_bits());
 			if (live(tid))
 			{
-				if constexpr (UL < 0) cp_store_conv_down<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
-				else cp_store_conv<LN, UL, BM>(L, st, k_of(tid), chA, chB, bvalid, lt);
+				DstView pd = L.dst;
+				long long pend = L.b;
+				cp_park_view(ex, XM, st, k_of(tid), cur, pd, pend);
+				if constexpr (UL < 0) cp_store_conv_down<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt, pd, pend);
+				else cp_store_conv<LN, UL, BM>(L, st, k_of(tid), chA, chB, bvalid, lt, pd, pend);
 			}
 		});
 	}
@@ -1678,6 +1752,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
+			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
 			cp_back2<LN, UL>(buf_of(tid), st, lt);
 			cp_silence<LN, UL>(st, ex.collect_bits());
 			if constexpr ((R8B_ABL & 64) != 0)
@@ -1688,7 +1763,13 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				for (int p = 0; p < 16; p++) acc += st.vr[p] * st.vi[p];
 				if (acc != 1.2345e300) return;
 			}
-			if (live(tid)) cp_store_conv<LN, UL, BM>(L, st, k_of(tid), chA, chB, bvalid, lt);
+			if (live(tid))
+			{
+				DstView pd = L.dst;
+				long long pend = L.b;
+				cp_park_view(ex, XM, st, k_of(tid), cur, pd, pend);
+				cp_store_conv<LN, UL, BM>(L, st, k_of(tid), chA, chB, bvalid, lt, pd, pend);
+			}
 		});
 	}
 	else if constexpr (MODE == 4 || MODE == 5)

@@ -607,7 +607,11 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 			const StagePlan& sp = plan_.stages[s];
 			StageDev& d = dev_[s];
 			const long long hist = stage_history(s);
-			d.ring_size = pow2_at_least(s == 0 ? hist : hist + plan_.stage_max_in[s]);
+			// (+ one block of the convolver in front of it: the block that holds a call's last output is written whole,
+			// ahead of what the call owes -- launch_stage, conv_once)
+			const long long ahead = s > 0 && plan_.stages[s - 1].desc.kind == kConv ?
+				plan_.stages[s - 1].cg.in_len / plan_.stages[s - 1].cg.down + 2 : 0;
+			d.ring_size = pow2_at_least(s == 0 ? hist : hist + plan_.stage_max_in[s] + ahead);
 			// rings are allocated on first use (ensure_ring): the ring between two fused stages is
 			// never touched and would be the largest allocation (cfg2: 512 MB)
 			if (sp.desc.kind == kConv)
@@ -876,22 +880,46 @@ bool Engine::use_pair_two(size_t s, int* run_off) const
 	return true;
 }
 
-// Does the fused pair (convolver s, whole-step interpolator s + 1) park the outputs its last block holds beyond a
-// call (launch_fused)?  Only at the end of the chain -- the caller's rows are the one destination that cannot take
-// outputs ahead of their call -- and only in the two-phase pair form.  A constant of the object and its options.
+// Does stage s keep a park buffer for the outputs its call's last block holds beyond the call?  A fused pair
+// (convolver s, whole-step interpolator s + 1) in the two-phase pair form, or a pair-kernel convolver on its own, AT THE
+// END OF THE CHAIN: the caller's rows are the one destination that cannot take outputs ahead of their call.  (In the
+// middle of a chain the same block simply writes ahead into the next stage's ring: conv_once.)  A constant of the
+// object and its options.
 bool Engine::stage_parks(size_t s) const
 {
-	if (!opt_.at("park") || s + 2 != plan_.stages.size() || !fuse_with_next(s)) return false;
-	return use_pair_two(s, nullptr);
+	if (!opt_.at("park") || s >= plan_.stages.size() || plan_.stages[s].desc.kind != kConv) return false;
+	if (s + 2 == plan_.stages.size() && fuse_with_next(s)) return use_pair_two(s, nullptr);
+	if (s + 1 != plan_.stages.size()) return false;
+	const int path = conv_path(plan_.stages[s].cg);
+	return path == kPathPair || path == kPathPair3;
+}
+
+// How an unfused pair-kernel convolver treats the block that holds a call's last output (launch_stage): 0 -- computed
+// again by the next call (option park = 0); 2 -- computed once, the outputs beyond the call parked (end of the chain,
+// fp64 rows of the caller); 3 -- computed once, written ahead into the next stage's ring.
+int Engine::conv_once(size_t s, const DstView& dst) const
+{
+	if (!opt_.at("park")) return 0;
+	if (s + 1 == plan_.stages.size()) return dst.mask == -1 && dst.fmt == kPcmF64 && stage_parks(s) ? 2 : 0;
+	return dst.mask != -1 && dst.fmt == kPcmF64 ? 3 : 0;
 }
 
 // doubles per channel of a park buffer: what one block can hold, rounded up to whole 64-byte lines
 long long Engine::park_row_len(size_t s) const
 {
-	long long S = 0, off = 0;
-	fused_blocking(s, &S, &off);
-	const StagePlan& w = plan_.stages[s + 1];
-	const long long n = (S * w.out_step + w.in_step - 1) / w.in_step + 2;
+	long long n;
+	if (s + 2 == plan_.stages.size() && fuse_with_next(s))
+	{
+		long long S = 0, off = 0;
+		fused_blocking(s, &S, &off);
+		const StagePlan& w = plan_.stages[s + 1];
+		n = (S * w.out_step + w.in_step - 1) / w.in_step + 2;
+	}
+	else
+	{
+		const ConvGeom& g = plan_.stages[s].cg;
+		n = g.in_len / g.down + 2;
+	}
 	return (n + 7) / 8 * 8 + 8;
 }
 
@@ -1197,7 +1225,8 @@ void Engine::load_state(const void* buf, size_t size, void* stream)
 		}
 		if (st.park_len != (stage_parks(s) ? park_row_len(s) : 0))
 			throw std::runtime_error("state blob park layout mismatch");
-		if (st.park_base < 0 || st.park_end < st.park_base || st.park_end - st.park_base > st.park_len)
+		// (a stage that writes its last block ahead into a ring has counters but no buffer)
+		if (st.park_base < 0 || st.park_end < st.park_base || (st.park_len > 0 && st.park_end - st.park_base > st.park_len))
 			throw std::runtime_error("state blob holds impossible counters");
 		if (st.park_len > 0)
 		{
@@ -1252,28 +1281,95 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		ConvxLaunch X;
 		ConvLaunch& L = X.c;
 		fill_conv(s, L, src);
-		L.k0 = ((long long) g.down * a + g.fl2) / g.in_len;
-		const long long k1 = ((long long) g.down * (b - 1) + g.fl2) / g.in_len;
-		L.nblk = (int) (k1 - L.k0 + 1);
-		L.a = a; L.b = b;
-		L.dst = dst;
 		const int path = conv_path(g);
+		// Every block once (pair kernels): the block that holds the call's last output is computed whole -- what it
+		// holds beyond b goes ahead into the next stage's ring (once = 3: nobody reads it before it is due) or, at the
+		// end of the chain, into the park buffer (once = 2; ConvxLaunch::park_*) -- and the next call starts behind it
+		// instead of computing that block again (one block in 13.4 for 44100 -> 88200 at BASELINE's call size, one in
+		// 7.1 for 88200 -> 44100, one in 6.4 for 48000 -> 32000; cf. launch_fused)
+		const int once = (path == kPathPair || path == kPathPair3) ? conv_once(s, dst) : 0;
+		StageDev& dd = dev_[s];
+		auto blk_of = [&](long long q) { return ((long long) g.down * q + g.fl2) / g.in_len; };
+		auto blk_end = [&](long long k) // the first output block k does not hold
+		{
+			const long long v = (k + 1) * (long long) g.in_len - g.fl2;
+			return v <= 0 ? 0LL : (v + g.down - 1) / g.down;
+		};
+		X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
+		X.park_src = nullptr; X.park_dst = nullptr;
+		X.park_blk = SpanInfo();
+		long long ca = a; // the first output this call has to compute
+		if (once == 2) ensure_park(s);
+		if (once != 0 && dd.park_end > a)
+		{
+			ca = std::min(dd.park_end, b);
+			if (once == 2)
+			{
+				if (dd.park_base > a) throw std::logic_error("parked outputs start behind the call's first output");
+				X.park_src = dd.park[dd.park_cur] + (long long) ch0_ * dd.park_stride + (a - dd.park_base);
+				X.park_stride = dd.park_stride;
+				X.park_j0 = a;
+				X.park_n = (int) (ca - a);
+				if (ch0_ == 0) stat_["park_calls"]++;
+			}
+		}
+		if (ca >= b)
+		{
+			// nothing left to compute: the outputs are in the next stage's ring already, or come out of the park buffer
+			if (once == 2)
+			{
+				TailLaunch T;
+				T.src.ring = X.park_src; T.src.ring_stride = 0; T.src.ring_mask = 0;
+				T.src.cur = X.park_src; T.src.cur_stride = X.park_stride; T.src.cur_base = a;
+				T.src.cur_fmt = kPcmF64;
+				T.p0 = a; T.p1 = b;
+				T.ring = dst.p + dst.off; T.ring_stride = dst.stride; T.ring_mask = -1;
+				T.nch = nchw_;
+				launch_tail(T, stream);
+				if (ch0_ == 0) stat_["park_only_calls"]++;
+			}
+			break;
+		}
+		L.k0 = blk_of(ca);
+		const long long k1 = blk_of(b - 1);
+		L.nblk = (int) (k1 - L.k0 + 1);
+		L.a = ca; L.b = b;
+		L.dst = dst;
+		long long pend = b; // end of what the call's last block holds
+		if (once != 0)
+		{
+			pend = blk_end(k1);
+			if (pend < b) throw std::logic_error("block bookkeeping of the convolver");
+			if (once == 3)
+			{
+				// (ahead into the ring: the ring was sized for it -- Engine::Engine)
+				if (dst.mask == -1 || dst.mask + 1 < stage_history(s + 1) + plan_.stage_max_in[s + 1] + (pend - b))
+					throw std::logic_error("ring too small for a block written ahead");
+				L.b = pend;
+			}
+		}
 		if (path != kPathGeneric)
 		{
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0; X.run_off = 0;
 			X.ptab = nullptr; X.ctab = nullptr; X.nsets = 0;
 			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
-			X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
-			X.park_src = nullptr; X.park_dst = nullptr;
-			X.park_blk = SpanInfo();
+			if (once == 2 && pend > b)
+			{
+				if (pend - b > dd.park_stride) throw std::logic_error("park buffer too small");
+				X.park_out = 1;
+				X.park_dst = dd.park[dd.park_cur ^ 1] + (long long) ch0_ * dd.park_stride;
+				X.park_stride = dd.park_stride;
+				X.park_blk.jlo = b;
+				X.park_blk.jhi = pend;
+			}
 			if (path == kPathPair && L.tail_ring != nullptr && g.up_pow2)
 			{
 				// (history for the next call, exactly -- cf. launch_fused: the next call's first block is the one that
-				// holds output b, blocks sit at multiples of in_len, a block's window is n_in input samples ending
-				// in_len / up behind its start)
+				// holds output b -- the one behind this call's last when every block is computed once --, blocks sit at
+				// multiples of in_len, a block's window is n_in input samples ending in_len / up behind its start)
 				// (up is 1 or 2 on this path: convp_geometry_ok)
 				if (g.up > 2) throw std::logic_error("pair convolver: up-sampling factor");
-				const long long kn = ((long long) g.down * b + g.fl2) / g.in_len;
+				const long long kn = once != 0 ? k1 + 1 : blk_of(b);
 				const long long wstart = ((kn * g.in_len) >> (g.up > 1 ? 1 : 0)) - ((long long) g.n_in - g.in_len / g.up);
 				const long long p0 = std::min(std::max(L.tail_p0, wstart - 8), L.tail_p1);
 				L.tail_p0 = p0 < 0 ? 0 : (p0 & ~1LL);
@@ -1284,6 +1380,13 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			else if (path == kPathPair) launch_convp(X, g.complex_h ? 6 : 0, stream);
 			else launch_convx(X, 0, stream);
 			if (L.tail_ring != nullptr) tail_done_ = true;
+			if (once != 0 && ch0_ + nchw_ >= nch_)
+			{
+				// (the counters once per call, after its last channel window)
+				if (once == 2 && pend > b) dd.park_cur ^= 1;
+				dd.park_base = b;
+				dd.park_end = pend;
+			}
 		}
 		else
 		{

@@ -113,6 +113,7 @@ private:
 	bool use_pair_two(size_t s, int* run_off) const;
 	void fused_blocking(size_t s, long long* S, long long* off) const;
 	bool stage_parks(size_t s) const;
+	int conv_once(size_t s, const DstView& dst) const;
 	long long park_row_len(size_t s) const;
 	void ensure_park(size_t s);
 	void prepare_two_phase(size_t s);

@@ -233,28 +233,40 @@ def check_pair_scales(batch, case):
     return float(rms.max()), float(pk.max())
 
 
-# Parked outputs (Engine::launch_fused, ConvxLaunch::park_*): the block that holds a call's last output is computed
-# once; what it holds of the next call(s) waits in a park buffer.  (src, dst, maxin, tb, atten): cfg2 and cfg3
-# topologies, a short filter (several blocks per workgroup), the 16IR preset, an interpolator with more phases than
-# threads stays on the one-phase form (no parking: counted blocks equal with and without)
+# Every block once (Engine::launch_fused / launch_stage, ConvxLaunch::park_*): the block that holds a call's last output
+# is computed once; what it holds of the next call(s) waits in a park buffer (end of the chain) or goes ahead into the
+# next stage's ring.  (src, dst, maxin, tb, atten, kind): "park" / "ahead" / "none" = what the chain's pair kernels do
 PARK_CASES = [
-    (44100.0, 96000.0, 8192, 2.0, 180.15),
-    (96000.0, 44100.0, 16384, 2.0, 180.15),
-    (44100.0, 96000.0, 4096, 2.0, 109.56),      # 16IR preset: two blocks per workgroup
-    (48000.0, 44100.0, 6000, 2.0, 109.56),
-    (44100.0, 48000.0, 5000, 2.0, 180.15),
-    (44100.0, 96000.0, 4096, 10.0, 109.56),     # 512-point blocks, one phase per thread: does not park
+    (44100.0, 96000.0, 8192, 2.0, 180.15, "park"),        # cfg2: fused, two phases per thread
+    (96000.0, 44100.0, 16384, 2.0, 180.15, "park"),       # cfg3
+    (44100.0, 96000.0, 4096, 2.0, 109.56, "park"),        # 16IR preset: two blocks per workgroup
+    (48000.0, 44100.0, 6000, 2.0, 109.56, "park"),
+    (44100.0, 48000.0, 5000, 2.0, 180.15, "park"),
+    (44100.0, 88200.0, 6000, 2.0, 180.15, "park"),        # convolver alone (mode 0), 2x up
+    (88200.0, 44100.0, 12000, 2.0, 180.15, "park"),       # 2x decimating form
+    (48000.0, 32000.0, 16384, 2.0, 180.15, "park"),       # 8192-point blocks, strided store (mode 3)
+    (44100.0, 132300.0, 3000, 10.0, 109.56, "park"),      # 3x zero stuffing, several blocks per workgroup
+    (176400.0, 44100.0, 9000, 2.0, 180.15, "park"),       # half-band decimator in front (input from a ring)
+    (44100.0, 2822400.0, 1024, 2.0, 180.15, "ahead"),     # cfg5: convolver -> half-band cascade (ahead into its ring)
+    (44100.0, 44101.0, 4096, 2.0, 180.15, "ahead"),       # convolver -> polynomial interpolator
+    (44100.0, 192000.0, 2048, 2.0, 180.15, "ahead"),      # fused pair -> ring -> convolver -> half-band
+    (44100.0, 96000.0, 4096, 10.0, 109.56, "none"),       # 512-point blocks, one phase per thread: as before
 ]
-PARK_CASES_THAT_PARK = PARK_CASES[:5]
+PARK_CASES_MINPHASE = [
+    (44100.0, 88200.0, 4096, 2.0, 180.15, "park"),        # complex kernel spectrum (mode 6)
+    (48000.0, 32000.0, 8192, 2.0, 180.15, "park"),        # mode 7
+    (44100.0, 96000.0, 4096, 2.0, 180.15, "ahead"),       # convolver -> k_whole with a fractional start
+]
 
 
 def check_parked_outputs(make, case):
     """`make(park)` builds a 3-channel batch object (odd: a block pair without a partner) with option park = 1 / 0.
     Calls of every length -- MaxInLen, a third, a few samples, one sample (served from the park buffer alone) -- give
-    the same outputs BIT FOR BIT with parked outputs and with the call's last block computed again by the next call,
-    across clear(); with parking every block of the stream is computed exactly once."""
-    src, dst, maxin, tb, att = case
-    lens = [maxin, maxin, maxin // 3, 300, 1, 1, 2, maxin, 17, 1, maxin - 5, 2500 % maxin + 1, maxin, 40, maxin]
+    the same outputs BIT FOR BIT with every block computed once and with the call's last block computed again by the
+    next call, across clear(); the counters say which of the two happened."""
+    src, dst, maxin, tb, att, kind = case
+    lens = [maxin, maxin, maxin // 3, 300 % maxin + 1, 1, 1, 2, maxin, 17, 1, maxin - 5, 2500 % maxin + 1, maxin, 40,
+            maxin]
     a, b = make(1), make(0)
     rng = np.random.default_rng(7)
     for rep in range(2):
@@ -267,11 +279,12 @@ def check_parked_outputs(make, case):
             a.clear()
             b.clear()
     parked = a.stat("park_calls")
-    if parked == 0:
-        assert na == nb           # (a topology that does not park)
-        return 0, na, nb
-    # without parking nearly every call with work computes one block twice; with it the blocks of the stream are
-    # consecutive: their number is (index of the last one + 1), which the run without parking reaches as well
-    assert a.stat("park_only_calls") > 0
-    assert na < nb, (na, nb)
+    assert b.stat("park_calls") == 0
+    if kind == "none":
+        assert na == nb and parked == 0, (na, nb, parked)
+    elif kind == "ahead":
+        assert na < nb and parked == 0, (na, nb, parked)
+    else:
+        # without parking nearly every call with work computes one block twice
+        assert na < nb and parked > 0 and a.stat("park_only_calls") > 0, (na, nb, parked)
     return parked, na, nb

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES, PARK_CASES_THAT_PARK, RMS_TOL,
+from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES, PARK_CASES_MINPHASE, RMS_TOL,
                    PEAK_TOL, compare_stream, make_input, check_pair_scales, check_parked_outputs)
 from conftest import ROOT
 
@@ -571,18 +571,26 @@ def test_emulated_history_from_registers_equals_the_copy_kernel(emul, src, dst, 
         assert ya.shape == yb.shape and np.array_equal(ya, yb), (i, l)
 
 
-@pytest.mark.parametrize("case", PARK_CASES)
-def test_emulated_parked_outputs_equal_recomputation(emul, case):
-    """cases.check_parked_outputs on the emulated engine"""
-    src, dst, maxin, tb, att = case
+def run_parked_outputs(lib_kw, case, phase=0):
+    src, dst, maxin, tb, att, kind = case
 
     def make(park):
-        r = r8b.BatchResampler(src, dst, maxin, tb, att, nch=3, lib=emul)
+        r = r8b.BatchResampler(src, dst, maxin, tb, att, nch=3, phase=phase, **lib_kw)
         r.set_option("park", park)
         return r
 
-    parked, na, nb = check_parked_outputs(make, case)
-    assert (parked > 0) == (case in PARK_CASES_THAT_PARK), (case, parked, na, nb)
+    return check_parked_outputs(make, case)
+
+
+@pytest.mark.parametrize("case", PARK_CASES)
+def test_emulated_parked_outputs_equal_recomputation(emul, case):
+    """cases.check_parked_outputs on the emulated engine"""
+    run_parked_outputs({"lib": emul}, case)
+
+
+@pytest.mark.parametrize("case", PARK_CASES_MINPHASE)
+def test_emulated_parked_outputs_minimum_phase(emul, case):
+    run_parked_outputs({"lib": emul}, case, phase=1)
 
 
 def test_emulated_every_block_once_with_parked_outputs(emul):

@@ -13,7 +13,7 @@ import pytest
 
 import r8b_oracle as O
 from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES,
-                   PARK_CASES_THAT_PARK, RMS_TOL, PEAK_TOL, compare_stream, make_input, check_pair_scales,
+                   PARK_CASES_MINPHASE, RMS_TOL, PEAK_TOL, compare_stream, make_input, check_pair_scales,
                    check_parked_outputs)
 from conftest import rms, peak
 
@@ -512,37 +512,17 @@ def test_hip_history_from_registers_equals_the_copy_kernel(torch, src, dst, maxi
 
 @pytest.mark.parametrize("case", PARK_CASES)
 def test_hip_parked_outputs_equal_recomputation(torch, case):
-    """the call's last block computed once, its outputs of the next call parked (r8b_convp.h cp_park_back, the second
-    cp_whole2_compute of the last block) == the block computed again by the next call, bit for bit, on the real
-    kernels (cases.check_parked_outputs)"""
-    src, dst, maxin, tb, att = case
-
-    def make(park):
-        r = r8b.BatchResampler(src, dst, maxin, tb, att, nch=3, device=0)
-        r.set_option("park", park)
-        return r
-
-    parked, na, nb = check_parked_outputs(make, case)
-    assert (parked > 0) == (case in PARK_CASES_THAT_PARK), (case, parked, na, nb)
+    """every block once -- the call's last block parks what it holds of the next call (r8b_convp.h cp_park_*, the second
+    cp_whole2_compute of the last block, cp_store_conv's park view) or writes it ahead into the next stage's ring -- ==
+    the block computed again by the next call, bit for bit, on the real kernels (cases.check_parked_outputs)"""
+    from test_emul import run_parked_outputs
+    run_parked_outputs({"device": 0}, case)
 
 
-def test_root_pipeline_on_one_gpu_nccl(torch):
-    """sharding.RootPipeline's side stream, events and allocator registration are dead code under gloo;
-    here they run on the GPU through a world-size-1 NCCL (RCCL) process group on cuda:0 -- 56 pipelined steps, bitwise
-    equal to the unsharded object (tests/nccl_world1_worker.py, a process of its own)"""
-    import socket
-    import subprocess
-    import sys
-    from conftest import ROOT
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_world1_worker.py"), str(port)],
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    last = [l for l in r.stdout.split("\n") if l.startswith("OK")]
-    assert last and int(last[-1].split()[1]) > 56 * 6000, r.stdout[-500:]
+@pytest.mark.parametrize("case", PARK_CASES_MINPHASE)
+def test_hip_parked_outputs_minimum_phase(torch, case):
+    from test_emul import run_parked_outputs
+    run_parked_outputs({"device": 0}, case, phase=1)
 
 
 @pytest.mark.parametrize("src,dst,maxin", [(44100.0, 96000.0, 8192), (96000.0, 44100.0, 16384), (88200.0, 44100.0, 12000)])
