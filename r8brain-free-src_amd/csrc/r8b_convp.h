@@ -55,6 +55,10 @@
 #ifndef R8B_FORCE4
 #define R8B_FORCE4(a, b, c, d)
 #endif
+// R8B_OUT_STORE16: a 16-byte store of an output pair to the caller's rows (the device build may mark it non-temporal)
+#ifndef R8B_OUT_STORE16
+#define R8B_OUT_STORE16(ptr, v) { *reinterpret_cast<cd*>(ptr) = (v); }
+#endif
 
 namespace r8bhip {
 
@@ -1004,6 +1008,43 @@ struct ConvpPost
 	}
 };
 
+// Convolver outputs straight from the registers, lean form: everything that is the same for the whole block is folded
+// once on the scalar unit -- the two row pointers, the low 32 bits of (first output + view offset), the block's slice of
+// the wanted output range as [ulo, uhi) in the block's own index space -- and an element is left with a 32-bit index,
+// one range test and the view's mask (rings are far below 2^32 elements, linear views are indexed from the call's first
+// output).  (Through dst_store every element repeats ~12 instructions of 64-bit position and address arithmetic: with
+// 16 elements per thread and two channels that was as many integer instructions as the last pass has fp64 ones.)
+struct CpStoreView
+{
+	double* pa;
+	double* pb;
+	unsigned qoff, m;   // element index = (qoff + i) & m, i = the output's index counted from the block's first one
+	unsigned ulo, uhi;  // outputs i in [ulo, uhi) are wanted (0 <= ulo <= uhi < 2^31)
+};
+// first: the block's first output position; [a, b): the wanted outputs; nmax: outputs a block can hold (< 2^30)
+R8B_HD CpStoreView cp_store_view(const DstView& d, int chA, int chB, long long first, long long a, long long b, int nmax)
+{
+	CpStoreView v;
+	v.pa = d.p + (long long) chA * d.stride;
+	v.pb = d.p + (long long) chB * d.stride;
+	v.qoff = (unsigned) (unsigned long long) (first + d.off);
+	v.m = (unsigned) (unsigned long long) d.mask;
+	const long long lo = a - first, hi = b - first;
+	v.ulo = (unsigned) (lo < 0 ? 0 : (lo > nmax ? nmax : lo));
+	v.uhi = (unsigned) (hi < 0 ? 0 : (hi > nmax ? nmax : hi));
+	if (v.uhi < v.ulo) v.uhi = v.ulo;
+	return v;
+}
+R8B_HD void cp_store1(const CpStoreView& v, unsigned i, double ya, double yb, bool bvalid)
+{
+	if (i - v.ulo < v.uhi - v.ulo)
+	{
+		const unsigned e = (v.qoff + i) & v.m;
+		v.pa[e] = ya;
+		if (bvalid) v.pb[e] = yb;
+	}
+}
+
 // K7 of the decimating form, from the registers: output q sits at virtual time q * down; the block's first
 // one is (block start) / down - floor(fl2 / down), in_len and the block starts being multiples of down
 // (reference CDSPBlockConvolver.h:150-165; cf. cx_store_conv)
@@ -1017,37 +1058,17 @@ R8B_HD void cp_store_conv_down(const ConvLaunch& L, const ConvpState<LN, UL>& st
 	constexpr int mask = G::N2 - 1;
 	const int fl2 = L.fl2 >> G::DL, n = L.in_len >> G::DL;
 	const long long q0 = ((k * (long long) L.blk_stride + L.blk_offset) >> G::DL) - fl2;
+	const CpStoreView v = cp_store_view(L.dst, chA, chB, q0, L.a, L.b, n);
+#pragma unroll
+	for (int p = 0; p < G::E2; p++)
+		cp_store1(v, (unsigned) ((lt + G::NT * p + fl2) & mask), st.vr[p], st.vi[p], bvalid);
 	if (pend > L.b)
 	{
 		// (the call's last block: what lies behind the call's range goes to the park view)
+		const CpStoreView w = cp_store_view(pd, chA, chB, q0, L.b, pend, n);
 #pragma unroll
 		for (int p = 0; p < G::E2; p++)
-		{
-			const int u = (lt + G::NT * p + fl2) & mask;
-			const long long q = q0 + u;
-			if (u < n && q >= L.a && q < L.b)
-			{
-				dst_store(L.dst, chA, q, st.vr[p]);
-				if (bvalid) dst_store(L.dst, chB, q, st.vi[p]);
-			}
-			else if (u < n && q >= L.b && q < pend)
-			{
-				dst_store(pd, chA, q, st.vr[p]);
-				if (bvalid) dst_store(pd, chB, q, st.vi[p]);
-			}
-		}
-		return;
-	}
-#pragma unroll
-	for (int p = 0; p < G::E2; p++)
-	{
-		const int u = (lt + G::NT * p + fl2) & mask;
-		const long long q = q0 + u;
-		if (u < n && q >= L.a && q < L.b)
-		{
-			dst_store(L.dst, chA, q, st.vr[p]);
-			if (bvalid) dst_store(L.dst, chB, q, st.vi[p]);
-		}
+			cp_store1(w, (unsigned) ((lt + G::NT * p + fl2) & mask), st.vr[p], st.vi[p], bvalid);
 	}
 }
 
@@ -1141,62 +1162,37 @@ R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 		// CDSPBlockConvolver.h:564-583); the thread's element p is virtual time t0 + u
 		if (!L.down_pow2 && L.down > 1)
 		{
-			const int down = L.down;
-			const long long qf = t0 >= 0 ? t0 / down : -((-t0 + down - 1) / down); // floor
-			const unsigned r0 = (unsigned) (t0 - qf * down);
-#pragma unroll
-			for (int p = 0; p < 16; p++)
+			const unsigned down = (unsigned) L.down;
+			const long long qf = t0 >= 0 ? t0 / (long long) down : -((-t0 + down - 1) / (long long) down); // floor
+			const unsigned r0 = (unsigned) (t0 - qf * (long long) down);
+			// (the block's outputs counted from qf: output i = (r0 + u) / down where down divides r0 + u, u < in_len)
+			const int nmax = (int) ((r0 + (unsigned) L.in_len) / down) + 1;
+			auto run = [&](const CpStoreView& v)
 			{
-				const int u = (lt + G::NT * p + L.fl2r) & mask;
-				const unsigned w = r0 + (unsigned) u;
-				const unsigned wq = down == 3 ? w / 3u : w / (unsigned) down;
-				const long long q = qf + wq;
-				if (u < L.in_len && wq * (unsigned) down == w && q >= L.a && q < L.b)
+#pragma unroll
+				for (int p = 0; p < 16; p++)
 				{
-					dst_store(L.dst, chA, q, st.vr[p]);
-					if (bvalid) dst_store(L.dst, chB, q, st.vi[p]);
+					const unsigned u = (unsigned) ((lt + G::NT * p + L.fl2r) & mask);
+					const unsigned w = r0 + u;
+					const unsigned wq = down == 3u ? w / 3u : w / down;
+					if (u < (unsigned) L.in_len && wq * down == w) cp_store1(v, wq, st.vr[p], st.vi[p], bvalid);
 				}
-				else if (pend > L.b && u < L.in_len && wq * (unsigned) down == w && q >= L.b && q < pend)
-				{
-					dst_store(pd, chA, q, st.vr[p]);
-					if (bvalid) dst_store(pd, chB, q, st.vi[p]);
-				}
-			}
+			};
+			run(cp_store_view(L.dst, chA, chB, qf, L.a, L.b, nmax));
+			if (pend > L.b) run(cp_store_view(pd, chA, chB, qf, L.b, pend, nmax));
 			return;
 		}
 	}
-	if (pend > L.b)
+	// (valid outputs: u < in_len)
+	auto run = [&](const CpStoreView& v)
 	{
-		// (the call's last block: what lies behind the call's range goes to the park view)
 #pragma unroll
 		for (int p = 0; p < 16; p++)
-		{
-			const int u = (lt + G::NT * p + L.fl2r) & mask;
-			const long long q = t0 + u;
-			if (u < L.in_len && q >= L.a && q < L.b)
-			{
-				dst_store(L.dst, chA, q, st.vr[p]);
-				if (bvalid) dst_store(L.dst, chB, q, st.vi[p]);
-			}
-			else if (u < L.in_len && q >= L.b && q < pend)
-			{
-				dst_store(pd, chA, q, st.vr[p]);
-				if (bvalid) dst_store(pd, chB, q, st.vi[p]);
-			}
-		}
-		return;
-	}
-#pragma unroll
-	for (int p = 0; p < 16; p++)
-	{
-		const int u = (lt + G::NT * p + L.fl2r) & mask;
-		const long long q = t0 + u;
-		if (u < L.in_len && q >= L.a && q < L.b)
-		{
-			dst_store(L.dst, chA, q, st.vr[p]);
-			if (bvalid) dst_store(L.dst, chB, q, st.vi[p]);
-		}
-	}
+			cp_store1(v, (unsigned) ((lt + G::NT * p + L.fl2r) & mask), st.vr[p], st.vi[p], bvalid);
+	};
+	run(cp_store_view(L.dst, chA, chB, t0, L.a, L.b, L.in_len));
+	// (the call's last block: what lies behind the call's range goes to the park view)
+	if (pend > L.b) run(cp_store_view(pd, chA, chB, t0, L.b, pend, L.in_len));
 }
 
 // MODE 1: K8 on the pair run (cf. cx_whole_compute): one 16-byte LDS read per tap feeds both channels
@@ -1375,8 +1371,8 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 			va.im = a1[0] + a1[1];
 			vb.re = b0[0] + b0[1];
 			vb.im = b1[0] + b1[1];
-			*reinterpret_cast<cd*>(pa0 + o) = va;
-			if (bvalid) *reinterpret_cast<cd*>(pb0 + o) = vb;
+			R8B_OUT_STORE16(pa0 + o, va);
+			if (bvalid) R8B_OUT_STORE16(pb0 + o, vb);
 		}
 		return;
 	}
@@ -1430,8 +1426,8 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 				va.im = a1[0] + a1[1];
 				vb.re = b0[0] + b0[1];
 				vb.im = b1[0] + b1[1];
-				*reinterpret_cast<cd*>(pa + o) = va;
-				if (bvalid) *reinterpret_cast<cd*>(pb + o) = vb;
+				R8B_OUT_STORE16(pa + o, va);
+				if (bvalid) R8B_OUT_STORE16(pb + o, vb);
 				continue;
 			}
 			if (v0)

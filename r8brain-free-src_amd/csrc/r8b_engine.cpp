@@ -609,8 +609,13 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 			const long long hist = stage_history(s);
 			// (+ one block of the convolver in front of it: the block that holds a call's last output is written whole,
 			// ahead of what the call owes -- launch_stage, conv_once)
-			const long long ahead = s > 0 && plan_.stages[s - 1].desc.kind == kConv ?
+			// (the same behind a fused convolver + whole-step interpolator: a block's interpolated outputs -- launch_fused)
+			long long ahead = s > 0 && plan_.stages[s - 1].desc.kind == kConv ?
 				plan_.stages[s - 1].cg.in_len / plan_.stages[s - 1].cg.down + 2 : 0;
+			if (s > 1 && plan_.stages[s - 1].desc.kind == kFrac && plan_.stages[s - 1].whole &&
+				plan_.stages[s - 2].desc.kind == kConv)
+				ahead = (long long) plan_.stages[s - 2].cg.in_len * plan_.stages[s - 1].out_step / plan_.stages[s - 1].in_step +
+					plan_.stages[s - 1].out_step + 2;
 			d.ring_size = pow2_at_least(s == 0 ? hist : hist + plan_.stage_max_in[s] + ahead);
 			// rings are allocated on first use (ensure_ring): the ring between two fused stages is
 			// never touched and would be the largest allocation (cfg2: 512 MB)
@@ -2047,18 +2052,26 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	// in 13.4 for BASELINE's cfg2 call, one in 7.5 for cfg3).  ja: the first output this call has to compute.
 	StageDev& dp = dev_[s];
 	const bool parks = stage_parks(s) && dst.mask == -1 && dst.fmt == kPcmF64;
+	// ... and in the middle of a chain the same block writes what it holds beyond the call AHEAD into the next stage's
+	// ring (nobody reads it before it is due; the ring was sized for it -- Engine::Engine)
+	const bool ahead = !parks && opt_.at("park") && pair_two && dst.mask != -1 && dst.fmt == kPcmF64 &&
+		s + 2 < plan_.stages.size();
 	if (parks) ensure_park(s);
 	long long ja = wa;
-	if (parks && dp.park_end > wa)
+	if ((parks || ahead) && dp.park_end > wa)
 	{
-		if (dp.park_base > wa) throw std::logic_error("parked outputs start behind the call's first output");
 		ja = std::min(dp.park_end, wb);
-		X.park_src = dp.park[dp.park_cur] + (long long) ch0_ * dp.park_stride + (wa - dp.park_base);
-		X.park_stride = dp.park_stride;
-		X.park_j0 = wa;
-		X.park_n = (int) (ja - wa);
-		if (ch0_ == 0) stat_["park_calls"]++;
+		if (parks)
+		{
+			if (dp.park_base > wa) throw std::logic_error("parked outputs start behind the call's first output");
+			X.park_src = dp.park[dp.park_cur] + (long long) ch0_ * dp.park_stride + (wa - dp.park_base);
+			X.park_stride = dp.park_stride;
+			X.park_j0 = wa;
+			X.park_n = (int) (ja - wa);
+			if (ch0_ == 0) stat_["park_calls"]++;
+		}
 	}
+	if (ja >= wb && ahead) return; // (everything this call owes is in the ring already)
 	if (ja >= wb)
 	{
 		// the whole call comes out of the park buffer (a short call): a plain copy; the stream's history is kept by
@@ -2077,7 +2090,11 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	const long long kfirst = owner(ja), klast = owner(wb - 1);
 	// (with parked outputs the next call's first block is the one behind this call's last: whatever that one holds
 	// beyond wb is parked below)
-	const long long knext = parks ? klast + 1 : owner(wb);
+	const long long knext = parks || ahead ? klast + 1 : owner(wb);
+	// (written ahead: the last block's outputs are not cut at the call's end)
+	const long long wcut = ahead ? block_jhi(klast) : wb;
+	if (ahead && (wcut < wb || dst.mask + 1 < stage_history(s + 2) + plan_.stage_max_in[s + 2] + (wcut - wb)))
+		throw std::logic_error("ring too small for a block written ahead");
 	if (X.c.tail_ring != nullptr && pair_two && c.cg.up_pow2)
 	{
 		// History for the next call, exactly: its first block is knext -- the first block whose outputs this call
@@ -2114,7 +2131,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			long long jlo = block_jlo(k);
 			long long jhi = block_jhi(k);
 			if (jlo < ja) jlo = ja;
-			if (jhi > wb) jhi = wb;
+			if (jhi > wcut) jhi = wcut;
 			if (jhi < jlo) jhi = jlo;
 			B.jlo = jlo; B.jhi = jhi;
 			B.jlo_mod = (int) (jlo % Out);
@@ -2155,10 +2172,11 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 		else launch_convx(X, 1, stream);
 		if (X.c.tail_ring != nullptr) tail_done_ = true;
 	}
-	if (parks && ch0_ + nchw_ >= nch_)
+	if ((parks || ahead) && ch0_ + nchw_ >= nch_)
 	{
 		// (the counters once per call, after its last channel window)
-		if (park_b > wb) dp.park_cur ^= 1;
+		if (ahead) park_b = wcut;
+		if (parks && park_b > wb) dp.park_cur ^= 1;
 		dp.park_base = wb;
 		dp.park_end = park_b;
 	}

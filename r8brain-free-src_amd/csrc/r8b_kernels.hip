@@ -100,6 +100,16 @@
 	}
 #endif
 #define R8B_FORCE4(a, b, c, d) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d))
+// the interpolator's 16-byte output stores (r8b_convp.h R8B_OUT_STORE16): R8B_NT_STORE = 1 marks them non-temporal
+// (streaming: the outputs are not read again by this kernel and need not displace tables and history in L2)
+#ifndef R8B_NT_STORE
+#define R8B_NT_STORE 0
+#endif
+#if R8B_NT_STORE
+typedef double r8b_d2_t __attribute__((ext_vector_type(2)));
+#define R8B_OUT_STORE16(ptr, v) { r8b_d2_t t_; t_.x = (v).re; t_.y = (v).im; \
+	__builtin_nontemporal_store(t_, reinterpret_cast<r8b_d2_t*>(ptr)); }
+#endif
 // nothing is scheduled across this point (no instruction is emitted)
 #ifndef R8B_NO_SCHED_FENCE
 #define R8B_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
