@@ -1490,16 +1490,11 @@ struct ConvpItem
 
 // X: the launch descriptor as the phases read it -- on the GPU a copy whose hot scalars k_convp has pinned in
 // scalar registers (see there); XM: the descriptor in kernel-argument memory, for its per-block array only.
-// PF (walker form, k_convp<..., WALK>: a workgroup walks the blocks of its channel pair): the samples of block cur.k
-// already sit in st.pr / st.pi -- requested while the block before it was being transformed --, and those of block
-// knext (>= 0) are requested here, behind the last wave-local pass (st.pr / st.pi are free from the first pass on).
-template<int LN, int UL, int MODE, int FLENP, bool PF = false, class Exec>
-R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd* buf, const ConvpItem& cur,
-	long long knext = -1)
+template<int LN, int UL, int MODE, int FLENP, class Exec>
+R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd* buf, const ConvpItem& cur)
 {
 	typedef ConvpGeom<LN, UL> G;
 	typedef ConvpState<LN, UL> St;
-	static_assert(!PF || G::SUB == 1, "walker form: one block pair per workgroup at a time");
 	// modes 6 / 7: modes 0 / 3 with a complex kernel spectrum
 	constexpr bool CX = MODE == 6 || MODE == 7;
 	constexpr int BM = MODE == 6 ? 0 : (MODE == 7 ? 3 : MODE);
@@ -1531,7 +1526,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		// (the first pass's twiddles -- L2 -- requested ahead of the samples -- HBM --, not behind their wait)
 		ptw_fetch_lean<G::E1, G::NT>(st.tw, L.ptw, 0, lt);
 		ex.stamp2();
-		if constexpr (!(R8B_ABL & 8) && !PF) cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
+		if constexpr (!(R8B_ABL & 8)) cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
 		if ((L.tail_flags & 2) != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) > L.k0 + L.tail_bf)
 		{
 			// (the launch's last block: the samples behind its window -- read by no block of this call -- requested
@@ -1567,21 +1562,6 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	});
 	// forward passes 1 .., the middle pass and the first backward pass stay inside each wave's own range
 	// of the array (ConvpGeom): wave-level ordering points instead of workgroup barriers between them
-	// (walker form: the next block's samples)
-	auto pf_next = [&](int tid, St& st)
-	{
-		if constexpr (PF)
-		{
-			if (knext >= 0) cp_load<LN, UL, BM>(L, st, knext, chA, chB, lt_of(tid));
-		}
-	};
-	auto run_steps = [&](auto... f)
-	{
-		// (BEHIND the last wave-local step and its table prefetch: loads return in order, a request that goes to HBM in
-		// front of a table fetch would make the pass that needs the table wait for HBM)
-		if constexpr (PF) ex.wave_steps(f..., pf_next);
-		else ex.wave_steps(f...);
-	};
 	auto s_pre1 = [&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
@@ -1661,7 +1641,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		// geometry where the last but one does not -- 8192 points decimated by 4 -- takes a barrier more)
 		static_assert(G::NPOST < 5 || G::N2 / G::E2 > 64 * G::E2, "pass plan");
 		static_assert(G::NPOST == 5 || G::NW == 1 || G::N2 / G::E2 <= 64 * G::E2, "pass plan");
-		run_steps(d_pre1, d_pre2, d_midc, d_midw, d_post1, d_post2, d_post3);
+		ex.wave_steps(d_pre1, d_pre2, d_midc, d_midw, d_post1, d_post2, d_post3);
 		if constexpr (G::NPOST > 4) ex.wave_steps(d_post4);
 	}
 	else
@@ -1682,11 +1662,11 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	};
 	static_assert(G::NPRE >= 1 && G::NPRE <= 3, "pair kernel: one to three forward passes before the middle");
 	if constexpr ((R8B_ABL & 2) != 0) ex.wave_steps([](int, St&) {});
-	else if constexpr (G::NPRE == 3) run_steps(s_pre1, s_pre2, s_midc, s_midw, s_b1);
-	else if constexpr (G::NPRE == 2 && G::B1) run_steps(s_pre1, s_midc, s_midw, s_b1);
-	else if constexpr (G::NPRE == 2) run_steps(s_pre1, s_midc, s_midw);
-	else if constexpr (G::B1) run_steps(s_midc, s_midw, s_b1);
-	else run_steps(s_midc, s_midw);
+	else if constexpr (G::NPRE == 3) ex.wave_steps(s_pre1, s_pre2, s_midc, s_midw, s_b1);
+	else if constexpr (G::NPRE == 2 && G::B1) ex.wave_steps(s_pre1, s_midc, s_midw, s_b1);
+	else if constexpr (G::NPRE == 2) ex.wave_steps(s_pre1, s_midc, s_midw);
+	else if constexpr (G::B1) ex.wave_steps(s_midc, s_midw, s_b1);
+	else ex.wave_steps(s_midc, s_midw);
 	}
 	// History for the next call (stage 0 only): the tail of the caller's buffers goes into the other history ring.
 	// Calls whose blocks read the caller's fp64 buffer (tail_flags & 2, convp_tail_owners): the blocks that hold the tail
@@ -1851,7 +1831,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 template<int LN, int UL, int MODE, int FLENP, class Exec>
 R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem& cur)
 {
-	convp_body<LN, UL, MODE, FLENP, false>(ex, X, X, buf, cur);
+	convp_body<LN, UL, MODE, FLENP>(ex, X, X, buf, cur);
 }
 
 // What a launcher (r8b_kernels.hip, tests/emul) sets in its copy of the descriptor before the kernel runs: the

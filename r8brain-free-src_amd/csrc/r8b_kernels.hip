@@ -663,15 +663,7 @@ struct GpuExecP
 };
 
 // 64 KB of LDS per workgroup: two workgroups per CU, i.e. two waves per SIMD and 256 registers each
-// WALK (512-thread geometries -- 8192-point blocks, one workgroup per CU -- on batches that fill the chip with one
-// workgroup per channel pair): the workgroup walks ALL blocks of its channel pair instead of ending after one.  With
-// a single workgroup on the CU nobody covers what a fresh workgroup pays per block -- dispatch and LDS allocation,
-// the kernel-argument loads, the memory latency of its first samples (5 000-7 000 of a block's 33 000 cycles by the
-// per-phase stamps), the drain of its last stores --, so the next block's samples are requested behind the first
-// pass's barrier and arrive while the block is transformed.  (With TWO workgroups per CU -- the 4096-point
-// geometries -- the other workgroup covers those gaps and every walker / persistent form measured slower: DESIGN.md
-// section 5.)
-template<int LN, int UL, int MODE, int FLENP, bool WALK = false>
+template<int LN, int UL, int MODE, int FLENP>
 __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) > 256 ? 1 : 2)) void k_convp(const ConvxLaunch X)
 {
 	extern __shared__ __align__(256) unsigned char smem[];
@@ -743,12 +735,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	// between items -- were built and measured 25-30 % SLOWER, as was a 512-thread workgroup carrying two block pairs
 	// in step: DESIGN.md section 5; the code is in the history of this file, the round-3 commits "Pair kernel: persistent workgroups on per-XCD work queues" ... "twin-block experiment".)
 	unsigned bg, pr;
-	if constexpr (WALK)
-	{
-		bg = 0;
-		pr = blockIdx.x;
-	}
-	else decode(blockIdx.x, bg, pr);
+	decode(blockIdx.x, bg, pr);
 	const int chA = (int) (2u * pr);
 	const bool bvalid = chA + 1 < X.c.nch;
 	ConvpItem cur;
@@ -760,27 +747,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) >
 	cur.bvalid = bvalid;
 	// (MODE 1 -- one phase per thread -- already fills the scalar file with its span bookkeeping: it reads the
 	// arguments where it needs them, as before)
-	if constexpr (WALK)
-	{
-		static_assert(SUB == 1 && MODE != 1, "walker form");
-		constexpr int BM = MODE == 6 ? 0 : (MODE == 7 ? 3 : MODE);
-		cp_load<LN, UL, BM>(H.c, ex.st, cur.k, cur.chA, cur.chB, (int) threadIdx.x);
-#pragma unroll 1
-		for (int b = 0; b < X.c.nblk; b++)
-		{
-			// (what a block fetches and derives from the thread index is loop invariant: hoisted out of the loop it would
-			// occupy every register the transforms need -- a compiler-level barrier and a laundered index keep it per block)
-			asm volatile("" ::: "memory");
-			asm volatile("" : "+v"(ex.tid_));
-			__builtin_assume(ex.tid_ >= 0 && ex.tid_ < ConvpGeom<LN, UL>::WT);
-			cur.k = H.c.k0 + b;
-			convp_body<LN, UL, MODE, FLENP, true>(ex, H, X, reinterpret_cast<cd*>(smem), cur,
-				b + 1 < X.c.nblk ? cur.k + 1 : -1LL);
-			// (the block's last phase reads the array the next block's first pass writes)
-			lds_barrier();
-		}
-	}
-	else if constexpr (MODE == 1) convp_body<LN, UL, MODE, FLENP>(ex, X, X, reinterpret_cast<cd*>(smem), cur);
+	if constexpr (MODE == 1) convp_body<LN, UL, MODE, FLENP>(ex, X, X, reinterpret_cast<cd*>(smem), cur);
 	else convp_body<LN, UL, MODE, FLENP>(ex, H, X, reinterpret_cast<cd*>(smem), cur);
 #ifdef R8B_TIMELINE
 	if (threadIdx.x == 0 && blockIdx.x < 16384)
@@ -822,33 +789,6 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 			throw std::runtime_error("launch_convp: too many blocks per call for the workgroup map (split the call)");
 	}
 	convp_prepare<LN, UL>(X);
-	const unsigned npair_ = ((unsigned) X.c.nch + 1u) >> 1;
-	if constexpr (ConvpGeom<LN, UL>::WT > 256 && MODE != 1)
-	{
-		// walker form (k_convp WALK): one workgroup per channel pair walks the pair's blocks -- when that alone fills the
-		// chip (one 512-thread workgroup per CU) and a pair has more than one block
-		static int cus = 0;
-		if (cus == 0)
-		{
-			int dev = 0, n = 256;
-			check(hipGetDevice(&dev), "hipGetDevice");
-			check(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute");
-			cus = n;
-		}
-		static const bool walk_on = getenv("R8B_NO_WALK") == nullptr;
-		if (walk_on && X.c.nblk > 1 && npair_ >= (unsigned) cus)
-		{
-			// (the copy-back of parked outputs in slices is indexed by the workgroup's place among its pair's workgroups:
-			// here there is one per pair -- the short form, by the first block)
-			X.park_slices = 0;
-			auto kw = k_convp<LN, UL, MODE, FLENP, true>;
-			lds_opt_in(reinterpret_cast<const void*>(kw), "hipFuncSetAttribute(k_convp walk)");
-			const size_t ldsw = (size_t) convp_lds_bytes<LN, UL>();
-			hipLaunchKernelGGL(kw, dim3(npair_), dim3(ConvpGeom<LN, UL>::WT), ldsw, stream, X);
-			check(hipGetLastError(), "launch k_convp (walker form)");
-			return;
-		}
-	}
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
 #ifdef R8B_DEV_ONLY_MODE
