@@ -4,7 +4,7 @@
   python tools/ab.py --out gpurun_out/ab_park --reps 3 --steps 200 --config cfg2 \
       park1 park0:opt=park=0 old:lib=variants/old.so "diet:lib=variants/diet.so:opt=fold_tail=0"
 
-Every variant is `name[:lib=<library>][:opt=<k=v>[,<k=v>...]][:args=<extra bench.py args>]`.  The variants run in
+Every variant is `name[:lib=<library>][:opt=<k=v>[,<k=v>...]][:args=<extra bench.py args>][:env=<K=V>[,<K=V>...]]`.  The variants run in
 alternation (A B C A B C ...), `reps` times each, every run a fresh `python bench.py --steps S --warmup W --settle 0
 --no-cpu` process on the same box, so that box-to-box differences (+-3 %) and clock drift cancel; the table gives
 the median and the spread per variant.  Libraries come from tools/variant.sh (variants/<name>.so).
@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def parse_variant(text):
     parts = text.split(":")
-    v = {"name": parts[0], "lib": None, "opts": [], "args": []}
+    v = {"name": parts[0], "lib": None, "opts": [], "args": [], "env": []}
     for p in parts[1:]:
         k, _, val = p.partition("=")
         if k == "lib":
@@ -30,8 +30,10 @@ def parse_variant(text):
             v["opts"] += val.split(",")
         elif k == "args":
             v["args"] += val.split()
+        elif k == "env":
+            v["env"] += val.split(",")
         else:
-            raise SystemExit("variant field %r (lib= / opt= / args=)" % p)
+            raise SystemExit("variant field %r (lib= / opt= / args= / env=)" % p)
     return v
 
 
@@ -59,6 +61,8 @@ def main():
             for o in v["opts"]:
                 cmd += ["--opt", o]
             env = dict(os.environ)
+            for kv in v["env"]:
+                env[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
             if v["lib"]:
                 env["R8B_HIP_LIB"] = os.path.join(ROOT, v["lib"]) if not os.path.isabs(v["lib"]) else v["lib"]
             r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
