@@ -213,6 +213,8 @@ struct ConvpState
 	double pk[2];         // ... the thread's element of the previous call's parked outputs and where it goes (cp_park_slice_*)
 	double* pka;
 	int pf;               // ... and whether the workgroup holds the call's last block and parks what lies beyond the call
+	double tk[2];         // the thread's element of the history tail behind the last block's window (cp_tail_slice_*)
+	double* tka;
 };
 
 // (+ 64 bytes behind the array: one word per wave for the workgroup-wide "channel has a non-zero sample" bits)
@@ -618,6 +620,33 @@ R8B_HD void cp_park_slice_store(const DstView& wd, const St& st, int chA, int ch
 	{
 		st.pka[0] = st.pk[0];
 		if (bvalid) st.pka[(long long) (chB - chA) * wd.stride] = st.pk[1];
+	}
+}
+
+// The part of the history tail no block of the call holds in registers -- [tail_c1, tail_p1), the input behind the last
+// block's window -- shared by the workgroups of the pair's blocks (tail_flags & 8, convp_prepare) like the parked
+// outputs: one element per thread and channel requested at entry behind the samples, stored in the workgroup's last
+// phase.  (Fetched by the last block alone -- cp_tail_rest -- it made that block 5 000 cycles longer than the others.)
+template<int WT, class St>
+R8B_HD void cp_tail_slice_load(const ConvLaunch& L, St& st, int bgi, int chA, int chB, int tid)
+{
+	const long long i = L.tail_c1 + (long long) bgi * WT + tid;
+	st.tk[0] = st.tk[1] = 0.0;
+	st.tka = nullptr;
+	if (i < L.tail_p1)
+	{
+		st.tk[0] = L.src.cur[(long long) chA * L.src.cur_stride + (i - L.src.cur_base)];
+		st.tk[1] = L.src.cur[(long long) chB * L.src.cur_stride + (i - L.src.cur_base)];
+		st.tka = L.tail_ring + ((long long) chA * L.src.ring_stride + (i & L.src.ring_mask));
+	}
+}
+template<class St>
+R8B_HD void cp_tail_slice_store(const ConvLaunch& L, const St& st, int chA, int chB, bool bvalid)
+{
+	if (st.tka != nullptr)
+	{
+		st.tka[0] = st.tk[0];
+		if (bvalid) st.tka[(long long) (chB - chA) * L.src.ring_stride] = st.tk[1];
 	}
 }
 
@@ -1531,10 +1560,15 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		{
 			// (the launch's last block: the samples behind its window -- read by no block of this call -- requested
 			// beside its own, one wait for both; all of them in the caller's fp64 buffer: convp_tail_owners)
-			if (cur.k + (G::SUB == 1 ? 1 : cur.nvalid) == L.k0 + L.nblk)
+			if ((L.tail_flags & 8) == 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) == L.k0 + L.nblk)
 				cp_tail_rest<G::WT>(L, L.tail_c1, L.tail_p1, chA, chB, bvalid, tid);
 			ex.stamp2();
 			if (live(tid)) cp_tail_owned<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
+		}
+		if constexpr (MODE != 1)
+		{
+			st.tka = nullptr;
+			if ((L.tail_flags & 8) != 0) cp_tail_slice_load<G::WT>(L, st, (int) (cur.k - L.k0) / G::SUB, chA, chB, tid);
 		}
 		if constexpr (MODE != 1)
 		{
@@ -1731,6 +1765,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		{
 			const int lt = lt_of(tid);
 			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
+			cp_tail_slice_store(L, st, chA, chB, bvalid);
 			ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
 			cp_silence<LN, UL>(st, ex.collect_bits());
 			if (live(tid))
@@ -1749,6 +1784,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		{
 			const int lt = lt_of(tid);
 			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
+			cp_tail_slice_store(L, st, chA, chB, bvalid);
 			cp_back2<LN, UL>(buf_of(tid), st, lt);
 			cp_silence<LN, UL>(st, ex.collect_bits());
 			if constexpr ((R8B_ABL & 64) != 0)
@@ -1788,6 +1824,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		if constexpr (!(R8B_ABL & 1)) ex.each([&](int tid, St& st)
 		{
 			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
+			cp_tail_slice_store(L, st, chA, chB, bvalid);
 			const int nv = G::SUB == 1 ? 1 : cur.nvalid;
 			for (int sb = 0; sb < nv; sb++)
 				cp_whole2_compute<T2>(X, X.wdst, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
@@ -1867,19 +1904,17 @@ inline void convp_tail_owners(ConvLaunch& L)
 	L.tail_c1 = c1;
 }
 
+// (slices: the kernel shares the parked outputs' copy-back and the history tail's rest among the pair's workgroups --
+// every mode but 1)
 template<int LN, int UL>
-inline void convp_prepare(ConvxLaunch& X)
+inline void convp_prepare(ConvxLaunch& X, bool slices = true)
 {
 	X.c.rot = 0;
 	X.c.fl2r = X.c.fl2;
 	X.c.tail_flags = X.c.tail_ring != nullptr ? 1 : 0;
 	X.c.tail_bf = 0;
 	X.c.tail_c0 = X.c.tail_c1 = 0;
-	{
-		typedef ConvpGeom<LN, UL> G;
-		const long long nwg = (X.c.nblk + G::SUB - 1) / G::SUB;
-		X.park_slices = X.park_n > 0 && X.park_n <= nwg * G::WT ? 1 : 0;
-	}
+
 	if constexpr (UL >= 0)
 	{
 		if (X.c.up_pow2 && X.c.up == (1 << (UL > 0 ? UL : 0)))
@@ -1894,6 +1929,18 @@ inline void convp_prepare(ConvxLaunch& X)
 	{
 		// (decimation in the spectrum: the block is loaded as in the 1:1 form)
 		if (X.c.up == 1) convp_tail_owners<ConvpGeom<LN, UL>::N, 0>(X.c);
+	}
+	{
+		// what the workgroups of a pair's blocks can share, one element per thread and channel (cp_park_slice_*,
+		// cp_tail_slice_*; mode 1 -- one phase per thread -- keeps the forms of one workgroup)
+		typedef ConvpGeom<LN, UL> G;
+		const long long nwg = (X.c.nblk + G::SUB - 1) / G::SUB;
+		X.park_slices = slices && X.park_n > 0 && X.park_n <= nwg * G::WT ? 1 : 0;
+#ifndef R8B_NO_TAIL_SLICES // (development A/B: the last block fetches the rest alone)
+		if (slices && (X.c.tail_flags & 2) != 0 && X.c.tail_p1 > X.c.tail_c1 && X.c.tail_p1 - X.c.tail_c1 <= nwg * G::WT &&
+			X.c.tail_c1 >= X.c.src.cur_base)
+			X.c.tail_flags |= 8;
+#endif
 	}
 }
 

@@ -788,7 +788,7 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 		if (nbg > 1 && imax * nbg >= 0x100000000ull)
 			throw std::runtime_error("launch_convp: too many blocks per call for the workgroup map (split the call)");
 	}
-	convp_prepare<LN, UL>(X);
+	convp_prepare<LN, UL>(X, MODE != 1);
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
 #ifdef R8B_DEV_ONLY_MODE

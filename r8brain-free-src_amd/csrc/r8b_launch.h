@@ -67,6 +67,8 @@ struct ConvLaunch
 	// 2 -- positions [tail_c0, tail_c1) of the tail go to the ring from the registers of the blocks that load them
 	// anyway (blocks k0 + tail_bf ..: the ones that read the caller's buffer alone and hold a part of it), the launch's
 	// last block fetches [tail_c1, tail_p1) beside its samples; 4 (with 2) -- the first block copies [tail_p0, tail_c0).
+	// 8 (with 2) -- [tail_c1, tail_p1) is shared by the workgroups of the pair's blocks, one element per thread and channel
+	// (cp_tail_slice_*), instead of being fetched by the last block alone.
 	// 0: nothing to do (tail_ring == nullptr).  (Two integers the kernel keeps in scalar registers: a block with
 	// nothing to do finds that out without a load.)
 	int tail_flags, tail_bf;

@@ -264,7 +264,7 @@ template<int LN, int UL, int MODE, int FLENP>
 void emul_convp_t(const ConvxLaunch& X0)
 {
 	ConvxLaunch X = X0;
-	convp_prepare<LN, UL>(X);
+	convp_prepare<LN, UL>(X, MODE != 1);
 	std::vector<double> lds((size_t) convp_lds_bytes<LN, UL>() / sizeof(double) + 2);
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
