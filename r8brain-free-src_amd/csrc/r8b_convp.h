@@ -64,6 +64,16 @@ namespace r8bhip {
 
 static const int kConvpThreads = 256;
 
+// R8B_SPLIT_UP2 (development builds, tools/variant.sh: the occupancy experiment of round 4): the 2x up-sampling pair
+// kernel with 2048 -> 4096-point transforms computes its backward transform as TWO 2048-point transforms -- the even
+// outputs from Z (H[k] + H[k+N]), the odd ones from Z (H[k] - H[k+N]) e^{+2 pi i k / 2N} -- one after the other in a
+// 32 KB array, so that three or four workgroups fit a CU instead of two (cp_split_*, convolver-only modes).
+#ifdef R8B_SPLIT_UP2
+template<int LN, int UL> constexpr bool kSplit = LN == 11 && UL == 1;
+#else
+template<int LN, int UL> constexpr bool kSplit = false;
+#endif
+
 // physical slot of complex element e: index bits 0-3 XOR bits 4-7.  Every access pattern of the
 // passes below (lanes = consecutive elements, lanes = elements 4 / 8 / 16 apart, 8 or 16
 // consecutive elements per lane) then touches 16 different 16-byte bank groups per 16-lane
@@ -128,7 +138,7 @@ template<int LN, int UL>
 R8B_HD int fslot(int p)
 {
 	typedef ConvpGeom<LN, UL> G;
-	if constexpr (UL <= 0 || G::NW == 1) return pswz(p);
+	if constexpr (UL <= 0 || G::NW == 1 || kSplit<LN, UL>) return pswz(p);
 	else return pswz((p / G::FW) * G::BW + (p & (G::FW - 1)));
 }
 
@@ -151,7 +161,7 @@ template<int LN, int UL>
 R8B_HD constexpr int fmap_c(int d)
 {
 	typedef ConvpGeom<LN, UL> G;
-	return (UL <= 0 || G::NW == 1) ? d : (d / G::FW) * G::BW + (d & (G::FW - 1));
+	return (UL <= 0 || G::NW == 1 || kSplit<LN, UL>) ? d : (d / G::FW) * G::BW + (d & (G::FW - 1));
 }
 template<int LN, int UL>
 R8B_HD constexpr int bmap_c(int d)
@@ -219,7 +229,10 @@ struct ConvpState
 
 // (+ 64 bytes behind the array: one word per wave for the workgroup-wide "channel has a non-zero sample" bits)
 static const int kConvpFlagBytes = 64;
-template<int LN, int UL> constexpr int convp_array_bytes() { return ConvpGeom<LN, UL>::SUB * ConvpGeom<LN, UL>::NA * 16; }
+template<int LN, int UL> constexpr int convp_array_bytes()
+{
+	return kSplit<LN, UL> ? ConvpGeom<LN, UL>::N * 16 : ConvpGeom<LN, UL>::SUB * ConvpGeom<LN, UL>::NA * 16;
+}
 template<int LN, int UL> constexpr int convp_lds_bytes() { return convp_array_bytes<LN, UL>() + kConvpFlagBytes; }
 
 // Silence stays silence.  Two channels share one complex transform, so each picks up rounding residue of the
@@ -1224,6 +1237,12 @@ R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 	if (pend > L.b) run(cp_store_view(pd, chA, chB, t0, L.b, pend, L.in_len));
 }
 
+#ifdef R8B_SPLIT_UP2
+} // namespace r8bhip
+#include "r8b_convp_split.h" // (development builds only: the occupancy experiment of round 4)
+namespace r8bhip {
+#endif
+
 // MODE 1: K8 on the pair run (cf. cx_whole_compute): one 16-byte LDS read per tap feeds both channels
 // Thread -> (phase, group set).  Fewer phases than threads (88200 -> 48000: 40): nsets = wt / out_step lanes
 // share a phase and take its output groups in turn (set, set + nsets, ...).  More phases than threads
@@ -1527,6 +1546,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	// modes 6 / 7: modes 0 / 3 with a complex kernel spectrum
 	constexpr bool CX = MODE == 6 || MODE == 7;
 	constexpr int BM = MODE == 6 ? 0 : (MODE == 7 ? 3 : MODE);
+	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
+	constexpr bool SPLIT = kSplit<LN, UL> && !CX && (BM == 0 || BM == 3);
+	(void) SPLIT;
 	const ConvLaunch& L = X.c;
 	const int chA = cur.chA, chB = cur.chB;
 	const bool bvalid = cur.bvalid;
@@ -1695,6 +1717,44 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		cp_back2_prefetch<LN, UL>(L, st, lt);
 	};
 	static_assert(G::NPRE >= 1 && G::NPRE <= 3, "pair kernel: one to three forward passes before the middle");
+#ifdef R8B_SPLIT_UP2
+	if constexpr (SPLIT)
+	{
+		static_assert(G::NPRE == 3, "split form: 2048 -> 4096 points");
+		// even half: middle + radix 8 in registers, sub-lengths 64 and 512 inside the wave, last pass across the waves
+		auto p_mid = [&](int tid, St& st)
+		{
+			const int lt = lt_of(tid);
+			cp_split_middle<LN, UL>(L, buf_of(tid), st, lt);
+			cp_split_first<LN, UL>(buf_of(tid), st.vr, st.vi, lt);
+			tw_fetch<8>(st.tw, L.tw, L.tw_len, 64, lt & 7);
+		};
+		auto p_b = [&](int tid, St& st)
+		{
+			const int lt = lt_of(tid);
+			cp_split_pass<64>(buf_of(tid), st.tw, lt);
+			tw_fetch<8>(st.tw, L.tw, L.tw_len, 512, lt & 63);
+		};
+		auto p_c = [&](int tid, St& st)
+		{
+			const int lt = lt_of(tid);
+			cp_split_pass<512>(buf_of(tid), st.tw, lt);
+			tw_fetch<4>(st.tw, L.tw, L.tw_len, 2048, lt);
+			tw_fetch<4>(st.tw + 3, L.tw, L.tw_len, 2048, lt + 256);
+		};
+		ex.wave_steps(s_pre1, s_pre2, p_mid, p_b, p_c);
+		ex.phase([&](int tid, St& st) { cp_split_last<LN, UL>(buf_of(tid), st.tw, st.vr, st.vi, lt_of(tid)); });
+		// odd half
+		auto q_first = [&](int tid, St& st)
+		{
+			const int lt = lt_of(tid);
+			cp_split_first<LN, UL>(buf_of(tid), st.vr + 8, st.vi + 8, lt);
+			tw_fetch<8>(st.tw, L.tw, L.tw_len, 64, lt & 7);
+		};
+		ex.wave_steps(q_first, p_b, p_c);
+	}
+	else
+#endif
 	if constexpr ((R8B_ABL & 2) != 0) ex.wave_steps([](int, St&) {});
 	else if constexpr (G::NPRE == 3) ex.wave_steps(s_pre1, s_pre2, s_midc, s_midw, s_b1);
 	else if constexpr (G::NPRE == 2 && G::B1) ex.wave_steps(s_pre1, s_midc, s_midw, s_b1);
@@ -1759,6 +1819,27 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			}
 		});
 	}
+#ifdef R8B_SPLIT_UP2
+	if constexpr (SPLIT)
+	{
+		ex.each([&](int tid, St& st)
+		{
+			const int lt = lt_of(tid);
+			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
+			cp_tail_slice_store(L, st, chA, chB, bvalid);
+			cp_split_last<LN, UL>(buf_of(tid), st.tw, st.vr + 8, st.vi + 8, lt);
+			cp_silence<LN, UL>(st, ex.collect_bits());
+			if (live(tid))
+			{
+				DstView pd = L.dst;
+				long long pend = L.b;
+				cp_park_view(ex, XM, st, k_of(tid), cur, pd, pend);
+				cp_split_store<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt, pd, pend);
+			}
+		});
+	}
+	else
+#endif
 	if constexpr (G::POST && (BM == 0 || BM == 3))
 	{
 		ex.each([&](int tid, St& st)

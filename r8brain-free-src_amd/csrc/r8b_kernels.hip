@@ -663,8 +663,11 @@ struct GpuExecP
 };
 
 // 64 KB of LDS per workgroup: two workgroups per CU, i.e. two waves per SIMD and 256 registers each
+#ifndef R8B_SPLIT_MINBLOCKS
+#define R8B_SPLIT_MINBLOCKS 3 // (R8B_SPLIT_UP2 development builds: workgroups per CU the register budget is cut for)
+#endif
 template<int LN, int UL, int MODE, int FLENP>
-__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), ((ConvpGeom<LN, UL>::WT) > 256 ? 1 : 2)) void k_convp(const ConvxLaunch X)
+__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLIT_MINBLOCKS : (ConvpGeom<LN, UL>::WT) > 256 ? 1 : 2)) void k_convp(const ConvxLaunch X)
 {
 	extern __shared__ __align__(256) unsigned char smem[];
 #ifdef R8B_TIMELINE
