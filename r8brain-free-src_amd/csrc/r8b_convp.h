@@ -43,14 +43,6 @@
 #include <cstdlib>
 #include "r8b_convx.h"
 
-// R8B_ABL (development builds only, tools/variant.sh: timing ablations, results are wrong): bit 0 no interpolator,
-// bit 1 no transform passes between the first forward and the last backward one, bit 2 no last backward pass,
-// bit 3 no global loads of samples, bit 4 no first pass, bit 5 interpolator without its stores,
-// bit 6 convolver-only modes without their stores, bit 7 twiddles / bit 8 kernel constants / bit 9 interpolator rows without table fetches
-#ifndef R8B_ABL
-#define R8B_ABL 0
-#endif
-
 // R8B_FORCE4: the four values are computed HERE (device: an empty asm statement that reads them)
 #ifndef R8B_FORCE4
 #define R8B_FORCE4(a, b, c, d)
@@ -290,17 +282,6 @@ R8B_HD void ptw_fetch(cd* twr, const cd* ptw, int slot, int lt)
 {
 	constexpr int NB = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
 	if constexpr (JM < NT) lt &= JM - 1;
-	if constexpr ((R8B_ABL & 128) != 0)
-	{
-		// (timing ablation: no table traffic)
-#pragma unroll
-		for (int c = 0; c < NB; c++)
-		{
-			twr[c].re = 0.7 + 0.01 * lt;
-			twr[c].im = 0.3 * c;
-		}
-		return;
-	}
 	const cd* p = ptw + (slot * 6 * NT + lt);
 #pragma unroll
 	for (int c = 0; c < NB; c++) twr[c] = p[c * NT];
@@ -319,7 +300,7 @@ template<int R, int NT>
 R8B_HD void ptw_fetch_lean(cd* twr, const cd* ptw, int slot, int lt)
 {
 	constexpr int NB = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
-	if constexpr (!R8B_TW_DERIVE || (R8B_ABL & 128) != 0) ptw_fetch<R, NT>(twr, ptw, slot, lt);
+	if constexpr (!R8B_TW_DERIVE) ptw_fetch<R, NT>(twr, ptw, slot, lt);
 	else
 	{
 		const cd* p = ptw + (slot * 6 * NT + lt);
@@ -346,7 +327,7 @@ template<int R>
 R8B_HD void tw_expand(cd* twr)
 {
 	constexpr int NB = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
-	if constexpr (R8B_TW_DERIVE && (R8B_ABL & 128) == 0 && NB >= 3)
+	if constexpr (R8B_TW_DERIVE && NB >= 3)
 	{
 		twr[1] = tw_sq(twr[0]);
 		twr[2] = tw_mul(twr[1], twr[0]);
@@ -732,12 +713,7 @@ R8B_HD void cp_hp_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 #pragma unroll
 	for (int c = 0; c < NHP; c++)
 	{
-		if constexpr ((R8B_ABL & 256) != 0)
-		{
-			st.hp[c].re = 1.0 + 1e-3 * lt;
-			st.hp[c].im = 0.5 - 1e-3 * c;
-		}
-		else st.hp[c] = L.hp[c * ConvpGeom<LN, UL>::NT + lt];
+		st.hp[c] = L.hp[c * ConvpGeom<LN, UL>::NT + lt];
 	}
 }
 
@@ -1322,12 +1298,6 @@ R8B_HD int cp_ptab_fetch(const ConvxLaunch& X, int tid)
 template<int T2>
 R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int pt)
 {
-	if constexpr ((R8B_ABL & 512) != 0)
-	{
-#pragma unroll
-		for (int i = 0; i < 2 * T2; i++) rows[i] = 0.01 * i + 1e-3 * pt;
-		return;
-	}
 	// X.ctab holds the 2 T2 values of a phase pair as T2 pairs, pair i of phase pair q at [(i * ctp + q) * 2], ctp = the
 	// number of phase pairs rounded up to whole quads: a lane quad reads 64 consecutive bytes, and the lanes of other
 	// sets with the same phase pairs find them in the CU's cache (idle lanes read pair 0)
@@ -1369,7 +1339,7 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 	const bool pair16 = (((size_t) pa0 | (size_t) pb0) & 15) == 0 && (out_step & 1) == 0;
 	constexpr int CH = T2 == 25 ? 5 : 3, NCH = T2 / CH;
 	static_assert(CH * NCH == T2, "chunks");
-	if (lo_mod == 0 && hi_mod == out_step && linear && pair16 && (R8B_ABL & 32) == 0)
+	if (lo_mod == 0 && hi_mod == out_step && linear && pair16)
 	{
 		// Whole groups only (every block of a call but those cut by its ends, when the blocks are aligned to
 		// groups -- Engine::launch_fused): nothing to mask, every output pair is one 16-byte store.
@@ -1379,7 +1349,7 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 			double a0[2] = { 0.0, 0.0 }, b0[2] = { 0.0, 0.0 }, a1[2] = { 0.0, 0.0 }, b1[2] = { 0.0, 0.0 };
 			cd v[2][CH];
 #pragma unroll
-			for (int i = 0; i < CH; i++) v[0][i] = w[(R8B_ABL & 1024) ? 0 : i];
+			for (int i = 0; i < CH; i++) v[0][i] = w[i];
 #pragma unroll
 			for (int c = 0; c < NCH; c++)
 			{
@@ -1387,15 +1357,7 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 				if (c + 1 < NCH)
 				{
 #pragma unroll
-					for (int i = 0; i < CH; i++)
-					{
-						// (timing ablation, bit 10: the window without its LDS reads)
-						if constexpr ((R8B_ABL & 1024) != 0)
-						{
-							v[(c + 1) & 1][i] = v[c & 1][i];
-						}
-						else v[(c + 1) & 1][i] = w[CH * (c + 1) + i];
-					}
+					for (int i = 0; i < CH; i++) v[(c + 1) & 1][i] = w[CH * (c + 1) + i];
 				}
 				// (last pair of the chunk first: LDS returns in order, so the wait in front of its multiply-adds covers
 				// the whole chunk -- one wait instruction per chunk instead of one per pair)
@@ -1456,11 +1418,6 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 		}
 		const bool v0 = (gl > 0 || f0) && (gl < gmax || l0);
 		const bool v1 = (gl > 0 ? 2 * q + 1 < out_step : f1) && (gl < gmax || l1);
-		if constexpr ((R8B_ABL & 32) != 0)
-		{
-			// (timing ablation: the arithmetic without its stores)
-			if (a0[0] + a1[0] + b0[0] + b1[0] + a0[1] + a1[1] + b0[1] + b1[1] != 1.2345e300) continue;
-		}
 		if (linear)
 		{
 			// caller's buffer: row pointers once, a 32-bit index per output; the two phases of a
@@ -1577,7 +1534,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		// (the first pass's twiddles -- L2 -- requested ahead of the samples -- HBM --, not behind their wait)
 		ptw_fetch_lean<G::E1, G::NT>(st.tw, L.ptw, 0, lt);
 		ex.stamp2();
-		if constexpr (!(R8B_ABL & 8)) cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
+		cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
 		if ((L.tail_flags & 2) != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) > L.k0 + L.tail_bf)
 		{
 			// (the launch's last block: the samples behind its window -- read by no block of this call -- requested
@@ -1610,7 +1567,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.stamp2();
 		ex.post_bits(tid, cp_nonzero_bits<LN, UL>(st));
 		ex.stamp2();
-		if constexpr (!(R8B_ABL & 16)) cp_first<LN, UL>(L, buf_of(tid), st, lt);
+		cp_first<LN, UL>(L, buf_of(tid), st, lt);
 		// (modes 4 / 5: the thread's entry of the interpolator's lane table, long before its rows are addressed with it)
 		if constexpr (MODE == 4 || MODE == 5) st.pt = cp_ptab_fetch(X, tid);
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
@@ -1755,8 +1712,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	}
 	else
 #endif
-	if constexpr ((R8B_ABL & 2) != 0) ex.wave_steps([](int, St&) {});
-	else if constexpr (G::NPRE == 3) ex.wave_steps(s_pre1, s_pre2, s_midc, s_midw, s_b1);
+	if constexpr (G::NPRE == 3) ex.wave_steps(s_pre1, s_pre2, s_midc, s_midw, s_b1);
 	else if constexpr (G::NPRE == 2 && G::B1) ex.wave_steps(s_pre1, s_midc, s_midw, s_b1);
 	else if constexpr (G::NPRE == 2) ex.wave_steps(s_pre1, s_midc, s_midw);
 	else if constexpr (G::B1) ex.wave_steps(s_midc, s_midw, s_b1);
@@ -1868,14 +1824,6 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_tail_slice_store(L, st, chA, chB, bvalid);
 			cp_back2<LN, UL>(buf_of(tid), st, lt);
 			cp_silence<LN, UL>(st, ex.collect_bits());
-			if constexpr ((R8B_ABL & 64) != 0)
-			{
-				// (timing ablation: the transform without its stores)
-				double acc = 0.0;
-#pragma unroll
-				for (int p = 0; p < 16; p++) acc += st.vr[p] * st.vi[p];
-				if (acc != 1.2345e300) return;
-			}
 			if (live(tid))
 			{
 				DstView pd = L.dst;
@@ -1891,8 +1839,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		static_assert(UL >= 0, "the decimating form has no fused interpolator");
 		ex.phase([&](int tid, St& st)
 		{
-			if constexpr ((R8B_ABL & 4) != 0) {}
-			else if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
+			if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
 			else cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
 			cp_rows2_fetch<T2>(X, st.rows2, st.pt);
 		});
@@ -1902,7 +1849,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_final_store<LN, UL>(L, buf_of(tid), buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
 		});
 		// the interpolator: all 256 threads over the run of one block pair after the other
-		if constexpr (!(R8B_ABL & 1)) ex.each([&](int tid, St& st)
+		ex.each([&](int tid, St& st)
 		{
 			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
 			cp_tail_slice_store(L, st, chA, chB, bvalid);

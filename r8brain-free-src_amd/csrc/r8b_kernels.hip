@@ -556,32 +556,10 @@ __global__ __launch_bounds__(kConvxThreads, (LOGN + (UPLOG > 0 ? UPLOG : 0) >= 1
 
 #if R8B_HAS_PAIR && R8B_HAS_FAST
 // ------------------------------------------------------------------ fast path, pair form (r8b_convp.h)
-#ifdef R8B_CP_STAMPS
-__device__ long long g_cp_stamps[8 * 8 * 32];
-} // namespace
-} // namespace r8bhip
-// (development builds: the stamps of workgroups R8B_CP_STAMPS .. + 7 of the last launch; tools/stamps_probe.py)
-extern "C" __attribute__((visibility("default"))) void r8b_dev_stamps(long long* out)
-{
-	(void) hipDeviceSynchronize();
-	(void) hipMemcpyFromSymbol(out, HIP_SYMBOL(r8bhip::g_cp_stamps), sizeof(long long) * 8 * 8 * 32);
-}
-namespace r8bhip {
-namespace {
-#endif
-#ifdef R8B_TIMELINE
-// (development, tools/timeline_probe.py: every workgroup of the last pair-kernel launch leaves where and when it ran --
-// hardware id, cycle counter at its first instruction, at the arrival of its samples and at its last store's issue)
-__device__ long long g_timeline[16384 * 4];
-} // namespace
-} // namespace r8bhip
-extern "C" __attribute__((visibility("default"))) void r8b_dev_timeline(long long* out, int n)
-{
-	(void) hipDeviceSynchronize();
-	(void) hipMemcpyFromSymbol(out, HIP_SYMBOL(r8bhip::g_timeline), sizeof(long long) * 4 * (size_t) n);
-}
-namespace r8bhip {
-namespace {
+#if defined(R8B_CP_STAMPS) || defined(R8B_TIMELINE)
+// (development builds only -- tools/stamps_probe.py, tools/timeline_probe.py: per-phase cycle stamps / where and when every
+// workgroup ran; the shipped library compiles none of it)
+#include "r8b_dev_probes.h"
 #endif
 template<int LN, int UL>
 struct GpuExecP
@@ -699,12 +677,6 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLI
 		bg = (unsigned) __builtin_amdgcn_readfirstlane((int) bg);
 		pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
 	};
-	if constexpr ((R8B_ABL & 2048) != 0)
-	{
-		// (timing ablation, bit 11: what dispatching the grid costs -- every workgroup ends at once)
-		if (X.c.nch < 0) smem[threadIdx.x] = 1;
-		return;
-	}
 	GpuExecP<LN, UL> ex(smem);
 	// Kernel arguments live in memory: left to itself the compiler fetches each one where it is first needed --
 	// chains of dependent scalar loads at the start of the workgroup (measured: 3 300 cycles before the first sample
