@@ -11,6 +11,12 @@ are independent streams, so ranks own disjoint channel shards and the data path 
 torch.distributed (RCCL) is used for the barrier and the MAX over ranks of the timed region only.
 Inputs are resident in HBM before the timed region starts; outputs stay in HBM.
 
+`value` / `ms_per_step` are ALWAYS the K steps timed straight after the W warm-up calls (barrier + synchronize on both
+sides), with every call's outputs written from column 0 of the output rows (`config.placement`).  Side fields (with
+--settle N > 0, the default): `settled` = the same K steps timed again after N further untimed calls (the board's
+power controller answers the load step after an idle gap with a clock dip that a 5 + 20-call window falls into), and
+`other_placement` = that window once more with the stream-aligned output placement (--align-out).
+
 Prints ONE JSON line on rank 0 with the contract fields plus
   "roofline":     HBM roofline of the dominant kernel, timed live with HIP events on the
                   launching stream (engine option "timing"), algorithmic bytes 8*(N_in+N_out);

@@ -186,7 +186,12 @@ R8BSRC_DECL CR8BBatch r8b_batch_create_stage(int kind, double a, double b, doubl
 R8BSRC_DECL int r8b_batch_describe(CR8BBatch b, char* buf, int cap);
 
 /* Kernel tuning/instrumentation knob: name/value pairs understood by the engine
- * ("fuse", "conv_threads", ...).  Returns 0 if the knob exists. */
+ * ("fuse", "conv_threads", ...).  Returns 0 if the knob exists.  Knobs that change where a stream's state lives
+ * ("fuse", "fuse_hb", "fuse_hbd", "fold_tail", "fast_conv", "pair_conv", "pair_two", "align_groups", "park") are
+ * refused (-1) once samples have been processed, until r8b_batch_clear().  "park" (default 1): every overlap-save
+ * block is computed once -- the block that holds a call's last output keeps what it holds of the next call in a
+ * per-channel park buffer (or writes it ahead into the next stage's ring) instead of being computed again by the next
+ * call; 0 restores the recomputation.  The output stream is bit for bit the same either way. */
 R8BSRC_DECL int r8b_batch_set_option(CR8BBatch b, const char* name, int value);
 
 /* Instrumentation: with option "timing" = 1 every stage launch is bracketed by HIP events on the
