@@ -598,7 +598,6 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	stat_["conv_blocks"] = 0;
 	stat_["park_calls"] = 0;
 	stat_["park_only_calls"] = 0;
-	stat_["pcm_staged_sides"] = 0; // planar PCM sides that went through the staging rows (r8b_capi.cpp)
 	// a constructor that throws half way must not leak what it has already put on the device
 	try
 	{
@@ -1872,37 +1871,23 @@ bool Engine::latency_chain() const
 	return false;
 }
 
-// PCM at the edges (Engine::process_planar): a streaming kernel, the generic convolver or the pair kernel of a headline
-// geometry (convp_pcm_geometry_ok) decodes / encodes planar PCM caller buffers in place; the other compile-time-sized
-// convolvers (r8b_convx.h, r8b_convp.h) exist for fp64 views only -- r8b_kernels.hip, top -- and have the samples
-// brought to them through the staging rows (r8b_capi.cpp).
+// PCM at the edges (Engine::process_planar): a streaming kernel or the generic convolver decodes / encodes planar PCM
+// caller buffers in place; the compile-time-sized convolvers (r8b_convx.h, r8b_convp.h) exist for fp64 views only --
+// r8b_kernels.hip, top -- and have the samples brought to them through the staging rows (r8b_capi.cpp).
 bool Engine::pcm_fused_in() const
 {
 	if (plan_.stages.empty()) return false;
 	const StagePlan& sp = plan_.stages[0];
-	if (sp.desc.kind != kConv) return true;
-	const int path = conv_path(sp.cg);
-	if (path == kPathGeneric) return true;
-	// (the pair kernels of the headline geometries are built for PCM views too)
-	return (path == kPathPair || (fuse_with_next(0) && use_pair_fused(sp.cg))) &&
-		convp_pcm_geometry_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2);
+	return !(sp.desc.kind == kConv && conv_path(sp.cg) != kPathGeneric);
 }
 
 bool Engine::pcm_fused_out() const
 {
 	const size_t ns = plan_.stages.size();
 	if (ns == 0) return false;
-	if (ns >= 2 && fuse_with_next(ns - 2))
-	{
-		// (convolver + whole-step interpolator as one fast-path kernel: the pair form of the headline geometries)
-		const ConvGeom& g = plan_.stages[ns - 2].cg;
-		return use_pair_fused(g) && convp_pcm_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2);
-	}
+	if (ns >= 2 && fuse_with_next(ns - 2)) return false; // (convolver + whole-step interpolator as one fast-path kernel)
 	const StagePlan& sp = plan_.stages[ns - 1];
-	if (sp.desc.kind != kConv) return true;
-	const int path = conv_path(sp.cg);
-	if (path == kPathGeneric) return true;
-	return path == kPathPair && convp_pcm_geometry_ok(sp.cg.n_in, sp.cg.n_out, sp.cg.up, sp.cg.down, sp.cg.up_pow2);
+	return !(sp.desc.kind == kConv && conv_path(sp.cg) != kPathGeneric);
 }
 
 bool Engine::fuse_with_next(size_t s) const

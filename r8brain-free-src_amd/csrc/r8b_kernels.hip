@@ -44,9 +44,7 @@
 #define R8B_HAS_REST 1
 #define R8B_HAS_PAIR 1
 #endif
-// (the PCM twin has the pair kernels of the two headline geometries -- -DR8B_PCM_VARIANT -DR8B_TU_PAIR=5: BASELINE
-// configs 2-5 run on them -- and no other fast-path convolver)
-#if defined(R8B_PCM_VARIANT) && !defined(R8B_TU_PAIR)
+#ifdef R8B_PCM_VARIANT
 #define R8B_HAS_FAST 0
 #else
 #define R8B_HAS_FAST 1
@@ -869,13 +867,9 @@ void R8B_LAUNCH(launch_convx)(const ConvxLaunch&, int, void*)
 {
 	throw std::logic_error("launch_convx: a PCM view reached a fast-path convolver (it is fed through the staging rows)");
 }
-// (the pair kernels of the headline geometries exist for PCM views: part 5, r8b_launch.h convp_pcm_geometry_ok)
-bool launch_convp_part5(const ConvxLaunch& X, int mode, void* stream);
-void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
+void R8B_LAUNCH(launch_convp)(const ConvxLaunch&, int, void*)
 {
-	if (launch_convp_part5(X, mode, stream)) return;
-	throw std::logic_error("launch_convp: a PCM view reached a fast-path convolver that is built for fp64 views only "
-		"(it is fed through the staging rows)");
+	throw std::logic_error("launch_convp: a PCM view reached a fast-path convolver (it is fed through the staging rows)");
 }
 #else
 void R8B_LAUNCH(launch_convx)(const ConvxLaunch& X, int mode, void* stream)

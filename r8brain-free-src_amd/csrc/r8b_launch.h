@@ -314,14 +314,6 @@ inline bool convp_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow
 	return n_out == 64 || n_out == 128 || n_out == 256 || n_out == 512 || n_out == 1024 || n_out == 2048 ||
 		n_out == 4096 || n_out == 8192;
 }
-// pair-kernel geometries that also exist for planar PCM caller buffers (decoded by the block's loads, encoded by its
-// stores: csrc/Makefile part 5): the 2048 -> 4096-point 2x up-sampling form (BASELINE configs 2, 4, 5) and the
-// 4096 -> 4096-point 1:1 form (config 3); every other fast-path convolver takes fp64 rows (Engine::pcm_fused_in / _out)
-inline bool convp_pcm_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow2)
-{
-	if (!up_pow2 || down != 1) return false;
-	return (n_in == 2048 && n_out == 4096 && up == 2) || (n_in == 4096 && n_out == 4096 && up == 1);
-}
 // ... with the whole-step interpolator fused in (modes 1 and 4)
 inline bool convp_fused_ok(int n_in, int n_out, int up, int down, bool up_pow2)
 {
