@@ -203,7 +203,9 @@ R8BSRC_DECL int r8b_batch_stage_count(CR8BBatch b);
 /* Instrumentation: a counter of the engine since creation (-1: unknown name).  "conv_blocks": overlap-save blocks
  * per channel the compile-time-sized convolver kernels were launched for (the reference computes every block once,
  * CDSPBlockConvolver.h:283-350; so does this library where a call's last block parks what it holds of the next
- * call); "park_calls": calls that took outputs from the park buffer; "park_only_calls": calls served from it alone. */
+ * call); "park_calls": calls that took outputs from the park buffer; "park_only_calls": calls served from it alone;
+ * "pcm_staged_sides": planar PCM sides of r8b_batch_process_pcm calls that had to go through the staging rows (the
+ * first / last stage's kernel is built for fp64 rows only). */
 R8BSRC_DECL long long r8b_batch_stat(CR8BBatch b, const char* name);
 R8BSRC_DECL int r8b_batch_stage_timing(CR8BBatch b, int stage, double* ms_sum, int* launches,
 	long long* in_samples, long long* out_samples, char* kernel, int cap);

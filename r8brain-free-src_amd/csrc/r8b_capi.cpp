@@ -116,6 +116,8 @@ int batch_process_pcm(Batch* h, const void* d_in, int in_fmt, int in_interleaved
 	const bool stage_in = in_interleaved || pass || (in_fmt != kPcmF64 && !e.pcm_fused_in());
 	const bool stage_out = out_interleaved || pass || (out_fmt != kPcmF64 && !e.pcm_fused_out());
 	if (stage_in || stage_out) h->need_staging();
+	if (stage_in && !in_interleaved && !pass) e.bump("pcm_staged_sides");
+	if (stage_out && !out_interleaved && !pass) e.bump("pcm_staged_sides");
 	PcmLaunch P;
 	P.nch = e.channels();
 	if (stage_in)

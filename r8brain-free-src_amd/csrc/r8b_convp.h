@@ -1038,6 +1038,7 @@ struct CpStoreView
 	double* pb;
 	unsigned qoff, m;   // element index = (qoff + i) & m, i = the output's index counted from the block's first one
 	unsigned ulo, uhi;  // outputs i in [ulo, uhi) are wanted (0 <= ulo <= uhi < 2^31)
+	int fmt;            // PcmFormat of the rows (builds with planar PCM views: encoded by the store)
 };
 // first: the block's first output position; [a, b): the wanted outputs; nmax: outputs a block can hold (< 2^30)
 R8B_HD CpStoreView cp_store_view(const DstView& d, int chA, int chB, long long first, long long a, long long b, int nmax)
@@ -1045,8 +1046,18 @@ R8B_HD CpStoreView cp_store_view(const DstView& d, int chA, int chB, long long f
 	CpStoreView v;
 	v.pa = d.p + (long long) chA * d.stride;
 	v.pb = d.p + (long long) chB * d.stride;
+#ifndef R8B_NO_PCM_FUSE
+	if (d.fmt != kPcmF64)
+	{
+		// (row starts in BYTES: the view's stride counts samples of its own format)
+		const long long bs = pcm_bytes(d.fmt);
+		v.pa = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(d.p) + (long long) chA * d.stride * bs);
+		v.pb = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(d.p) + (long long) chB * d.stride * bs);
+	}
+#endif
 	v.qoff = (unsigned) (unsigned long long) (first + d.off);
 	v.m = (unsigned) (unsigned long long) d.mask;
+	v.fmt = d.fmt;
 	const long long lo = a - first, hi = b - first;
 	v.ulo = (unsigned) (lo < 0 ? 0 : (lo > nmax ? nmax : lo));
 	v.uhi = (unsigned) (hi < 0 ? 0 : (hi > nmax ? nmax : hi));
@@ -1058,6 +1069,16 @@ R8B_HD void cp_store1(const CpStoreView& v, unsigned i, double ya, double yb, bo
 	if (i - v.ulo < v.uhi - v.ulo)
 	{
 		const unsigned e = (v.qoff + i) & v.m;
+#ifndef R8B_NO_PCM_FUSE
+		if (v.fmt != kPcmF64)
+		{
+			// (planar PCM rows: v.pa / v.pb were formed with the row stride in SAMPLES, element sizes differ)
+			const int bs = pcm_bytes(v.fmt);
+			pcm_encode(reinterpret_cast<unsigned char*>(v.pa) + (size_t) e * bs, v.fmt, ya);
+			if (bvalid) pcm_encode(reinterpret_cast<unsigned char*>(v.pb) + (size_t) e * bs, v.fmt, yb);
+			return;
+		}
+#endif
 		v.pa[e] = ya;
 		if (bvalid) v.pb[e] = yb;
 	}

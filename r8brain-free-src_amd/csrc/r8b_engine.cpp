@@ -598,6 +598,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	stat_["conv_blocks"] = 0;
 	stat_["park_calls"] = 0;
 	stat_["park_only_calls"] = 0;
+	stat_["pcm_staged_sides"] = 0; // planar PCM sides that went through the staging rows (r8b_capi.cpp)
 	// a constructor that throws half way must not leak what it has already put on the device
 	try
 	{

@@ -41,6 +41,7 @@ public:
 	bool set_option(const std::string& name, int value);
 	// counters since creation ("conv_blocks", "park_calls", "park_only_calls"); -1: unknown name
 	long long stat(const std::string& name) const;
+	void bump(const std::string& name) { stat_[name]++; } // (counters kept for the layers above: "pcm_staged_sides")
 
 	// per-stage kernel time accumulated since the last call (only while option "timing" is 1):
 	// resolves pending events, returns total milliseconds and the number of launches
