@@ -339,7 +339,7 @@ def main():
         sh = r8b.ShardedBatchResampler(
             lambda nch: r8b.BatchResampler(args.src, args.dst, L, args.tb, args.atten, nch=nch,
                                            device=local_rank), total)
-        pipe = r8b.RootPipeline(sh, L, root=0, device=dev)
+        pipe = r8b.RootPipeline(sh, L, root=0, device=dev, keep_last_only=True)
         if rank == 0:
             full = [torch.from_numpy(np.stack([splitmix_uniform(1 + c, L * nbuf)[i * L:(i + 1) * L]
                                                for c in range(total)])).to(dev) for i in range(nbuf)]

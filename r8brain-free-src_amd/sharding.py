@@ -49,14 +49,16 @@ def _run_p2p(ops):
         req.wait()
 
 
-def scatter_channels(x_full, total_channels, length, src=0, device=None, dtype=torch.float64):
+def scatter_channels(x_full, total_channels, length, src=0, device=None, dtype=torch.float64, out=None):
     """x_full: [total_channels, length] on rank `src` (ignored elsewhere).  Returns this rank's
-    shard [hi-lo, length].  One grouped send per peer: on xGMI each point-to-point link carries
-    exactly one shard and all links are busy together."""
+    shard [hi-lo, length] (in `out` when given: a preallocated [hi-lo, >= length] buffer).  One grouped send per
+    peer: on xGMI each point-to-point link carries exactly one shard and all links are busy together."""
     rank, world = _rank_world()
     lo, hi = channel_shard(total_channels, rank, world)
     device = device if device is not None else (x_full.device if x_full is not None else "cpu")
-    local = torch.empty((hi - lo, length), dtype=dtype, device=device)
+    local = out[:, :length] if out is not None else torch.empty((hi - lo, length), dtype=dtype, device=device)
+    if world > 1 and not local.is_contiguous():
+        local = torch.empty((hi - lo, length), dtype=dtype, device=device)  # (receives need a dense buffer)
     ops = []
     if rank == src:
         keep = []
@@ -73,7 +75,7 @@ def scatter_channels(x_full, total_channels, length, src=0, device=None, dtype=t
     return local
 
 
-def gather_channels(y_local, total_channels, dst=0, n=None):
+def gather_channels(y_local, total_channels, dst=0, n=None, out=None):
     """Inverse of scatter_channels for the per-rank outputs [hi-lo, n] (same n on every rank that owns
     channels: all ranks follow the same schedule).  Returns [total_channels, n] on `dst`, None elsewhere.
     A rank WITHOUT channels (fewer channel pairs than ranks) has no resampler and so no n of its own:
@@ -88,7 +90,13 @@ def gather_channels(y_local, total_channels, dst=0, n=None):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             n = int(t.item())
     if rank == dst:
-        out = torch.empty((total_channels, n), dtype=y_local.dtype, device=y_local.device)
+        # (`out`: a preallocated [total_channels, >= n] buffer of the caller, e.g. RootPipeline's rotation)
+        if out is not None and out.shape[1] == n:
+            pass
+        elif out is not None and world == 1:
+            out = out[:, :n]
+        else:
+            out = torch.empty((total_channels, n), dtype=y_local.dtype, device=y_local.device)
         ops = []
         for r in range(world):
             a, b = channel_shard(total_channels, r, world)
@@ -134,12 +142,20 @@ class RootPipeline:
     `sharded`: a ShardedBatchResampler; `length`: samples per channel and call.  With CPU tensors
     (gloo, the tests) there are no streams and the steps simply run in order."""
 
-    def __init__(self, sharded, length, root=0, device=None):
+    def __init__(self, sharded, length, root=0, device=None, keep_last_only=False):
+        """keep_last_only: run() reuses three result buffers in rotation (a streaming consumer that is done with a
+        result before the third call after it); False: every result is a tensor of its own."""
         self.sh, self.length, self.root = sharded, int(length), root
+        self.keep_last_only = bool(keep_last_only)
         self.device = torch.device(device if device is not None else "cpu")
         self.cuda = self.device.type == "cuda"
         self.side = torch.cuda.Stream(self.device) if self.cuda else None
         self._ybuf = [None, None]  # two output buffers in rotation (process(out=)): no copy per call
+        # shard and result buffers in rotation as well: a buffer that has been used on two streams goes back to the
+        # caching allocator only when both have passed it, so a fresh allocation per call ends in a device malloc per
+        # call (measured on one GPU: 8.5 ms per step instead of 0.6)
+        self._xbuf = [None, None, None]
+        self._obuf = [None, None, None]
         import inspect
         loc = sharded.local
         try:
@@ -166,8 +182,13 @@ class RootPipeline:
         def scatter(i):
             with self._on_side():
                 x = batches[i] if rank == self.root else None
+                if self.cuda and self._xbuf[i % 3] is None:
+                    self._xbuf[i % 3] = torch.empty((self.sh.hi - self.sh.lo, self.length), dtype=torch.float64,
+                                                    device=self.device)
+                # (shard i - 3 was consumed by the resampling of call i - 3, which the gather of that call -- queued on
+                # this side stream before this scatter -- waited for)
                 shards[i] = scatter_channels(x, self.sh.total, self.length, src=self.root,
-                                             device=self.device)
+                                             device=self.device, out=self._xbuf[i % 3] if self.cuda else None)
                 if self.cuda:
                     ready[i] = torch.cuda.Event()
                     ready[i].record(self.side)
@@ -176,7 +197,16 @@ class RootPipeline:
             with self._on_side():
                 if self.cuda:
                     self.side.wait_event(done[i])
-                outs[i] = gather_channels(y, self.sh.total, dst=self.root)
+                ob = None
+                if self.cuda and rank == self.root and hasattr(self.sh.local, "max_out_len"):
+                    # (three result buffers in rotation: the caller gets views; a result stays valid until the third
+                    # call after it has been gathered -- run() hands all of them back at its end, so callers that keep
+                    # more than three results alive copy them)
+                    if self._obuf[i % 3] is None:
+                        self._obuf[i % 3] = torch.empty((self.sh.total, self.sh.local.max_out_len), dtype=y.dtype,
+                                                        device=self.device)
+                    ob = self._obuf[i % 3]
+                outs[i] = gather_channels(y, self.sh.total, dst=self.root, out=ob if self.keep_last_only else None)
 
         if n:
             scatter(0)
