@@ -150,11 +150,14 @@ R8BSRC_DECL int r8b_pcm_sample_bytes(int format);
 
 /* Checkpoint / resume of the streaming state of all channels (the reference
  * keeps this state inside each CDSPProcessor and offers only clear()).  The blob is host memory:
- * the schedule's counters plus every history ring.  r8b_batch_state_size() is the size a save
- * would need right now; save returns the bytes written; load accepts only a blob saved by an
- * object created with the same parameters and options, after which the stream continues
- * bit-identically.  Both wait for `stream` (the stream the process calls were enqueued on).
- * Return -1 on error. */
+ * the schedule's counters plus every history ring and the park buffer (outputs a call's last block
+ * has computed for the next call).  r8b_batch_state_size() is a constant of the object; save returns
+ * the bytes written; load accepts only a blob saved by an object created with the same parameters and
+ * options (checked as a whole before anything changes), after which the stream continues
+ * bit-identically.  Blobs are not canonical: ring and buffer positions that no later call reads keep
+ * whatever earlier calls left there, so two blobs of the same stream position taken after different ways
+ * of cutting the stream into calls may differ in bytes (never in the stream that follows).  Both wait
+ * for `stream` (the stream the process calls were enqueued on).  Return -1 on error. */
 R8BSRC_DECL long long r8b_batch_state_size(CR8BBatch b);
 R8BSRC_DECL long long r8b_batch_state_save(CR8BBatch b, void* buf, long long cap, void* stream);
 R8BSRC_DECL int r8b_batch_state_load(CR8BBatch b, const void* buf, long long size, void* stream);
