@@ -481,6 +481,21 @@ def test_emulated_structural_options_are_frozen_while_a_stream_runs(emul):
     b.set_option("timing", 0)        # non-structural: fine
     b.clear()
     b.set_option("fuse", 0)          # after clear(): fine again
+    # "park" decides where the outputs behind a call's last block live (park buffer / ahead in a ring): structural too
+    c = r8b.BatchResampler(44100.0, 96000.0, 1024, 2.0, 180.15, nch=1, lib=emul)
+    c.process_host(x[:, :1024])
+    with pytest.raises(KeyError):
+        c.set_option("park", 0)
+    c.set_option("park", 1)
+    # counters: known names only
+    assert c.stat("conv_blocks") > 0 and c.stat("park_only_calls") == 0
+    with pytest.raises(KeyError):
+        c.stat("no_such_counter")
+    # a checkpoint of an object with parked outputs is refused by an object that does not park (other option set)
+    d = r8b.BatchResampler(44100.0, 96000.0, 1024, 2.0, 180.15, nch=1, lib=emul)
+    d.set_option("park", 0)
+    with pytest.raises(RuntimeError, match="differently configured"):
+        d.load_state_dict(c.state_dict())
 
 
 def test_emulated_process_rejects_overlapping_rows_and_null_pointers(emul):
