@@ -487,6 +487,8 @@ def test_emulated_structural_options_are_frozen_while_a_stream_runs(emul):
     with pytest.raises(KeyError):
         c.set_option("park", 0)
     c.set_option("park", 1)
+    c.process_host(x[:, 1024:2048])
+    c.process_host(x[:, 2048:3000])
     # counters: known names only
     assert c.stat("conv_blocks") > 0 and c.stat("park_only_calls") == 0
     with pytest.raises(KeyError):
