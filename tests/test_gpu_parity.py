@@ -554,3 +554,17 @@ def test_hip_error_budget_does_not_creep(torch, refwrap, case):
     r, p = refwrap.batch_check(src, dst, maxin, [maxin] * (n // maxin), x, np.concatenate(ys, axis=1),
                                [y.shape[1] for y in ys], 2.0, 180.15)
     assert r.max() <= 1.12 * r0 and p.max() <= 1.12 * p0 + 2.3e-16, (r.max(), r0, p.max(), p0)
+
+
+def test_cxx_batch_sharded(torch, tmp_path):
+    """include/r8b/BatchSharded.h, the C++ host's helper for several devices -- three shards of whole
+    channel pairs (here all on device 0, each on its own stream) equal ONE object over all channels bit for bit
+    (tests/cxx_sharded.cpp)"""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "cxx_sharded")
+    libdir = os.path.dirname(r8b.lib_path())
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cxx_sharded.cpp"),
+                    "-L" + libdir, "-lr8bsrc_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.returncode, out.stdout)
