@@ -897,7 +897,8 @@ bool Engine::stage_parks(size_t s) const
 	if (s + 2 == plan_.stages.size() && fuse_with_next(s)) return use_pair_two(s, nullptr);
 	if (s + 1 != plan_.stages.size()) return false;
 	const int path = conv_path(plan_.stages[s].cg);
-	return path == kPathPair || path == kPathPair3;
+	// (the one-channel fast path at the end of a chain keeps an output ring in the same buffer: launch_stage)
+	return path == kPathPair || path == kPathPair3 || path == kPathConvx || path == kPathConvx3;
 }
 
 // How an unfused pair-kernel convolver treats the block that holds a call's last output (launch_stage): 0 -- computed
@@ -925,6 +926,9 @@ long long Engine::park_row_len(size_t s) const
 	{
 		const ConvGeom& g = plan_.stages[s].cg;
 		n = g.in_len / g.down + 2;
+		const int path = conv_path(g);
+		// (output ring of the one-channel fast path: a call's outputs plus one block's, a power of two)
+		if (path == kPathConvx || path == kPathConvx3) return pow2_at_least(plan_.max_out_len + n + 16);
 	}
 	return (n + 7) / 8 * 8 + 8;
 }
@@ -1293,7 +1297,15 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		// end of the chain, into the park buffer (once = 2; ConvxLaunch::park_*) -- and the next call starts behind it
 		// instead of computing that block again (one block in 13.4 for 44100 -> 88200 at BASELINE's call size, one in
 		// 7.1 for 88200 -> 44100, one in 6.4 for 48000 -> 32000; cf. launch_fused)
-		const int once = (path == kPathPair || path == kPathPair3) ? conv_once(s, dst) : 0;
+		// One-channel fast path (r8b_convx.h: 16384-point blocks and what else the pair form does not cover): its store
+		// clips at L.b, so the same is had without a kernel change -- in the middle of a chain by moving L.b to the
+		// block's end (once = 3), at the end of the chain by letting the kernel write into an OUTPUT RING of the stage's
+		// own (once = 4: the park buffer used as a ring of max_out_len + one block's outputs) and copying the call's
+		// outputs from there to the caller's rows (k_tail: 2 x 8 bytes per output more, for one block in 5.2 less at
+		// 48000 -> 32000 with a 0.5 % transition band)
+		int once = (path == kPathPair || path == kPathPair3) ? conv_once(s, dst) : 0;
+		if ((path == kPathConvx || path == kPathConvx3) && opt_.at("park") && dst.fmt == kPcmF64)
+			once = s + 1 == plan_.stages.size() ? (dst.mask == -1 && stage_parks(s) ? 4 : 0) : (dst.mask != -1 ? 3 : 0);
 		StageDev& dd = dev_[s];
 		auto blk_of = [&](long long q) { return ((long long) g.down * q + g.fl2) / g.in_len; };
 		auto blk_end = [&](long long k) // the first output block k does not hold
@@ -1305,7 +1317,28 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		X.park_src = nullptr; X.park_dst = nullptr;
 		X.park_blk = SpanInfo();
 		long long ca = a; // the first output this call has to compute
-		if (once == 2) ensure_park(s);
+		if (once == 2 || once == 4) ensure_park(s);
+		// (once = 4: where the kernel writes, and what copies the call's outputs out of it afterwards)
+		DstView rdst = dst;
+		auto ring_to_rows = [&]()
+		{
+			TailLaunch T;
+			T.src.ring = dd.park[0] + (long long) ch0_ * dd.park_stride;
+			T.src.ring_stride = dd.park_stride; T.src.ring_mask = dd.park_stride - 1;
+			T.src.cur = T.src.ring; T.src.cur_stride = 0; T.src.cur_base = LLONG_MAX;
+			T.src.cur_fmt = kPcmF64;
+			T.p0 = a; T.p1 = b;
+			T.ring = dst.p + dst.off; T.ring_stride = dst.stride; T.ring_mask = -1;
+			T.nch = nchw_;
+			launch_tail(T, stream);
+		};
+		if (once == 4)
+		{
+			rdst.p = dd.park[0] + (long long) ch0_ * dd.park_stride;
+			rdst.stride = dd.park_stride;
+			rdst.mask = dd.park_stride - 1;
+			rdst.off = 0;
+		}
 		if (once != 0 && dd.park_end > a)
 		{
 			ca = std::min(dd.park_end, b);
@@ -1334,13 +1367,18 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 				launch_tail(T, stream);
 				if (ch0_ == 0) stat_["park_only_calls"]++;
 			}
+			if (once == 4)
+			{
+				ring_to_rows();
+				if (ch0_ == 0) stat_["park_only_calls"]++;
+			}
 			break;
 		}
 		L.k0 = blk_of(ca);
 		const long long k1 = blk_of(b - 1);
 		L.nblk = (int) (k1 - L.k0 + 1);
 		L.a = ca; L.b = b;
-		L.dst = dst;
+		L.dst = once == 4 ? rdst : dst;
 		long long pend = b; // end of what the call's last block holds
 		if (once != 0)
 		{
@@ -1353,12 +1391,17 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 					throw std::logic_error("ring too small for a block written ahead");
 				L.b = pend;
 			}
+			if (once == 4)
+			{
+				if (pend - a > dd.park_stride) throw std::logic_error("output ring too small");
+				L.b = pend;
+			}
 		}
 		if (path != kPathGeneric)
 		{
 			X.in_step = X.out_step = 1; X.flen = 2; X.fl2w = X.fllw = 0; X.run_off = 0;
 			X.ptab = nullptr; X.ctab = nullptr; X.nsets = 0;
-			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = dst;
+			X.table = nullptr; X.wtab = nullptr; X.wa = X.wb = 0; X.wdst = L.dst;
 			if (once == 2 && pend > b)
 			{
 				if (pend - b > dd.park_stride) throw std::logic_error("park buffer too small");
@@ -1386,6 +1429,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			else if (path == kPathPair) launch_convp(X, g.complex_h ? 6 : 0, stream);
 			else launch_convx(X, 0, stream);
 			if (L.tail_ring != nullptr) tail_done_ = true;
+			if (once == 4) ring_to_rows();
 			if (once != 0 && ch0_ + nchw_ >= nch_)
 			{
 				// (the counters once per call, after its last channel window)

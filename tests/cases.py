@@ -251,6 +251,11 @@ PARK_CASES = [
     (44100.0, 44101.0, 4096, 2.0, 180.15, "ahead"),       # convolver -> polynomial interpolator
     (44100.0, 192000.0, 2048, 2.0, 180.15, "ahead"),      # fused pair -> ring -> convolver -> half-band
     (44100.0, 96000.0, 4096, 10.0, 109.56, "none"),       # 512-point blocks, one phase per thread: as before
+    # the one-channel fast path (16384-point blocks): at the end of a chain through an output ring of its own and a copy
+    (48000.0, 32000.0, 4096, 0.5, 180.15, "ahead"),       # re-blocked 8 507-tap filter, strided store
+    (44100.0, 88200.0, 2048, 0.5, 180.15, "ahead"),       # 8192 -> 16384 points
+    (176400.0, 44100.0, 16384, 0.5, 180.15, "ahead"),     # half-band decimator + 16384 -> 8192 points (decimating form)
+    (44100.0, 96000.0, 2048, 0.5, 180.15, "none"),        # 8192 -> 16384 points fused with the interpolator: as before
 ]
 PARK_CASES_MINPHASE = [
     (44100.0, 88200.0, 4096, 2.0, 180.15, "park"),        # complex kernel spectrum (mode 6)
