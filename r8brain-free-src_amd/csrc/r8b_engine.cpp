@@ -894,7 +894,8 @@ bool Engine::use_pair_two(size_t s, int* run_off) const
 bool Engine::stage_parks(size_t s) const
 {
 	if (!opt_.at("park") || s >= plan_.stages.size() || plan_.stages[s].desc.kind != kConv) return false;
-	if (s + 2 == plan_.stages.size() && fuse_with_next(s)) return use_pair_two(s, nullptr);
+	if (s + 2 == plan_.stages.size() && fuse_with_next(s))
+		return use_pair_two(s, nullptr) || !use_pair_fused(plan_.stages[s].cg); // (the latter: an output ring)
 	if (s + 1 != plan_.stages.size()) return false;
 	const int path = conv_path(plan_.stages[s].cg);
 	// (the one-channel fast path at the end of a chain keeps an output ring in the same buffer: launch_stage)
@@ -921,6 +922,8 @@ long long Engine::park_row_len(size_t s) const
 		fused_blocking(s, &S, &off);
 		const StagePlan& w = plan_.stages[s + 1];
 		n = (S * w.out_step + w.in_step - 1) / w.in_step + 2;
+		// (output ring of the one-channel fused kernel: a call's outputs plus one block's, a power of two)
+		if (!use_pair_fused(plan_.stages[s].cg)) return pow2_at_least(plan_.max_out_len + n + 16);
 	}
 	else
 	{
@@ -2096,12 +2099,34 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	// holds beyond wb waits in the park buffer for the next call(s) instead of being computed again there (one block
 	// in 13.4 for BASELINE's cfg2 call, one in 7.5 for cfg3).  ja: the first output this call has to compute.
 	StageDev& dp = dev_[s];
-	const bool parks = stage_parks(s) && dst.mask == -1 && dst.fmt == kPcmF64;
+	// (the one-channel kernel fused with the interpolator -- 16384-point blocks -- at the end of a chain: an output ring
+	// of the stage's own and a copy, as in launch_stage)
+	const bool oring = opt_.at("park") && !use_pair_fused(c.cg) && stage_parks(s) && dst.mask == -1 && dst.fmt == kPcmF64;
+	const bool parks = !oring && stage_parks(s) && dst.mask == -1 && dst.fmt == kPcmF64;
 	// ... and in the middle of a chain the same block writes what it holds beyond the call AHEAD into the next stage's
 	// ring (nobody reads it before it is due; the ring was sized for it -- Engine::Engine)
-	const bool ahead = !parks && opt_.at("park") && pair_two && dst.mask != -1 && dst.fmt == kPcmF64 &&
-		s + 2 < plan_.stages.size();
-	if (parks) ensure_park(s);
+	const bool ahead = oring || (!parks && opt_.at("park") && (pair_two || !use_pair_fused(c.cg)) && dst.mask != -1 &&
+		dst.fmt == kPcmF64 && s + 2 < plan_.stages.size());
+	if (parks || oring) ensure_park(s);
+	auto ring_to_rows = [&]()
+	{
+		TailLaunch T;
+		T.src.ring = dp.park[0] + (long long) ch0_ * dp.park_stride;
+		T.src.ring_stride = dp.park_stride; T.src.ring_mask = dp.park_stride - 1;
+		T.src.cur = T.src.ring; T.src.cur_stride = 0; T.src.cur_base = LLONG_MAX;
+		T.src.cur_fmt = kPcmF64;
+		T.p0 = wa; T.p1 = wb;
+		T.ring = dst.p + dst.off; T.ring_stride = dst.stride; T.ring_mask = -1;
+		T.nch = nchw_;
+		launch_tail(T, stream);
+	};
+	if (oring)
+	{
+		X.wdst.p = dp.park[0] + (long long) ch0_ * dp.park_stride;
+		X.wdst.stride = dp.park_stride;
+		X.wdst.mask = dp.park_stride - 1;
+		X.wdst.off = 0;
+	}
 	long long ja = wa;
 	if ((parks || ahead) && dp.park_end > wa)
 	{
@@ -2116,7 +2141,16 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			if (ch0_ == 0) stat_["park_calls"]++;
 		}
 	}
-	if (ja >= wb && ahead) return; // (everything this call owes is in the ring already)
+	if (ja >= wb && ahead)
+	{
+		// (everything this call owes is in the ring already)
+		if (oring)
+		{
+			ring_to_rows();
+			if (ch0_ == 0) stat_["park_only_calls"]++;
+		}
+		return;
+	}
 	if (ja >= wb)
 	{
 		// the whole call comes out of the park buffer (a short call): a plain copy; the stream's history is kept by
@@ -2138,7 +2172,8 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	const long long knext = parks || ahead ? klast + 1 : owner(wb);
 	// (written ahead: the last block's outputs are not cut at the call's end)
 	const long long wcut = ahead ? block_jhi(klast) : wb;
-	if (ahead && (wcut < wb || dst.mask + 1 < stage_history(s + 2) + plan_.stage_max_in[s + 2] + (wcut - wb)))
+	if (oring ? wcut - wa > dp.park_stride :
+		ahead && (wcut < wb || dst.mask + 1 < stage_history(s + 2) + plan_.stage_max_in[s + 2] + (wcut - wb)))
 		throw std::logic_error("ring too small for a block written ahead");
 	if (X.c.tail_ring != nullptr && pair_two && c.cg.up_pow2)
 	{
@@ -2217,6 +2252,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 		else launch_convx(X, 1, stream);
 		if (X.c.tail_ring != nullptr) tail_done_ = true;
 	}
+	if (oring) ring_to_rows();
 	if ((parks || ahead) && ch0_ + nchw_ >= nch_)
 	{
 		// (the counters once per call, after its last channel window)

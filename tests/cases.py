@@ -255,7 +255,8 @@ PARK_CASES = [
     (48000.0, 32000.0, 4096, 0.5, 180.15, "ahead"),       # re-blocked 8 507-tap filter, strided store
     (44100.0, 88200.0, 2048, 0.5, 180.15, "ahead"),       # 8192 -> 16384 points
     (176400.0, 44100.0, 16384, 0.5, 180.15, "ahead"),     # half-band decimator + 16384 -> 8192 points (decimating form)
-    (44100.0, 96000.0, 2048, 0.5, 180.15, "none"),        # 8192 -> 16384 points fused with the interpolator: as before
+    (44100.0, 96000.0, 2048, 0.5, 180.15, "ahead"),       # 8192 -> 16384 points fused with the interpolator (output ring)
+    (192000.0, 44100.0, 8192, 0.5, 180.15, "ahead"),      # half-band decimator + fused 16384 -> 16384 points
 ]
 PARK_CASES_MINPHASE = [
     (44100.0, 88200.0, 4096, 2.0, 180.15, "park"),        # complex kernel spectrum (mode 6)
