@@ -217,6 +217,7 @@ struct ConvpState
 	int pf;               // ... and whether the workgroup holds the call's last block and parks what lies beyond the call
 	double tk[2];         // the thread's element of the history tail behind the last block's window (cp_tail_slice_*)
 	double* tka;
+	double er[16], ei[16]; // split 2x up-sampling form (modes 8 / 9): the even half's outputs while the odd half is transformed
 };
 
 // (+ 64 bytes behind the array: one word per wave for the workgroup-wide "channel has a non-zero sample" bits)
@@ -415,7 +416,8 @@ R8B_HD void pdit_regs(const cd* buf, int n, int b, const cd* twr, double* vr, do
 // K1: thread lt owns the radix-E1 butterfly over elements lt + NT p of the first pass; element i of the
 // circular block is sample i of channel A (real part) and of channel B (imaginary part).  A wave
 // reads 64 consecutive samples of each channel per load.
-template<int LN, int UL, int MODE = 0>
+// (SPU: the split 2x up-sampling form -- modes 8 / 9 on a 1:1 geometry: the block is loaded as a 2x up-sampling one)
+template<int LN, int UL, int MODE = 0, bool SPU = false>
 R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, int chA, int chB, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
@@ -443,7 +445,7 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 			return;
 		}
 	}
-	constexpr int US = UL > 0 ? UL : 0; // (L.up == 1 << US)
+	constexpr int US = SPU ? 1 : (UL > 0 ? UL : 0); // (L.up == 1 << US)
 	const int iln = L.in_len >> US;
 	const long long base = (k * (long long) L.blk_stride + L.blk_offset) >> US; // (>= 0, even)
 	// Element i of the circular array holds sample base + rel((i + rot) mod N), rel(j) = j < iln ? j : j - N: the N
@@ -482,12 +484,12 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 // History for the next call out of the registers cp_load() filled (convp_tail_owners): the block's own part of the
 // tail -- positions base(k) .. base(k + 1) - 1 of its window, clipped to [tail_c0, tail_c1) -- goes to the other
 // history ring as it arrives; no load, no wait.
-template<int LN, int UL>
+template<int LN, int UL, bool SPU = false>
 R8B_HD void cp_tail_owned(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int chA, int chB, bool bvalid, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int R = G::E1, q = G::N / R;
-	constexpr int US = UL > 0 ? UL : 0;
+	constexpr int US = SPU ? 1 : (UL > 0 ? UL : 0);
 	if (k < L.k0 + L.tail_bf) return;
 	const int iln = L.in_len >> US;
 	const long long base = (k * (long long) L.blk_stride + L.blk_offset) >> US;
@@ -885,6 +887,91 @@ R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 	}
 }
 
+// ---- split 2x up-sampling form (modes 8 / 9; geometry <13, 0>: 8192 -> 16384-point blocks) -----------------
+// A 2x up-sampling block whose backward transform would be 16384 points -- 256 KB as a pair, more than a CU's LDS --
+// runs on the 8192-point 1:1 geometry: forward transform of the N = 8192 input samples as there, then the backward
+// transform as TWO N-point transforms, one after the other in the same array: the even outputs y[2m] =
+// IDFT_N(Z (H[k] + H[k+N]))[m] and the odd ones y[2m+1] = IDFT_N(Z (H[k] - H[k+N]) th^k)[m], th = e^{+2 pi i / 2N}
+// (the zero-stuffed spectrum is the forward spectrum repeated, reference CDSPBlockConvolver.h:606-629; the first
+// radix-2 stage of the 2N-point transform separates the output parities).  Thread lt owns forward positions 16 lt + c
+// (bit-reversed: bin k = bitrev4(c) 512 + bitrev9(lt)), so th^k = conj(tw[bitrev9(lt)]) e^{+2 pi i bitrev4(c) / 32}: one
+// entry of the exp(-2 pi i e / 16384) table per thread and the 32nd roots of unity as constants.  hp[c * NT + lt] =
+// (H[k] + H[k+N], H[k] - H[k+N]) of position 16 lt + c (Engine: pair_constants_split).  Each half then takes the
+// backward passes of the 1:1 geometry (ConvpPost).  Replaces the one-channel kernel k_convx for these blocks (filters
+// with a transition band of about 1 % and below): two channels per workgroup instead of one.
+template<int LN, int UL>
+R8B_HD void cp_sp_hp_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
+{
+#pragma unroll
+	for (int c = 0; c < 16; c++) st.hp[c] = L.hp[c * ConvpGeom<LN, UL>::NT + lt];
+}
+// middle: the last forward butterflies, the two half spectra; the even one goes on (first backward butterflies in
+// st.vr / st.vi), the odd one waits in st.er / st.ei
+template<int LN, int UL>
+R8B_HD void cp_sp_middle(const ConvLaunch& L, const cd* buf, ConvpState<LN, UL>& st, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	static_assert(UL == 0 && G::E1 == 16 && G::POST && G::NT == 512, "split 2x up-sampling form: the 8192-point 1:1 geometry");
+	double zr[16], zi[16];
+	const SwBase bbf = sw_base(buf, fslot<LN, UL>(16 * lt));
+#pragma unroll
+	for (int c = 0; c < 16; c++)
+	{
+		const cd v = sw_ld(bbf, fmap_c<LN, UL>(c));
+		zr[c] = v.re;
+		zi[c] = v.im;
+	}
+#pragma unroll
+	for (int f = 0; f < G::NBF; f++) dif_regs<G::RM>(zr + G::RM * f, zi + G::RM * f);
+	// th^(bitrev9(lt)): conj of the table's entry (the table has 2N = 16384 entries: tw_len / 16384 = 1)
+	unsigned r = (unsigned) lt;
+	r = ((r & 0xaaaau) >> 1) | ((r & 0x5555u) << 1);
+	r = ((r & 0xccccu) >> 2) | ((r & 0x3333u) << 2);
+	r = ((r & 0xf0f0u) >> 4) | ((r & 0x0f0fu) << 4);
+	r = ((r & 0xff00u) >> 8) | ((r & 0x00ffu) << 8);
+	r >>= 7; // (a 16-bit reversal shifted down: the reversal of the 9 bits of lt)
+	const cd wt = L.tw[(L.tw_len >> 14) * (int) r];
+#pragma unroll
+	for (int c = 0; c < 16; c++)
+	{
+		// e^{+2 pi i j / 32}, j = bitrev4(c)
+		constexpr double kC[9] = { 1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+			0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785, 0.0 };
+		const int j = ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3);
+		// cos(2 pi j / 32), sin(2 pi j / 32) for j = 0 .. 15 from the first-octant values
+		const double cr = j <= 8 ? kC[j] : -kC[16 - j];
+		const double ci = j <= 8 ? kC[8 - j] : kC[j - 8];
+		const double hs = st.hp[c].re, hd = st.hp[c].im;
+		st.vr[c] = zr[c] * hs;
+		st.vi[c] = zi[c] * hs;
+		// conj(wt) * (cr + i ci)
+		const double tr = wt.re * cr + wt.im * ci, ti = wt.re * ci - wt.im * cr;
+		const double dr = zr[c] * hd, di = zi[c] * hd;
+		st.er[c] = dr * tr - di * ti;
+		st.ei[c] = dr * ti + di * tr;
+	}
+#pragma unroll
+	for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
+}
+// between the halves: the even half's outputs (st.vr / st.vi after its last pass) change places with the odd half's
+// spectrum, whose first backward butterflies follow
+template<int LN, int UL>
+R8B_HD void cp_sp_swap(ConvpState<LN, UL>& st)
+{
+	typedef ConvpGeom<LN, UL> G;
+#pragma unroll
+	for (int c = 0; c < 16; c++)
+	{
+		const double a = st.vr[c], b = st.vi[c];
+		st.vr[c] = st.er[c];
+		st.vi[c] = st.ei[c];
+		st.er[c] = a;
+		st.ei[c] = b;
+	}
+#pragma unroll
+	for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
+}
+
 // ---- decimating form (UL < 0) -------------------------------------------------------------------------
 // The reference decimates by 2^d in the spectrum (CDSPBlockConvolver.h:329-344): the backward transform has
 // N2 = N / D points and keeps the bins below the new Nyquist frequency, k < N2/2 and k > N - N2/2 -- in the
@@ -1234,6 +1321,58 @@ R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 	if (pend > L.b) run(cp_store_view(pd, chA, chB, t0, L.b, pend, L.in_len));
 }
 
+// split 2x up-sampling form: the even half's outputs sit in st.er / st.ei (E[i] = y at circular position 2 (lt + NT i)),
+// the odd half's in st.vr / st.vi (that position + 1); MODE 3: with the 3x strided store (output q at virtual time 3 q)
+template<int LN, int UL, int MODE>
+R8B_HD void cp_sp_store(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int chA, int chB, bool bvalid,
+	int lt, const DstView& pd, long long pend)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int mask = 2 * G::N - 1;
+	const long long t0 = cx_block_t0(L, k);
+	if constexpr (MODE == 3)
+	{
+		if (!L.down_pow2 && L.down > 1)
+		{
+			const unsigned down = (unsigned) L.down;
+			const long long qf = t0 >= 0 ? t0 / (long long) down : -((-t0 + down - 1) / (long long) down); // floor
+			const unsigned r0 = (unsigned) (t0 - qf * (long long) down);
+			const int nmax = (int) ((r0 + (unsigned) L.in_len) / down) + 1;
+			auto run = [&](const CpStoreView& v)
+			{
+#pragma unroll
+				for (int i = 0; i < 16; i++)
+				{
+#pragma unroll
+					for (int h = 0; h < 2; h++)
+					{
+						const unsigned u = (unsigned) ((2 * (lt + G::NT * i) + h + L.fl2r) & mask);
+						const unsigned w = r0 + u;
+						const unsigned wq = down == 3u ? w / 3u : w / down;
+						if (u < (unsigned) L.in_len && wq * down == w)
+							cp_store1(v, wq, h ? st.vr[i] : st.er[i], h ? st.vi[i] : st.ei[i], bvalid);
+					}
+				}
+			};
+			run(cp_store_view(L.dst, chA, chB, qf, L.a, L.b, nmax));
+			if (pend > L.b) run(cp_store_view(pd, chA, chB, qf, L.b, pend, nmax));
+			return;
+		}
+	}
+	auto run = [&](const CpStoreView& v)
+	{
+#pragma unroll
+		for (int i = 0; i < 16; i++)
+		{
+			const int c0 = 2 * (lt + G::NT * i);
+			cp_store1(v, (unsigned) ((c0 + L.fl2r) & mask), st.er[i], st.ei[i], bvalid);
+			cp_store1(v, (unsigned) ((c0 + 1 + L.fl2r) & mask), st.vr[i], st.vi[i], bvalid);
+		}
+	};
+	run(cp_store_view(L.dst, chA, chB, t0, L.a, L.b, L.in_len));
+	if (pend > L.b) run(cp_store_view(pd, chA, chB, t0, L.b, pend, L.in_len));
+}
+
 #ifdef R8B_SPLIT_UP2
 } // namespace r8bhip
 #include "r8b_convp_split.h" // (development builds only: the occupancy experiment of round 4)
@@ -1523,7 +1662,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	typedef ConvpState<LN, UL> St;
 	// modes 6 / 7: modes 0 / 3 with a complex kernel spectrum
 	constexpr bool CX = MODE == 6 || MODE == 7;
-	constexpr int BM = MODE == 6 ? 0 : (MODE == 7 ? 3 : MODE);
+	// modes 8 / 9: modes 0 / 3 of the split 2x up-sampling form (cp_sp_*: geometry <13, 0> only)
+	constexpr bool SP = MODE == 8 || MODE == 9;
+	constexpr int BM = MODE == 6 ? 0 : (MODE == 7 ? 3 : (MODE == 8 ? 0 : (MODE == 9 ? 3 : MODE)));
 	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
 	constexpr bool SPLIT = kSplit<LN, UL> && !CX && (BM == 0 || BM == 3);
 	(void) SPLIT;
@@ -1532,6 +1673,11 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	const bool bvalid = cur.bvalid;
 	// a thread's block pair: its own part of the array; slots past the launch's last block redo that block
 	// (they take part in every barrier) and store nothing
+	auto hp_prefetch = [&](St& st, int lt)
+	{
+		if constexpr (SP) cp_sp_hp_prefetch<LN, UL>(L, st, lt);
+		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
+	};
 	auto sub_of = [&](int tid) { return convp_sub<LN, UL>(tid); };
 	auto lt_of = [&](int tid) { return convp_lt<LN, UL>(tid); };
 	auto buf_of = [&](int tid) { return buf + sub_of(tid) * G::NA; };
@@ -1555,7 +1701,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		// (the first pass's twiddles -- L2 -- requested ahead of the samples -- HBM --, not behind their wait)
 		ptw_fetch_lean<G::E1, G::NT>(st.tw, L.ptw, 0, lt);
 		ex.stamp2();
-		cp_load<LN, UL, BM>(L, st, k_of(tid), chA, chB, lt);
+		cp_load<LN, UL, BM, SP>(L, st, k_of(tid), chA, chB, lt);
 		if ((L.tail_flags & 2) != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) > L.k0 + L.tail_bf)
 		{
 			// (the launch's last block: the samples behind its window -- read by no block of this call -- requested
@@ -1563,7 +1709,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			if ((L.tail_flags & 8) == 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) == L.k0 + L.nblk)
 				cp_tail_rest<G::WT>(L, L.tail_c1, L.tail_p1, chA, chB, bvalid, tid);
 			ex.stamp2();
-			if (live(tid)) cp_tail_owned<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt);
+			if (live(tid)) cp_tail_owned<LN, UL, SP>(L, st, k_of(tid), chA, chB, bvalid, lt);
 		}
 		if constexpr (MODE != 1)
 		{
@@ -1592,7 +1738,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		// (modes 4 / 5: the thread's entry of the interpolator's lane table, long before its rows are addressed with it)
 		if constexpr (MODE == 4 || MODE == 5) st.pt = cp_ptab_fetch(X, tid);
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
-		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
+		else hp_prefetch(st, lt);
 	});
 	// forward passes 1 .., the middle pass and the first backward pass stay inside each wave's own range
 	// of the array (ConvpGeom): wave-level ordering points instead of workgroup barriers between them
@@ -1601,13 +1747,13 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		const int lt = lt_of(tid);
 		ConvpPre<LN, UL, 1>::run(buf_of(tid), st, lt);
 		if constexpr (G::NPRE > 2) ConvpPre<LN, UL, 2>::prefetch(L, st, lt);
-		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
+		else hp_prefetch(st, lt);
 	};
 	auto s_pre2 = [&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
 		ConvpPre<LN, UL, 2>::run(buf_of(tid), st, lt);
-		cp_hp_prefetch<LN, UL, CX>(L, st, lt);
+		hp_prefetch(st, lt);
 	};
 	// (two steps: every lane has read its forward data before any lane's backward data overwrites it --
 	// on the GPU program order alone guarantees that, LDS serves a wave's accesses in issue order)
@@ -1625,7 +1771,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		auto d_midc = [&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
-			if constexpr (UL < 0) cp_middle_compute_down<LN, UL, CX>(buf_of(tid), st, lt);
+			if constexpr (SP) cp_sp_middle<LN, UL>(L, buf_of(tid), st, lt);
+			else if constexpr (UL < 0) cp_middle_compute_down<LN, UL, CX>(buf_of(tid), st, lt);
 			else cp_middle_compute<LN, UL, CX>(buf_of(tid), st, lt);
 			ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
 		};
@@ -1677,6 +1824,20 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		static_assert(G::NPOST == 5 || G::NW == 1 || G::N2 / G::E2 <= 64 * G::E2, "pass plan");
 		ex.wave_steps(d_pre1, d_pre2, d_midc, d_midw, d_post1, d_post2, d_post3);
 		if constexpr (G::NPOST > 4) ex.wave_steps(d_post4);
+		if constexpr (SP)
+		{
+			// split 2x up-sampling form: the even half's last pass (across the waves), then the odd half through the same
+			// passes; the even outputs wait in st.er / st.ei
+			static_assert(G::NPOST == 3, "split 2x up-sampling form: pass plan of the 8192-point geometry");
+			ex.phase([&](int tid, St& st)
+			{
+				const int lt = lt_of(tid);
+				ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
+				ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
+			});
+			auto o_mid = [&](int, St& st) { cp_sp_swap<LN, UL>(st); };
+			ex.wave_steps(o_mid, d_midw, d_post1, d_post2);
+		}
 	}
 	else
 	{
@@ -1825,13 +1986,28 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
 			cp_tail_slice_store(L, st, chA, chB, bvalid);
 			ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
-			cp_silence<LN, UL>(st, ex.collect_bits());
+			const unsigned nzb = ex.collect_bits();
+			cp_silence<LN, UL>(st, nzb);
+			if constexpr (SP)
+			{
+				// (the even half's outputs too)
+				if (nzb != 3u)
+				{
+#pragma unroll
+					for (int p = 0; p < 16; p++)
+					{
+						if (!(nzb & 1u)) st.er[p] = 0.0;
+						if (!(nzb & 2u)) st.ei[p] = 0.0;
+					}
+				}
+			}
 			if (live(tid))
 			{
 				DstView pd = L.dst;
 				long long pend = L.b;
 				cp_park_view(ex, XM, st, k_of(tid), cur, pd, pend);
-				if constexpr (UL < 0) cp_store_conv_down<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt, pd, pend);
+				if constexpr (SP) cp_sp_store<LN, UL, BM>(L, st, k_of(tid), chA, chB, bvalid, lt, pd, pend);
+				else if constexpr (UL < 0) cp_store_conv_down<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt, pd, pend);
 				else cp_store_conv<LN, UL, BM>(L, st, k_of(tid), chA, chB, bvalid, lt, pd, pend);
 			}
 		});
@@ -1955,16 +2131,26 @@ inline void convp_tail_owners(ConvLaunch& L)
 
 // (slices: the kernel shares the parked outputs' copy-back and the history tail's rest among the pair's workgroups --
 // every mode but 1)
+// (spu: the split 2x up-sampling form on a 1:1 geometry -- modes 8 / 9)
 template<int LN, int UL>
-inline void convp_prepare(ConvxLaunch& X, bool slices = true)
+inline void convp_prepare(ConvxLaunch& X, bool slices = true, bool spu = false)
 {
 	X.c.rot = 0;
 	X.c.fl2r = X.c.fl2;
 	X.c.tail_flags = X.c.tail_ring != nullptr ? 1 : 0;
 	X.c.tail_bf = 0;
 	X.c.tail_c0 = X.c.tail_c1 = 0;
-
-	if constexpr (UL >= 0)
+	if (spu)
+	{
+		if (UL == 0 && X.c.up_pow2 && X.c.up == 2)
+		{
+			constexpr int N = ConvpGeom<LN, UL>::N;
+			X.c.rot = (N - ((X.c.fl2 / 2) & (N - 1))) & (N - 1);
+			X.c.fl2r = X.c.fl2 % 2;
+			convp_tail_owners<N, 1>(X.c);
+		}
+	}
+	else if constexpr (UL >= 0)
 	{
 		if (X.c.up_pow2 && X.c.up == (1 << (UL > 0 ? UL : 0)))
 		{

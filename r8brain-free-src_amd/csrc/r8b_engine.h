@@ -162,6 +162,9 @@ std::vector<double> spectral_constants(const std::vector<double>& H, const std::
 // bitrev(position), N = n_in; 1:1: H of backward positions 16 t + 2 c and 16 t + 2 c + 1.  H is the
 // scaled kernel spectrum (bl2/2 + 1 reals), mirrored for bins above bl2/2.
 std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n_out);
+// ... of the split 2x up-sampling form (r8b_convp.h cp_sp_middle): 16 x (n_in / 16) pairs, entry c * NT + t = (H[k] +
+// H[k + n_in], H[k] - H[k + n_in]) for forward position 16 t + c, bin k = bitrev(position); H over 2 n_in points
+std::vector<double> pair_constants_split(const std::vector<double>& H, int n_in);
 // twiddle base powers of the pair kernel's passes per thread (r8b_convp.h ptw_fetch): 5 slots x 6 x 256
 // complex; tw = exp(-2 pi i e / tw_len) table (interleaved), n_in = forward length (2048 or 4096)
 std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int n_in);

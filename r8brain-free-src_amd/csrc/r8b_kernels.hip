@@ -763,7 +763,7 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 		if (nbg > 1 && imax * nbg >= 0x100000000ull)
 			throw std::runtime_error("launch_convp: too many blocks per call for the workgroup map (split the call)");
 	}
-	convp_prepare<LN, UL>(X, MODE != 1);
+	convp_prepare<LN, UL>(X, MODE != 1, MODE == 8 || MODE == 9);
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
 #ifdef R8B_DEV_ONLY_MODE
@@ -775,6 +775,16 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	unsigned grid = nbg * npair;
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
+	}
+}
+
+template<int LN, int UL>
+void launch_convp_sp(const ConvxLaunch& X, int mode, hipStream_t stream)
+{
+	if constexpr (LN == 13 && UL == 0)
+	{
+		if (mode == 8) launch_convp_t<LN, UL, 8, 24>(X, stream);
+		else launch_convp_t<LN, UL, 9, 24>(X, stream);
 	}
 }
 
@@ -969,8 +979,14 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 		throw std::runtime_error("launch_convp: decimating geometry not instantiated");
 #endif
 	}
+	// (modes 8 / 9: the split 2x up-sampling form -- r8b_convp.h cp_sp_* -- lives on the 8192-point 1:1 geometry)
 #define R8B_CONVP_DISPATCH_BIG(LN, UL) \
-	if (ln == LN && up == (1 << UL)) \
+	if (ln == LN && LN == 13 && UL == 0 && (mode == 8 || mode == 9)) \
+	{ \
+		launch_convp_sp<LN, UL>(X, mode, (hipStream_t) stream); \
+		R8B_PAIR_DONE; \
+	} \
+	if (ln == LN && up == (1 << UL) && mode != 8 && mode != 9) \
 	{ \
 		if (mode == 3) launch_convp_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
 		else if (mode == 6) launch_convp_t<LN, UL, 6, 24>(X, (hipStream_t) stream); \

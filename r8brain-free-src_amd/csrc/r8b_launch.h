@@ -314,6 +314,13 @@ inline bool convp_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow
 	return n_out == 64 || n_out == 128 || n_out == 256 || n_out == 512 || n_out == 1024 || n_out == 2048 ||
 		n_out == 4096 || n_out == 8192;
 }
+// split 2x up-sampling form of the pair kernel (r8b_convp.h cp_sp_*, modes 8 / 9 on the 8192-point 1:1 geometry): 8192 ->
+// 16384-point blocks -- a 2x up-sampling filter with a transition band of about 1 % and below --, optionally in front of
+// the 3x strided store
+inline bool convp_split_ok(int n_in, int n_out, int up, int down, bool up_pow2, bool down_pow2)
+{
+	return up_pow2 && up == 2 && n_in == 8192 && n_out == 16384 && (down == 1 || (!down_pow2 && down == 3));
+}
 // ... with the whole-step interpolator fused in (modes 1 and 4)
 inline bool convp_fused_ok(int n_in, int n_out, int up, int down, bool up_pow2)
 {
@@ -354,7 +361,7 @@ void launch_pcm_in(const PcmLaunch& L, void* stream);  // PCM -> planar fp64
 void launch_pcm_out(const PcmLaunch& L, void* stream); // planar fp64 -> PCM
 // mode 0: convolver output to X.c.dst; mode 1: fused interpolator output to X.wdst; mode 3: radix-3 edges
 void launch_convx(const ConvxLaunch& X, int mode, void* stream);
-// the same work in pair form (modes 0, 1, 3 and 4; needs X.c.hp)
+// the same work in pair form (modes 0, 1, 3, 4 ... 9; needs X.c.hp)
 void launch_convp(const ConvxLaunch& X, int mode, void* stream);
 
 // memory helpers; all throw std::runtime_error with the HIP error text on failure

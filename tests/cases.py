@@ -125,6 +125,18 @@ REBLOCK_CASES = [
 ]
 
 
+# 8192 -> 16384-point blocks (2x up-sampling filters with a transition band of 0.5 ... 0.6 %, among them the re-blocked
+# 2/3 filters above): the split 2x up-sampling form of the pair kernel (r8b_convp.h cp_sp_*, modes 8 / 9), and the
+# one-channel kernel behind option pair_split = 0.  (src, dst, maxin, chunk, n_in, tb, atten)
+SPLIT_CASES = [
+    (44100.0, 88200.0, 4096, 3000, 70000, 0.5, 180.15),       # convolver alone, ragged calls
+    (44100.0, 96000.0, 4096, 4096, 60000, 0.5, 180.15),       # ... in front of the whole-step interpolator
+    (44100.0, 176400.0, 2048, 2048, 50000, 0.55, 206.91),     # ... in front of a half-band up-sampler
+    (96000.0, 64000.0, 8192, 5000, 90000, 0.5, 180.15),       # strided store (mode 9)
+    (44100.0, 44101.0, 4096, 1500, 60000, 0.5, 180.15),       # ... in front of the polynomial interpolator
+]
+
+
 # Minimum-phase chains (reference fprMinPhase).  Per-call counts must equal the reference's exactly.
 # Samples: the reference derives the filter by a cepstral transform whose result in the deep stop band
 # is set by the rounding noise of ITS fp64 FFT (CDSPRealFFT.h:681-785): two correct evaluations of the
@@ -190,6 +202,8 @@ PAIR_SCALE_CASES = [
     (44100.0, 132300.0, 2048, 2048, 2048 * 4, 10.0, 109.56),
     (44100.0, 96000.0, 4096, 1000, 4096 * 3, 10.0, 109.56),
     (44100.0, 705600.0, 512, 512, 2048, 5.0, 109.56),
+    (44100.0, 88200.0, 4096, 4096, 4096 * 8, 0.5, 180.15),      # split 2x up-sampling form (8192 -> 16384 points)
+    (48000.0, 32000.0, 4096, 3000, 4096 * 8, 0.5, 180.15),      # ... with the strided store
 ]
 
 
@@ -251,11 +265,14 @@ PARK_CASES = [
     (44100.0, 44101.0, 4096, 2.0, 180.15, "ahead"),       # convolver -> polynomial interpolator
     (44100.0, 192000.0, 2048, 2.0, 180.15, "ahead"),      # fused pair -> ring -> convolver -> half-band
     (44100.0, 96000.0, 4096, 10.0, 109.56, "none"),       # 512-point blocks, one phase per thread: as before
+    # 8192 -> 16384-point blocks: the split 2x up-sampling form of the pair kernel (modes 8 / 9)
+    (48000.0, 32000.0, 4096, 0.5, 180.15, "park"),        # re-blocked 8 507-tap filter, strided store
+    (44100.0, 88200.0, 2048, 0.5, 180.15, "park"),
+    (44100.0, 96000.0, 2048, 0.5, 180.15, "ahead"),       # ... in front of the (unfused) interpolator
     # the one-channel fast path (16384-point blocks): at the end of a chain through an output ring of its own and a copy
-    (48000.0, 32000.0, 4096, 0.5, 180.15, "ahead"),       # re-blocked 8 507-tap filter, strided store
-    (44100.0, 88200.0, 2048, 0.5, 180.15, "ahead"),       # 8192 -> 16384 points
+    (48000.0, 16000.0, 8192, 0.5, 180.15, "ahead"),       # re-blocked 8 507-tap filter, 16384 points 1:1, strided store
+    (48000.0, 36000.0, 6000, 0.5, 180.15, "ahead"),       # 3x zero stuffing into 16384 points, decimated by 4
     (176400.0, 44100.0, 16384, 0.5, 180.15, "ahead"),     # half-band decimator + 16384 -> 8192 points (decimating form)
-    (44100.0, 96000.0, 2048, 0.5, 180.15, "ahead"),       # 8192 -> 16384 points fused with the interpolator (output ring)
     (192000.0, 44100.0, 8192, 0.5, 180.15, "ahead"),      # half-band decimator + fused 16384 -> 16384 points
 ]
 PARK_CASES_MINPHASE = [

@@ -264,7 +264,7 @@ template<int LN, int UL, int MODE, int FLENP>
 void emul_convp_t(const ConvxLaunch& X0)
 {
 	ConvxLaunch X = X0;
-	convp_prepare<LN, UL>(X, MODE != 1);
+	convp_prepare<LN, UL>(X, MODE != 1, MODE == 8 || MODE == 9);
 	std::vector<double> lds((size_t) convp_lds_bytes<LN, UL>() / sizeof(double) + 2);
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
@@ -277,6 +277,16 @@ void emul_convp_t(const ConvxLaunch& X0)
 		for (auto& s : ex.st)
 			for (int j = 0; j < 16; j++) s.vr[j] = s.vi[j] = std::numeric_limits<double>::quiet_NaN();
 		convp_body<LN, UL, MODE, FLENP>(ex, X, reinterpret_cast<cd*>(base), convp_item<SUB>(X.c, i));
+	}
+}
+
+template<int LN, int UL>
+void emul_convp_sp(const ConvxLaunch& X, int mode)
+{
+	if constexpr (LN == 13 && UL == 0)
+	{
+		if (mode == 8) emul_convp_t<LN, UL, 8, 24>(X);
+		else emul_convp_t<LN, UL, 9, 24>(X);
 	}
 }
 
@@ -315,7 +325,12 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 		throw std::runtime_error("launch_convp: decimating geometry not instantiated");
 	}
 #define R8B_CONVP_DISPATCH_BIG(LN, UL) \
-	if (ln == LN && up == (1 << UL)) \
+	if (ln == LN && LN == 13 && UL == 0 && (mode == 8 || mode == 9)) \
+	{ \
+		emul_convp_sp<LN, UL>(X, mode); \
+		return; \
+	} \
+	if (ln == LN && up == (1 << UL) && mode != 8 && mode != 9) \
 	{ \
 		if (mode == 3) emul_convp_t<LN, UL, 3, 24>(X); \
 		else if (mode == 6) emul_convp_t<LN, UL, 6, 24>(X); \

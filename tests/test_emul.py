@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES, PARK_CASES_MINPHASE, RMS_TOL,
+from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, SPLIT_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES, PARK_CASES_MINPHASE, RMS_TOL,
                    PEAK_TOL, compare_stream, make_input, check_pair_scales, check_parked_outputs)
 from conftest import ROOT
 
@@ -98,6 +98,28 @@ def test_emulated_long_filters_on_shorter_blocks(emul, refwrap, case):
         pos += l
     r, p = refwrap.batch_check(src, dst, maxin, lens, x, np.concatenate(ys, axis=1), counts, tb, att)
     assert r.max() <= rtol and p.max() <= ptol, (r.max(), p.max())
+
+
+def run_split_form_case(lib_kw, case, split, nch=3):
+    """8192 -> 16384-point blocks on the pair kernel's split 2x up-sampling form (default) and on the one-channel
+    kernel (option pair_split = 0): the same stream to the same tolerance, odd channel count"""
+    src, dst, maxin, chunk, n, tb, att = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, **lib_kw)
+    assert "fft=8192/16384" in b.describe() or "fft=16384/32768" in b.describe(), b.describe()
+    b.set_option("pair_split", split)
+    b.set_option("timing", 1)
+    names = [t[0] for t in b.stage_timings()]
+    assert any(t.startswith("k_convp") for t in names) == bool(split), names
+    assert any(t.startswith("k_convx") for t in names) == (not split), names
+    b.set_option("timing", 0)
+    r, p = compare_stream(b, src, dst, maxin, chunk, n, tb, att, nch)
+    assert r <= RMS_TOL and p <= PEAK_TOL, (r, p)
+
+
+@pytest.mark.parametrize("split", [1, 0])
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_emulated_split_upsampling_form(emul, case, split):
+    run_split_form_case({"lib": emul}, case, split)
 
 
 MINPHASE_PAIR_TOPOLOGIES = [(44100.0, 96000.0, 2.0, 180.15), (96000.0, 44100.0, 5.0, 109.56),

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES,
+from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, SPLIT_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES,
                    PARK_CASES_MINPHASE, RMS_TOL, PEAK_TOL, compare_stream, make_input, check_pair_scales,
                    check_parked_outputs)
 from conftest import rms, peak
@@ -266,6 +266,15 @@ def test_hip_short_filters_in_block_groups(torch, case, nch):
     b.set_option("timing", 0)
     r, p = compare_stream(b, src, dst, maxin, chunk, n, tb, att, nch)
     assert r <= RMS_TOL and p <= PEAK_TOL, (r, p)
+
+
+@pytest.mark.parametrize("split", [1, 0])
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_hip_split_upsampling_form(torch, case, split):
+    """8192 -> 16384-point blocks: the pair kernel's split 2x up-sampling form (modes 8 / 9) and the one-channel
+    kernel behind option pair_split = 0, each against the oracle"""
+    from test_emul import run_split_form_case
+    run_split_form_case({"device": 0}, case, split, nch=5)
 
 
 @pytest.mark.parametrize("case", REBLOCK_CASES)

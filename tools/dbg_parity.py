@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/dbg_parity.py <src> <dst> <nch> <L> <calls> : HIP path (R8B_HIP_LIB honoured) vs the oracle on a few channels"""
+"""tools/dbg_parity.py <src> <dst> <nch> <L> <calls> [opt=v ...] : HIP path (R8B_DBG_TB = transition band, default 2; (R8B_HIP_LIB honoured) vs the oracle on a few channels"""
 import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,11 +8,12 @@ import torch
 r8b = importlib.import_module("r8brain-free-src_amd")
 import r8b_oracle as O
 src, dst, nch, L, calls = float(sys.argv[1]), float(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
-rs = r8b.BatchResampler(src, dst, L, 2.0, 180.15, nch=nch, device=0)
+TB = float(os.environ.get("R8B_DBG_TB", "2.0"))
+rs = r8b.BatchResampler(src, dst, L, TB, 180.15, nch=nch, device=0)
 for o in sys.argv[6:]:
     k, v = o.split("="); rs.set_option(k, int(v))
 chk = sorted(set([0, 1, nch // 2, nch - 1]))
-orc = {c: O.OracleResampler(src, dst, L, 2.0, 180.15) for c in chk}
+orc = {c: O.OracleResampler(src, dst, L, TB, 180.15) for c in chk}
 x = np.stack([O.splitmix_uniform(1 + c, L * calls) for c in range(nch)])
 worst = 0.0
 for i in range(calls):

@@ -10,12 +10,14 @@ import refwrap as R
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 rng = np.random.default_rng(seed)
+# (R8B_FUZZ_TB=lo,hi narrows the transition band range: 0.5,0.62 = the 8192 -> 16384-point blocks of the split form)
+TB = [float(v) for v in os.environ.get("R8B_FUZZ_TB", "0.5,45").split(",")]
 emul = T.r8b.bind(os.path.join(ROOT, "tests", "emul", "_build", "libr8bsrc_emul.so"))
 bad = skipped = known = known32 = 0
 geoms = {}
 for i, c in enumerate(T._cases(n, seed)):
     src, dst, maxin, _, _, s = c
-    tb = float(np.round(np.exp(rng.uniform(np.log(0.5), np.log(45.0))), 2))
+    tb = float(np.round(np.exp(rng.uniform(np.log(TB[0]), np.log(TB[1]))), 2))
     att = float(np.round(rng.uniform(49.0, 218.0), 2))
     case = (src, dst, maxin, tb, att, s)
     try:
