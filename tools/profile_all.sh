@@ -61,4 +61,6 @@ prof down2 --src 88200 --dst 44100
 prof ir16 --src 44100 --dst 96000 --atten 109.56
 prof tb10 --src 44100 --dst 96000 --tb 10 --atten 109.56
 prof r23 --src 48000 --dst 32000
+prof split --src 44100 --dst 88200 --tb 0.5
+prof split23 --src 48000 --dst 32000 --tb 0.5
 ls $out/*
