@@ -175,6 +175,11 @@ R8B_HD SwBase sw_base(const cd* buf, int slot0)
 	b.a = (unsigned) (size_t) (const lds_cd_t*) buf + ((unsigned) slot0 << 4);
 	return b;
 }
+// (the element as ONE 16-byte access -- ds_read_b128 / ds_write_b128 -- by its type: left to the compiler's merging of
+// the two 8-byte halves some phases came out as pairs of ds_read_b64, which the swizzle is not conflict free for)
+typedef double lds_d2_t __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) lds_d2_t lds_d2a_t;
+#ifdef R8B_LDS_STRUCT_ACCESS // (development A/B: the element accessed as the struct it is, merging left to the compiler)
 R8B_HD cd sw_ld(SwBase b, int m)
 {
 	return *(const lds_cd_t*) (size_t) ((b.a ^ (unsigned) (sw_xc(m) << 4)) + (unsigned) (sw_hi(m) << 4));
@@ -183,6 +188,23 @@ R8B_HD void sw_st(SwBase b, int m, cd v)
 {
 	*(lds_cd_t*) (size_t) ((b.a ^ (unsigned) (sw_xc(m) << 4)) + (unsigned) (sw_hi(m) << 4)) = v;
 }
+#else
+R8B_HD cd sw_ld(SwBase b, int m)
+{
+	const lds_d2_t t = *(const lds_d2a_t*) (size_t) ((b.a ^ (unsigned) (sw_xc(m) << 4)) + (unsigned) (sw_hi(m) << 4));
+	cd v;
+	v.re = t.x;
+	v.im = t.y;
+	return v;
+}
+R8B_HD void sw_st(SwBase b, int m, cd v)
+{
+	lds_d2_t t;
+	t.x = v.re;
+	t.y = v.im;
+	*(lds_d2a_t*) (size_t) ((b.a ^ (unsigned) (sw_xc(m) << 4)) + (unsigned) (sw_hi(m) << 4)) = t;
+}
+#endif
 #else
 struct SwBase { char* p; int bb; };
 R8B_HD SwBase sw_base(const cd* buf, int slot0)
@@ -514,6 +536,94 @@ R8B_HD void cp_tail_owned(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 			ra[e] = st.pr[p];
 			if (bvalid) rb[e] = st.pi[p];
 		}
+	}
+}
+
+// ---- one-channel form (modes 10 / 11; geometry <13, 0>: 16384-point blocks of ONE channel) ------------------------
+// A block whose transforms are 16384 real points does not fit a pair's array twice (256 KB); it runs on the 8192-point
+// 1:1 geometry as ONE channel in the classic packing z[n] = x[2n] + i x[2n+1]: element i of the circular array holds
+// samples 2i, 2i + 1 of the 16384-sample circular block.  (cp_solo_mid_a / _b: what the spectrum needs for that.)
+// K1 of the one-channel form: a wave reads 128 consecutive samples per load
+template<int LN, int UL, int MODE = 0>
+R8B_HD void cp_load_solo(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, int ch, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int R = G::E1, q = G::N / R, NR = 2 * G::N;
+	if constexpr (MODE == 3)
+	{
+		// 3x zero stuffing folded into the load, as in cp_load
+		if (!L.up_pow2)
+		{
+			const long long base_v = k * (long long) L.blk_stride + L.blk_offset;
+			const long long B = base_v / L.up;
+			const int bm = (int) (base_v - B * L.up);
+			const int bias = L.up * (NR / L.up + 2);
+			const SrcBlock sa = src_block(L.src, ch, B);
+#pragma unroll
+			for (int p = 0; p < R; p++)
+			{
+				const int e = 2 * (lt + p * q);
+				st.pr[p] = cx_stuffed_sample(sa, L.up, bm, e < L.in_len ? e : e - NR, bias);
+				st.pi[p] = cx_stuffed_sample(sa, L.up, bm, e + 1 < L.in_len ? e + 1 : e + 1 - NR, bias);
+			}
+			return;
+		}
+	}
+	// (in_len is even -- convp_solo_ok --: a pair of samples never straddles the block's seam)
+	const int iln = L.in_len;
+	const long long base = k * (long long) L.blk_stride + L.blk_offset;
+	// Real element e holds sample base + rel((e + 2 rot) mod 2N), rel(j) = j < iln ? j : j - 2N: the 2N consecutive
+	// samples base - (2N - iln) ... base + iln - 1, samples 2w, 2w + 1 of that window at element (w - wr) mod N
+	const int wr = (L.rot + G::N - iln / 2) & (G::N - 1);
+	if (L.src.cur_fmt == kPcmF64 && base - (NR - iln) >= L.src.cur_base && base - (NR - iln) >= 0)
+	{
+		const long long w0 = base - (NR - iln) - L.src.cur_base;
+		const double* const pa = L.src.cur + ((long long) ch * L.src.cur_stride + w0);
+		const unsigned l0 = (unsigned) (lt + wr);
+#pragma unroll
+		for (int p = 0; p < R; p++)
+		{
+			const unsigned w = (l0 + (unsigned) (p * q)) & (unsigned) (G::N - 1);
+			st.pr[p] = pa[2u * w];
+			st.pi[p] = pa[2u * w + 1u];
+		}
+		return;
+	}
+	const SrcBlock sa = src_block(L.src, ch, base);
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		const int e = 2 * ((lt + p * q + L.rot) & (G::N - 1));
+		const int rel = e < iln ? e : e - NR;
+		st.pr[p] = src_block_load1(sa, rel);
+		st.pi[p] = src_block_load1(sa, rel + 1);
+	}
+}
+
+// ... and its cp_tail_owned: the window is 2N samples, the thread's registers hold samples 2w, 2w + 1 of it
+template<int LN, int UL>
+R8B_HD void cp_tail_owned_solo(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int ch, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int R = G::E1, q = G::N / R, NR = 2 * G::N;
+	if (k < L.k0 + L.tail_bf) return;
+	const int iln = L.in_len;
+	const long long base = k * (long long) L.blk_stride + L.blk_offset;
+	const long long nbase = (k + 1) * (long long) L.blk_stride + L.blk_offset;
+	const long long lo = k == L.k0 + L.tail_bf || base < L.tail_c0 ? L.tail_c0 : base;
+	const long long hi = k == L.k0 + L.nblk - 1 || nbase > L.tail_c1 ? L.tail_c1 : nbase;
+	if (lo >= hi) return;
+	const long long w0 = base - (NR - iln);
+	const unsigned lo_r = (unsigned) (lo - w0), n_r = (unsigned) (hi - lo);
+	const unsigned m = (unsigned) L.src.ring_mask, w0m = (unsigned) (w0 & L.src.ring_mask);
+	double* const ra = L.tail_ring + (long long) ch * L.src.ring_stride;
+	const unsigned l0 = (unsigned) (lt + ((L.rot + G::N - iln / 2) & (G::N - 1)));
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		const unsigned w = 2u * ((l0 + (unsigned) (p * q)) & (unsigned) (G::N - 1));
+		if (w - lo_r < n_r) ra[(w0m + w) & m] = st.pr[p];
+		if (w + 1u - lo_r < n_r) ra[(w0m + w + 1u) & m] = st.pi[p];
 	}
 }
 
@@ -972,6 +1082,156 @@ R8B_HD void cp_sp_swap(ConvpState<LN, UL>& st)
 	for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
 }
 
+// ---- one-channel form, the spectrum (modes 10 / 11) ---------------------------------------------------------------
+// With z[n] = x[2n] + i x[2n+1], Z = DFT_N(z), N = 8192: the spectrum of the even samples is E = (Z[k] + conj Z[N-k]) / 2,
+// that of the odd ones O = (Z[k] - conj Z[N-k]) / 2i, the block's 2N-point spectrum X[k] = E + w^k O, X[k+N] = E - w^k O,
+// w = e^{-i pi / N}.  Multiplying by the (real, symmetric) kernel spectrum H and packing the result the same way --
+// y[2m] + i y[2m+1] = IDFT_N(Z'), Z' = (Y[k] + Y[k+N]) + i w^-k (Y[k] - Y[k+N]) for the unnormalised 2N-point transform --
+// collapses into
+//     Z'[k] = a[k] Z[k] + i b[k] conj(Z[N-k]),
+//     a = (H[k] + H[k+N]) - (H[k] - H[k+N]) sin(pi k / N),   b = (H[k] - H[k+N]) cos(pi k / N):
+// two REAL constants per bin (hp[c * NT + lt] = (a, b) of forward position 16 lt + c; Engine: pair_constants_solo) and
+// the partner bin N - k.  Thread lt owns forward positions 16 lt + c, bins k = bitrev4(c) 512 + bitrev9(lt); bin N - k
+// sits at position 16 lt' + 15 - c, lt' = bitrev9(512 - bitrev9(lt)) -- thread 0 is its own partner with the positions
+// permuted --, in another wave: the spectrum goes through the array once (cp_solo_mid_a writes it back, a workgroup
+// barrier, cp_solo_mid_b reads the partners' values; another barrier before the backward side overwrites them).
+// The rest -- passes, rotation, stores -- is the pair kernel's, with the two "channels" of an element being the even
+// and the odd sample.  Replaces the one-channel kernel k_convx (12 barrier phases, 3.4x the time per block).
+template<int LN, int UL>
+R8B_HD void cp_solo_mid_a(cd* buf, ConvpState<LN, UL>& st, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	static_assert((UL == 0 || UL == -1) && G::E1 == 16 && G::POST && G::NT == 512,
+		"one-channel form: the 8192-point 1:1 geometry and its 2x decimating one");
+	const SwBase bbf = sw_base(buf, fslot<LN, UL>(16 * lt));
+#pragma unroll
+	for (int c = 0; c < 16; c++)
+	{
+		const cd v = sw_ld(bbf, fmap_c<LN, UL>(c));
+		st.vr[c] = v.re;
+		st.vi[c] = v.im;
+	}
+#pragma unroll
+	for (int f = 0; f < G::NBF; f++) dif_regs<G::RM>(st.vr + G::RM * f, st.vi + G::RM * f);
+#pragma unroll
+	for (int c = 0; c < 16; c++)
+	{
+		cd v;
+		v.re = st.vr[c];
+		v.im = st.vi[c];
+		sw_st(bbf, fmap_c<LN, UL>(c), v);
+	}
+}
+template<int LN, int UL>
+R8B_HD void cp_solo_mid_b(const cd* buf, ConvpState<LN, UL>& st, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	const int lp = bitrev_n((512 - bitrev_n(lt, 9)) & 511, 9);
+	const SwBase bp = sw_base(const_cast<cd*>(buf), fslot<LN, UL>(16 * lp));
+	double qr[16], qi[16];
+#pragma unroll
+	for (int c = 0; c < 16; c++)
+	{
+		const cd v = sw_ld(bp, fmap_c<LN, UL>(15 - c));
+		qr[c] = v.re;
+		qi[c] = v.im;
+	}
+	if (lt == 0)
+	{
+		// (bins b 512: partner (16 - b) 512, among the thread's own values)
+#pragma unroll
+		for (int c = 0; c < 16; c++)
+		{
+			constexpr int kRev[16] = { 0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15 };
+			const int cp = kRev[(16 - kRev[c]) & 15];
+			qr[c] = st.vr[cp];
+			qi[c] = st.vi[cp];
+		}
+	}
+#pragma unroll
+	for (int c = 0; c < 16; c++)
+	{
+		const double a = st.hp[c].re, b = st.hp[c].im;
+		const double zr = st.vr[c], zi = st.vi[c];
+		// a Z + i b conj(Q)
+		st.vr[c] = a * zr + b * qi[c];
+		st.vi[c] = a * zi + b * qr[c];
+	}
+#pragma unroll
+	for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
+}
+
+// ... decimating by 2 in the spectrum (geometry <13, -1>: 16384 -> 8192 real points; reference CDSPBlockConvolver.h:329-344):
+// the output block's spectrum is Y[k] = H[k] X[k] for k < N2 = 4096 and the reference's real fix-up value at the new
+// Nyquist bin, Y[N2] = H[N2] (Re X[N2] + Im X[N2]); packed for the N2-point backward transform,
+//     Z'[k] = Y[k] (1 + g) + conj(Y[j]) (1 - g),   j = N2 - k,   g = i e^{+2 pi i k / 8192}.
+// X[k] takes Z[k] and Z[N - k], X[j] takes Z[j] and Z[N - j] = Z[N2 + k]: of the thread's sixteen forward positions the
+// even ones c are the kept bins k (backward position 8 lt + c / 2), c + 1 holds Z[N2 + k], and the partner thread's
+// positions 15 - c and 14 - c hold Z[N - k] and Z[N2 - k].  hp[c * NT + lt], c even: (H[k], H[j]); c + 1: (cos, sin) of
+// 2 pi k / 16384 (Engine: pair_constants_solo_down).
+template<int LN, int UL>
+R8B_HD void cp_solo_mid_b_down(const cd* buf, ConvpState<LN, UL>& st, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	static_assert(UL == -1 && G::E1 == 16 && G::E2 == 8 && G::POST && G::NT == 512,
+		"one-channel form, decimating: the 8192 -> 4096-point geometry");
+	const int lp = bitrev_n((512 - bitrev_n(lt, 9)) & 511, 9);
+	const SwBase bp = sw_base(const_cast<cd*>(buf), pswz(16 * lp));
+	double qr[16], qi[16];
+#pragma unroll
+	for (int c = 0; c < 16; c++)
+	{
+		const cd v = sw_ld(bp, c);
+		qr[c] = v.re;
+		qi[c] = v.im;
+	}
+	double yr[8], yi[8];
+#pragma unroll
+	for (int e = 0; e < 8; e++)
+	{
+		constexpr int kRev[16] = { 0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15 };
+		const int c = 2 * e;
+		const double pr = st.vr[c], pi = st.vi[c], sr = st.vr[c + 1], si = st.vi[c + 1];
+		double ar = qr[15 - c], ai = qi[15 - c], rr = qr[14 - c], ri = qi[14 - c]; // Z[N - k], Z[N2 - k]
+		if (lt == 0)
+		{
+			// (bins b 512: the partners are among the thread's own values)
+			ar = st.vr[kRev[(16 - kRev[c]) & 15]];
+			ai = st.vi[kRev[(16 - kRev[c]) & 15]];
+			rr = st.vr[kRev[(8 - kRev[c]) & 15]];
+			ri = st.vi[kRev[(8 - kRev[c]) & 15]];
+		}
+		const double hk = st.hp[c].re, hj = st.hp[c].im, cs = st.hp[c + 1].re, sn = st.hp[c + 1].im;
+		// X[k] = E + w^k O: E = (P + conj A) / 2, O = -i (P - conj A) / 2, w^k = cs - i sn
+		const double er = 0.5 * (pr + ar), ei = 0.5 * (pi - ai), o_r = 0.5 * (pi + ai), oi = -0.5 * (pr - ar);
+		const double xr = er + cs * o_r + sn * oi, xi = ei + cs * oi - sn * o_r;
+		// X[j]: E = (R + conj S) / 2, O = -i (R - conj S) / 2, w^j = sn - i cs
+		const double fr = 0.5 * (rr + sr), fi = 0.5 * (ri - si), p_r = 0.5 * (ri + si), p_i = -0.5 * (rr - sr);
+		const double ur = fr + sn * p_r + cs * p_i, ui = fi + sn * p_i - cs * p_r;
+		const double ykr = hk * xr, yki = hk * xi;
+		double yjr = hj * ur, yji = hj * ui;
+		if (lt == 0 && e == 0)
+		{
+			// the new Nyquist bin: the reference's real fix-up value
+			yjr = hj * (ur + ui);
+			yji = 0.0;
+		}
+		// g = i (cs + i sn)^2; Z' = Y[k] (1 + g) + conj(Y[j]) (1 - g)
+		const double gr = -2.0 * cs * sn, gi = cs * cs - sn * sn;
+		const double m_r = 1.0 + gr, n_r = 1.0 - gr;
+		yr[e] = ykr * m_r - yki * gi + yjr * n_r - yji * gi;
+		yi[e] = ykr * gi + yki * m_r - yjr * gi - yji * n_r;
+	}
+#pragma unroll
+	for (int e = 0; e < 8; e++)
+	{
+		st.vr[e] = yr[e];
+		st.vi[e] = yi[e];
+	}
+#pragma unroll
+	for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
+}
+
 // ---- decimating form (UL < 0) -------------------------------------------------------------------------
 // The reference decimates by 2^d in the spectrum (CDSPBlockConvolver.h:329-344): the backward transform has
 // N2 = N / D points and keeps the bins below the new Nyquist frequency, k < N2/2 and k > N - N2/2 -- in the
@@ -1198,6 +1458,41 @@ R8B_HD void cp_store_conv_down(const ConvLaunch& L, const ConvpState<LN, UL>& st
 	}
 }
 
+// ... of the one-channel form: the thread's element p is (y[2 i], y[2 i + 1]) of the decimated block, i = lt + NT p
+template<int LN, int UL>
+R8B_HD void cp_solo_store_down(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int ch, int lt,
+	const DstView& pd, long long pend)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int mask = 2 * G::N2 - 1;
+	const int fl2 = L.fl2 >> G::DL, n = L.in_len >> G::DL;
+	const long long q0 = ((k * (long long) L.blk_stride + L.blk_offset) >> G::DL) - fl2;
+	auto run = [&](const CpStoreView& v)
+	{
+		const bool al = ((v.qoff + (unsigned) fl2) & 1u) == 0 && v.fmt == kPcmF64 && (v.m & 1u) != 0 &&
+			(reinterpret_cast<unsigned long long>(v.pa) & 15ull) == 0;
+#pragma unroll
+		for (int p = 0; p < G::E2; p++)
+		{
+			const unsigned iE = (unsigned) ((2 * (lt + G::NT * p) + fl2) & mask), iO = (unsigned) ((iE + 1u) & mask);
+			if (al && iO == iE + 1 && iE - v.ulo < v.uhi - v.ulo && iO < v.uhi)
+			{
+				cd va;
+				va.re = st.vr[p];
+				va.im = st.vi[p];
+				R8B_OUT_STORE16(v.pa + ((v.qoff + iE) & v.m), va);
+			}
+			else
+			{
+				cp_store1(v, iE, st.vr[p], 0.0, false);
+				cp_store1(v, iO, st.vi[p], 0.0, false);
+			}
+		}
+	};
+	run(cp_store_view(L.dst, ch, ch, q0, L.a, L.b, n));
+	if (pend > L.b) run(cp_store_view(pd, ch, ch, q0, L.b, pend, n));
+}
+
 // MODE 1: the block's valid outputs as one linear run of (A, B) pairs, y[u] = outputs at time t0 + u
 template<int LN, int UL>
 R8B_HD void cp_final_store(const ConvLaunch& L, cd* ybase, cd* y, const ConvpState<LN, UL>& st, long long k, int lt)
@@ -1323,9 +1618,10 @@ R8B_HD void cp_store_conv(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 
 // split 2x up-sampling form: the even half's outputs sit in st.er / st.ei (E[i] = y at circular position 2 (lt + NT i)),
 // the odd half's in st.vr / st.vi (that position + 1); MODE 3: with the 3x strided store (output q at virtual time 3 q)
+// (ea / oa, eb / ob: the even and odd outputs of channels A and B -- the one-channel form passes its single channel's)
 template<int LN, int UL, int MODE>
-R8B_HD void cp_sp_store(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int chA, int chB, bool bvalid,
-	int lt, const DstView& pd, long long pend)
+R8B_HD void cp_sp_store(const ConvLaunch& L, const double* ea, const double* oa, const double* eb, const double* ob,
+	long long k, int chA, int chB, bool bvalid, int lt, const DstView& pd, long long pend)
 {
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int mask = 2 * G::N - 1;
@@ -1350,7 +1646,7 @@ R8B_HD void cp_sp_store(const ConvLaunch& L, const ConvpState<LN, UL>& st, long 
 						const unsigned w = r0 + u;
 						const unsigned wq = down == 3u ? w / 3u : w / down;
 						if (u < (unsigned) L.in_len && wq * down == w)
-							cp_store1(v, wq, h ? st.vr[i] : st.er[i], h ? st.vi[i] : st.ei[i], bvalid);
+							cp_store1(v, wq, h ? oa[i] : ea[i], h ? ob[i] : eb[i], bvalid);
 					}
 				}
 			};
@@ -1376,15 +1672,15 @@ R8B_HD void cp_sp_store(const ConvLaunch& L, const ConvpState<LN, UL>& st, long 
 			{
 				const unsigned e = (v.qoff + iE) & v.m;
 				cd va, vb;
-				va.re = st.er[i]; va.im = st.vr[i];
-				vb.re = st.ei[i]; vb.im = st.vi[i];
+				va.re = ea[i]; va.im = oa[i];
+				vb.re = eb[i]; vb.im = ob[i];
 				R8B_OUT_STORE16(v.pa + e, va);
 				if (bvalid) R8B_OUT_STORE16(v.pb + e, vb);
 			}
 			else
 			{
-				cp_store1(v, iE, st.er[i], st.ei[i], bvalid);
-				cp_store1(v, iO, st.vr[i], st.vi[i], bvalid);
+				cp_store1(v, iE, ea[i], eb[i], bvalid);
+				cp_store1(v, iO, oa[i], ob[i], bvalid);
 			}
 		}
 	};
@@ -1683,7 +1979,11 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	constexpr bool CX = MODE == 6 || MODE == 7;
 	// modes 8 / 9: modes 0 / 3 of the split 2x up-sampling form (cp_sp_*: geometry <13, 0> only)
 	constexpr bool SP = MODE == 8 || MODE == 9;
-	constexpr int BM = MODE == 6 ? 0 : (MODE == 7 ? 3 : (MODE == 8 ? 0 : (MODE == 9 ? 3 : MODE)));
+	// modes 10 / 11: modes 0 / 3 of the one-channel form (cp_solo_*: geometry <13, 0> only; cur.chA is the channel,
+	// cur.bvalid false)
+	constexpr bool SOLO = MODE == 10 || MODE == 11;
+	constexpr int BM = MODE == 6 ? 0 : (MODE == 7 ? 3 : (MODE == 8 ? 0 : (MODE == 9 ? 3 : (MODE == 10 ? 0 :
+		(MODE == 11 ? 3 : MODE)))));
 	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
 	constexpr bool SPLIT = kSplit<LN, UL> && !CX && (BM == 0 || BM == 3);
 	(void) SPLIT;
@@ -1694,7 +1994,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	// (they take part in every barrier) and store nothing
 	auto hp_prefetch = [&](St& st, int lt)
 	{
-		if constexpr (SP) cp_sp_hp_prefetch<LN, UL>(L, st, lt);
+		if constexpr (SOLO) { (void) st; (void) lt; } // (fetched behind the spectrum's write: cp_solo_mid_a)
+		else if constexpr (SP) cp_sp_hp_prefetch<LN, UL>(L, st, lt);
 		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
 	};
 	auto sub_of = [&](int tid) { return convp_sub<LN, UL>(tid); };
@@ -1720,7 +2021,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		// (the first pass's twiddles -- L2 -- requested ahead of the samples -- HBM --, not behind their wait)
 		ptw_fetch_lean<G::E1, G::NT>(st.tw, L.ptw, 0, lt);
 		ex.stamp2();
-		cp_load<LN, UL, BM, SP>(L, st, k_of(tid), chA, chB, lt);
+		if constexpr (SOLO) cp_load_solo<LN, UL, BM>(L, st, k_of(tid), chA, lt);
+		else cp_load<LN, UL, BM, SP>(L, st, k_of(tid), chA, chB, lt);
 		if ((L.tail_flags & 2) != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) > L.k0 + L.tail_bf)
 		{
 			// (the launch's last block: the samples behind its window -- read by no block of this call -- requested
@@ -1728,7 +2030,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			if ((L.tail_flags & 8) == 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) == L.k0 + L.nblk)
 				cp_tail_rest<G::WT>(L, L.tail_c1, L.tail_p1, chA, chB, bvalid, tid);
 			ex.stamp2();
-			if (live(tid)) cp_tail_owned<LN, UL, SP>(L, st, k_of(tid), chA, chB, bvalid, lt);
+			if constexpr (SOLO) cp_tail_owned_solo<LN, UL>(L, st, k_of(tid), chA, lt);
+			else if (live(tid)) cp_tail_owned<LN, UL, SP>(L, st, k_of(tid), chA, chB, bvalid, lt);
 		}
 		if constexpr (MODE != 1)
 		{
@@ -1841,6 +2144,27 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		// geometry where the last but one does not -- 8192 points decimated by 4 -- takes a barrier more)
 		static_assert(G::NPOST < 5 || G::N2 / G::E2 > 64 * G::E2, "pass plan");
 		static_assert(G::NPOST == 5 || G::NW == 1 || G::N2 / G::E2 <= 64 * G::E2, "pass plan");
+		if constexpr (SOLO)
+		{
+			// one-channel form: the spectrum through the array for the partner bins, a barrier either side of their reads
+			static_assert(G::NPOST == 3, "one-channel form: pass plan of the 8192-point geometries");
+			auto q_mida = [&](int tid, St& st)
+			{
+				const int lt = lt_of(tid);
+				cp_solo_mid_a<LN, UL>(buf_of(tid), st, lt);
+				cp_sp_hp_prefetch<LN, UL>(L, st, lt);
+			};
+			ex.wave_steps(d_pre1, d_pre2, q_mida);
+			ex.phase([&](int tid, St& st)
+			{
+				const int lt = lt_of(tid);
+				if constexpr (UL < 0) cp_solo_mid_b_down<LN, UL>(buf_of(tid), st, lt);
+				else cp_solo_mid_b<LN, UL>(buf_of(tid), st, lt);
+				ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
+			});
+			ex.wave_steps(d_midw, d_post1, d_post2);
+		}
+		else
 		ex.wave_steps(d_pre1, d_pre2, d_midc, d_midw, d_post1, d_post2, d_post3);
 		if constexpr (G::NPOST > 4) ex.wave_steps(d_post4);
 		if constexpr (SP)
@@ -2005,7 +2329,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
 			cp_tail_slice_store(L, st, chA, chB, bvalid);
 			ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
-			const unsigned nzb = ex.collect_bits();
+			unsigned nzb = ex.collect_bits();
+			// (one-channel form: the element's two parts are one channel's samples)
+			if constexpr (SOLO) nzb = nzb != 0 ? 3u : 0u;
 			cp_silence<LN, UL>(st, nzb);
 			if constexpr (SP)
 			{
@@ -2025,7 +2351,11 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				DstView pd = L.dst;
 				long long pend = L.b;
 				cp_park_view(ex, XM, st, k_of(tid), cur, pd, pend);
-				if constexpr (SP) cp_sp_store<LN, UL, BM>(L, st, k_of(tid), chA, chB, bvalid, lt, pd, pend);
+				if constexpr (SOLO && UL < 0) cp_solo_store_down<LN, UL>(L, st, k_of(tid), chA, lt, pd, pend);
+				else if constexpr (SOLO)
+					cp_sp_store<LN, UL, BM>(L, st.vr, st.vi, st.vr, st.vi, k_of(tid), chA, chB, false, lt, pd, pend);
+				else if constexpr (SP)
+					cp_sp_store<LN, UL, BM>(L, st.er, st.vr, st.ei, st.vi, k_of(tid), chA, chB, bvalid, lt, pd, pend);
 				else if constexpr (UL < 0) cp_store_conv_down<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt, pd, pend);
 				else cp_store_conv<LN, UL, BM>(L, st, k_of(tid), chA, chB, bvalid, lt, pd, pend);
 			}
@@ -2151,15 +2481,31 @@ inline void convp_tail_owners(ConvLaunch& L)
 // (slices: the kernel shares the parked outputs' copy-back and the history tail's rest among the pair's workgroups --
 // every mode but 1)
 // (spu: the split 2x up-sampling form on a 1:1 geometry -- modes 8 / 9)
+// (solo: the one-channel form on that geometry -- modes 10 / 11: the window is 2N samples, rotated by pairs)
 template<int LN, int UL>
-inline void convp_prepare(ConvxLaunch& X, bool slices = true, bool spu = false)
+inline void convp_prepare(ConvxLaunch& X, bool slices = true, bool spu = false, bool solo = false)
 {
 	X.c.rot = 0;
 	X.c.fl2r = X.c.fl2;
 	X.c.tail_flags = X.c.tail_ring != nullptr ? 1 : 0;
 	X.c.tail_bf = 0;
 	X.c.tail_c0 = X.c.tail_c1 = 0;
-	if (spu)
+	if (solo && UL < 0)
+	{
+		// (decimation in the spectrum: no rotation)
+		if (X.c.up == 1 && (X.c.in_len & 1) == 0) convp_tail_owners<2 * ConvpGeom<LN, UL>::N, 0>(X.c);
+	}
+	else if (solo)
+	{
+		if (UL == 0 && X.c.up_pow2 && X.c.up == 1 && (X.c.in_len & 1) == 0)
+		{
+			constexpr int N = ConvpGeom<LN, UL>::N;
+			X.c.rot = (N - ((X.c.fl2 / 2) & (N - 1))) & (N - 1);
+			X.c.fl2r = X.c.fl2 % 2;
+			convp_tail_owners<2 * N, 0>(X.c);
+		}
+	}
+	else if (spu)
 	{
 		if (UL == 0 && X.c.up_pow2 && X.c.up == 2)
 		{
@@ -2199,8 +2545,9 @@ inline void convp_prepare(ConvxLaunch& X, bool slices = true, bool spu = false)
 }
 
 // workgroup i of a launch, pair major: the block groups of one channel pair are consecutive
+// (solo: the one-channel form -- item pr is channel pr)
 template<int SUB>
-R8B_HD ConvpItem convp_item(const ConvLaunch& L, long long i)
+R8B_HD ConvpItem convp_item(const ConvLaunch& L, long long i, bool solo = false)
 {
 	ConvpItem it;
 	const int nbg = (L.nblk + SUB - 1) / SUB;
@@ -2208,8 +2555,8 @@ R8B_HD ConvpItem convp_item(const ConvLaunch& L, long long i)
 	const int b0 = (int) (i - (long long) pr * nbg) * SUB;
 	it.k = L.k0 + b0;
 	it.nvalid = L.nblk - b0 < SUB ? L.nblk - b0 : SUB;
-	it.chA = 2 * pr;
-	it.bvalid = it.chA + 1 < L.nch;
+	it.chA = solo ? pr : 2 * pr;
+	it.bvalid = !solo && it.chA + 1 < L.nch;
 	it.chB = it.bvalid ? it.chA + 1 : it.chA;
 	return it;
 }

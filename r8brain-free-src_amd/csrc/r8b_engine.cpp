@@ -400,6 +400,59 @@ std::vector<double> pair_constants_split(const std::vector<double>& H, int n_in)
 	return out;
 }
 
+std::vector<double> pair_constants_solo(const std::vector<double>& H, int n)
+{
+	const int N = n, NT = N / 16, NH = 2 * N;
+	int ln = 0;
+	while ((1 << ln) < N) ln++;
+	auto Hf = [&](int m) -> long double { return H[(size_t) (m <= NH / 2 ? m : NH - m)]; };
+	auto rev = [](int v, int bits)
+	{
+		int r = 0;
+		for (int b = 0; b < bits; b++)
+			if (v & (1 << b)) r |= 1 << (bits - 1 - b);
+		return r;
+	};
+	const long double pi = 3.14159265358979323846264338327950288L;
+	std::vector<double> out((size_t) 16 * NT * 2, 0.0);
+	for (int t = 0; t < NT; t++)
+		for (int c = 0; c < 16; c++)
+		{
+			const int k = rev(16 * t + c, ln);
+			const long double hs = Hf(k) + Hf(k + N), hd = Hf(k) - Hf(k + N), th = pi * k / N;
+			out[((size_t) c * NT + t) * 2] = (double) (hs - hd * sinl(th));
+			out[((size_t) c * NT + t) * 2 + 1] = (double) (hd * cosl(th));
+		}
+	return out;
+}
+
+std::vector<double> pair_constants_solo_down(const std::vector<double>& H, int n)
+{
+	const int N = n, NT = N / 16, N2 = N / 2;
+	int ln = 0;
+	while ((1 << ln) < N) ln++;
+	auto rev = [](int v, int bits)
+	{
+		int r = 0;
+		for (int b = 0; b < bits; b++)
+			if (v & (1 << b)) r |= 1 << (bits - 1 - b);
+		return r;
+	};
+	const long double pi = 3.14159265358979323846264338327950288L;
+	std::vector<double> out((size_t) 16 * NT * 2, 0.0);
+	for (int t = 0; t < NT; t++)
+		for (int c = 0; c < 16; c += 2)
+		{
+			const int k = rev(16 * t + c, ln); // (< N2: the lowest bit of c is the highest of k)
+			const long double th = pi * k / N;
+			out[((size_t) c * NT + t) * 2] = H[(size_t) k];
+			out[((size_t) c * NT + t) * 2 + 1] = H[(size_t) (N2 - k)];
+			out[((size_t) (c + 1) * NT + t) * 2] = (double) cosl(th);
+			out[((size_t) (c + 1) * NT + t) * 2 + 1] = (double) sinl(th);
+		}
+	return out;
+}
+
 // The same with a complex kernel spectrum Hc (bl2/2 + 1 complex bins, Hermitian beyond): one complex value
 // per entry (r8b_convp.h cp_hp_prefetch, CX) -- 1:1: H of backward position 16 t + c; 2x up: Hs (c < 8) / Hd
 // (c >= 8) of forward position 8 t + (c & 7); decimating: H of the thread's kept position c.
@@ -614,7 +667,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// ... with two adjacent phases per thread in the fused interpolator when it up-samples (In <= Out:
 	// half the LDS reads per output, nearly all lanes busy)
 	opt_["pair_two"] = 1;
-	opt_["pair_split"] = 1; // 8192 -> 16384-point 2x up-sampling blocks on the pair kernel's split form (else k_convx)
+	opt_["pair_split"] = 1;
+	opt_["pair_solo"] = 1; // 16384-point 1:1 blocks on the pair kernel's one-channel form (else k_convx) // 8192 -> 16384-point 2x up-sampling blocks on the pair kernel's split form (else k_convx)
 	opt_["align_groups"] = 1; // ... with whole output groups per block (launch_fused)
 	opt_["fold_tail"] = 1; // fast convolver at stage 0 keeps the input history itself
 	// the call's last block of a fused pair at the end of the chain is computed once: what it holds beyond the call
@@ -706,7 +760,27 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 						dev_upload(d.spec2, s2.data(), s2.size() * sizeof(double));
 					}
 				}
-				if (convp_split_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2))
+				if (convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len))
+				{
+					// one-channel form decimating by 2: the passes of the 8192 -> 4096-point geometry
+					const std::vector<double> hp = pair_constants_solo_down(H, g.n_in / 2);
+					d.hp = (cd*) dev_alloc(hp.size() * sizeof(double));
+					dev_upload(d.hp, hp.data(), hp.size() * sizeof(double));
+					const std::vector<double> pt = pair_twiddles(tw, g.bl2, g.n_in / 2, g.n_out / 2);
+					d.ptw = (cd*) dev_alloc(pt.size() * sizeof(double));
+					dev_upload(d.ptw, pt.data(), pt.size() * sizeof(double));
+				}
+				else if (convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len))
+				{
+					// one-channel form: constants per forward position, the passes of the 8192-point 1:1 geometry
+					const std::vector<double> hp = pair_constants_solo(H, g.n_in / 2);
+					d.hp = (cd*) dev_alloc(hp.size() * sizeof(double));
+					dev_upload(d.hp, hp.data(), hp.size() * sizeof(double));
+					const std::vector<double> pt = pair_twiddles(tw, g.bl2, g.n_in / 2, g.n_in / 2);
+					d.ptw = (cd*) dev_alloc(pt.size() * sizeof(double));
+					dev_upload(d.ptw, pt.data(), pt.size() * sizeof(double));
+				}
+				else if (convp_split_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2))
 				{
 					// split 2x up-sampling form: constants per forward position, the passes of the 1:1 geometry
 					const std::vector<double> hp = pair_constants_split(H, g.n_in);
@@ -1039,7 +1113,7 @@ bool Engine::set_option(const std::string& name, int value)
 	// (unfused stages keep it in rings the fused kernels never write): once a stream has started they
 	// may only change after clear().
 	static const char* const structural[] = { "fuse", "fuse_hb", "fuse_hbd", "fold_tail", "fast_conv",
-		"pair_conv", "pair_two", "pair_split", "align_groups", "park" };
+		"pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park" };
 	bool started = false;
 	for (const StagePlan& sp : plan_.stages) started = started || sp.m != 0;
 	for (const char* n : structural)
@@ -1463,9 +1537,11 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			}
 			if (ch0_ == 0) stat_["conv_blocks"] += L.nblk;
 			const bool sp = !g.complex_h && convp_split_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
-			if (path == kPathPair3) launch_convp(X, sp ? 9 : (g.complex_h ? 7 : 3), stream);
+			const bool solo = !g.complex_h && (convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len) ||
+				convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len));
+			if (path == kPathPair3) launch_convp(X, solo ? 11 : (sp ? 9 : (g.complex_h ? 7 : 3)), stream);
 			else if (path == kPathConvx3) launch_convx(X, 3, stream);
-			else if (path == kPathPair) launch_convp(X, sp ? 8 : (g.complex_h ? 6 : 0), stream);
+			else if (path == kPathPair) launch_convp(X, solo ? 10 : (sp ? 8 : (g.complex_h ? 6 : 0)), stream);
 			else launch_convx(X, 0, stream);
 			if (L.tail_ring != nullptr) tail_done_ = true;
 			if (once == 4) ring_to_rows();
@@ -1926,6 +2002,13 @@ int Engine::conv_path(const ConvGeom& g) const
 	if (opt_.at("pair_conv") && opt_.at("pair_split") && !g.complex_h &&
 		convp_split_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2))
 		return g.down == 3 ? kPathPair3 : kPathPair;
+	// (16384-point blocks 1:1: the one-channel form of the pair kernel instead of the one-channel kernel)
+	if (opt_.at("pair_conv") && opt_.at("pair_solo") && !g.complex_h &&
+		convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len))
+		return (!g.up_pow2 && g.up == 3) || (!g.down_pow2 && g.down == 3) ? kPathPair3 : kPathPair;
+	if (opt_.at("pair_conv") && opt_.at("pair_solo") && !g.complex_h &&
+		convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len))
+		return !g.up_pow2 && g.up == 3 ? kPathPair3 : kPathPair;
 	if (opt_.at("pair_conv") && convp_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2))
 		return kPathPair3;
 	if (g.complex_h) return use_pair(g) ? kPathPair : kPathGeneric; // (complex spectrum: pair kernel or generic)

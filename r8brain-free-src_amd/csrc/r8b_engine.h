@@ -165,6 +165,13 @@ std::vector<double> pair_constants(const std::vector<double>& H, int n_in, int n
 // ... of the split 2x up-sampling form (r8b_convp.h cp_sp_middle): 16 x (n_in / 16) pairs, entry c * NT + t = (H[k] +
 // H[k + n_in], H[k] - H[k + n_in]) for forward position 16 t + c, bin k = bitrev(position); H over 2 n_in points
 std::vector<double> pair_constants_split(const std::vector<double>& H, int n_in);
+// ... of the one-channel form (r8b_convp.h cp_solo_mid_b): 16 x (n / 16) pairs (a, b) per forward position 16 t + c of the
+// n-point complex transform, bin k = bitrev(position): a = (H[k] + H[k + n]) - (H[k] - H[k + n]) sin(pi k / n),
+// b = (H[k] - H[k + n]) cos(pi k / n); H over 2 n points
+std::vector<double> pair_constants_solo(const std::vector<double>& H, int n);
+// ... decimating by 2 (cp_solo_mid_b_down): per forward position 16 t + c, c even -- kept bin k --: (H[k], H[n / 2 - k]);
+// c + 1: (cos, sin) of pi k / n
+std::vector<double> pair_constants_solo_down(const std::vector<double>& H, int n);
 // twiddle base powers of the pair kernel's passes per thread (r8b_convp.h ptw_fetch): 5 slots x 6 x 256
 // complex; tw = exp(-2 pi i e / tw_len) table (interleaved), n_in = forward length (2048 or 4096)
 std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int n_in);

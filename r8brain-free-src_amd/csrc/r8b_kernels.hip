@@ -654,7 +654,9 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLI
 	// XCD-aware mapping as in k_convx, over channel PAIRS and groups of SUB consecutive blocks: item w of a launch
 	// is block group bg of channel pair pr
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
-	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
+	// (modes 10 / 11, the one-channel form: an item is a channel, not a pair)
+	constexpr bool SOLO = MODE == 10 || MODE == 11;
+	const unsigned npair = SOLO ? (unsigned) X.c.nch : ((unsigned) X.c.nch + 1u) >> 1;
 	const unsigned nbg = ((unsigned) X.c.nblk + SUB - 1u) / SUB;
 	auto decode = [&](unsigned wi, unsigned& bg, unsigned& pr)
 	{
@@ -711,8 +713,8 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLI
 	// in step: DESIGN.md section 5; the code is in the history of this file, the round-3 commits "Pair kernel: persistent workgroups on per-XCD work queues" ... "twin-block experiment".)
 	unsigned bg, pr;
 	decode(blockIdx.x, bg, pr);
-	const int chA = (int) (2u * pr);
-	const bool bvalid = chA + 1 < X.c.nch;
+	const int chA = SOLO ? (int) pr : (int) (2u * pr);
+	const bool bvalid = !SOLO && chA + 1 < X.c.nch;
 	ConvpItem cur;
 	const int b0 = (int) bg * SUB;
 	cur.k = X.c.k0 + b0;
@@ -758,12 +760,13 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 		// convp_div(i, magic) is floor(i / nbg) only while i * nbg < 2^32; i runs up to the grid size (an eighth of
 		// it in the XCD-interleaved mapping).  Far out of reach of audio batches -- tens of millions of input
 		// samples per call and channel pair --, refused rather than mapped wrongly
-		const unsigned long long np = ((unsigned long long) X.c.nch + 1ull) >> 1;
+		const unsigned long long np = MODE == 10 || MODE == 11 ? (unsigned long long) X.c.nch :
+			((unsigned long long) X.c.nch + 1ull) >> 1;
 		const unsigned long long imax = (np & 7ull) == 0 ? (np >> 3) * nbg : np * nbg;
 		if (nbg > 1 && imax * nbg >= 0x100000000ull)
 			throw std::runtime_error("launch_convp: too many blocks per call for the workgroup map (split the call)");
 	}
-	convp_prepare<LN, UL>(X, MODE != 1, MODE == 8 || MODE == 9);
+	convp_prepare<LN, UL>(X, MODE != 1, MODE == 8 || MODE == 9, MODE == 10 || MODE == 11);
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
 #ifdef R8B_DEV_ONLY_MODE
@@ -771,10 +774,21 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	if (const char* e = getenv("R8B_FAKE_LDS")) lds = (size_t) atoi(e);
 #endif
 	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
-	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
+	const unsigned npair = MODE == 10 || MODE == 11 ? (unsigned) X.c.nch : ((unsigned) X.c.nch + 1u) >> 1;
 	unsigned grid = nbg * npair;
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
+	}
+}
+
+// (the one-channel form decimating by 2: geometry <13, -1>)
+template<int LN, int DL>
+void launch_convp_solo_down(const ConvxLaunch& X, int mode, hipStream_t stream)
+{
+	if constexpr (LN == 13 && DL == 1)
+	{
+		if (mode == 10) launch_convp_t<LN, -DL, 10, 24>(X, stream);
+		else launch_convp_t<LN, -DL, 11, 24>(X, stream);
 	}
 }
 
@@ -784,7 +798,9 @@ void launch_convp_sp(const ConvxLaunch& X, int mode, hipStream_t stream)
 	if constexpr (LN == 13 && UL == 0)
 	{
 		if (mode == 8) launch_convp_t<LN, UL, 8, 24>(X, stream);
-		else launch_convp_t<LN, UL, 9, 24>(X, stream);
+		else if (mode == 9) launch_convp_t<LN, UL, 9, 24>(X, stream);
+		else if (mode == 10) launch_convp_t<LN, UL, 10, 24>(X, stream);
+		else launch_convp_t<LN, UL, 11, 24>(X, stream);
 	}
 }
 
@@ -963,7 +979,12 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 	if (X.c.down_pow2 && X.c.down > 1)
 	{
 #define R8B_CONVP_DISPATCH_DOWN(LN, DL) \
-		if (ln == LN && X.c.down == (1 << DL)) \
+		if (LN == 13 && DL == 1 && ln == 14 && X.c.down == 2 && (mode == 10 || mode == 11)) \
+		{ \
+			launch_convp_solo_down<LN, DL>(X, mode, (hipStream_t) stream); \
+			R8B_PAIR_DONE; \
+		} \
+		if (ln == LN && X.c.down == (1 << DL) && mode < 8) \
 		{ \
 			if (mode == 3) launch_convp_t<LN, -DL, 3, 24>(X, (hipStream_t) stream); \
 			else if (mode == 6) launch_convp_t<LN, -DL, 6, 24>(X, (hipStream_t) stream); \
@@ -979,14 +1000,15 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 		throw std::runtime_error("launch_convp: decimating geometry not instantiated");
 #endif
 	}
-	// (modes 8 / 9: the split 2x up-sampling form -- r8b_convp.h cp_sp_* -- lives on the 8192-point 1:1 geometry)
+	// (modes 8 / 9: the split 2x up-sampling form -- r8b_convp.h cp_sp_* --, modes 10 / 11: the one-channel form -- cp_solo_*,
+	// 16384-point blocks -- live on the 8192-point 1:1 geometry)
 #define R8B_CONVP_DISPATCH_BIG(LN, UL) \
-	if (ln == LN && LN == 13 && UL == 0 && (mode == 8 || mode == 9)) \
+	if (LN == 13 && UL == 0 && ((ln == 13 && (mode == 8 || mode == 9)) || (ln == 14 && (mode == 10 || mode == 11)))) \
 	{ \
 		launch_convp_sp<LN, UL>(X, mode, (hipStream_t) stream); \
 		R8B_PAIR_DONE; \
 	} \
-	if (ln == LN && up == (1 << UL) && mode != 8 && mode != 9) \
+	if (ln == LN && up == (1 << UL) && mode < 8) \
 	{ \
 		if (mode == 3) launch_convp_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
 		else if (mode == 6) launch_convp_t<LN, UL, 6, 24>(X, (hipStream_t) stream); \

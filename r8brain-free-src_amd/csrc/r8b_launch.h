@@ -321,6 +321,21 @@ inline bool convp_split_ok(int n_in, int n_out, int up, int down, bool up_pow2, 
 {
 	return up_pow2 && up == 2 && n_in == 8192 && n_out == 16384 && (down == 1 || (!down_pow2 && down == 3));
 }
+// one-channel form of the pair kernel (r8b_convp.h cp_solo_*, modes 10 / 11 on the 8192-point 1:1 geometry): 16384-point
+// blocks 1:1 (an even number of new samples per block: the samples travel in pairs), optionally behind the 3x zero
+// stuffing load or in front of the 3x strided store
+inline bool convp_solo_ok(int n_in, int n_out, int up, int down, bool up_pow2, bool down_pow2, int in_len)
+{
+	if (n_in != 16384 || n_out != 16384) return false;
+	if (up_pow2 && up == 1) return (in_len & 1) == 0 && (down == 1 || (!down_pow2 && down == 3));
+	return !up_pow2 && up == 3 && down == 1;
+}
+// ... decimating by 2 in the spectrum (geometry <13, -1>: 16384 -> 8192 points), optionally behind the 3x zero stuffing load
+inline bool convp_solo_down_ok(int n_in, int n_out, int up, int down, bool up_pow2, bool down_pow2, int in_len)
+{
+	if (n_in != 16384 || n_out != 8192 || !down_pow2 || down != 2) return false;
+	return up_pow2 ? (up == 1 && (in_len & 1) == 0) : up == 3;
+}
 // ... with the whole-step interpolator fused in (modes 1 and 4)
 inline bool convp_fused_ok(int n_in, int n_out, int up, int down, bool up_pow2)
 {

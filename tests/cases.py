@@ -137,6 +137,20 @@ SPLIT_CASES = [
 ]
 
 
+# 16384-point blocks (1:1 and 2x decimating filters with a transition band of 0.5 ... 0.6 %, the re-blocked 1/3, 3/1 and 3/2
+# filters): the one-channel form of the pair kernel (r8b_convp.h cp_solo_*, modes 10 / 11), and the one-channel kernel
+# k_convx behind option pair_solo = 0.  (src, dst, maxin, chunk, n_in, tb, atten[, rms_tol, peak_tol])
+SOLO_CASES = [
+    (96000.0, 44100.0, 8192, 5000, 100000, 0.5, 180.15),      # 1:1 in front of the whole-step interpolator, ragged calls
+    (48000.0, 16000.0, 8192, 8192, 110000, 0.5, 180.15),      # strided store (mode 11)
+    (44100.0, 132300.0, 2048, 2048, 40000, 0.5, 180.15),      # 3x zero stuffing load (mode 11)
+    (88200.0, 44100.0, 8192, 3000, 90000, 0.5, 180.15),       # decimating by 2 in the spectrum
+    (176400.0, 44100.0, 16384, 16384, 200000, 0.55, 206.91),  # ... behind a half-band decimator (input from a ring)
+    (32000.0, 48000.0, 2048, 2048, 60000, 0.5, 180.15, 1e-13, 5e-12),   # 3x zero stuffing + decimating (REBLOCK_CASES' bound)
+    (192000.0, 44100.0, 8192, 8192, 150000, 0.5, 180.15),     # half-band decimator + 16384 points 1:1 + interpolator
+]
+
+
 # Minimum-phase chains (reference fprMinPhase).  Per-call counts must equal the reference's exactly.
 # Samples: the reference derives the filter by a cepstral transform whose result in the deep stop band
 # is set by the rounding noise of ITS fp64 FFT (CDSPRealFFT.h:681-785): two correct evaluations of the
@@ -202,6 +216,8 @@ PAIR_SCALE_CASES = [
     (44100.0, 132300.0, 2048, 2048, 2048 * 4, 10.0, 109.56),
     (44100.0, 96000.0, 4096, 1000, 4096 * 3, 10.0, 109.56),
     (44100.0, 705600.0, 512, 512, 2048, 5.0, 109.56),
+    (96000.0, 48000.0, 4096, 4096, 4096 * 10, 0.5, 180.15),     # one-channel form (16384 points), decimating
+    (48000.0, 16000.0, 8192, 5000, 8192 * 6, 0.5, 180.15),      # ... 1:1 with the strided store
     (44100.0, 88200.0, 4096, 4096, 4096 * 8, 0.5, 180.15),      # split 2x up-sampling form (8192 -> 16384 points)
     (48000.0, 32000.0, 4096, 3000, 4096 * 8, 0.5, 180.15),      # ... with the strided store
 ]
@@ -249,7 +265,8 @@ def check_pair_scales(batch, case):
 
 # Every block once (Engine::launch_fused / launch_stage, ConvxLaunch::park_*): the block that holds a call's last output
 # is computed once; what it holds of the next call(s) waits in a park buffer (end of the chain) or goes ahead into the
-# next stage's ring.  (src, dst, maxin, tb, atten, kind): "park" / "ahead" / "none" = what the chain's pair kernels do
+# next stage's ring.  (src, dst, maxin, tb, atten, kind[, engine options]): "park" / "ahead" / "none" = what the chain's
+# convolver kernels do
 PARK_CASES = [
     (44100.0, 96000.0, 8192, 2.0, 180.15, "park"),        # cfg2: fused, two phases per thread
     (96000.0, 44100.0, 16384, 2.0, 180.15, "park"),       # cfg3
@@ -269,10 +286,16 @@ PARK_CASES = [
     (48000.0, 32000.0, 4096, 0.5, 180.15, "park"),        # re-blocked 8 507-tap filter, strided store
     (44100.0, 88200.0, 2048, 0.5, 180.15, "park"),
     (44100.0, 96000.0, 2048, 0.5, 180.15, "ahead"),       # ... in front of the (unfused) interpolator
-    # the one-channel fast path (16384-point blocks): at the end of a chain through an output ring of its own and a copy
-    (48000.0, 16000.0, 8192, 0.5, 180.15, "ahead"),       # re-blocked 8 507-tap filter, 16384 points 1:1, strided store
+    # 16384-point blocks: the one-channel form of the pair kernel (modes 10 / 11)
+    (48000.0, 16000.0, 8192, 0.5, 180.15, "park"),        # re-blocked 8 507-tap filter, 16384 points 1:1, strided store
+    (176400.0, 44100.0, 16384, 0.5, 180.15, "park"),      # half-band decimator + 16384 -> 8192 points (decimating form)
+    (96000.0, 44100.0, 8192, 0.5, 180.15, "ahead"),       # 16384 points 1:1 in front of the (unfused) interpolator
+    (44100.0, 132300.0, 3000, 0.5, 180.15, "park"),       # 3x zero stuffing into 16384 points
+    # the one-channel KERNEL (what is left for it: 16384 points decimated by 4, and option pair_solo = 0): at the end of
+    # a chain through an output ring of its own and a copy
     (48000.0, 36000.0, 6000, 0.5, 180.15, "ahead"),       # 3x zero stuffing into 16384 points, decimated by 4
-    (176400.0, 44100.0, 16384, 0.5, 180.15, "ahead"),     # half-band decimator + 16384 -> 8192 points (decimating form)
+    (48000.0, 16000.0, 8192, 0.5, 180.15, "ahead", {"pair_solo": 0}),
+    (96000.0, 44100.0, 8192, 0.5, 180.15, "ahead", {"pair_solo": 0}),   # fused with the interpolator (output ring)
     (192000.0, 44100.0, 8192, 0.5, 180.15, "ahead"),      # half-band decimator + fused 16384 -> 16384 points
 ]
 PARK_CASES_MINPHASE = [
@@ -287,7 +310,7 @@ def check_parked_outputs(make, case):
     Calls of every length -- MaxInLen, a third, a few samples, one sample (served from the park buffer alone) -- give
     the same outputs BIT FOR BIT with every block computed once and with the call's last block computed again by the
     next call, across clear(); the counters say which of the two happened."""
-    src, dst, maxin, tb, att, kind = case
+    src, dst, maxin, tb, att, kind = case[:6]
     lens = [maxin, maxin, maxin // 3, 300 % maxin + 1, 1, 1, 2, maxin, 17, 1, maxin - 5, 2500 % maxin + 1, maxin, 40,
             maxin]
     a, b = make(1), make(0)

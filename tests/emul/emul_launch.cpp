@@ -264,19 +264,30 @@ template<int LN, int UL, int MODE, int FLENP>
 void emul_convp_t(const ConvxLaunch& X0)
 {
 	ConvxLaunch X = X0;
-	convp_prepare<LN, UL>(X, MODE != 1, MODE == 8 || MODE == 9);
+	constexpr bool SOLO = MODE == 10 || MODE == 11;
+	convp_prepare<LN, UL>(X, MODE != 1, MODE == 8 || MODE == 9, SOLO);
 	std::vector<double> lds((size_t) convp_lds_bytes<LN, UL>() / sizeof(double) + 2);
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
-	const long long items = (long long) ((X.c.nblk + SUB - 1) / SUB) * ((X.c.nch + 1) / 2);
+	const long long items = (long long) ((X.c.nblk + SUB - 1) / SUB) * (SOLO ? X.c.nch : (X.c.nch + 1) / 2);
 	for (long long i = 0; i < items; i++)
 	{
 		EmulExecP<LN, UL> ex;
 		for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
 		for (auto& s : ex.st)
 			for (int j = 0; j < 16; j++) s.vr[j] = s.vi[j] = std::numeric_limits<double>::quiet_NaN();
-		convp_body<LN, UL, MODE, FLENP>(ex, X, reinterpret_cast<cd*>(base), convp_item<SUB>(X.c, i));
+		convp_body<LN, UL, MODE, FLENP>(ex, X, reinterpret_cast<cd*>(base), convp_item<SUB>(X.c, i, SOLO));
+	}
+}
+
+template<int LN, int DL>
+void emul_convp_solo_down(const ConvxLaunch& X, int mode)
+{
+	if constexpr (LN == 13 && DL == 1)
+	{
+		if (mode == 10) emul_convp_t<LN, -DL, 10, 24>(X);
+		else emul_convp_t<LN, -DL, 11, 24>(X);
 	}
 }
 
@@ -286,7 +297,9 @@ void emul_convp_sp(const ConvxLaunch& X, int mode)
 	if constexpr (LN == 13 && UL == 0)
 	{
 		if (mode == 8) emul_convp_t<LN, UL, 8, 24>(X);
-		else emul_convp_t<LN, UL, 9, 24>(X);
+		else if (mode == 9) emul_convp_t<LN, UL, 9, 24>(X);
+		else if (mode == 10) emul_convp_t<LN, UL, 10, 24>(X);
+		else emul_convp_t<LN, UL, 11, 24>(X);
 	}
 }
 
@@ -312,7 +325,12 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 	if (X.c.down_pow2 && X.c.down > 1)
 	{
 #define R8B_CONVP_DISPATCH_DOWN(LN, DL) \
-		if (ln == LN && X.c.down == (1 << DL)) \
+		if (LN == 13 && DL == 1 && ln == 14 && X.c.down == 2 && (mode == 10 || mode == 11)) \
+		{ \
+			emul_convp_solo_down<LN, DL>(X, mode); \
+			return; \
+		} \
+		if (ln == LN && X.c.down == (1 << DL) && mode < 8) \
 		{ \
 			if (mode == 3) emul_convp_t<LN, -DL, 3, 24>(X); \
 			else if (mode == 6) emul_convp_t<LN, -DL, 6, 24>(X); \
@@ -325,12 +343,12 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 		throw std::runtime_error("launch_convp: decimating geometry not instantiated");
 	}
 #define R8B_CONVP_DISPATCH_BIG(LN, UL) \
-	if (ln == LN && LN == 13 && UL == 0 && (mode == 8 || mode == 9)) \
+	if (LN == 13 && UL == 0 && ((ln == 13 && (mode == 8 || mode == 9)) || (ln == 14 && (mode == 10 || mode == 11)))) \
 	{ \
 		emul_convp_sp<LN, UL>(X, mode); \
 		return; \
 	} \
-	if (ln == LN && up == (1 << UL) && mode != 8 && mode != 9) \
+	if (ln == LN && up == (1 << UL) && mode < 8) \
 	{ \
 		if (mode == 3) emul_convp_t<LN, UL, 3, 24>(X); \
 		else if (mode == 6) emul_convp_t<LN, UL, 6, 24>(X); \

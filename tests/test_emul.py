@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, SPLIT_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES, PARK_CASES_MINPHASE, RMS_TOL,
+from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, SPLIT_CASES, SOLO_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES, PARK_CASES_MINPHASE, RMS_TOL,
                    PEAK_TOL, compare_stream, make_input, check_pair_scales, check_parked_outputs)
 from conftest import ROOT
 
@@ -120,6 +120,29 @@ def run_split_form_case(lib_kw, case, split, nch=3):
 @pytest.mark.parametrize("case", SPLIT_CASES)
 def test_emulated_split_upsampling_form(emul, case, split):
     run_split_form_case({"lib": emul}, case, split)
+
+
+def run_solo_form_case(lib_kw, case, solo, nch=3):
+    """16384-point blocks on the pair kernel's one-channel form (default) and on the one-channel kernel (option
+    pair_solo = 0): the same stream to the same tolerance, odd channel count"""
+    src, dst, maxin, chunk, n, tb, att = case[:7]
+    rtol, ptol = case[7:9] if len(case) > 7 else (RMS_TOL, PEAK_TOL)
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, **lib_kw)
+    assert "fft=16384/" in b.describe() or "fft=32768/" in b.describe(), b.describe()
+    b.set_option("pair_solo", solo)
+    b.set_option("timing", 1)
+    names = [t[0] for t in b.stage_timings()]
+    assert any(t.startswith("k_convx") for t in names) == (not solo), names
+    assert any(t.startswith("k_convp") for t in names) or not solo, names
+    b.set_option("timing", 0)
+    r, p = compare_stream(b, src, dst, maxin, chunk, n, tb, att, nch)
+    assert r <= rtol and p <= ptol, (r, p)
+
+
+@pytest.mark.parametrize("solo", [1, 0])
+@pytest.mark.parametrize("case", SOLO_CASES)
+def test_emulated_one_channel_form(emul, case, solo):
+    run_solo_form_case({"lib": emul}, case, solo)
 
 
 MINPHASE_PAIR_TOPOLOGIES = [(44100.0, 96000.0, 2.0, 180.15), (96000.0, 44100.0, 5.0, 109.56),
@@ -611,10 +634,12 @@ def test_emulated_history_from_registers_equals_the_copy_kernel(emul, src, dst, 
 
 
 def run_parked_outputs(lib_kw, case, phase=0):
-    src, dst, maxin, tb, att, kind = case
+    src, dst, maxin, tb, att, kind = case[:6]
 
     def make(park):
         r = r8b.BatchResampler(src, dst, maxin, tb, att, nch=3, phase=phase, **lib_kw)
+        for k, v in (case[6] if len(case) > 6 else {}).items():
+            r.set_option(k, v)
         r.set_option("park", park)
         return r
 

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, SPLIT_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES,
+from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, SPLIT_CASES, SOLO_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES,
                    PARK_CASES_MINPHASE, RMS_TOL, PEAK_TOL, compare_stream, make_input, check_pair_scales,
                    check_parked_outputs)
 from conftest import rms, peak
@@ -275,6 +275,15 @@ def test_hip_split_upsampling_form(torch, case, split):
     kernel behind option pair_split = 0, each against the oracle"""
     from test_emul import run_split_form_case
     run_split_form_case({"device": 0}, case, split, nch=5)
+
+
+@pytest.mark.parametrize("solo", [1, 0])
+@pytest.mark.parametrize("case", SOLO_CASES)
+def test_hip_one_channel_form(torch, case, solo):
+    """16384-point blocks: the pair kernel's one-channel form (modes 10 / 11, 1:1 and decimating by 2) and the one-channel
+    kernel behind option pair_solo = 0, each against the oracle"""
+    from test_emul import run_solo_form_case
+    run_solo_form_case({"device": 0}, case, solo, nch=5)
 
 
 @pytest.mark.parametrize("case", REBLOCK_CASES)

@@ -63,4 +63,7 @@ prof tb10 --src 44100 --dst 96000 --tb 10 --atten 109.56
 prof r23 --src 48000 --dst 32000
 prof split --src 44100 --dst 88200 --tb 0.5
 prof split23 --src 48000 --dst 32000 --tb 0.5
+prof solo --src 96000 --dst 44100 --tb 0.5
+prof solo13 --src 48000 --dst 16000 --tb 1
+prof pair13 --src 48000 --dst 16000 --tb 2
 ls $out/*
