@@ -2273,6 +2273,10 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.each([&](int tid, St&)
 		{
 			constexpr int TB = 8;
+			// (positions s0 + rel through the block form of the view -- uniform row pointers, a select per load, no
+			// branch: through src_load every load sat behind its own ring / buffer / zero branches and the sixteen of a
+			// thread went out one round trip after the other, 46 000 cycles for a call of one block per channel pair)
+			const SrcBlock sba = src_block(L.src, chA, s0), sbb = src_block(L.src, chB, s0);
 			for (long long i0 = s0 + tid; i0 < s1; i0 += (long long) TB * G::WT)
 			{
 				double va[TB], vb[TB];
@@ -2280,12 +2284,10 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				for (int j = 0; j < TB; j++)
 				{
 					const long long i = i0 + (long long) j * G::WT;
-					va[j] = vb[j] = 0.0;
-					if (i < s1)
-					{
-						va[j] = src_load(L.src, chA, i);
-						if (bvalid) vb[j] = src_load(L.src, chB, i);
-					}
+					// (lanes past the end load a clamped, valid position and store nothing)
+					const int rel = (int) ((i < s1 ? i : s1 - 1) - s0);
+					va[j] = src_block_load1(sba, rel);
+					vb[j] = src_block_load1(sbb, rel);
 				}
 #pragma unroll
 				for (int j = 0; j < TB; j++)
@@ -2452,7 +2454,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem&
 // form keep rot = 0, fl2r = fl2).
 // History tail from the registers (cp_tail_owned): which blocks of the launch put which part of [tail_p0, tail_p1)
 // into the ring.  Block k's window is the N samples ending at base(k) + iln (cp_load); blocks kf .. read it from the
-// caller's fp64 buffer alone, and consecutive windows start at most iln apart, so position i of
+// caller's fp64 buffer or the history ring in front of it, and consecutive windows start at most iln apart, so position i of
 // [max(tail_p0, window start of kf), min(tail_p1, window end of the last block)) lies in the window of the block with
 // base(k) <= i < base(k + 1) (kf below its base, the last block above the next base).
 template<int N, int US>
@@ -2462,10 +2464,13 @@ inline void convp_tail_owners(ConvLaunch& L)
 	const long long iln = L.in_len >> US, hist = N - iln;
 	auto base = [&](long long k) { return (k * (long long) L.blk_stride + L.blk_offset) >> US; };
 	const long long klast = L.k0 + L.nblk - 1;
-	const long long floor0 = L.src.cur_base > 0 ? L.src.cur_base : 0;
+	// (a block's registers hold its whole window wherever the samples came from -- the caller's buffer or, in front of
+	// it, the history ring: the launch's first block may own its part like any other.  Until round 4 the first owner
+	// was the first block whose window lay inside the caller's buffer, and a call of ONE block per channel pair copied
+	// its whole tail through the loop at the end of the kernel: 34 000 - 46 000 cycles on a block of 45 000.)
 	long long kf = L.k0;
-	while (kf <= klast && base(kf) - hist < floor0) kf++;
-	if (kf > klast) return;
+	// (what lies behind the last window is read from the caller's buffer: cp_tail_rest, cp_tail_slice_load)
+	if (base(klast) + iln < (L.src.cur_base > 0 ? L.src.cur_base : 0)) return;
 	long long c0 = base(kf) - hist, c1 = base(klast) + iln;
 	c0 = c0 < L.tail_p0 ? L.tail_p0 : (c0 > L.tail_p1 ? L.tail_p1 : c0);
 	c1 = c1 > L.tail_p1 ? L.tail_p1 : (c1 < c0 ? c0 : c1);

@@ -1523,7 +1523,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 				X.park_blk.jlo = b;
 				X.park_blk.jhi = pend;
 			}
-			if (path == kPathPair && L.tail_ring != nullptr && g.up_pow2)
+			if ((path == kPathPair || path == kPathPair3) && L.tail_ring != nullptr && g.up_pow2)
 			{
 				// (history for the next call, exactly -- cf. launch_fused: the next call's first block is the one that
 				// holds output b -- the one behind this call's last when every block is computed once --, blocks sit at

@@ -10,10 +10,12 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 180
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 101
 wide = len(sys.argv) > 3
 rng = np.random.default_rng(seed)
+# (R8B_FUZZ_TB=lo,hi narrows the transition band range, as in tools/wide_fuzz.py)
+TB = [float(v) for v in os.environ.get("R8B_FUZZ_TB", "0.5,45").split(",")]
 bad = 0; done = 0; skipped = 0; known = 0
 for case in [c for c in T._cases(3 * n, seed) if c[2] >= 300][:n]:
     if wide:
-        tb = float(np.round(np.exp(rng.uniform(np.log(0.5), np.log(45.0))), 2))
+        tb = float(np.round(np.exp(rng.uniform(np.log(TB[0]), np.log(TB[1]))), 2))
         att = float(np.round(rng.uniform(49.0, 218.0), 2))
         case = (case[0], case[1], case[2], tb, att, case[5])
     done += 1
