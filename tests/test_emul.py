@@ -612,19 +612,22 @@ def test_one_tap_halfband_start_of_stream(emul, refwrap, src, dst, att):
     assert seen > 100
 
 
-TAIL_TOPOLOGIES = [(44100.0, 96000.0, 8192), (96000.0, 44100.0, 16384), (88200.0, 44100.0, 12000), (44100.0, 88200.0, 6000),
-                   (48000.0, 32000.0, 16384)]
+# (src, dst, maxin, transition band): the last four on the split 2x up-sampling form and the one-channel form of the pair kernel
+TAIL_TOPOLOGIES = [(44100.0, 96000.0, 8192, 2.0), (96000.0, 44100.0, 16384, 2.0), (88200.0, 44100.0, 12000, 2.0),
+                   (44100.0, 88200.0, 6000, 2.0), (48000.0, 32000.0, 16384, 2.0),
+                   (44100.0, 88200.0, 9000, 0.5), (96000.0, 44100.0, 16384, 0.5), (88200.0, 44100.0, 12000, 0.5),
+                   (48000.0, 16000.0, 30000, 0.5)]
 
 
-@pytest.mark.parametrize("src,dst,maxin", TAIL_TOPOLOGIES)
-def test_emulated_history_from_registers_equals_the_copy_kernel(emul, src, dst, maxin):
+@pytest.mark.parametrize("src,dst,maxin,tb", TAIL_TOPOLOGIES)
+def test_emulated_history_from_registers_equals_the_copy_kernel(emul, src, dst, maxin, tb):
     """the stream's history for the next call, three ways: stored by the blocks that hold it in registers plus the last
     block's fetch (long calls, r8b_convp.h convp_tail_owners), copied in slices by every block (calls shorter than a
     window) and by a kernel of its own (option fold_tail = 0) -- the outputs are the same BIT FOR BIT, with an odd channel
     count (a block pair without a partner) and calls of every length in between"""
     lens = [maxin, maxin, maxin // 3, 300, maxin, 17, 1, maxin - 5, 2500, maxin]
-    a = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=3, lib=emul)
-    b = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=3, lib=emul)
+    a = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, lib=emul)
+    b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, lib=emul)
     b.set_option("fold_tail", 0)
     rng = np.random.default_rng(5)
     for i, l in enumerate(lens):
@@ -671,7 +674,7 @@ def test_emulated_every_block_once_with_parked_outputs(emul):
         assert nblk / calls < per_call + 0.35
 
 
-def run_chunk_invariance_with_no_work_calls_and_checkpoints(lib_kw, src, dst, maxin):
+def run_chunk_invariance_with_no_work_calls_and_checkpoints(lib_kw, src, dst, maxin, tb=2.0):
     """the history a call leaves is cut to what the NEXT call's first block reads back to (launch_fused /
     launch_stage), older ring positions keep stale samples, calls served from the park buffer alone keep the history
     with the copy kernel, and checkpoints carry rings and park buffer as they are (state blobs are not canonical:
@@ -680,10 +683,10 @@ def run_chunk_invariance_with_no_work_calls_and_checkpoints(lib_kw, src, dst, ma
     in fresh objects at those points equals the stream cut into MaxInLen calls bit for bit."""
     n = maxin * 5 + 1234
     x = make_input(3, n, 21)
-    a = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=3, **lib_kw)
+    a = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, **lib_kw)
     ya = np.concatenate([a.process_host(x[:, i:i + maxin]) for i in range(0, n, maxin)], axis=1)
     lens = [maxin, 1, 1, 3, maxin // 2 + 7, 1, maxin, 17, 2, 1, maxin - 9, 40, 5, maxin, 1, 1, maxin // 3]
-    b = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=3, **lib_kw)
+    b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, **lib_kw)
     ys, pos, k = [], 0, 0
     while pos < n:
         l = min(lens[k % len(lens)], n - pos)
@@ -693,13 +696,13 @@ def run_chunk_invariance_with_no_work_calls_and_checkpoints(lib_kw, src, dst, ma
         if k in (2, 3, 6, 9, 10, 15):
             # (behind single-sample calls, behind a long call, behind a call served from the park buffer)
             blob = b.state_dict()
-            b = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=3, **lib_kw)
+            b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, **lib_kw)
             b.process_host(x[:, :min(333, maxin)] * 0.25)   # unrelated history before the load
             b.load_state_dict(blob)
     yb = np.concatenate(ys, axis=1)
     assert ya.shape == yb.shape and np.array_equal(ya, yb)
 
 
-@pytest.mark.parametrize("src,dst,maxin", TAIL_TOPOLOGIES)
-def test_emulated_chunk_invariance_with_no_work_calls_and_checkpoints(emul, src, dst, maxin):
-    run_chunk_invariance_with_no_work_calls_and_checkpoints({"lib": emul}, src, dst, maxin)
+@pytest.mark.parametrize("src,dst,maxin,tb", TAIL_TOPOLOGIES)
+def test_emulated_chunk_invariance_with_no_work_calls_and_checkpoints(emul, src, dst, maxin, tb):
+    run_chunk_invariance_with_no_work_calls_and_checkpoints({"lib": emul}, src, dst, maxin, tb)

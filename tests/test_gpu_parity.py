@@ -511,15 +511,18 @@ def test_cxx_batch_device(tmp_path):
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.returncode, out.stdout)
 
 
-@pytest.mark.parametrize("src,dst,maxin", [(44100.0, 96000.0, 16384), (96000.0, 44100.0, 16384), (88200.0, 44100.0, 12000),
-                                           (44100.0, 88200.0, 6000), (48000.0, 32000.0, 16384)])
-def test_hip_history_from_registers_equals_the_copy_kernel(torch, src, dst, maxin):
+@pytest.mark.parametrize("src,dst,maxin,tb", [(44100.0, 96000.0, 16384, 2.0), (96000.0, 44100.0, 16384, 2.0),
+                                              (88200.0, 44100.0, 12000, 2.0), (44100.0, 88200.0, 6000, 2.0),
+                                              (48000.0, 32000.0, 16384, 2.0), (44100.0, 88200.0, 9000, 0.5),
+                                              (96000.0, 44100.0, 16384, 0.5), (88200.0, 44100.0, 12000, 0.5),
+                                              (48000.0, 16000.0, 30000, 0.5)])
+def test_hip_history_from_registers_equals_the_copy_kernel(torch, src, dst, maxin, tb):
     """the GPU twin of tests/test_emul.py test_emulated_history_from_registers_equals_the_copy_kernel: the next call's
     history stored from the blocks' registers / copied in slices / copied by a kernel of its own -- same stream bit for
     bit, odd channel count, ragged calls"""
     lens = [maxin, maxin, maxin // 3, 300, maxin, 17, 1, maxin - 5, 2500, maxin]
-    a = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=5, device=0)
-    b = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=5, device=0)
+    a = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=5, device=0)
+    b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=5, device=0)
     b.set_option("fold_tail", 0)
     rng = np.random.default_rng(5)
     for i, l in enumerate(lens):
@@ -543,10 +546,13 @@ def test_hip_parked_outputs_minimum_phase(torch, case):
     run_parked_outputs({"device": 0}, case, phase=1)
 
 
-@pytest.mark.parametrize("src,dst,maxin", [(44100.0, 96000.0, 8192), (96000.0, 44100.0, 16384), (88200.0, 44100.0, 12000)])
-def test_hip_chunk_invariance_with_no_work_calls_and_checkpoints(torch, src, dst, maxin):
+@pytest.mark.parametrize("src,dst,maxin,tb", [(44100.0, 96000.0, 8192, 2.0), (96000.0, 44100.0, 16384, 2.0),
+                                             (88200.0, 44100.0, 12000, 2.0), (44100.0, 88200.0, 9000, 0.5),
+                                             (96000.0, 44100.0, 16384, 0.5), (88200.0, 44100.0, 12000, 0.5),
+                                             (48000.0, 16000.0, 30000, 0.5)])
+def test_hip_chunk_invariance_with_no_work_calls_and_checkpoints(torch, src, dst, maxin, tb):
     from test_emul import run_chunk_invariance_with_no_work_calls_and_checkpoints
-    run_chunk_invariance_with_no_work_calls_and_checkpoints({"device": 0}, src, dst, maxin)
+    run_chunk_invariance_with_no_work_calls_and_checkpoints({"device": 0}, src, dst, maxin, tb)
 
 
 # Error budget: the tolerance of the path is RMS 1e-15 / peak 1e-13, the reference's own cross-build

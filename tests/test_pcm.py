@@ -79,12 +79,12 @@ CASES = [(r8b.PCM_S16, r8b.PCM_S16, 2), (r8b.PCM_S24, r8b.PCM_S24, 3), (r8b.PCM_
          (r8b.PCM_F32, r8b.PCM_S24, 5), (r8b.PCM_S16, r8b.PCM_F64, 65), (r8b.PCM_F64, r8b.PCM_S32, 1)]
 
 
-def run_emul(lib, fin, fout, nch, interleaved, src=44100.0, dst=48000.0, att=136.45, staged_sides=None):
-    frames, chunk = 3000, 1000
+def run_emul(lib, fin, fout, nch, interleaved, src=44100.0, dst=48000.0, att=136.45, staged_sides=None, tb=2.0,
+             frames=3000, chunk=1000):
     store, vals = make_pcm(fin, frames, nch, 11)
     x = np_decode(vals, fin)  # [frames, nch]
-    a = r8b.BatchResampler(src, dst, chunk, 2.0, att, nch=nch, lib=lib)
-    b = r8b.BatchResampler(src, dst, chunk, 2.0, att, nch=nch, lib=lib)
+    a = r8b.BatchResampler(src, dst, chunk, tb, att, nch=nch, lib=lib)
+    b = r8b.BatchResampler(src, dst, chunk, tb, att, nch=nch, lib=lib)
     cap = a.max_out_len
     tail = (3,) if fout == r8b.PCM_S24 else ()
     odt = np.uint8 if fout == r8b.PCM_S24 else NP_DTYPE[fout]
@@ -150,6 +150,13 @@ PCM_PAIR_TOPOLOGIES = [(44100.0, 96000.0, 2),      # fused pair, two phases per 
 def test_pcm_planar_at_the_pair_kernels_emulated(emul, src, dst, staged):
     run_emul(emul, r8b.PCM_S16, r8b.PCM_S24, 3, False, src, dst, att=180.15, staged_sides=staged)
     run_emul(emul, r8b.PCM_F32, r8b.PCM_S32, 2, False, src, dst, att=180.15, staged_sides=staged)
+
+
+@pytest.mark.parametrize("src,dst", [(44100.0, 88200.0), (88200.0, 44100.0), (48000.0, 16000.0)])
+def test_pcm_planar_at_the_long_block_forms_emulated(emul, src, dst):
+    """transition band 0.5 %: the split 2x up-sampling form and the one-channel form of the pair kernel (fp64 rows only)
+    between planar PCM edges -- both sides through the staging rows, enough frames to get past the filter's latency"""
+    run_emul(emul, r8b.PCM_S24, r8b.PCM_S16, 3, False, src, dst, att=180.15, staged_sides=2, tb=0.5, frames=45000, chunk=9000)
 
 
 def test_pcm_rounding_and_saturation(emul):
@@ -225,6 +232,29 @@ def test_pcm_planar_at_the_pair_kernels_gpu(src, dst, staged):
         assert got.shape == want.shape
         assert np.array_equal(got, np_encode(want, r8b.PCM_S24)), (src, dst, i)
     assert a.stat("pcm_staged_sides") == staged * (frames // chunk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src,dst", [(44100.0, 88200.0), (88200.0, 44100.0), (48000.0, 16000.0)])
+def test_pcm_planar_at_the_long_block_forms_gpu(src, dst):
+    """the GPU twin of test_pcm_planar_at_the_long_block_forms_emulated (transition band 0.5 %)"""
+    import torch
+    nch, frames, chunk = 3, 45000, 9000
+    store, vals = make_pcm(r8b.PCM_S24, frames, nch, 31)
+    x = np_decode(vals, r8b.PCM_S24)
+    a = r8b.BatchResampler(src, dst, chunk, 0.5, 180.15, nch=nch)
+    b = r8b.BatchResampler(src, dst, chunk, 0.5, 180.15, nch=nch)
+    seen = 0
+    for i in range(0, frames, chunk):
+        want = b.process_host(np.ascontiguousarray(x[i:i + chunk].T))
+        t = torch.from_numpy(np.ascontiguousarray(np.moveaxis(store[i:i + chunk], 1, 0))).cuda()  # [nch, l, 3]
+        y = a.process_pcm(t, out_format=r8b.PCM_S16, planar=True)
+        torch.cuda.synchronize()
+        got = y.cpu().numpy()
+        assert got.shape == want.shape
+        assert np.array_equal(got, np_encode(want, r8b.PCM_S16)), (src, dst, i)
+        seen += want.shape[1]
+    assert seen > 0 and a.stat("pcm_staged_sides") == 2 * (frames // chunk)
 
 
 @pytest.mark.gpu
