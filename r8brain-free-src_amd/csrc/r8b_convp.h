@@ -72,6 +72,11 @@ template<int LN, int UL> constexpr bool kSplit = false;
 // service group.
 R8B_HD int pswz(int e) { return e ^ ((e >> 4) & 15); }
 
+// kernel modes of the long-block forms on the 8192-point geometries (convp_body): split 2x up-sampling form 8 / 9
+// (12 / 13 with a complex kernel spectrum), one-channel form 10 / 11 (14 / 15)
+constexpr bool convp_mode_sp(int m) { return m == 8 || m == 9 || m == 12 || m == 13; }
+constexpr bool convp_mode_solo(int m) { return m == 10 || m == 11 || m == 14 || m == 15; }
+
 template<int LN, int UL>
 struct ConvpGeom
 {
@@ -1017,7 +1022,10 @@ R8B_HD void cp_sp_hp_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int l
 }
 // middle: the last forward butterflies, the two half spectra; the even one goes on (first backward butterflies in
 // st.vr / st.vi), the odd one waits in st.er / st.ei
-template<int LN, int UL>
+// (CX: complex kernel spectrum -- minimum phase, or an alignment moved by inherited latency: hp[c * NT + lt] = H[k] +
+// H[k+N], hp[(16 + c) * NT + lt] = (H[k] - H[k+N]) th^k, both complex, the twiddle folded in by the host --
+// pair_constants_split_complex; the second sixteen are fetched into the first sixteen's registers once those are spent)
+template<int LN, int UL, bool CX = false>
 R8B_HD void cp_sp_middle(const ConvLaunch& L, const cd* buf, ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
@@ -1033,6 +1041,28 @@ R8B_HD void cp_sp_middle(const ConvLaunch& L, const cd* buf, ConvpState<LN, UL>&
 	}
 #pragma unroll
 	for (int f = 0; f < G::NBF; f++) dif_regs<G::RM>(zr + G::RM * f, zi + G::RM * f);
+	if constexpr (CX)
+	{
+#pragma unroll
+		for (int c = 0; c < 16; c++)
+		{
+			const cd h = st.hp[c];
+			st.vr[c] = zr[c] * h.re - zi[c] * h.im;
+			st.vi[c] = zr[c] * h.im + zi[c] * h.re;
+		}
+#pragma unroll
+		for (int c = 0; c < 16; c++) st.hp[c] = L.hp[(16 + c) * G::NT + lt];
+#pragma unroll
+		for (int c = 0; c < 16; c++)
+		{
+			const cd h = st.hp[c];
+			st.er[c] = zr[c] * h.re - zi[c] * h.im;
+			st.ei[c] = zr[c] * h.im + zi[c] * h.re;
+		}
+#pragma unroll
+		for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
+		return;
+	}
 	// th^(bitrev9(lt)): conj of the table's entry (the table has 2N = 16384 entries: tw_len / 16384 = 1)
 	unsigned r = (unsigned) lt;
 	r = ((r & 0xaaaau) >> 1) | ((r & 0x5555u) << 1);
@@ -1122,8 +1152,11 @@ R8B_HD void cp_solo_mid_a(cd* buf, ConvpState<LN, UL>& st, int lt)
 		sw_st(bbf, fmap_c<LN, UL>(c), v);
 	}
 }
-template<int LN, int UL>
-R8B_HD void cp_solo_mid_b(const cd* buf, ConvpState<LN, UL>& st, int lt)
+// (CX: complex kernel spectrum: Z'[k] = A[k] Z[k] + B[k] conj(Z[N-k]) with COMPLEX A = (H[k] + H[k+N]) - (H[k] - H[k+N])
+// sin(pi k / N), B = i (H[k] - H[k+N]) cos(pi k / N); hp[c * NT + lt] = A, hp[(16 + c) * NT + lt] = B --
+// pair_constants_solo_complex; B is fetched into A's registers once A is spent)
+template<int LN, int UL, bool CX = false>
+R8B_HD void cp_solo_mid_b(const ConvLaunch& L, const cd* buf, ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
 	const int lp = bitrev_n((512 - bitrev_n(lt, 9)) & 511, 9);
@@ -1148,6 +1181,29 @@ R8B_HD void cp_solo_mid_b(const cd* buf, ConvpState<LN, UL>& st, int lt)
 			qi[c] = st.vi[cp];
 		}
 	}
+	if constexpr (CX)
+	{
+#pragma unroll
+		for (int c = 0; c < 16; c++)
+		{
+			const cd a = st.hp[c];
+			const double zr = st.vr[c], zi = st.vi[c];
+			st.vr[c] = a.re * zr - a.im * zi;
+			st.vi[c] = a.re * zi + a.im * zr;
+		}
+#pragma unroll
+		for (int c = 0; c < 16; c++) st.hp[c] = L.hp[(16 + c) * G::NT + lt];
+#pragma unroll
+		for (int c = 0; c < 16; c++)
+		{
+			// + B conj(Q)
+			const cd b = st.hp[c];
+			st.vr[c] += b.re * qr[c] + b.im * qi[c];
+			st.vi[c] += b.im * qr[c] - b.re * qi[c];
+		}
+	}
+	else
+	{
 #pragma unroll
 	for (int c = 0; c < 16; c++)
 	{
@@ -1156,6 +1212,7 @@ R8B_HD void cp_solo_mid_b(const cd* buf, ConvpState<LN, UL>& st, int lt)
 		// a Z + i b conj(Q)
 		st.vr[c] = a * zr + b * qi[c];
 		st.vi[c] = a * zi + b * qr[c];
+	}
 	}
 #pragma unroll
 	for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
@@ -1977,13 +2034,16 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	typedef ConvpState<LN, UL> St;
 	// modes 6 / 7: modes 0 / 3 with a complex kernel spectrum
 	constexpr bool CX = MODE == 6 || MODE == 7;
-	// modes 8 / 9: modes 0 / 3 of the split 2x up-sampling form (cp_sp_*: geometry <13, 0> only)
-	constexpr bool SP = MODE == 8 || MODE == 9;
-	// modes 10 / 11: modes 0 / 3 of the one-channel form (cp_solo_*: geometry <13, 0> only; cur.chA is the channel,
-	// cur.bvalid false)
-	constexpr bool SOLO = MODE == 10 || MODE == 11;
-	constexpr int BM = MODE == 6 ? 0 : (MODE == 7 ? 3 : (MODE == 8 ? 0 : (MODE == 9 ? 3 : (MODE == 10 ? 0 :
-		(MODE == 11 ? 3 : MODE)))));
+	// modes 8 / 9: modes 0 / 3 of the split 2x up-sampling form (cp_sp_*: geometry <13, 0> only); 12 / 13: the same with a
+	// complex kernel spectrum
+	constexpr bool SP = convp_mode_sp(MODE);
+	// modes 10 / 11: modes 0 / 3 of the one-channel form (cp_solo_*: geometries <13, 0> and <13, -1>; cur.chA is the
+	// channel, cur.bvalid false); 14 / 15: the same with a complex kernel spectrum (1:1 only)
+	constexpr bool SOLO = convp_mode_solo(MODE);
+	constexpr bool CXL = MODE >= 12 && MODE <= 15;
+	static_assert(!(CXL && SOLO) || UL == 0, "one-channel form with a complex spectrum: 1:1 only");
+	constexpr int BM = MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 14 ? 0 :
+		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : MODE);
 	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
 	constexpr bool SPLIT = kSplit<LN, UL> && !CX && (BM == 0 || BM == 3);
 	(void) SPLIT;
@@ -2093,7 +2153,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		auto d_midc = [&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
-			if constexpr (SP) cp_sp_middle<LN, UL>(L, buf_of(tid), st, lt);
+			if constexpr (SP) cp_sp_middle<LN, UL, CXL>(L, buf_of(tid), st, lt);
 			else if constexpr (UL < 0) cp_middle_compute_down<LN, UL, CX>(buf_of(tid), st, lt);
 			else cp_middle_compute<LN, UL, CX>(buf_of(tid), st, lt);
 			ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
@@ -2159,7 +2219,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			{
 				const int lt = lt_of(tid);
 				if constexpr (UL < 0) cp_solo_mid_b_down<LN, UL>(buf_of(tid), st, lt);
-				else cp_solo_mid_b<LN, UL>(buf_of(tid), st, lt);
+				else cp_solo_mid_b<LN, UL, CXL>(L, buf_of(tid), st, lt);
 				ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
 			});
 			ex.wave_steps(d_midw, d_post1, d_post2);

@@ -453,6 +453,60 @@ std::vector<double> pair_constants_solo_down(const std::vector<double>& H, int n
 	return out;
 }
 
+static std::vector<double> long_block_constants_complex(const std::vector<double>& Hc, int n, bool solo)
+{
+	typedef std::complex<long double> C;
+	const int N = n, NT = N / 16, NH = 2 * N;
+	int ln = 0;
+	while ((1 << ln) < N) ln++;
+	auto Hf = [&](int m) -> C
+	{
+		m &= NH - 1;
+		if (m <= NH / 2) return C(Hc[(size_t) m * 2], Hc[(size_t) m * 2 + 1]);
+		return std::conj(C(Hc[(size_t) (NH - m) * 2], Hc[(size_t) (NH - m) * 2 + 1]));
+	};
+	auto rev = [](int v, int bits)
+	{
+		int r = 0;
+		for (int b = 0; b < bits; b++)
+			if (v & (1 << b)) r |= 1 << (bits - 1 - b);
+		return r;
+	};
+	const long double pi = 3.14159265358979323846264338327950288L;
+	std::vector<double> out((size_t) 32 * NT * 2, 0.0);
+	auto put = [&](int row, int t, C v)
+	{
+		out[((size_t) row * NT + t) * 2] = (double) v.real();
+		out[((size_t) row * NT + t) * 2 + 1] = (double) v.imag();
+	};
+	for (int t = 0; t < NT; t++)
+		for (int c = 0; c < 16; c++)
+		{
+			const int k = rev(16 * t + c, ln);
+			const C hs = Hf(k) + Hf(k + N), hd = Hf(k) - Hf(k + N);
+			const long double th = pi * k / N;
+			if (solo)
+			{
+				put(c, t, hs - hd * sinl(th));
+				put(16 + c, t, C(0.0L, 1.0L) * hd * cosl(th));
+			}
+			else
+			{
+				put(c, t, hs);
+				put(16 + c, t, hd * C(cosl(th), sinl(th)));
+			}
+		}
+	return out;
+}
+std::vector<double> pair_constants_split_complex(const std::vector<double>& Hc, int n)
+{
+	return long_block_constants_complex(Hc, n, false);
+}
+std::vector<double> pair_constants_solo_complex(const std::vector<double>& Hc, int n)
+{
+	return long_block_constants_complex(Hc, n, true);
+}
+
 // The same with a complex kernel spectrum Hc (bl2/2 + 1 complex bins, Hermitian beyond): one complex value
 // per entry (r8b_convp.h cp_hp_prefetch, CX) -- 1:1: H of backward position 16 t + c; 2x up: Hs (c < 8) / Hd
 // (c >= 8) of forward position 8 t + (c & 7); decimating: H of the thread's kept position c.
@@ -715,7 +769,11 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 				{
 					// minimum phase (or an alignment moved by inherited latency): complex spectrum for the
 					// generic kernel ...
-					if (!generic_conv_fits(g))
+					// ... (16384 points 1:1 in place; 2x up-sampling or decimating at that length: neither array pair fits)
+					const bool split_cx = convp_split_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
+					const bool solo_cx = !split_cx && g.n_in == g.n_out &&
+						convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len);
+					if (!generic_conv_fits(g) && !split_cx && !solo_cx)
 						throw std::runtime_error("minimum-phase filter too long for the generic block convolver");
 					const std::vector<double> hc = kernel_spectrum_complex(*sp.lp, g.bl2, g.fl2, 1.0 / g.bl2);
 					d.Hc = (cd*) dev_alloc(hc.size() * sizeof(double));
@@ -724,7 +782,19 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 					d.tw_len = g.bl2;
 					d.tw = (cd*) dev_alloc(tw.size() * sizeof(double));
 					dev_upload(d.tw, tw.data(), tw.size() * sizeof(double));
-					if (convp_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2) ||
+					if (split_cx || solo_cx)
+					{
+						// ... the long-block forms of the pair kernel (modes 12 ... 15)
+						const int n = split_cx ? g.n_in : g.n_in / 2;
+						const std::vector<double> hp = split_cx ? pair_constants_split_complex(hc, n) :
+							pair_constants_solo_complex(hc, n);
+						d.hp = (cd*) dev_alloc(hp.size() * sizeof(double));
+						dev_upload(d.hp, hp.data(), hp.size() * sizeof(double));
+						const std::vector<double> pt = pair_twiddles(tw, g.bl2, n, n);
+						d.ptw = (cd*) dev_alloc(pt.size() * sizeof(double));
+						dev_upload(d.ptw, pt.data(), pt.size() * sizeof(double));
+					}
+					else if (convp_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2) ||
 						convp_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2))
 					{
 						// ... and the pair kernel with one complex multiplication per bin
@@ -1536,12 +1606,14 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 				L.tail_p0 = p0 < 0 ? 0 : (p0 & ~1LL);
 			}
 			if (ch0_ == 0) stat_["conv_blocks"] += L.nblk;
-			const bool sp = !g.complex_h && convp_split_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
-			const bool solo = !g.complex_h && (convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len) ||
-				convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len));
-			if (path == kPathPair3) launch_convp(X, solo ? 11 : (sp ? 9 : (g.complex_h ? 7 : 3)), stream);
+			const bool sp = convp_split_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
+			const bool solo = convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len) ||
+				(!g.complex_h && convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len));
+			// (long-block forms: + 4 with a complex kernel spectrum)
+			const int cxl = g.complex_h ? 4 : 0;
+			if (path == kPathPair3) launch_convp(X, solo ? 11 + cxl : (sp ? 9 + cxl : (g.complex_h ? 7 : 3)), stream);
 			else if (path == kPathConvx3) launch_convx(X, 3, stream);
-			else if (path == kPathPair) launch_convp(X, solo ? 10 : (sp ? 8 : (g.complex_h ? 6 : 0)), stream);
+			else if (path == kPathPair) launch_convp(X, solo ? 10 + cxl : (sp ? 8 + cxl : (g.complex_h ? 6 : 0)), stream);
 			else launch_convx(X, 0, stream);
 			if (L.tail_ring != nullptr) tail_done_ = true;
 			if (once == 4) ring_to_rows();
@@ -1999,11 +2071,14 @@ int Engine::conv_path(const ConvGeom& g) const
 	if (!(opt_.at("fast_conv") || !generic_conv_fits(g))) return kPathGeneric;
 	// (8192 -> 16384-point blocks: the split 2x up-sampling form of the pair kernel, two channels per workgroup, instead
 	// of the one-channel kernel)
-	if (opt_.at("pair_conv") && opt_.at("pair_split") && !g.complex_h &&
+	// (with a complex kernel spectrum -- modes 12 ... 15 -- these forms are the only path such blocks have when the generic
+	// kernel's arrays do not fit: the options do not switch them off then)
+	const bool cx_only = g.complex_h && !generic_conv_fits(g);
+	if (((opt_.at("pair_conv") && opt_.at("pair_split")) || cx_only) &&
 		convp_split_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2))
 		return g.down == 3 ? kPathPair3 : kPathPair;
 	// (16384-point blocks 1:1: the one-channel form of the pair kernel instead of the one-channel kernel)
-	if (opt_.at("pair_conv") && opt_.at("pair_solo") && !g.complex_h &&
+	if (((opt_.at("pair_conv") && opt_.at("pair_solo")) || cx_only) && (!g.complex_h || g.n_in == g.n_out) &&
 		convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len))
 		return (!g.up_pow2 && g.up == 3) || (!g.down_pow2 && g.down == 3) ? kPathPair3 : kPathPair;
 	if (opt_.at("pair_conv") && opt_.at("pair_solo") && !g.complex_h &&

@@ -172,6 +172,11 @@ std::vector<double> pair_constants_solo(const std::vector<double>& H, int n);
 // ... decimating by 2 (cp_solo_mid_b_down): per forward position 16 t + c, c even -- kept bin k --: (H[k], H[n / 2 - k]);
 // c + 1: (cos, sin) of pi k / n
 std::vector<double> pair_constants_solo_down(const std::vector<double>& H, int n);
+// ... of the split form and of the one-channel form (1:1) with a complex kernel spectrum Hc (n + 1 complex bins, Hermitian
+// beyond): 32 x (n / 16) complex entries -- split: H[k] + H[k+n], then (H[k] - H[k+n]) e^{+i pi k / n}; one-channel:
+// A = (H[k] + H[k+n]) - (H[k] - H[k+n]) sin(pi k / n), then B = i (H[k] - H[k+n]) cos(pi k / n)
+std::vector<double> pair_constants_split_complex(const std::vector<double>& Hc, int n);
+std::vector<double> pair_constants_solo_complex(const std::vector<double>& Hc, int n);
 // twiddle base powers of the pair kernel's passes per thread (r8b_convp.h ptw_fetch): 5 slots x 6 x 256
 // complex; tw = exp(-2 pi i e / tw_len) table (interleaved), n_in = forward length (2048 or 4096)
 std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int n_in);

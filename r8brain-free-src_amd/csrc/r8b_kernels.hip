@@ -655,7 +655,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLI
 	// is block group bg of channel pair pr
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
 	// (modes 10 / 11, the one-channel form: an item is a channel, not a pair)
-	constexpr bool SOLO = MODE == 10 || MODE == 11;
+	constexpr bool SOLO = convp_mode_solo(MODE);
 	const unsigned npair = SOLO ? (unsigned) X.c.nch : ((unsigned) X.c.nch + 1u) >> 1;
 	const unsigned nbg = ((unsigned) X.c.nblk + SUB - 1u) / SUB;
 	auto decode = [&](unsigned wi, unsigned& bg, unsigned& pr)
@@ -760,13 +760,13 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 		// convp_div(i, magic) is floor(i / nbg) only while i * nbg < 2^32; i runs up to the grid size (an eighth of
 		// it in the XCD-interleaved mapping).  Far out of reach of audio batches -- tens of millions of input
 		// samples per call and channel pair --, refused rather than mapped wrongly
-		const unsigned long long np = MODE == 10 || MODE == 11 ? (unsigned long long) X.c.nch :
+		const unsigned long long np = convp_mode_solo(MODE) ? (unsigned long long) X.c.nch :
 			((unsigned long long) X.c.nch + 1ull) >> 1;
 		const unsigned long long imax = (np & 7ull) == 0 ? (np >> 3) * nbg : np * nbg;
 		if (nbg > 1 && imax * nbg >= 0x100000000ull)
 			throw std::runtime_error("launch_convp: too many blocks per call for the workgroup map (split the call)");
 	}
-	convp_prepare<LN, UL>(X, MODE != 1, MODE == 8 || MODE == 9, MODE == 10 || MODE == 11);
+	convp_prepare<LN, UL>(X, MODE != 1, convp_mode_sp(MODE), convp_mode_solo(MODE));
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
 #ifdef R8B_DEV_ONLY_MODE
@@ -774,7 +774,7 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	if (const char* e = getenv("R8B_FAKE_LDS")) lds = (size_t) atoi(e);
 #endif
 	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
-	const unsigned npair = MODE == 10 || MODE == 11 ? (unsigned) X.c.nch : ((unsigned) X.c.nch + 1u) >> 1;
+	const unsigned npair = convp_mode_solo(MODE) ? (unsigned) X.c.nch : ((unsigned) X.c.nch + 1u) >> 1;
 	unsigned grid = nbg * npair;
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
@@ -800,7 +800,11 @@ void launch_convp_sp(const ConvxLaunch& X, int mode, hipStream_t stream)
 		if (mode == 8) launch_convp_t<LN, UL, 8, 24>(X, stream);
 		else if (mode == 9) launch_convp_t<LN, UL, 9, 24>(X, stream);
 		else if (mode == 10) launch_convp_t<LN, UL, 10, 24>(X, stream);
-		else launch_convp_t<LN, UL, 11, 24>(X, stream);
+		else if (mode == 11) launch_convp_t<LN, UL, 11, 24>(X, stream);
+		else if (mode == 12) launch_convp_t<LN, UL, 12, 24>(X, stream);
+		else if (mode == 13) launch_convp_t<LN, UL, 13, 24>(X, stream);
+		else if (mode == 14) launch_convp_t<LN, UL, 14, 24>(X, stream);
+		else launch_convp_t<LN, UL, 15, 24>(X, stream);
 	}
 }
 
@@ -1003,7 +1007,7 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 	// (modes 8 / 9: the split 2x up-sampling form -- r8b_convp.h cp_sp_* --, modes 10 / 11: the one-channel form -- cp_solo_*,
 	// 16384-point blocks -- live on the 8192-point 1:1 geometry)
 #define R8B_CONVP_DISPATCH_BIG(LN, UL) \
-	if (LN == 13 && UL == 0 && ((ln == 13 && (mode == 8 || mode == 9)) || (ln == 14 && (mode == 10 || mode == 11)))) \
+	if (LN == 13 && UL == 0 && ((ln == 13 && convp_mode_sp(mode)) || (ln == 14 && convp_mode_solo(mode)))) \
 	{ \
 		launch_convp_sp<LN, UL>(X, mode, (hipStream_t) stream); \
 		R8B_PAIR_DONE; \

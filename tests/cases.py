@@ -298,10 +298,26 @@ PARK_CASES = [
     (96000.0, 44100.0, 8192, 0.5, 180.15, "ahead", {"pair_solo": 0}),   # fused with the interpolator (output ring)
     (192000.0, 44100.0, 8192, 0.5, 180.15, "ahead"),      # half-band decimator + fused 16384 -> 16384 points
 ]
+# Minimum-phase filters on the long blocks (transition band 0.5 ... 1 %): 8192 -> 16384 points on the split form, 16384
+# points 1:1 on the one-channel form, both with a complex kernel spectrum (modes 12 ... 15) -- until round 4 these
+# chains were refused (2x up-sampling) or ran on the generic kernel in place (1:1).  Run on the REFERENCE's own taps
+# (test_emul.run_minphase_reference_taps: RMS <= 1e-15 / peak <= 1e-13).  (src, dst, maxin, chunk, n_in, tb, atten)
+MINPHASE_LONG_CASES = [
+    (44100.0, 88200.0, 4096, 3000, 60000, 0.5, 180.15),      # split form
+    (48000.0, 32000.0, 4096, 4096, 90000, 0.5, 180.15),      # ... with the strided store (the 1/3-band filter)
+    (44100.0, 96000.0, 4096, 4096, 60000, 0.5, 180.15),      # ... in front of the interpolator (fractional start)
+    (96000.0, 44100.0, 8192, 5000, 90000, 0.5, 180.15),      # one-channel form 1:1 + interpolator
+    (48000.0, 16000.0, 8192, 8192, 100000, 1.0, 180.15),     # ... strided store
+    (44100.0, 132300.0, 2048, 2048, 40000, 1.0, 180.15),     # ... 3x zero stuffing load
+]
+
+
 PARK_CASES_MINPHASE = [
     (44100.0, 88200.0, 4096, 2.0, 180.15, "park"),        # complex kernel spectrum (mode 6)
     (48000.0, 32000.0, 8192, 2.0, 180.15, "park"),        # mode 7
     (44100.0, 96000.0, 4096, 2.0, 180.15, "ahead"),       # convolver -> k_whole with a fractional start
+    (44100.0, 88200.0, 2048, 0.5, 180.15, "park"),        # split form, complex spectrum (mode 12)
+    (48000.0, 16000.0, 8192, 1.0, 180.15, "park"),        # one-channel form, complex spectrum, strided store (mode 15)
 ]
 
 

@@ -264,8 +264,8 @@ template<int LN, int UL, int MODE, int FLENP>
 void emul_convp_t(const ConvxLaunch& X0)
 {
 	ConvxLaunch X = X0;
-	constexpr bool SOLO = MODE == 10 || MODE == 11;
-	convp_prepare<LN, UL>(X, MODE != 1, MODE == 8 || MODE == 9, SOLO);
+	constexpr bool SOLO = convp_mode_solo(MODE);
+	convp_prepare<LN, UL>(X, MODE != 1, convp_mode_sp(MODE), SOLO);
 	std::vector<double> lds((size_t) convp_lds_bytes<LN, UL>() / sizeof(double) + 2);
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
@@ -299,7 +299,11 @@ void emul_convp_sp(const ConvxLaunch& X, int mode)
 		if (mode == 8) emul_convp_t<LN, UL, 8, 24>(X);
 		else if (mode == 9) emul_convp_t<LN, UL, 9, 24>(X);
 		else if (mode == 10) emul_convp_t<LN, UL, 10, 24>(X);
-		else emul_convp_t<LN, UL, 11, 24>(X);
+		else if (mode == 11) emul_convp_t<LN, UL, 11, 24>(X);
+		else if (mode == 12) emul_convp_t<LN, UL, 12, 24>(X);
+		else if (mode == 13) emul_convp_t<LN, UL, 13, 24>(X);
+		else if (mode == 14) emul_convp_t<LN, UL, 14, 24>(X);
+		else emul_convp_t<LN, UL, 15, 24>(X);
 	}
 }
 
@@ -343,7 +347,7 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 		throw std::runtime_error("launch_convp: decimating geometry not instantiated");
 	}
 #define R8B_CONVP_DISPATCH_BIG(LN, UL) \
-	if (LN == 13 && UL == 0 && ((ln == 13 && (mode == 8 || mode == 9)) || (ln == 14 && (mode == 10 || mode == 11)))) \
+	if (LN == 13 && UL == 0 && ((ln == 13 && convp_mode_sp(mode)) || (ln == 14 && convp_mode_solo(mode)))) \
 	{ \
 		emul_convp_sp<LN, UL>(X, mode); \
 		return; \

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, SPLIT_CASES, SOLO_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES, PARK_CASES_MINPHASE, RMS_TOL,
+from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, SPLIT_CASES, SOLO_CASES, MINPHASE_CASES, MINPHASE_LONG_CASES, PAIR_SCALE_CASES, PARK_CASES, PARK_CASES_MINPHASE, RMS_TOL,
                    PEAK_TOL, compare_stream, make_input, check_pair_scales, check_parked_outputs)
 from conftest import ROOT
 
@@ -290,6 +290,16 @@ def test_emulated_minimum_phase_kernels_on_reference_taps(emul, refwrap, case):
     run_minphase_reference_taps(emul, {"lib": emul}, refwrap, case)
 
 
+@pytest.mark.parametrize("case", MINPHASE_LONG_CASES)
+def test_emulated_minimum_phase_long_blocks_on_reference_taps(emul, refwrap, case):
+    """cases.MINPHASE_LONG_CASES: the split and one-channel forms of the pair kernel with a complex kernel spectrum"""
+    src, dst, maxin, chunk, n, tb, att = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, phase=1, lib=emul)
+    b.set_option("timing", 1)
+    assert any(t[0].startswith("k_convp") for t in b.stage_timings()), b.stage_timings()
+    run_minphase_reference_taps(emul, {"lib": emul}, refwrap, case)
+
+
 def test_minimum_phase_latency_split_matches_reference(emul, refwrap):
     """the designer's group-delay split (integer Latency / LatencyFrac) against the reference's for the
     filters of the presets -- an integer-boundary disagreement would shift a whole stream by one sample"""
@@ -444,6 +454,12 @@ def test_unsupported_geometry_fails_loudly(emul):
     r8b.BatchResampler(32000.0, 96000.0, 1024, 0.5, 218.0, nch=1, lib=emul)   # longest radix-3 case
     with pytest.raises(RuntimeError, match="too long"):
         r8b.BatchResampler(64000.0, 48000.0, 1024, 0.2, 218.0, nch=1, lib=emul)
+    # minimum phase: 2x up-sampling and 1:1 blocks of 16384 points run on the pair kernel's long-block forms (round 4);
+    # what has no kernel is such a block DECIMATED in the spectrum -- stated, and refused at creation
+    r8b.BatchResampler(44100.0, 88200.0, 1024, 0.5, 180.15, nch=1, phase=1, lib=emul)
+    r8b.BatchResampler(96000.0, 44100.0, 1024, 0.5, 180.15, nch=1, phase=1, lib=emul)
+    with pytest.raises(RuntimeError, match="too long"):
+        r8b.BatchResampler(88200.0, 44100.0, 1024, 0.5, 180.15, nch=1, phase=1, lib=emul)
 
 
 CKPT_CASES = [(44100.0, 96000.0), (96000.0, 44100.0), (44100.0, 44101.0), (44100.0, 2822400.0),

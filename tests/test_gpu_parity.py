@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, SPLIT_CASES, SOLO_CASES, MINPHASE_CASES, PAIR_SCALE_CASES, PARK_CASES,
+from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, SPLIT_CASES, SOLO_CASES, MINPHASE_CASES, MINPHASE_LONG_CASES, PAIR_SCALE_CASES, PARK_CASES,
                    PARK_CASES_MINPHASE, RMS_TOL, PEAK_TOL, compare_stream, make_input, check_pair_scales,
                    check_parked_outputs)
 from conftest import rms, peak
@@ -318,6 +318,14 @@ def test_hip_minimum_phase_kernels_on_reference_taps(torch, refwrap, hip_hooks, 
     """the minimum-phase chains on the real kernels with the REFERENCE's own minimum-phase taps
     (parity-test hook r8b_design_set_lp_provider of the test build, conftest.hip_hooks): pair-kernel modes 6 / 7, k_whole / k_poly / half-band kernels with
     fractional start positions -- RMS <= 1e-15 / peak <= 1e-13 against the reference stream"""
+    from test_emul import run_minphase_reference_taps
+    run_minphase_reference_taps(hip_hooks, {"device": 0, "lib": hip_hooks}, refwrap, case)
+
+
+@pytest.mark.parametrize("case", MINPHASE_LONG_CASES)
+def test_hip_minimum_phase_long_blocks_on_reference_taps(torch, refwrap, hip_hooks, case):
+    """cases.MINPHASE_LONG_CASES on the real kernels: the split and one-channel forms of the pair kernel with a complex
+    kernel spectrum (modes 12 ... 15), on the reference's own minimum-phase taps"""
     from test_emul import run_minphase_reference_taps
     run_minphase_reference_taps(hip_hooks, {"device": 0, "lib": hip_hooks}, refwrap, case)
 
