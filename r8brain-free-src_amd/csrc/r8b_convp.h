@@ -1226,14 +1226,23 @@ R8B_HD void cp_solo_mid_b(const ConvLaunch& L, const cd* buf, ConvpState<LN, UL>
 // even ones c are the kept bins k (backward position 8 lt + c / 2), c + 1 holds Z[N2 + k], and the partner thread's
 // positions 15 - c and 14 - c hold Z[N - k] and Z[N2 - k].  hp[c * NT + lt], c even: (H[k], H[j]); c + 1: (cos, sin) of
 // 2 pi k / 16384 (Engine: pair_constants_solo_down).
-template<int LN, int UL>
-R8B_HD void cp_solo_mid_b_down(const cd* buf, ConvpState<LN, UL>& st, int lt)
+// (CX: complex kernel spectrum: hp[c * NT + lt] = H[k] for even c, hp[(16 + c / 2) * NT + lt] = H[j], both complex; the
+// new Nyquist bin is Re(H[N2] X[N2]) then, reference CDSPBlockConvolver.h:340 behind multiplyBlocks --
+// pair_constants_solo_down_complex)
+template<int LN, int UL, bool CX = false>
+R8B_HD void cp_solo_mid_b_down(const ConvLaunch& L, const cd* buf, ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
 	static_assert(UL == -1 && G::E1 == 16 && G::E2 == 8 && G::POST && G::NT == 512,
 		"one-channel form, decimating: the 8192 -> 4096-point geometry");
 	const int lp = bitrev_n((512 - bitrev_n(lt, 9)) & 511, 9);
 	const SwBase bp = sw_base(const_cast<cd*>(buf), pswz(16 * lp));
+	cd h2[8];
+	if constexpr (CX)
+	{
+#pragma unroll
+		for (int e = 0; e < 8; e++) h2[e] = L.hp[(16 + e) * G::NT + lt];
+	}
 	double qr[16], qi[16];
 #pragma unroll
 	for (int c = 0; c < 16; c++)
@@ -1258,20 +1267,37 @@ R8B_HD void cp_solo_mid_b_down(const cd* buf, ConvpState<LN, UL>& st, int lt)
 			rr = st.vr[kRev[(8 - kRev[c]) & 15]];
 			ri = st.vi[kRev[(8 - kRev[c]) & 15]];
 		}
-		const double hk = st.hp[c].re, hj = st.hp[c].im, cs = st.hp[c + 1].re, sn = st.hp[c + 1].im;
+		const double cs = st.hp[c + 1].re, sn = st.hp[c + 1].im;
 		// X[k] = E + w^k O: E = (P + conj A) / 2, O = -i (P - conj A) / 2, w^k = cs - i sn
 		const double er = 0.5 * (pr + ar), ei = 0.5 * (pi - ai), o_r = 0.5 * (pi + ai), oi = -0.5 * (pr - ar);
 		const double xr = er + cs * o_r + sn * oi, xi = ei + cs * oi - sn * o_r;
 		// X[j]: E = (R + conj S) / 2, O = -i (R - conj S) / 2, w^j = sn - i cs
 		const double fr = 0.5 * (rr + sr), fi = 0.5 * (ri - si), p_r = 0.5 * (ri + si), p_i = -0.5 * (rr - sr);
 		const double ur = fr + sn * p_r + cs * p_i, ui = fi + sn * p_i - cs * p_r;
-		const double ykr = hk * xr, yki = hk * xi;
-		double yjr = hj * ur, yji = hj * ui;
-		if (lt == 0 && e == 0)
+		double ykr, yki, yjr, yji;
+		if constexpr (CX)
 		{
-			// the new Nyquist bin: the reference's real fix-up value
-			yjr = hj * (ur + ui);
-			yji = 0.0;
+			const cd hk = st.hp[c], hj = h2[e];
+			ykr = hk.re * xr - hk.im * xi;
+			yki = hk.re * xi + hk.im * xr;
+			yjr = hj.re * ur - hj.im * ui;
+			yji = hj.re * ui + hj.im * ur;
+			// the new Nyquist bin: Re(H X), the reference's fix-up value behind multiplyBlocks
+			if (lt == 0 && e == 0) yji = 0.0;
+		}
+		else
+		{
+			const double hk = st.hp[c].re, hj = st.hp[c].im;
+			ykr = hk * xr;
+			yki = hk * xi;
+			yjr = hj * ur;
+			yji = hj * ui;
+			if (lt == 0 && e == 0)
+			{
+				// the new Nyquist bin: the reference's real fix-up value
+				yjr = hj * (ur + ui);
+				yji = 0.0;
+			}
 		}
 		// g = i (cs + i sn)^2; Z' = Y[k] (1 + g) + conj(Y[j]) (1 - g)
 		const double gr = -2.0 * cs * sn, gi = cs * cs - sn * sn;
@@ -2038,10 +2064,10 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	// complex kernel spectrum
 	constexpr bool SP = convp_mode_sp(MODE);
 	// modes 10 / 11: modes 0 / 3 of the one-channel form (cp_solo_*: geometries <13, 0> and <13, -1>; cur.chA is the
-	// channel, cur.bvalid false); 14 / 15: the same with a complex kernel spectrum (1:1 only)
+	// channel, cur.bvalid false); 14 / 15: the same with a complex kernel spectrum
 	constexpr bool SOLO = convp_mode_solo(MODE);
 	constexpr bool CXL = MODE >= 12 && MODE <= 15;
-	static_assert(!(CXL && SOLO) || UL == 0, "one-channel form with a complex spectrum: 1:1 only");
+
 	constexpr int BM = MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 14 ? 0 :
 		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : MODE);
 	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
@@ -2218,7 +2244,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			ex.phase([&](int tid, St& st)
 			{
 				const int lt = lt_of(tid);
-				if constexpr (UL < 0) cp_solo_mid_b_down<LN, UL>(buf_of(tid), st, lt);
+				if constexpr (UL < 0) cp_solo_mid_b_down<LN, UL, CXL>(L, buf_of(tid), st, lt);
 				else cp_solo_mid_b<LN, UL, CXL>(L, buf_of(tid), st, lt);
 				ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
 			});

@@ -498,6 +498,34 @@ static std::vector<double> long_block_constants_complex(const std::vector<double
 		}
 	return out;
 }
+std::vector<double> pair_constants_solo_down_complex(const std::vector<double>& Hc, int n)
+{
+	const int N = n, NT = N / 16, N2 = N / 2;
+	int ln = 0;
+	while ((1 << ln) < N) ln++;
+	auto rev = [](int v, int bits)
+	{
+		int r = 0;
+		for (int b = 0; b < bits; b++)
+			if (v & (1 << b)) r |= 1 << (bits - 1 - b);
+		return r;
+	};
+	const long double pi = 3.14159265358979323846264338327950288L;
+	std::vector<double> out((size_t) 24 * NT * 2, 0.0);
+	for (int t = 0; t < NT; t++)
+		for (int c = 0; c < 16; c += 2)
+		{
+			const int k = rev(16 * t + c, ln), j = N2 - k; // (0 <= k < N2: both bins inside the stored half)
+			const long double th = pi * k / N;
+			out[((size_t) c * NT + t) * 2] = Hc[(size_t) k * 2];
+			out[((size_t) c * NT + t) * 2 + 1] = Hc[(size_t) k * 2 + 1];
+			out[((size_t) (c + 1) * NT + t) * 2] = (double) cosl(th);
+			out[((size_t) (c + 1) * NT + t) * 2 + 1] = (double) sinl(th);
+			out[((size_t) (16 + c / 2) * NT + t) * 2] = Hc[(size_t) j * 2];
+			out[((size_t) (16 + c / 2) * NT + t) * 2 + 1] = Hc[(size_t) j * 2 + 1];
+		}
+	return out;
+}
 std::vector<double> pair_constants_split_complex(const std::vector<double>& Hc, int n)
 {
 	return long_block_constants_complex(Hc, n, false);
@@ -773,7 +801,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 					const bool split_cx = convp_split_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
 					const bool solo_cx = !split_cx && g.n_in == g.n_out &&
 						convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len);
-					if (!generic_conv_fits(g) && !split_cx && !solo_cx)
+					const bool down_cx = convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len);
+					if (!generic_conv_fits(g) && !split_cx && !solo_cx && !down_cx)
 						throw std::runtime_error("minimum-phase filter too long for the generic block convolver");
 					const std::vector<double> hc = kernel_spectrum_complex(*sp.lp, g.bl2, g.fl2, 1.0 / g.bl2);
 					d.Hc = (cd*) dev_alloc(hc.size() * sizeof(double));
@@ -782,15 +811,15 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 					d.tw_len = g.bl2;
 					d.tw = (cd*) dev_alloc(tw.size() * sizeof(double));
 					dev_upload(d.tw, tw.data(), tw.size() * sizeof(double));
-					if (split_cx || solo_cx)
+					if (split_cx || solo_cx || down_cx)
 					{
 						// ... the long-block forms of the pair kernel (modes 12 ... 15)
 						const int n = split_cx ? g.n_in : g.n_in / 2;
 						const std::vector<double> hp = split_cx ? pair_constants_split_complex(hc, n) :
-							pair_constants_solo_complex(hc, n);
+							(down_cx ? pair_constants_solo_down_complex(hc, n) : pair_constants_solo_complex(hc, n));
 						d.hp = (cd*) dev_alloc(hp.size() * sizeof(double));
 						dev_upload(d.hp, hp.data(), hp.size() * sizeof(double));
-						const std::vector<double> pt = pair_twiddles(tw, g.bl2, n, n);
+						const std::vector<double> pt = pair_twiddles(tw, g.bl2, n, down_cx ? n / 2 : n);
 						d.ptw = (cd*) dev_alloc(pt.size() * sizeof(double));
 						dev_upload(d.ptw, pt.data(), pt.size() * sizeof(double));
 					}
@@ -1608,7 +1637,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			if (ch0_ == 0) stat_["conv_blocks"] += L.nblk;
 			const bool sp = convp_split_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
 			const bool solo = convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len) ||
-				(!g.complex_h && convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len));
+				convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len);
 			// (long-block forms: + 4 with a complex kernel spectrum)
 			const int cxl = g.complex_h ? 4 : 0;
 			if (path == kPathPair3) launch_convp(X, solo ? 11 + cxl : (sp ? 9 + cxl : (g.complex_h ? 7 : 3)), stream);
@@ -2081,7 +2110,7 @@ int Engine::conv_path(const ConvGeom& g) const
 	if (((opt_.at("pair_conv") && opt_.at("pair_solo")) || cx_only) && (!g.complex_h || g.n_in == g.n_out) &&
 		convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len))
 		return (!g.up_pow2 && g.up == 3) || (!g.down_pow2 && g.down == 3) ? kPathPair3 : kPathPair;
-	if (opt_.at("pair_conv") && opt_.at("pair_solo") && !g.complex_h &&
+	if (((opt_.at("pair_conv") && opt_.at("pair_solo")) || cx_only) &&
 		convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len))
 		return !g.up_pow2 && g.up == 3 ? kPathPair3 : kPathPair;
 	if (opt_.at("pair_conv") && convp_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2))

@@ -176,6 +176,9 @@ std::vector<double> pair_constants_solo_down(const std::vector<double>& H, int n
 // beyond): 32 x (n / 16) complex entries -- split: H[k] + H[k+n], then (H[k] - H[k+n]) e^{+i pi k / n}; one-channel:
 // A = (H[k] + H[k+n]) - (H[k] - H[k+n]) sin(pi k / n), then B = i (H[k] - H[k+n]) cos(pi k / n)
 std::vector<double> pair_constants_split_complex(const std::vector<double>& Hc, int n);
+// ... one-channel form decimating by 2: 24 x (n / 16) entries -- row c even: H[k]; c + 1: (cos, sin) of pi k / n; row
+// 16 + c / 2: H[n / 2 - k]
+std::vector<double> pair_constants_solo_down_complex(const std::vector<double>& Hc, int n);
 std::vector<double> pair_constants_solo_complex(const std::vector<double>& Hc, int n);
 // twiddle base powers of the pair kernel's passes per thread (r8b_convp.h ptw_fetch): 5 slots x 6 x 256
 // complex; tw = exp(-2 pi i e / tw_len) table (interleaved), n_in = forward length (2048 or 4096)

@@ -299,8 +299,10 @@ PARK_CASES = [
     (192000.0, 44100.0, 8192, 0.5, 180.15, "ahead"),      # half-band decimator + fused 16384 -> 16384 points
 ]
 # Minimum-phase filters on the long blocks (transition band 0.5 ... 1 %): 8192 -> 16384 points on the split form, 16384
-# points 1:1 on the one-channel form, both with a complex kernel spectrum (modes 12 ... 15) -- until round 4 these
-# chains were refused (2x up-sampling) or ran on the generic kernel in place (1:1).  Run on the REFERENCE's own taps
+# points 1:1 and decimating by 2 on the one-channel form, with a complex kernel spectrum (modes 12 ... 15) -- until round 4
+# these chains were refused (2x up-sampling, decimating) or ran on the generic kernel in place (1:1).  (Decimating
+# chains whose latency is odd carry the reference's InputDelay exception -- test_emul.run_minphase_reference_taps, the
+# 64000 -> 48000 case -- on every kernel path; the cases here have even latencies.)  Run on the REFERENCE's own taps
 # (test_emul.run_minphase_reference_taps: RMS <= 1e-15 / peak <= 1e-13).  (src, dst, maxin, chunk, n_in, tb, atten)
 MINPHASE_LONG_CASES = [
     (44100.0, 88200.0, 4096, 3000, 60000, 0.5, 180.15),      # split form
@@ -309,6 +311,8 @@ MINPHASE_LONG_CASES = [
     (96000.0, 44100.0, 8192, 5000, 90000, 0.5, 180.15),      # one-channel form 1:1 + interpolator
     (48000.0, 16000.0, 8192, 8192, 100000, 1.0, 180.15),     # ... strided store
     (44100.0, 132300.0, 2048, 2048, 40000, 1.0, 180.15),     # ... 3x zero stuffing load
+    (88200.0, 44100.0, 8192, 3000, 90000, 0.5, 180.15),      # ... decimating by 2 in the spectrum (Nyquist fix-up Re(H X))
+    (176400.0, 44100.0, 16384, 16384, 200000, 0.5, 180.15),  # ... behind a half-band decimator with inherited latency
 ]
 
 

@@ -454,12 +454,12 @@ def test_unsupported_geometry_fails_loudly(emul):
     r8b.BatchResampler(32000.0, 96000.0, 1024, 0.5, 218.0, nch=1, lib=emul)   # longest radix-3 case
     with pytest.raises(RuntimeError, match="too long"):
         r8b.BatchResampler(64000.0, 48000.0, 1024, 0.2, 218.0, nch=1, lib=emul)
-    # minimum phase: 2x up-sampling and 1:1 blocks of 16384 points run on the pair kernel's long-block forms (round 4);
-    # what has no kernel is such a block DECIMATED in the spectrum -- stated, and refused at creation
-    r8b.BatchResampler(44100.0, 88200.0, 1024, 0.5, 180.15, nch=1, phase=1, lib=emul)
-    r8b.BatchResampler(96000.0, 44100.0, 1024, 0.5, 180.15, nch=1, phase=1, lib=emul)
+    # minimum phase: the longest blocks -- 2x up-sampling, 1:1 and 2x decimating at 16384 points -- run on the pair
+    # kernel's long-block forms with a complex spectrum (round 4; refused or on the generic kernel in place before)
+    for src, dst in ((44100.0, 88200.0), (96000.0, 44100.0), (88200.0, 44100.0), (32000.0, 48000.0), (48000.0, 32000.0)):
+        r8b.BatchResampler(src, dst, 1024, 0.5, 218.0, nch=1, phase=1, lib=emul)
     with pytest.raises(RuntimeError, match="too long"):
-        r8b.BatchResampler(88200.0, 44100.0, 1024, 0.5, 180.15, nch=1, phase=1, lib=emul)
+        r8b.BatchResampler(64000.0, 48000.0, 1024, 0.2, 218.0, nch=1, phase=1, lib=emul)
 
 
 CKPT_CASES = [(44100.0, 96000.0), (96000.0, 44100.0), (44100.0, 44101.0), (44100.0, 2822400.0),
