@@ -208,6 +208,9 @@ def main():
                          "same JSON line (with its own roofline block) for each")
     ap.add_argument("--tb", type=float, default=2.0, help="transition band, percent (side runs)")
     ap.add_argument("--atten", type=float, default=180.15, help="stop-band attenuation (side runs)")
+    ap.add_argument("--phase", type=int, default=0, choices=[0, 1],
+                    help="1 = minimum-phase filters (side runs; the CPU leg and the error report are linear phase: use "
+                         "--no-cpu)")
     ap.add_argument("--settle", type=int, default=150,
                     help="`value` is ALWAYS the K steps timed straight after the W warm-up calls (the driver's contract).  "
                          "With --settle N > 0 the line also carries, as side fields, the same K steps timed again after N further "
@@ -264,7 +267,7 @@ def main():
     # channel_shard(channels*world, r, world)
     lo, hi = channel_shard(args.channels * world, rank, world)
     C, L = hi - lo, args.block
-    rs = r8b.BatchResampler(args.src, args.dst, L, args.tb, args.atten, nch=C, device=local_rank)
+    rs = r8b.BatchResampler(args.src, args.dst, L, args.tb, args.atten, nch=C, device=local_rank, phase=args.phase)
     for o in args.opt:
         k, v = o.split("=")
         rs.set_option(k, int(v))
@@ -380,7 +383,7 @@ def main():
                 "out_msamples_per_s": round(n * C * world / d / 1e6, 3), "what": what}
 
     # THE measurement: W untimed warm-up calls, then exactly K timed steps, barrier + synchronize on both sides
-    run(0, args.warmup, capture=not args.pcm and not args.no_cpu and world == 1)
+    run(0, args.warmup, capture=not args.pcm and not args.no_cpu and world == 1 and args.phase == 0)
     n_out, dt = timed(args.warmup)
     calls = args.warmup + args.steps
     settled = other = None
@@ -465,7 +468,7 @@ def main():
         if e2e is not None:
             # (kernel-only = the line's own `value`: shards at rest; end-to-end beside it)
             res["e2e"] = e2e
-        if not args.no_cpu and world == 1:
+        if not args.no_cpu and world == 1 and args.phase == 0:
             # (N = 1 only: the CPU leg is a per-box baseline, not part of the scaling runs)
             # error report: rows {0, C/2, C-1} of the timed batch's own output (what the object produced for its
             # first calls, captured during warm-up) against the reference on the same samples
