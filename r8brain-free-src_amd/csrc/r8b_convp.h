@@ -244,7 +244,7 @@ struct ConvpState
 	int pf;               // ... and whether the workgroup holds the call's last block and parks what lies beyond the call
 	double tk[2];         // the thread's element of the history tail behind the last block's window (cp_tail_slice_*)
 	double* tka;
-	double er[16], ei[16]; // split 2x up-sampling form (modes 8 / 9): the even half's outputs while the odd half is transformed
+	double er[16], ei[16]; // split 2x up-sampling form (modes 8 / 9 / 12 / 13): the even half's outputs while the odd half is transformed
 };
 
 // (+ 64 bytes behind the array: one word per wave for the workgroup-wide "channel has a non-zero sample" bits)
@@ -544,7 +544,8 @@ R8B_HD void cp_tail_owned(const ConvLaunch& L, const ConvpState<LN, UL>& st, lon
 	}
 }
 
-// ---- one-channel form (modes 10 / 11; geometry <13, 0>: 16384-point blocks of ONE channel) ------------------------
+// ---- one-channel form (modes 10 / 11, 14 / 15 with a complex spectrum; geometries <13, 0> and <13, -1>: 16384-point blocks
+// of ONE channel) --------------------------------------------------------------------------------------------------
 // A block whose transforms are 16384 real points does not fit a pair's array twice (256 KB); it runs on the 8192-point
 // 1:1 geometry as ONE channel in the classic packing z[n] = x[2n] + i x[2n+1]: element i of the circular array holds
 // samples 2i, 2i + 1 of the 16384-sample circular block.  (cp_solo_mid_a / _b: what the spectrum needs for that.)
@@ -1002,7 +1003,7 @@ R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 	}
 }
 
-// ---- split 2x up-sampling form (modes 8 / 9; geometry <13, 0>: 8192 -> 16384-point blocks) -----------------
+// ---- split 2x up-sampling form (modes 8 / 9, 12 / 13 with a complex spectrum; geometry <13, 0>: 8192 -> 16384-point blocks)
 // A 2x up-sampling block whose backward transform would be 16384 points -- 256 KB as a pair, more than a CU's LDS --
 // runs on the 8192-point 1:1 geometry: forward transform of the N = 8192 input samples as there, then the backward
 // transform as TWO N-point transforms, one after the other in the same array: the even outputs y[2m] =
@@ -1112,7 +1113,7 @@ R8B_HD void cp_sp_swap(ConvpState<LN, UL>& st)
 	for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
 }
 
-// ---- one-channel form, the spectrum (modes 10 / 11) ---------------------------------------------------------------
+// ---- one-channel form, the spectrum (modes 10 / 11; 14 / 15: cp_solo_mid_b<.., CX>) ---------------------------------
 // With z[n] = x[2n] + i x[2n+1], Z = DFT_N(z), N = 8192: the spectrum of the even samples is E = (Z[k] + conj Z[N-k]) / 2,
 // that of the odd ones O = (Z[k] - conj Z[N-k]) / 2i, the block's 2N-point spectrum X[k] = E + w^k O, X[k+N] = E - w^k O,
 // w = e^{-i pi / N}.  Multiplying by the (real, symmetric) kernel spectrum H and packing the result the same way --

@@ -654,7 +654,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLI
 	// XCD-aware mapping as in k_convx, over channel PAIRS and groups of SUB consecutive blocks: item w of a launch
 	// is block group bg of channel pair pr
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
-	// (modes 10 / 11, the one-channel form: an item is a channel, not a pair)
+	// (the one-channel form -- convp_mode_solo --: an item is a channel, not a pair)
 	constexpr bool SOLO = convp_mode_solo(MODE);
 	const unsigned npair = SOLO ? (unsigned) X.c.nch : ((unsigned) X.c.nch + 1u) >> 1;
 	const unsigned nbg = ((unsigned) X.c.nblk + SUB - 1u) / SUB;
@@ -1006,7 +1006,7 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 		throw std::runtime_error("launch_convp: decimating geometry not instantiated");
 #endif
 	}
-	// (modes 8 / 9: the split 2x up-sampling form -- r8b_convp.h cp_sp_* --, modes 10 / 11: the one-channel form -- cp_solo_*,
+	// (modes 8 / 9 / 12 / 13: the split 2x up-sampling form -- r8b_convp.h cp_sp_* --, modes 10 / 11 / 14 / 15: the one-channel form -- cp_solo_*,
 	// 16384-point blocks -- live on the 8192-point 1:1 geometry)
 #define R8B_CONVP_DISPATCH_BIG(LN, UL) \
 	if (LN == 13 && UL == 0 && ((ln == 13 && convp_mode_sp(mode)) || (ln == 14 && convp_mode_solo(mode)))) \

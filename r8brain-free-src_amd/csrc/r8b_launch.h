@@ -314,14 +314,14 @@ inline bool convp_geometry_ok(int n_in, int n_out, int up, int down, bool up_pow
 	return n_out == 64 || n_out == 128 || n_out == 256 || n_out == 512 || n_out == 1024 || n_out == 2048 ||
 		n_out == 4096 || n_out == 8192;
 }
-// split 2x up-sampling form of the pair kernel (r8b_convp.h cp_sp_*, modes 8 / 9 on the 8192-point 1:1 geometry): 8192 ->
+// split 2x up-sampling form of the pair kernel (r8b_convp.h cp_sp_*, modes 8 / 9 -- 12 / 13 with a complex spectrum -- on the 8192-point 1:1 geometry): 8192 ->
 // 16384-point blocks -- a 2x up-sampling filter with a transition band of about 1 % and below --, optionally in front of
 // the 3x strided store
 inline bool convp_split_ok(int n_in, int n_out, int up, int down, bool up_pow2, bool down_pow2)
 {
 	return up_pow2 && up == 2 && n_in == 8192 && n_out == 16384 && (down == 1 || (!down_pow2 && down == 3));
 }
-// one-channel form of the pair kernel (r8b_convp.h cp_solo_*, modes 10 / 11 on the 8192-point 1:1 geometry): 16384-point
+// one-channel form of the pair kernel (r8b_convp.h cp_solo_*, modes 10 / 11 -- 14 / 15 with a complex spectrum -- on the 8192-point 1:1 geometry): 16384-point
 // blocks 1:1 (an even number of new samples per block: the samples travel in pairs), optionally behind the 3x zero
 // stuffing load or in front of the 3x strided store
 inline bool convp_solo_ok(int n_in, int n_out, int up, int down, bool up_pow2, bool down_pow2, int in_len)
