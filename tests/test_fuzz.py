@@ -177,7 +177,10 @@ def test_fuzz_gpu_vs_reference(reference, case):
 
 @pytest.mark.parametrize("cfg", [(44100.0, 96000.0, 1024, 2.0, 180.15), (44100.0, 44101.0, 700, 2.0, 136.45),
                                  (2822400.0, 176400.0, 4096, 2.0, 180.15), (48000.0, 32000.0, 333, 2.0, 109.56),
-                                 (96000.0, 11025.0, 2048, 3.0, 160.0)])
+                                 (96000.0, 11025.0, 2048, 3.0, 160.0),
+                                 # the long-block forms of the pair kernel (split 2x up-sampling, one-channel 1:1 / decimating)
+                                 (44100.0, 88200.0, 1500, 0.5, 180.15), (96000.0, 44100.0, 3000, 0.5, 180.15),
+                                 (88200.0, 44100.0, 2500, 0.5, 180.15)])
 def test_soak_long_streams_emulated(emul, reference, cfg):
     """thousands of ragged calls, millions of samples: ring wrap-arounds, the polynomial
     interpolator's counter re-base (every 1000 outputs), split launches -- still the reference's

@@ -350,7 +350,11 @@ def test_hip_minphase_pair_kernel_vs_generic(torch):
                                   # past 1000 outputs (reference CDSPFracInterpolator.h:909-917): thousands of times here
                                   (44100.0, 44101.0, 1024, 2.0, 180.15, 3000),
                                   (44100.0, 2822400.0, 128, 2.0, 180.15, 1200),  # cfg5: convolver + k_hbcascade (5 stages)
-                                  (2822400.0, 176400.0, 4096, 2.0, 180.15, 1200)])  # k_hbdcascade + decimating convolver
+                                  (2822400.0, 176400.0, 4096, 2.0, 180.15, 1200),   # k_hbdcascade + decimating convolver
+                                  # the long-block forms of the pair kernel: split 2x up-sampling, one-channel 1:1 (+
+                                  # k_whole) and decimating, one-channel with the strided store
+                                  (44100.0, 88200.0, 4096, 0.5, 180.15, 800), (96000.0, 44100.0, 8192, 0.5, 180.15, 600),
+                                  (88200.0, 44100.0, 8192, 0.5, 180.15, 600), (48000.0, 16000.0, 8192, 1.0, 180.15, 600)])
 def test_hip_soak_ragged_calls_vs_reference(torch, refwrap, topo):
     """thousands of ragged process() calls of one stream per channel on the real kernels (position
     wrap, ring masks, block schedule and partly filled block groups over a long run), every call's
