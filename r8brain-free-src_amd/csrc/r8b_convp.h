@@ -1132,8 +1132,8 @@ template<int LN, int UL>
 R8B_HD void cp_solo_mid_a(cd* buf, ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
-	static_assert((UL == 0 || UL == -1) && G::E1 == 16 && G::POST && G::NT == 512,
-		"one-channel form: the 8192-point 1:1 geometry and its 2x decimating one");
+	static_assert((UL == 0 || UL == -1 || UL == -2) && G::E1 == 16 && G::POST && G::NT == 512,
+		"one-channel form: the 8192-point 1:1 geometry and its decimating ones");
 	const SwBase bbf = sw_base(buf, fslot<LN, UL>(16 * lt));
 #pragma unroll
 	for (int c = 0; c < 16; c++)
@@ -1234,8 +1234,11 @@ template<int LN, int UL, bool CX = false>
 R8B_HD void cp_solo_mid_b_down(const ConvLaunch& L, const cd* buf, ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
-	static_assert(UL == -1 && G::E1 == 16 && G::E2 == 8 && G::POST && G::NT == 512,
-		"one-channel form, decimating: the 8192 -> 4096-point geometry");
+	// (D = 2 or 4: the kept bins are the thread's positions c = D e, e < 16 / D; Z[N - k] at the partner's 15 - c, Z[N2 - k]
+	// at its 16 - D - c, Z[N2 + k] at the thread's own c + D - 1; w^j = e^{-i pi / D} conj(w^k), g = i (cs + i sn)^D)
+	constexpr int D = 1 << G::DL, NE = 16 / D;
+	static_assert((UL == -1 || (UL == -2 && !CX)) && G::E1 == 16 && G::E2 == NE && G::POST && G::NT == 512,
+		"one-channel form, decimating: the 8192 -> 4096 / 2048-point geometries");
 	const int lp = bitrev_n((512 - bitrev_n(lt, 9)) & 511, 9);
 	const SwBase bp = sw_base(const_cast<cd*>(buf), pswz(16 * lp));
 	cd h2[8];
@@ -1252,29 +1255,31 @@ R8B_HD void cp_solo_mid_b_down(const ConvLaunch& L, const cd* buf, ConvpState<LN
 		qr[c] = v.re;
 		qi[c] = v.im;
 	}
-	double yr[8], yi[8];
+	double yr[NE], yi[NE];
 #pragma unroll
-	for (int e = 0; e < 8; e++)
+	for (int e = 0; e < NE; e++)
 	{
 		constexpr int kRev[16] = { 0, 8, 4, 12, 2, 10, 6, 14, 1, 9, 5, 13, 3, 11, 7, 15 };
-		const int c = 2 * e;
-		const double pr = st.vr[c], pi = st.vi[c], sr = st.vr[c + 1], si = st.vi[c + 1];
-		double ar = qr[15 - c], ai = qi[15 - c], rr = qr[14 - c], ri = qi[14 - c]; // Z[N - k], Z[N2 - k]
+		const int c = D * e;
+		const double pr = st.vr[c], pi = st.vi[c], sr = st.vr[c + D - 1], si = st.vi[c + D - 1];
+		double ar = qr[15 - c], ai = qi[15 - c], rr = qr[16 - D - c], ri = qi[16 - D - c]; // Z[N - k], Z[N2 - k]
 		if (lt == 0)
 		{
 			// (bins b 512: the partners are among the thread's own values)
 			ar = st.vr[kRev[(16 - kRev[c]) & 15]];
 			ai = st.vi[kRev[(16 - kRev[c]) & 15]];
-			rr = st.vr[kRev[(8 - kRev[c]) & 15]];
-			ri = st.vi[kRev[(8 - kRev[c]) & 15]];
+			rr = st.vr[kRev[(16 / D - kRev[c]) & 15]];
+			ri = st.vi[kRev[(16 / D - kRev[c]) & 15]];
 		}
 		const double cs = st.hp[c + 1].re, sn = st.hp[c + 1].im;
 		// X[k] = E + w^k O: E = (P + conj A) / 2, O = -i (P - conj A) / 2, w^k = cs - i sn
 		const double er = 0.5 * (pr + ar), ei = 0.5 * (pi - ai), o_r = 0.5 * (pi + ai), oi = -0.5 * (pr - ar);
 		const double xr = er + cs * o_r + sn * oi, xi = ei + cs * oi - sn * o_r;
-		// X[j]: E = (R + conj S) / 2, O = -i (R - conj S) / 2, w^j = sn - i cs
+		// X[j]: E = (R + conj S) / 2, O = -i (R - conj S) / 2, w^j = e^{-i pi / D} (cs + i sn)  (D = 2: sn - i cs)
 		const double fr = 0.5 * (rr + sr), fi = 0.5 * (ri - si), p_r = 0.5 * (ri + si), p_i = -0.5 * (rr - sr);
-		const double ur = fr + sn * p_r + cs * p_i, ui = fi + sn * p_i - cs * p_r;
+		constexpr double kCD = D == 2 ? 0.0 : 0.70710678118654752440, kSD = D == 2 ? 1.0 : 0.70710678118654752440;
+		const double wjr = D == 2 ? sn : kCD * cs + kSD * sn, wji = D == 2 ? -cs : kCD * sn - kSD * cs;
+		const double ur = fr + wjr * p_r - wji * p_i, ui = fi + wjr * p_i + wji * p_r;
 		double ykr, yki, yjr, yji;
 		if constexpr (CX)
 		{
@@ -1300,14 +1305,15 @@ R8B_HD void cp_solo_mid_b_down(const ConvLaunch& L, const cd* buf, ConvpState<LN
 				yji = 0.0;
 			}
 		}
-		// g = i (cs + i sn)^2; Z' = Y[k] (1 + g) + conj(Y[j]) (1 - g)
-		const double gr = -2.0 * cs * sn, gi = cs * cs - sn * sn;
+		// g = i (cs + i sn)^D; Z' = Y[k] (1 + g) + conj(Y[j]) (1 - g)
+		const double q2r = cs * cs - sn * sn, q2i = 2.0 * cs * sn; // (cs + i sn)^2
+		const double gr = D == 2 ? -q2i : -2.0 * q2r * q2i, gi = D == 2 ? q2r : q2r * q2r - q2i * q2i;
 		const double m_r = 1.0 + gr, n_r = 1.0 - gr;
 		yr[e] = ykr * m_r - yki * gi + yjr * n_r - yji * gi;
 		yi[e] = ykr * gi + yki * m_r - yjr * gi - yji * n_r;
 	}
 #pragma unroll
-	for (int e = 0; e < 8; e++)
+	for (int e = 0; e < NE; e++)
 	{
 		st.vr[e] = yr[e];
 		st.vi[e] = yi[e];
@@ -2234,7 +2240,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		if constexpr (SOLO)
 		{
 			// one-channel form: the spectrum through the array for the partner bins, a barrier either side of their reads
-			static_assert(G::NPOST == 3, "one-channel form: pass plan of the 8192-point geometries");
+			static_assert(G::NPOST == 3 || G::NPOST == 5, "one-channel form: pass plans of the 8192-point geometries");
 			auto q_mida = [&](int tid, St& st)
 			{
 				const int lt = lt_of(tid);
@@ -2249,7 +2255,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				else cp_solo_mid_b<LN, UL, CXL>(L, buf_of(tid), st, lt);
 				ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
 			});
-			ex.wave_steps(d_midw, d_post1, d_post2);
+			ex.wave_steps(d_midw, d_post1, d_post2, d_post3);
 		}
 		else
 		ex.wave_steps(d_pre1, d_pre2, d_midc, d_midw, d_post1, d_post2, d_post3);

@@ -426,9 +426,9 @@ std::vector<double> pair_constants_solo(const std::vector<double>& H, int n)
 	return out;
 }
 
-std::vector<double> pair_constants_solo_down(const std::vector<double>& H, int n)
+std::vector<double> pair_constants_solo_down(const std::vector<double>& H, int n, int down)
 {
-	const int N = n, NT = N / 16, N2 = N / 2;
+	const int N = n, NT = N / 16, N2 = N / down;
 	int ln = 0;
 	while ((1 << ln) < N) ln++;
 	auto rev = [](int v, int bits)
@@ -441,9 +441,9 @@ std::vector<double> pair_constants_solo_down(const std::vector<double>& H, int n
 	const long double pi = 3.14159265358979323846264338327950288L;
 	std::vector<double> out((size_t) 16 * NT * 2, 0.0);
 	for (int t = 0; t < NT; t++)
-		for (int c = 0; c < 16; c += 2)
+		for (int c = 0; c < 16; c += down)
 		{
-			const int k = rev(16 * t + c, ln); // (< N2: the lowest bit of c is the highest of k)
+			const int k = rev(16 * t + c, ln); // (< N2: the lowest bits of c are the highest of k)
 			const long double th = pi * k / N;
 			out[((size_t) c * NT + t) * 2] = H[(size_t) k];
 			out[((size_t) c * NT + t) * 2 + 1] = H[(size_t) (N2 - k)];
@@ -801,7 +801,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 					const bool split_cx = convp_split_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
 					const bool solo_cx = !split_cx && g.n_in == g.n_out &&
 						convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len);
-					const bool down_cx = convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len);
+					const bool down_cx = g.down == 2 &&
+						convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len);
 					if (!generic_conv_fits(g) && !split_cx && !solo_cx && !down_cx)
 						throw std::runtime_error("minimum-phase filter too long for the generic block convolver");
 					const std::vector<double> hc = kernel_spectrum_complex(*sp.lp, g.bl2, g.fl2, 1.0 / g.bl2);
@@ -862,7 +863,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 				if (convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len))
 				{
 					// one-channel form decimating by 2: the passes of the 8192 -> 4096-point geometry
-					const std::vector<double> hp = pair_constants_solo_down(H, g.n_in / 2);
+					const std::vector<double> hp = pair_constants_solo_down(H, g.n_in / 2, g.down);
 					d.hp = (cd*) dev_alloc(hp.size() * sizeof(double));
 					dev_upload(d.hp, hp.data(), hp.size() * sizeof(double));
 					const std::vector<double> pt = pair_twiddles(tw, g.bl2, g.n_in / 2, g.n_out / 2);
@@ -1637,7 +1638,8 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			if (ch0_ == 0) stat_["conv_blocks"] += L.nblk;
 			const bool sp = convp_split_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
 			const bool solo = convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len) ||
-				convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len);
+				((!g.complex_h || g.down == 2) &&
+					convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len));
 			// (long-block forms: + 4 with a complex kernel spectrum)
 			const int cxl = g.complex_h ? 4 : 0;
 			if (path == kPathPair3) launch_convp(X, solo ? 11 + cxl : (sp ? 9 + cxl : (g.complex_h ? 7 : 3)), stream);
@@ -2110,7 +2112,7 @@ int Engine::conv_path(const ConvGeom& g) const
 	if (((opt_.at("pair_conv") && opt_.at("pair_solo")) || cx_only) && (!g.complex_h || g.n_in == g.n_out) &&
 		convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len))
 		return (!g.up_pow2 && g.up == 3) || (!g.down_pow2 && g.down == 3) ? kPathPair3 : kPathPair;
-	if (((opt_.at("pair_conv") && opt_.at("pair_solo")) || cx_only) &&
+	if (((opt_.at("pair_conv") && opt_.at("pair_solo")) || cx_only) && (!g.complex_h || g.down == 2) &&
 		convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len))
 		return !g.up_pow2 && g.up == 3 ? kPathPair3 : kPathPair;
 	if (opt_.at("pair_conv") && convp_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2))

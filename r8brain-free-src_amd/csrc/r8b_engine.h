@@ -169,9 +169,10 @@ std::vector<double> pair_constants_split(const std::vector<double>& H, int n_in)
 // n-point complex transform, bin k = bitrev(position): a = (H[k] + H[k + n]) - (H[k] - H[k + n]) sin(pi k / n),
 // b = (H[k] - H[k + n]) cos(pi k / n); H over 2 n points
 std::vector<double> pair_constants_solo(const std::vector<double>& H, int n);
-// ... decimating by 2 (cp_solo_mid_b_down): per forward position 16 t + c, c even -- kept bin k --: (H[k], H[n / 2 - k]);
+// ... decimating by `down` = 2 or 4 (cp_solo_mid_b_down): per forward position 16 t + c, c a multiple of down -- kept bin k --:
+// (H[k], H[n / down - k]);
 // c + 1: (cos, sin) of pi k / n
-std::vector<double> pair_constants_solo_down(const std::vector<double>& H, int n);
+std::vector<double> pair_constants_solo_down(const std::vector<double>& H, int n, int down);
 // ... of the split form and of the one-channel form (1:1) with a complex kernel spectrum Hc (n + 1 complex bins, Hermitian
 // beyond): 32 x (n / 16) complex entries -- split: H[k] + H[k+n], then (H[k] - H[k+n]) e^{+i pi k / n}; one-channel:
 // A = (H[k] + H[k+n]) - (H[k] - H[k+n]) sin(pi k / n), then B = i (H[k] - H[k+n]) cos(pi k / n)

@@ -792,6 +792,12 @@ void launch_convp_solo_down(const ConvxLaunch& X, int mode, hipStream_t stream)
 		else if (mode == 14) launch_convp_t<LN, -DL, 14, 24>(X, stream);
 		else launch_convp_t<LN, -DL, 15, 24>(X, stream);
 	}
+	// (decimating by 4: real spectra only)
+	if constexpr (LN == 13 && DL == 2)
+	{
+		if (mode == 10) launch_convp_t<LN, -DL, 10, 24>(X, stream);
+		else launch_convp_t<LN, -DL, 11, 24>(X, stream);
+	}
 }
 
 template<int LN, int UL>
@@ -990,7 +996,8 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 	if (X.c.down_pow2 && X.c.down > 1)
 	{
 #define R8B_CONVP_DISPATCH_DOWN(LN, DL) \
-		if (LN == 13 && DL == 1 && ln == 14 && X.c.down == 2 && convp_mode_solo(mode)) \
+		if (LN == 13 && ln == 14 && X.c.down == (1 << DL) && ((DL == 1 && convp_mode_solo(mode)) || \
+			(DL == 2 && (mode == 10 || mode == 11)))) \
 		{ \
 			launch_convp_solo_down<LN, DL>(X, mode, (hipStream_t) stream); \
 			R8B_PAIR_DONE; \

@@ -330,10 +330,11 @@ inline bool convp_solo_ok(int n_in, int n_out, int up, int down, bool up_pow2, b
 	if (up_pow2 && up == 1) return (in_len & 1) == 0 && (down == 1 || (!down_pow2 && down == 3));
 	return !up_pow2 && up == 3 && down == 1;
 }
-// ... decimating by 2 in the spectrum (geometry <13, -1>: 16384 -> 8192 points), optionally behind the 3x zero stuffing load
+// ... decimating by 2 or 4 in the spectrum (geometries <13, -1> / <13, -2>: 16384 -> 8192 / 4096 points; by 4: real spectra
+// only), optionally behind the 3x zero stuffing load
 inline bool convp_solo_down_ok(int n_in, int n_out, int up, int down, bool up_pow2, bool down_pow2, int in_len)
 {
-	if (n_in != 16384 || n_out != 8192 || !down_pow2 || down != 2) return false;
+	if (n_in != 16384 || !down_pow2 || !((down == 2 && n_out == 8192) || (down == 4 && n_out == 4096))) return false;
 	return up_pow2 ? (up == 1 && (in_len & 1) == 0) : up == 3;
 }
 // ... with the whole-step interpolator fused in (modes 1 and 4)

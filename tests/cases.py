@@ -137,8 +137,8 @@ SPLIT_CASES = [
 ]
 
 
-# 16384-point blocks (1:1 and 2x decimating filters with a transition band of 0.5 ... 0.6 %, the re-blocked 1/3, 3/1 and 3/2
-# filters): the one-channel form of the pair kernel (r8b_convp.h cp_solo_*, modes 10 / 11), and the one-channel kernel
+# 16384-point blocks (1:1 and 2x decimating filters with a transition band of 0.5 ... 0.6 %, the re-blocked 1/3, 3/1, 3/2 and
+# 3/4 filters): the one-channel form of the pair kernel (r8b_convp.h cp_solo_*, modes 10 / 11), and the one-channel kernel
 # k_convx behind option pair_solo = 0.  (src, dst, maxin, chunk, n_in, tb, atten[, rms_tol, peak_tol])
 SOLO_CASES = [
     (96000.0, 44100.0, 8192, 5000, 100000, 0.5, 180.15),      # 1:1 in front of the whole-step interpolator, ragged calls
@@ -147,6 +147,7 @@ SOLO_CASES = [
     (88200.0, 44100.0, 8192, 3000, 90000, 0.5, 180.15),       # decimating by 2 in the spectrum
     (176400.0, 44100.0, 16384, 16384, 200000, 0.55, 206.91),  # ... behind a half-band decimator (input from a ring)
     (32000.0, 48000.0, 2048, 2048, 60000, 0.5, 180.15, 1e-13, 5e-12),   # 3x zero stuffing + decimating (REBLOCK_CASES' bound)
+    (64000.0, 48000.0, 2048, 777, 70000, 0.5, 180.15, 1e-10, 5e-10),    # ... decimating by 4 (REBLOCK_CASES' bound)
     (192000.0, 44100.0, 8192, 8192, 150000, 0.5, 180.15),     # half-band decimator + 16384 points 1:1 + interpolator
 ]
 
@@ -291,9 +292,10 @@ PARK_CASES = [
     (176400.0, 44100.0, 16384, 0.5, 180.15, "park"),      # half-band decimator + 16384 -> 8192 points (decimating form)
     (96000.0, 44100.0, 8192, 0.5, 180.15, "ahead"),       # 16384 points 1:1 in front of the (unfused) interpolator
     (44100.0, 132300.0, 3000, 0.5, 180.15, "park"),       # 3x zero stuffing into 16384 points
-    # the one-channel KERNEL (what is left for it: 16384 points decimated by 4, and option pair_solo = 0): at the end of
-    # a chain through an output ring of its own and a copy
-    (48000.0, 36000.0, 6000, 0.5, 180.15, "ahead"),       # 3x zero stuffing into 16384 points, decimated by 4
+    (48000.0, 36000.0, 6000, 0.5, 180.15, "park"),        # 3x zero stuffing into 16384 points, decimated by 4
+    # the one-channel KERNEL (what is left for it: option pair_solo = 0): at the end of a chain through an output ring of
+    # its own and a copy
+    (48000.0, 36000.0, 6000, 0.5, 180.15, "ahead", {"pair_solo": 0}),
     (48000.0, 16000.0, 8192, 0.5, 180.15, "ahead", {"pair_solo": 0}),
     (96000.0, 44100.0, 8192, 0.5, 180.15, "ahead", {"pair_solo": 0}),   # fused with the interpolator (output ring)
     (192000.0, 44100.0, 8192, 0.5, 180.15, "ahead"),      # half-band decimator + fused 16384 -> 16384 points

@@ -291,6 +291,11 @@ void emul_convp_solo_down(const ConvxLaunch& X, int mode)
 		else if (mode == 14) emul_convp_t<LN, -DL, 14, 24>(X);
 		else emul_convp_t<LN, -DL, 15, 24>(X);
 	}
+	if constexpr (LN == 13 && DL == 2)
+	{
+		if (mode == 10) emul_convp_t<LN, -DL, 10, 24>(X);
+		else emul_convp_t<LN, -DL, 11, 24>(X);
+	}
 }
 
 template<int LN, int UL>
@@ -331,7 +336,8 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 	if (X.c.down_pow2 && X.c.down > 1)
 	{
 #define R8B_CONVP_DISPATCH_DOWN(LN, DL) \
-		if (LN == 13 && DL == 1 && ln == 14 && X.c.down == 2 && convp_mode_solo(mode)) \
+		if (LN == 13 && ln == 14 && X.c.down == (1 << DL) && ((DL == 1 && convp_mode_solo(mode)) || \
+			(DL == 2 && (mode == 10 || mode == 11)))) \
 		{ \
 			emul_convp_solo_down<LN, DL>(X, mode); \
 			return; \
