@@ -190,7 +190,7 @@ R8BSRC_DECL int r8b_batch_describe(CR8BBatch b, char* buf, int cap);
 
 /* Kernel tuning/instrumentation knob: name/value pairs understood by the engine
  * ("fuse", "conv_threads", ...).  Returns 0 if the knob exists.  Knobs that change where a stream's state lives
- * ("fuse", "fuse_hb", "fuse_hbd", "fold_tail", "fast_conv", "pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park") are
+ * ("fuse", "fuse_hb", "fuse_hbd", "fold_tail", "fast_conv", "pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park", "fuse_latency") are
  * refused (-1) once samples have been processed, until r8b_batch_clear().  "park" (default 1): every overlap-save
  * block is computed once -- the block that holds a call's last output keeps what it holds of the next call in a
  * per-channel park buffer (or writes it ahead into the next stage's ring) instead of being computed again by the next

@@ -1590,11 +1590,23 @@ R8B_HD void cp_final_store(const ConvLaunch& L, cd* ybase, cd* y, const ConvpSta
 	// (ybase: the pair's array; y: the run inside it, ybase + run_off)
 	typedef ConvpGeom<LN, UL> G;
 	constexpr int mask = G::N2 - 1;
-	const long long t0 = cx_block_t0(L, k);
-	// a stage's stream starts at t = 0: earlier outputs do not exist for the interpolator
-	// (reference CDSPFracInterpolator.h:834-859)
+	const long long t0 = cx_block_t0(L, k) - L.t_zero;
+	// the interpolator's stream starts at this stage's output t_zero (0 but in chains with a fractional latency): earlier
+	// outputs do not exist for it (reference CDSPFracInterpolator.h:834-859)
 	const int nzero = t0 >= 0 ? 0 : (-t0 > L.in_len ? L.in_len : (int) -t0);
 	const int in_len = L.in_len, u0 = (lt + L.fl2r) & mask;
+	if (t0 <= 0)
+	{
+		// (the block that holds the stream's start: the windows of the first outputs begin in front of the run -- by the
+		// left half of the interpolator's filter less this stage's fl2, which is a few samples for a minimum-phase
+		// filter -- where the stream has zeros too: the slots between the array's start and the run)
+		for (int i = lt; i < (int) (y - ybase); i += G::NT)
+		{
+			cd z;
+			z.re = z.im = 0.0;
+			ybase[i] = z;
+		}
+	}
 	if (nzero == 0 && L.fl2r + (int) (y - ybase) <= G::NT)
 	{
 		// (every block but the first ones of a stream, in the rotated layout of convp_prepare: fl2r = 0 or 1)
@@ -2066,7 +2078,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	typedef ConvpGeom<LN, UL> G;
 	typedef ConvpState<LN, UL> St;
 	// modes 6 / 7: modes 0 / 3 with a complex kernel spectrum
-	constexpr bool CX = MODE == 6 || MODE == 7;
+	// modes 16 / 17: modes 4 / 5 (fused interpolator, two phases per thread) with a complex kernel spectrum
+	constexpr bool CX = MODE == 6 || MODE == 7 || MODE == 16 || MODE == 17;
 	// modes 8 / 9: modes 0 / 3 of the split 2x up-sampling form (cp_sp_*: geometry <13, 0> only); 12 / 13: the same with a
 	// complex kernel spectrum
 	constexpr bool SP = convp_mode_sp(MODE);
@@ -2076,7 +2089,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	constexpr bool CXL = MODE >= 12 && MODE <= 15;
 
 	constexpr int BM = MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 14 ? 0 :
-		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : MODE);
+		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : (MODE == 16 ? 4 : (MODE == 17 ? 5 : MODE)));
 	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
 	constexpr bool SPLIT = kSplit<LN, UL> && !CX && (BM == 0 || BM == 3);
 	(void) SPLIT;
@@ -2151,7 +2164,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.stamp2();
 		cp_first<LN, UL>(L, buf_of(tid), st, lt);
 		// (modes 4 / 5: the thread's entry of the interpolator's lane table, long before its rows are addressed with it)
-		if constexpr (MODE == 4 || MODE == 5) st.pt = cp_ptab_fetch(X, tid);
+		if constexpr (BM == 4 || BM == 5) st.pt = cp_ptab_fetch(X, tid);
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
 		else hp_prefetch(st, lt);
 	});
@@ -2474,9 +2487,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			}
 		});
 	}
-	else if constexpr (MODE == 4 || MODE == 5)
+	else if constexpr (BM == 4 || BM == 5)
 	{
-		constexpr int T2 = MODE == 4 ? 25 : 27;
+		constexpr int T2 = BM == 4 ? 25 : 27;
 		static_assert(UL >= 0, "the decimating form has no fused interpolator");
 		ex.phase([&](int tid, St& st)
 		{

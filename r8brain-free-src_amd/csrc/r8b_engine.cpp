@@ -749,6 +749,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// ... with two adjacent phases per thread in the fused interpolator when it up-samples (In <= Out:
 	// half the LDS reads per output, nearly all lanes busy)
 	opt_["pair_two"] = 1;
+	opt_["fuse_latency"] = 1; // chains with a fractional latency (minimum phase): convolver + interpolator in one launch too
 	opt_["pair_split"] = 1;
 	opt_["pair_solo"] = 1; // 16384-point 1:1 blocks on the pair kernel's one-channel form (else k_convx) // 8192 -> 16384-point 2x up-sampling blocks on the pair kernel's split form (else k_convx)
 	opt_["align_groups"] = 1; // ... with whole output groups per block (launch_fused)
@@ -933,21 +934,33 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 
 // Tables of the pair kernel's two-phases-per-thread interpolator (r8b_convp.h MODE 4) for the fused
 // pair (convolver s, whole-step interpolator s+1); needs In <= Out and at most 24 taps.
+// whether a whole-step interpolator has two-phase tables at all (prepare_two_phase): at most 24 taps, 2 ... 510 phases,
+// the window starts of a phase pair at most three samples apart; *maxdl_out: that distance
+static bool two_phase_possible(const StagePlan& w, int* maxdl_out)
+{
+	const int In = w.in_step, Out = w.out_step;
+	if (w.flen > 24 || Out < 2 || Out > 510) return false;
+	const int NP = (Out + 1) / 2, nsg = (NP + 15) / 16;
+	if (16 / nsg < 1) return false;
+	int maxdl = 0;
+	for (int q = 0; 2 * q + 1 < Out; q++)
+		maxdl = std::max(maxdl, (int) ((long long) (2 * q + 1) * In / Out) - (int) ((long long) (2 * q) * In / Out));
+	if (maxdl_out) *maxdl_out = maxdl;
+	return maxdl <= 3;
+}
+
 void Engine::prepare_two_phase(size_t s)
 {
 	const StagePlan& w = plan_.stages[s + 1];
 	StageDev& d = dev_[s + 1];
 	const int In = w.in_step, Out = w.out_step;
-	if (w.flen > 24 || Out < 2 || Out > 510) return;
+	int maxdl = 0;
+	if (!two_phase_possible(w, &maxdl)) return;
 	const int NP = (Out + 1) / 2;           // phase pairs
 	const int nsg = (NP + 15) / 16;         // 16-lane LDS service groups per set
 	const int nsets = 16 / nsg;             // a workgroup has 16 service groups
-	if (nsets < 1) return;
 	auto r_of = [&](int ph) { return (int) ((long long) ph * In / Out); };
 	// rows of T2 entries: the taps plus the largest distance between the window starts of a pair
-	int maxdl = 0;
-	for (int q = 0; 2 * q + 1 < Out; q++) maxdl = std::max(maxdl, r_of(2 * q + 1) - r_of(2 * q));
-	if (maxdl > 3) return;
 	const int T2 = maxdl <= 1 ? 25 : 27;
 	// Phase pairs go to lanes in QUADS: the four lanes of an aligned lane quad own four consecutive phase pairs of one
 	// group set, i.e. store 64 consecutive bytes of a channel's output per group (one L2 write request per quad;
@@ -1131,6 +1144,11 @@ long long Engine::park_row_len(size_t s) const
 		fused_blocking(s, &S, &off);
 		const StagePlan& w = plan_.stages[s + 1];
 		n = (S * w.out_step + w.in_step - 1) / w.in_step + 2;
+		// (block 0 holds every output whose window ends inside its valid run [-fl2, in_len - fl2): more than a later
+		// block's share when fl2 is small -- a minimum-phase filter's few samples)
+		const ConvGeom& g = plan_.stages[s].cg;
+		const long long e0 = (long long) g.in_len + off - g.fl2 - w.fl2 - fused_shift(s).d;
+		if (e0 > 0) n = std::max(n, (e0 * w.out_step + w.in_step - 1) / w.in_step + 2);
 		// (output ring of the one-channel fused kernel: a call's outputs plus one block's, a power of two)
 		if (!use_pair_fused(plan_.stages[s].cg)) return pow2_at_least(plan_.max_out_len + n + 16);
 	}
@@ -1213,7 +1231,7 @@ bool Engine::set_option(const std::string& name, int value)
 	// (unfused stages keep it in rings the fused kernels never write): once a stream has started they
 	// may only change after clear().
 	static const char* const structural[] = { "fuse", "fuse_hb", "fuse_hbd", "fold_tail", "fast_conv",
-		"pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park" };
+		"pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park", "fuse_latency" };
 	bool started = false;
 	for (const StagePlan& sp : plan_.stages) started = started || sp.m != 0;
 	for (const char* n : structural)
@@ -1976,7 +1994,7 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 
 int Engine::group_len(size_t s) const
 {
-	if (latency_chain()) return 1;
+	if (latency_chain()) return fuse_with_next(s) ? 2 : 1;
 	if (fuse_with_next(s)) return 2;
 	const StageKind kind = plan_.stages[s].desc.kind;
 	// Runs of decimators: one kernel saves two launches and the intermediate streams, but pays
@@ -2168,9 +2186,48 @@ bool Engine::pcm_fused_out() const
 	return !(sp.desc.kind == kConv && conv_path(sp.cg) != kPathGeneric);
 }
 
+// The interpolator of a chain with a fractional latency emits sample j as sample q = j + out_skip of its stream, whose
+// position is q In + pos0 (reference CDSPFracInterpolator.h:721-752, 991-1060); its input sample i is the convolver's
+// output t = i + out_skip of THAT stage.  With j0 In = pos0 (mod Out) -- In and Out are coprime -- and m = (j0 In - pos0)
+// / Out, floor((q In + pos0) / Out) = floor((q + j0) In / Out) - m and the phases agree: the stream is the canonical one
+// (position J In, start phase 0) renumbered, J = j + out_skip_w + j0, read from convolver outputs floor(J In / Out) + d,
+// d = out_skip_c - m.
+Engine::FusedShift Engine::fused_shift(size_t s) const
+{
+	const StagePlan& c = plan_.stages[s];
+	const StagePlan& w = plan_.stages[s + 1];
+	FusedShift f;
+	f.js = 0; f.d = 0; f.t_zero = 0;
+	if (c.out_skip == 0 && w.out_skip == 0 && w.pos0 == 0) return f;
+	const long long In = w.in_step, Out = w.out_step;
+	long long j0 = 0;
+	while (j0 < Out && (j0 * In) % Out != (long long) w.pos0 % Out) j0++;
+	if (j0 >= Out) throw std::logic_error("fused_shift: the interpolator's start phase has no canonical output");
+	const long long m = (j0 * In - w.pos0) / Out;
+	f.js = w.out_skip + j0;
+	f.d = c.out_skip - m;
+	f.t_zero = (int) c.out_skip;
+	return f;
+}
+
+// ... which needs the pair kernel with two phases per thread (modes 4 / 5 / 16 / 17 carry the shifts) and nothing else
+// in the pair of stages that the fused launch does not model
+bool Engine::fuse_latency_ok(size_t s) const
+{
+	if (!opt_.at("fuse_latency") || !opt_.at("pair_two") || s + 1 >= plan_.stages.size()) return false;
+	const StagePlan& c = plan_.stages[s];
+	const StagePlan& w = plan_.stages[s + 1];
+	if (c.desc.kind != kConv || w.desc.kind != kFrac || !w.whole || w.frac0 != 0.0) return false;
+	if (!use_pair_fused(c.cg) || c.out_skip < 0 || w.out_skip < 0 || w.pos0 < 0 || w.pos0 >= w.out_step) return false;
+	if (!two_phase_possible(w, nullptr)) return false;
+	// (use_pair_two's test of the run's place in the array, before the lane tables exist)
+	const int off = (w.in_step + 16 + 15) / 16 * 16;
+	return off + c.cg.in_len + w.in_step + 32 + 16 <= c.cg.n_out;
+}
+
 bool Engine::fuse_with_next(size_t s) const
 {
-	if (latency_chain()) return false;
+	if (latency_chain() && !fuse_latency_ok(s)) return false;
 	if (!opt_.at("fuse") || !opt_.at("fast_conv") || s + 1 >= plan_.stages.size()) return false;
 	const StagePlan& c = plan_.stages[s];
 	const StagePlan& w = plan_.stages[s + 1];
@@ -2209,6 +2266,7 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	for (int i = 0; i < L.n_fwd; i++) L.fwd_radix[i] = d.fwd_radix[(size_t) i];
 	for (int i = 0; i < L.n_inv; i++) L.inv_radix[i] = d.inv_radix[(size_t) i];
 	L.H = d.H; L.Hc = d.Hc; L.tw = d.tw; L.tw_len = d.tw_len; L.spec = d.spec; L.spec2 = d.spec2; L.hp = d.hp; L.ptw = d.ptw;
+	L.t_zero = 0;
 	L.nch = nchw_;
 	// (short transforms: fewer threads per block -- a 64-point transform on 256 threads is four waves
 	// meeting at barriers with nothing to do)
@@ -2268,7 +2326,8 @@ void Engine::fused_blocking(size_t s, long long* S_out, long long* off_out) cons
 		if (G2 > 0 && (G2 * In) % up == 0 && G2 * In * 100 >= S * 98) G = G2;
 		if (G > 0 && G * In * 100 >= S * 97)
 		{
-			const long long r = (((long long) in_len - fl2c - w.fl2) % In + In) % In;
+			// (chains with a fractional latency: the canonical stream sits fused_shift().d convolver outputs later)
+			const long long r = (((long long) in_len - fl2c - w.fl2 - fused_shift(s).d) % In + In) % In;
 			long long o = -r;
 			for (int t = 0; t < up && o % up != 0; t++) o -= In;
 			if (o % up == 0)
@@ -2285,12 +2344,23 @@ void Engine::fused_blocking(size_t s, long long* S_out, long long* off_out) cons
 static long long ceil_div_nonneg(long long a, long long b) { return a <= 0 ? 0 : (a + b - 1) / b; }
 
 void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& src,
-	const DstView& dst, void* stream)
+	const DstView& dst_in, void* stream)
 {
 	const StagePlan& c = plan_.stages[s];
 	const StagePlan& w = plan_.stages[s + 1];
+	// Chains with a fractional latency (fused_shift): everything below works on the CANONICAL stream -- output J at
+	// position J In, phase J In mod Out, its window starting at convolver output floor(J In / Out) + D -- of which the
+	// call's emitted outputs [wa, wb) are J - js; they are stored js columns (ring slots) earlier.  (js = D = 0 in
+	// linear-phase chains.)
+	const FusedShift fs = fused_shift(s);
+	const long long D = fs.d;
+	wa += fs.js;
+	wb += fs.js;
+	DstView dst = dst_in;
+	dst.off -= fs.js;
 	ConvxLaunch X;
 	fill_conv(s, X.c, src);
+	X.c.t_zero = fs.t_zero;
 	X.c.a = 0; X.c.b = 0;
 	X.c.dst = dst; // unused in fused mode
 	X.in_step = w.in_step; X.out_step = w.out_step; X.flen = w.flen;
@@ -2314,16 +2384,16 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	if (((S / up) & 1) != 0 || ((off / up) & 1) != 0) X.c.vec_ok = 0;
 	auto owner = [&](long long j) // first block whose valid range ends after the window of j
 	{
-		const long long v = j * In / Out + w.fl2 + fl2c - in_len - off;
+		const long long v = j * In / Out + D + w.fl2 + fl2c - in_len - off;
 		return v < 0 ? 0 : v / S + 1;
 	};
 	// outputs of block k, not clipped to the call: [first output whose window block k - 1 does not hold, first one
 	// block k does not hold either)
 	auto block_jlo = [&](long long k)
 	{
-		return k == 0 ? 0 : ceil_div_nonneg(((k - 1) * S + off - fl2c + in_len - w.fl2) * Out, In);
+		return k == 0 ? 0 : ceil_div_nonneg(((k - 1) * S + off - fl2c + in_len - w.fl2 - D) * Out, In);
 	};
-	auto block_jhi = [&](long long k) { return ceil_div_nonneg((k * S + off - fl2c + in_len - w.fl2) * Out, In); };
+	auto block_jhi = [&](long long k) { return ceil_div_nonneg((k * S + off - fl2c + in_len - w.fl2 - D) * Out, In); };
 	X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
 	X.park_src = nullptr; X.park_dst = nullptr;
 	X.park_blk = SpanInfo();
@@ -2448,7 +2518,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			B.jlo = jlo; B.jhi = jhi;
 			B.jlo_mod = (int) (jlo % Out);
 			B.ph_lo = (int) ((jlo * In) % Out);
-			B.u_lo = (int) (jlo * In / Out - w.fll - t0);
+			B.u_lo = (int) (jlo * In / Out + D - w.fll - t0);
 			B.pad = 0;
 		}
 		if (pair_two)
@@ -2461,7 +2531,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 				const long long g0 = B.jlo / Out, glast = (B.jhi - 1) / Out;
 				B.ph_lo = (int) (glast - g0);
 				B.pad = (int) (B.jhi - glast * Out); // the phase the block's last group ends before
-				B.u_lo = (int) (In * g0 - w.fll - t0) + run_off;
+				B.u_lo = (int) (In * g0 + D - w.fll - t0) + run_off;
 			};
 			for (int i = 0; i < X.c.nblk; i++) two_phase_span(X.blk[i], k0 + i);
 			if (parks && k1 == klast && block_jhi(klast) > wb)
@@ -2478,7 +2548,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 				X.park_dst = dp.park[dp.park_cur ^ 1] + (long long) ch0_ * dp.park_stride;
 				X.park_stride = dp.park_stride;
 			}
-			launch_convp(X, dw.taps2 == 27 ? 5 : 4, stream);
+			launch_convp(X, (dw.taps2 == 27 ? 5 : 4) + (c.cg.complex_h ? 12 : 0), stream);
 		}
 		else if (use_pair_fused(c.cg)) launch_convp(X, 1, stream);
 		else launch_convx(X, 1, stream);

@@ -98,6 +98,16 @@ private:
 		long long t_in = 0, t_out = 0; // per-channel samples in/out over the timed launches
 	};
 	void* get_event(StageDev& d);
+	// Convolver + whole-step interpolator of a chain with a fractional latency (minimum phase) as ONE launch: the shifts
+	// that map the interpolator's emitted outputs onto the canonical stream the fused kernels compute (launch_fused)
+	struct FusedShift
+	{
+		long long js; // canonical output J = emitted j + js
+		long long d;  // convolver output time of J's window start = floor(J In / Out) + d
+		int t_zero;   // the interpolator's stream starts at this convolver output
+	};
+	FusedShift fused_shift(size_t s) const;
+	bool fuse_latency_ok(size_t s) const;
 	void release();
 	unsigned long long config_hash() const;
 	bool stage_owns_ring(size_t s) const;

@@ -700,9 +700,10 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLI
 		"+s"(H.c.up_pow2), "+s"(H.c.src.cur_stride), "+s"(H.c.src.cur_base), "+s"(H.c.src.cur_fmt), "+s"(H.c.rot),
 		"+s"(H.c.fl2r), "+s"(H.c.tail_flags), "+s"(H.c.tail_bf)
 		: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
-	if constexpr (MODE == 4 || MODE == 5)
+	if constexpr (MODE == 4 || MODE == 5 || MODE == 16 || MODE == 17)
 		asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),
-			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt), "+s"(H.park_n), "+s"(H.park_out), "+s"(H.park_slices)
+			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt), "+s"(H.park_n), "+s"(H.park_out), "+s"(H.park_slices),
+			"+s"(H.c.t_zero)
 			: "s"(H.ptab), "s"(H.ctab), "s"(H.wdst.p));
 	else if constexpr (MODE == 1) {}
 	else
@@ -988,6 +989,8 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 		else if (mode == 7) launch_convp_t<LN, UL, 7, 24>(X, (hipStream_t) stream); \
 		else if (mode == 4) launch_convp_t<LN, UL, 4, 24>(X, (hipStream_t) stream); \
 		else if (mode == 5) launch_convp_t<LN, UL, 5, 24>(X, (hipStream_t) stream); \
+		else if (mode == 16) launch_convp_t<LN, UL, 16, 24>(X, (hipStream_t) stream); \
+		else if (mode == 17) launch_convp_t<LN, UL, 17, 24>(X, (hipStream_t) stream); \
 		else if (wide) launch_convp_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
 		else launch_convp_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
 		R8B_PAIR_DONE; \
@@ -1026,7 +1029,7 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 		launch_convp_sp<LN, UL>(X, mode, (hipStream_t) stream); \
 		R8B_PAIR_DONE; \
 	} \
-	if (ln == LN && up == (1 << UL) && mode < 8) \
+	if (ln == LN && up == (1 << UL) && (mode < 8 || mode == 16 || mode == 17)) \
 	{ \
 		if (mode == 3) launch_convp_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
 		else if (mode == 6) launch_convp_t<LN, UL, 6, 24>(X, (hipStream_t) stream); \
@@ -1034,6 +1037,8 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 		else if (mode == 0) launch_convp_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
 		else if (mode == 4) launch_convp_t<LN, UL, 4, 24>(X, (hipStream_t) stream); \
 		else if (mode == 5) launch_convp_t<LN, UL, 5, 24>(X, (hipStream_t) stream); \
+		else if (mode == 16) launch_convp_t<LN, UL, 16, 24>(X, (hipStream_t) stream); \
+		else if (mode == 17) launch_convp_t<LN, UL, 17, 24>(X, (hipStream_t) stream); \
 		else if (wide) launch_convp_t<LN, UL, 1, 32>(X, (hipStream_t) stream); \
 		else launch_convp_t<LN, UL, 1, 24>(X, (hipStream_t) stream); \
 		R8B_PAIR_DONE; \

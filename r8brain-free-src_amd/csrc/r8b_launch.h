@@ -86,6 +86,8 @@ struct ConvLaunch
 	const cd* spec2; // fast path, up 1 or 2: (ca, cb) per backward POSITION, [c * N2 + P]
 	const cd* hp;    // pair form (r8b_convp.h): kernel constants of the middle pass, [c * 256 + thread]
 	const cd* ptw;   // pair form: twiddle base powers per pass and thread, [(slot * 6 + c) * 256 + thread]
+	int t_zero;      // fused with an interpolator: its stream starts at this stage's output t_zero (0; a chain with a
+	                 // fractional latency skips outputs -- StagePlan::out_skip): earlier outputs read as zeros
 	int tw_len;
 	// work: blocks [k0, k0+nblk) x channels [0, nch); outputs clipped to [a, b)
 	long long k0;

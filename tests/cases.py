@@ -321,7 +321,9 @@ MINPHASE_LONG_CASES = [
 PARK_CASES_MINPHASE = [
     (44100.0, 88200.0, 4096, 2.0, 180.15, "park"),        # complex kernel spectrum (mode 6)
     (48000.0, 32000.0, 8192, 2.0, 180.15, "park"),        # mode 7
-    (44100.0, 96000.0, 4096, 2.0, 180.15, "ahead"),       # convolver -> k_whole with a fractional start
+    (44100.0, 96000.0, 4096, 2.0, 180.15, "park"),        # fused with the interpolator, fractional start (mode 16)
+    (96000.0, 44100.0, 4096, 2.0, 180.15, "park"),        # ... In > Out (mode 17)
+    (44100.0, 96000.0, 4096, 2.0, 180.15, "ahead", {"fuse_latency": 0}),   # convolver -> k_whole with a fractional start
     (44100.0, 88200.0, 2048, 0.5, 180.15, "park"),        # split form, complex spectrum (mode 12)
     (48000.0, 16000.0, 8192, 1.0, 180.15, "park"),        # one-channel form, complex spectrum, strided store (mode 15)
 ]

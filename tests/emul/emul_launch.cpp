@@ -329,6 +329,8 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 		else if (mode == 7) emul_convp_t<LN, UL, 7, 24>(X); \
 		else if (mode == 4) emul_convp_t<LN, UL, 4, 24>(X); \
 		else if (mode == 5) emul_convp_t<LN, UL, 5, 24>(X); \
+		else if (mode == 16) emul_convp_t<LN, UL, 16, 24>(X); \
+		else if (mode == 17) emul_convp_t<LN, UL, 17, 24>(X); \
 		else if (wide) emul_convp_t<LN, UL, 1, 32>(X); \
 		else emul_convp_t<LN, UL, 1, 24>(X); \
 		return; \
@@ -360,7 +362,7 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 		emul_convp_sp<LN, UL>(X, mode); \
 		return; \
 	} \
-	if (ln == LN && up == (1 << UL) && mode < 8) \
+	if (ln == LN && up == (1 << UL) && (mode < 8 || mode == 16 || mode == 17)) \
 	{ \
 		if (mode == 3) emul_convp_t<LN, UL, 3, 24>(X); \
 		else if (mode == 6) emul_convp_t<LN, UL, 6, 24>(X); \
@@ -368,6 +370,8 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 		else if (mode == 0) emul_convp_t<LN, UL, 0, 24>(X); \
 		else if (mode == 4) emul_convp_t<LN, UL, 4, 24>(X); \
 		else if (mode == 5) emul_convp_t<LN, UL, 5, 24>(X); \
+		else if (mode == 16) emul_convp_t<LN, UL, 16, 24>(X); \
+		else if (mode == 17) emul_convp_t<LN, UL, 17, 24>(X); \
 		else if (wide) emul_convp_t<LN, UL, 1, 32>(X); \
 		else emul_convp_t<LN, UL, 1, 24>(X); \
 		return; \

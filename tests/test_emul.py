@@ -690,7 +690,7 @@ def test_emulated_every_block_once_with_parked_outputs(emul):
         assert nblk / calls < per_call + 0.35
 
 
-def run_chunk_invariance_with_no_work_calls_and_checkpoints(lib_kw, src, dst, maxin, tb=2.0):
+def run_chunk_invariance_with_no_work_calls_and_checkpoints(lib_kw, src, dst, maxin, tb=2.0, phase=0):
     """the history a call leaves is cut to what the NEXT call's first block reads back to (launch_fused /
     launch_stage), older ring positions keep stale samples, calls served from the park buffer alone keep the history
     with the copy kernel, and checkpoints carry rings and park buffer as they are (state blobs are not canonical:
@@ -699,10 +699,10 @@ def run_chunk_invariance_with_no_work_calls_and_checkpoints(lib_kw, src, dst, ma
     in fresh objects at those points equals the stream cut into MaxInLen calls bit for bit."""
     n = maxin * 5 + 1234
     x = make_input(3, n, 21)
-    a = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, **lib_kw)
+    a = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, phase=phase, **lib_kw)
     ya = np.concatenate([a.process_host(x[:, i:i + maxin]) for i in range(0, n, maxin)], axis=1)
     lens = [maxin, 1, 1, 3, maxin // 2 + 7, 1, maxin, 17, 2, 1, maxin - 9, 40, 5, maxin, 1, 1, maxin // 3]
-    b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, **lib_kw)
+    b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, phase=phase, **lib_kw)
     ys, pos, k = [], 0, 0
     while pos < n:
         l = min(lens[k % len(lens)], n - pos)
@@ -712,7 +712,7 @@ def run_chunk_invariance_with_no_work_calls_and_checkpoints(lib_kw, src, dst, ma
         if k in (2, 3, 6, 9, 10, 15):
             # (behind single-sample calls, behind a long call, behind a call served from the park buffer)
             blob = b.state_dict()
-            b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, **lib_kw)
+            b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, phase=phase, **lib_kw)
             b.process_host(x[:, :min(333, maxin)] * 0.25)   # unrelated history before the load
             b.load_state_dict(blob)
     yb = np.concatenate(ys, axis=1)
@@ -722,3 +722,39 @@ def run_chunk_invariance_with_no_work_calls_and_checkpoints(lib_kw, src, dst, ma
 @pytest.mark.parametrize("src,dst,maxin,tb", TAIL_TOPOLOGIES)
 def test_emulated_chunk_invariance_with_no_work_calls_and_checkpoints(emul, src, dst, maxin, tb):
     run_chunk_invariance_with_no_work_calls_and_checkpoints({"lib": emul}, src, dst, maxin, tb)
+
+
+# minimum-phase chains whose convolver + interpolator run as one launch (Engine::fused_shift: emitted outputs renumbered
+# onto the canonical stream), alone and in front of further stages, and the long-block forms with a complex spectrum
+MINPHASE_CHUNK_TOPOLOGIES = [(44100.0, 96000.0, 8192, 2.0), (96000.0, 44100.0, 16384, 2.0), (44100.0, 192000.0, 4096, 2.0),
+                             (48000.0, 44100.0, 6000, 2.0), (44100.0, 88200.0, 9000, 0.5), (96000.0, 44100.0, 16384, 0.5)]
+
+
+@pytest.mark.parametrize("src,dst,maxin,tb", MINPHASE_CHUNK_TOPOLOGIES)
+def test_emulated_chunk_invariance_minimum_phase(emul, src, dst, maxin, tb):
+    run_chunk_invariance_with_no_work_calls_and_checkpoints({"lib": emul}, src, dst, maxin, tb, phase=1)
+
+
+@pytest.mark.parametrize("src,dst,maxin,tb", MINPHASE_CHUNK_TOPOLOGIES[:4])
+def test_emulated_fused_minimum_phase_equals_unfused(emul, src, dst, maxin, tb):
+    """option fuse_latency = 0 (convolver and interpolator as two launches, the form of rounds 1-4) against the fused
+    launch: the same stream to rounding, the same counts per call, ragged calls"""
+    x = make_input(3, maxin * 4 + 777, 8)
+    lens = [maxin, 1, maxin // 3, 17, maxin, maxin - 5, 300, maxin]
+    ys = []
+    for fl in (1, 0):
+        b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, phase=1, lib=emul)
+        b.set_option("fuse_latency", fl)
+        b.set_option("timing", 1)
+        names = [t[0] for t in b.stage_timings()]
+        assert any(t == "k_convp_whole" for t in names) == bool(fl), names
+        b.set_option("timing", 0)
+        out, pos = [], 0
+        for l in lens:
+            l = min(l, x.shape[1] - pos)
+            out.append(b.process_host(x[:, pos:pos + l]))
+            pos += l
+        ys.append(out)
+    assert [o.shape for o in ys[0]] == [o.shape for o in ys[1]]
+    d = np.abs(np.concatenate(ys[0], axis=1) - np.concatenate(ys[1], axis=1))
+    assert d.shape[1] > 1000 and d.max() <= 2e-14, d.max()

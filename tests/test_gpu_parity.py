@@ -567,6 +567,42 @@ def test_hip_chunk_invariance_with_no_work_calls_and_checkpoints(torch, src, dst
     run_chunk_invariance_with_no_work_calls_and_checkpoints({"device": 0}, src, dst, maxin, tb)
 
 
+@pytest.mark.parametrize("src,dst,maxin,tb", [(44100.0, 96000.0, 8192, 2.0), (96000.0, 44100.0, 16384, 2.0),
+                                             (44100.0, 192000.0, 4096, 2.0), (48000.0, 44100.0, 6000, 2.0),
+                                             (44100.0, 88200.0, 9000, 0.5), (96000.0, 44100.0, 16384, 0.5)])
+def test_hip_chunk_invariance_minimum_phase(torch, src, dst, maxin, tb):
+    """minimum-phase chains -- convolver + interpolator as one launch on the renumbered canonical stream
+    (Engine::fused_shift), long-block forms with a complex spectrum --: ragged calls, single samples and checkpoints
+    leave the stream bit for bit the same"""
+    from test_emul import run_chunk_invariance_with_no_work_calls_and_checkpoints
+    run_chunk_invariance_with_no_work_calls_and_checkpoints({"device": 0}, src, dst, maxin, tb, phase=1)
+
+
+@pytest.mark.parametrize("src,dst,maxin", [(44100.0, 96000.0, 8192), (96000.0, 44100.0, 16384), (44100.0, 192000.0, 4096),
+                                          (48000.0, 44100.0, 6000), (192000.0, 44100.0, 8192)])
+def test_hip_fused_minimum_phase_equals_unfused(torch, src, dst, maxin):
+    """option fuse_latency = 0 (two launches) against the fused launch of a minimum-phase convolver + interpolator
+    pair on the real kernels: same counts per call, same samples to rounding"""
+    x = make_input(5, maxin * 4 + 777, 8)
+    lens = [maxin, 1, maxin // 3, 17, maxin, maxin - 5, 300, maxin]
+    ys = []
+    for fl in (1, 0):
+        b = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=5, phase=1, device=0)
+        b.set_option("fuse_latency", fl)
+        b.set_option("timing", 1)
+        assert any(t[0] == "k_convp_whole" for t in b.stage_timings()) == bool(fl), b.stage_timings()
+        b.set_option("timing", 0)
+        out, pos = [], 0
+        for l in lens:
+            l = min(l, x.shape[1] - pos)
+            out.append(b.process_host(x[:, pos:pos + l]))
+            pos += l
+        ys.append(out)
+    assert [o.shape for o in ys[0]] == [o.shape for o in ys[1]]
+    d = np.abs(np.concatenate(ys[0], axis=1) - np.concatenate(ys[1], axis=1))
+    assert d.shape[1] > 1000 and d.max() <= 2e-14, d.max()
+
+
 # Error budget (VERDICT r3 weak #3): the tolerance of the path is RMS 1e-15 / peak 1e-13, the reference's own cross-build
 # noise 3e-16 / 2.3e-15.  "Derive instead of fetch" optimisations stack roundings, so the TREND is pinned too: the
 # levels measured on the final build of round 4 against the compiled reference (4 channels, 6-24 calls) plus 12 %.
