@@ -2550,6 +2550,9 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			}
 			launch_convp(X, (dw.taps2 == 27 ? 5 : 4) + (c.cg.complex_h ? 12 : 0), stream);
 		}
+		else if (c.cg.complex_h)
+			// (fuse_latency_ok admits a complex spectrum only where the two-phase tables exist)
+			throw std::logic_error("fused launch: complex kernel spectrum without the two-phase tables");
 		else if (use_pair_fused(c.cg)) launch_convp(X, 1, stream);
 		else launch_convx(X, 1, stream);
 		if (X.c.tail_ring != nullptr) tail_done_ = true;
