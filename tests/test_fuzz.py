@@ -175,6 +175,58 @@ def test_fuzz_gpu_vs_reference(reference, case):
     assert cnt > 0 and rms <= RMS_TOL and pk <= PEAK_TOL, (case, rms, pk)
 
 
+def _minphase_fused_cases(n, seed):
+    """random (ratio, MaxInLen, filter) draws whose minimum-phase chain has a convolver + interpolator pair in one launch"""
+    from conftest import ROOT
+    lib = r8b.bind(os.path.join(ROOT, "tests", "emul", "_build", "libr8bsrc_emul.so")) if os.path.exists(
+        os.path.join(ROOT, "tests", "emul", "_build", "libr8bsrc_emul.so")) else None
+    rng = np.random.default_rng(seed)
+    out = []
+    for src, dst, maxin, _, _, s in _cases(40 * n, seed):
+        if len(out) >= n:
+            break
+        tb = float(np.round(np.exp(rng.uniform(np.log(0.8), np.log(30.0))), 2))
+        att = float(np.round(rng.uniform(60.0, 218.0), 2))
+        if lib is None:
+            out.append((src, dst, maxin, tb, att, s))   # (not built yet: filtered inside the test)
+            continue
+        try:
+            b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=1, phase=1, lib=lib)
+        except RuntimeError:
+            continue
+        b.set_option("timing", 1)
+        if any(t[0] == "k_convp_whole" for t in b.stage_timings()):
+            out.append((src, dst, maxin, tb, att, s))
+    return out
+
+
+@pytest.mark.parametrize("case", _minphase_fused_cases(24, 4242))
+def test_fuzz_minimum_phase_fused_equals_two_launches(emul, case):
+    """minimum-phase chains: convolver + interpolator in one launch (Engine::fused_shift, kernel modes 16 / 17) against
+    the two launches behind option fuse_latency = 0 -- same counts per call, same samples to rounding, ragged calls
+    (tools/minphase_fuse_fuzz.py is the one-off long form of this test)"""
+    src, dst, maxin, tb, att, seed = case
+    objs = [r8b.BatchResampler(src, dst, maxin, tb, att, nch=3, phase=1, lib=emul) for _ in range(2)]
+    objs[1].set_option("fuse_latency", 0)
+    objs[0].set_option("timing", 1)
+    if not any(t[0] == "k_convp_whole" for t in objs[0].stage_timings()):
+        pytest.skip("this draw's chain has no fused pair")
+    objs[0].set_option("timing", 0)
+    rng = np.random.default_rng(seed)
+    total = int(min(100000, max(6000, objs[0].getInputRequiredForOutput(300) + 4 * maxin)))
+    x = rng.uniform(-1.0, 1.0, (3, total))
+    pos, worst, cnt = 0, 0.0, 0
+    while pos < total:
+        l = int(min(total - pos, rng.integers(1, maxin + 1)))
+        ya, yb = objs[0].process_host(x[:, pos:pos + l]), objs[1].process_host(x[:, pos:pos + l])
+        assert ya.shape == yb.shape, (case, pos, l, ya.shape, yb.shape)
+        if ya.shape[1]:
+            worst = max(worst, float(np.abs(ya - yb).max()))
+            cnt += ya.shape[1]
+        pos += l
+    assert worst <= 1e-13, (case, cnt, worst)
+
+
 @pytest.mark.parametrize("cfg", [(44100.0, 96000.0, 1024, 2.0, 180.15), (44100.0, 44101.0, 700, 2.0, 136.45),
                                  (2822400.0, 176400.0, 4096, 2.0, 180.15), (48000.0, 32000.0, 333, 2.0, 109.56),
                                  (96000.0, 11025.0, 2048, 3.0, 160.0),
