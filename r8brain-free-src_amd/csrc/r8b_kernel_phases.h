@@ -1150,8 +1150,10 @@ R8B_HD void hbc_ranges(const HBCascadeLaunch& L, long long q0, long long q1, HBC
 		R.hi[s] = hi;
 		const int T = L.ntaps[s];
 		const long long ilo = floor_half(lo) - (T - 1), ihi = floor_half(hi - 1) + T + 1;
-		lo = ilo;
-		hi = ihi;
+		// (input n of stage s is output n + skip[s - 1] of the stage in front of it)
+		const long long sk = s > 0 ? L.skip[s - 1] : 0;
+		lo = ilo + sk;
+		hi = ihi + sk;
 	}
 	R.in_lo = lo;
 	R.in_hi = hi;
@@ -1204,9 +1206,11 @@ R8B_HD void hbc_point(const double (&f)[TP], LdsWin x, double& ev, double& od, d
 	od = a0 + a1;
 }
 
+// (kz: the stage's outputs below kz do not exist for the next stage -- 0, or the stage's out_skip in a chain with a
+// fractional latency --: they are stored as zeros)
 template<int TP, bool LAST>
 R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, const double (&taps)[14], const double* xin, long long in_lo,
-	long long lo, long long hi, double* yout, int ch, int tid, int nthr)
+	long long lo, long long hi, double* yout, int ch, int tid, int nthr, int kz)
 {
 	constexpr int U = TP <= 4 ? 4 : (TP <= 8 ? 2 : 1); // inputs of a thread per round (see kHbIlp): ~32 reads in flight
 	double f[TP];
@@ -1217,8 +1221,11 @@ R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, const double (&taps)[14], cons
 	const int xoff = (int) (n0 - in_lo);  // index of x[n0] in xin
 	const int qoff = (int) (2 * n0 - lo); // index of output 2*n0 relative to lo (0 or -1)
 	const int nout = (int) (hi - lo);
-	// A stage's stream starts at position 0: input index i lies before it iff i < ineg (first tile only).
-	const int ineg = n0 >= 0 ? 0 : (n0 < -(long long) cnt ? cnt : (int) -n0);
+	// A stage's stream starts at position kz (0): the outputs of input index i lie (partly) before it iff i < ineg (first
+	// tile only); zlim - 2 i = how many of that input's outputs 2 (n0 + i), + 1, + 2 do
+	const long long zlim = (long long) kz - 2 * n0;
+	const long long izero = (zlim + 1) >> 1; // inputs i < izero have an output below kz
+	const int ineg = izero <= 0 ? 0 : (izero > cnt ? cnt : (int) izero);
 	// last stage into a plain fp64 row: pq[2 i] is output 2 (n0 + i)
 	const bool linear = LAST && L.dst.mask == -1 && L.dst.fmt == kPcmF64;
 	double* const pq = linear ? L.dst.p + ((long long) ch * L.dst.stride + (2 * n0 + L.dst.off)) : nullptr;
@@ -1318,9 +1325,9 @@ R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, const double (&taps)[14], cons
 		const int i = j < ia ? j : j + (ib - ia);
 		double ev, od, nx;
 		hbc_point<TP>(f, lds_win(xb + i), ev, od, nx);
-		// outputs 2 (n0 + i) and 2 (n0 + i) + 1 exist iff n0 + i >= 0
-		const double e = i < ineg ? 0.0 : ev;
-		const double d = i < ineg ? 0.0 : od;
+		// output 2 (n0 + i) + h exists iff it is not below kz
+		const double e = 2LL * i < zlim ? 0.0 : ev;
+		const double d = 2LL * i + 1 < zlim ? 0.0 : od;
 		const int o = qoff + 2 * i;
 		if (LAST)
 		{
@@ -1334,7 +1341,7 @@ R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, const double (&taps)[14], cons
 				{
 					cd v;
 					v.re = d;
-					v.im = i + 1 < ineg ? 0.0 : nx;
+					v.im = 2LL * i + 2 < zlim ? 0.0 : nx;
 					*reinterpret_cast<cd*>(p + 1) = v;
 				}
 				else if (o + 1 < nout) p[1] = d;
@@ -1364,22 +1371,22 @@ R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, const double (&taps)[14], cons
 
 // stage with T taps (already rounded up to 4 / 8 / 14) whose values the caller holds
 R8B_HD void hbc_stage_f(const HBCascadeLaunch& L, const double (&taps)[14], int T, const double* xin,
-	long long in_lo, long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr)
+	long long in_lo, long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr, int kz = 0)
 {
 	if (T <= 4)
 	{
-		if (last) hbc_stage_t<4, true>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr);
-		else hbc_stage_t<4, false>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr);
+		if (last) hbc_stage_t<4, true>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr, kz);
+		else hbc_stage_t<4, false>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr, kz);
 	}
 	else if (T <= 8)
 	{
-		if (last) hbc_stage_t<8, true>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr);
-		else hbc_stage_t<8, false>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr);
+		if (last) hbc_stage_t<8, true>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr, kz);
+		else hbc_stage_t<8, false>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr, kz);
 	}
 	else
 	{
-		if (last) hbc_stage_t<14, true>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr);
-		else hbc_stage_t<14, false>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr);
+		if (last) hbc_stage_t<14, true>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr, kz);
+		else hbc_stage_t<14, false>(L, taps, xin, in_lo, lo, hi, yout, ch, tid, nthr, kz);
 	}
 }
 
@@ -1388,7 +1395,8 @@ R8B_HD void hbc_stage(const HBCascadeLaunch& L, int s, const double* xin, long l
 {
 	double taps[14];
 	for (int k = 0; k < 14; k++) taps[k] = L.taps[s][k];
-	hbc_stage_f(L, taps, L.ntaps[s], xin, in_lo, lo, hi, yout, last, ch, tid, nthr);
+	// (what the next stage of the run does not see of this one's stream: HBCascadeLaunch::skip)
+	hbc_stage_f(L, taps, L.ntaps[s], xin, in_lo, lo, hi, yout, last, ch, tid, nthr, last ? 0 : L.skip[s]);
 }
 
 // ------------------------------------------------------------------------------------ decimating cascade

@@ -163,6 +163,10 @@ struct HBCascadeLaunch
 	// and the input span of stage 0 with rlo[nst] / rhi[nst] and a shift of nst (hbc_fill_ranges); equal to
 	// walking the stages back from the tile (floors of halves compose), without a chain of dependent loads
 	long long rlo[kMaxCascade + 1], rhi[kMaxCascade + 1];
+	// chains with a fractional latency: stage s emits its stream from output skip[s] on (StagePlan::out_skip), i.e. input n
+	// of stage s + 1 is output n + skip[s] of stage s, and outputs below skip[s] read as zeros there (up-sampling run;
+	// the last stage's skip is folded into a, b and the destination's offset by the launcher: 0 here)
+	int skip[kMaxCascade];
 	long long in_end;              // input positions >= in_end have not arrived: the zero-padded
 	                               // taps reach past the real filter, those loads must not happen
 	int nch;
@@ -178,8 +182,10 @@ inline void hbc_fill_ranges(HBCascadeLaunch& L)
 		const int k = L.nst - 1 - s;
 		L.rlo[s] = cl;
 		L.rhi[s] = ch;
-		cl += (long long) (L.ntaps[s] - 1) << (k + 1);
-		ch += (long long) L.ntaps[s] << (k + 1);
+		// (stage s - 1 has to deliver the input range of stage s, skip[s - 1] outputs later)
+		const long long sk = s > 0 ? L.skip[s - 1] : 0;
+		cl += ((long long) (L.ntaps[s] - 1) - sk) << (k + 1);
+		ch += ((long long) L.ntaps[s] + sk) << (k + 1);
 	}
 	L.rlo[L.nst] = cl;
 	L.rhi[L.nst] = ch;

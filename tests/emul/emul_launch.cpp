@@ -446,7 +446,8 @@ void launch_hbcascade(const HBCascadeLaunch& L, void*)
 					throw std::runtime_error("emul: cascade LDS");
 				for (int t = 0; t < nthr; t++)
 					hbc_stage(L, s, xin, in_lo, R.lo[s], R.hi[s], yout, s + 1 == L.nst, ch, t, nthr);
-				in_lo = R.lo[s];
+				// (the next stage's input n is this stage's output n + skip: the buffer's first element is its input R.lo - skip)
+				in_lo = R.lo[s] - (s + 1 < L.nst ? L.skip[s] : 0);
 				std::swap(xin, yout);
 			}
 		}
