@@ -2041,9 +2041,11 @@ void Engine::launch_dcascade(size_t s, int glen, long long fa, long long fb, con
 {
 	HBCascadeLaunch L;
 	L.nst = glen;
+	L.has_skip = 0; // (the decimating run is not used in chains with a fractional latency: group_len)
 	for (int g = 0; g < kMaxCascade; g++)
 	{
 		L.ntaps[g] = 0;
+		L.skip[g] = 0;
 		for (int k = 0; k < 14; k++) L.taps[g][k] = 0.0;
 	}
 	for (int g = 0; g < glen; g++)
@@ -2090,7 +2092,12 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 	}
 	// chains with a fractional latency: a stage emits its stream from output out_skip on.  Between the stages of the run
 	// that is HBCascadeLaunch::skip; for the last one, as in launch_stage: the shifted range, stored out_skip earlier
-	for (int g = 0; g + 1 < glen; g++) L.skip[g] = (int) plan_.stages[s + g].out_skip;
+	L.has_skip = 0;
+	for (int g = 0; g + 1 < glen; g++)
+	{
+		L.skip[g] = (int) plan_.stages[s + g].out_skip;
+		if (L.skip[g] != 0) L.has_skip = 1;
+	}
 	const long long sk_last = plan_.stages[s + glen - 1].out_skip;
 	fa += sk_last;
 	fb += sk_last;

@@ -1396,7 +1396,10 @@ R8B_HD void hbc_stage(const HBCascadeLaunch& L, int s, const double* xin, long l
 	double taps[14];
 	for (int k = 0; k < 14; k++) taps[k] = L.taps[s][k];
 	// (what the next stage of the run does not see of this one's stream: HBCascadeLaunch::skip)
-	hbc_stage_f(L, taps, L.ntaps[s], xin, in_lo, lo, hi, yout, last, ch, tid, nthr, last ? 0 : L.skip[s]);
+	// (has_skip: one more scalar load per stage only where there is something to load -- in a linear-phase chain it cost
+	// cfg5 1.4 %: scalar loads in flight make the stage's first LDS wait a full drain)
+	hbc_stage_f(L, taps, L.ntaps[s], xin, in_lo, lo, hi, yout, last, ch, tid, nthr,
+		L.has_skip != 0 && !last ? L.skip[s] : 0);
 }
 
 // ------------------------------------------------------------------------------------ decimating cascade

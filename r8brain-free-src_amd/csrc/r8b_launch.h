@@ -167,6 +167,7 @@ struct HBCascadeLaunch
 	// of stage s + 1 is output n + skip[s] of stage s, and outputs below skip[s] read as zeros there (up-sampling run;
 	// the last stage's skip is folded into a, b and the destination's offset by the launcher: 0 here)
 	int skip[kMaxCascade];
+	int has_skip;                  // any of them non-zero
 	long long in_end;              // input positions >= in_end have not arrived: the zero-padded
 	                               // taps reach past the real filter, those loads must not happen
 	int nch;
