@@ -1994,13 +1994,13 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 
 int Engine::group_len(size_t s) const
 {
-	// (chains with a fractional latency: the convolver + interpolator pair -- fuse_latency_ok -- and runs of half-band
-	// UP-samplers, whose cascade kernel knows the stages' skipped outputs; the decimating cascade does not)
+	// (chains with a fractional latency: the convolver + interpolator pair -- fuse_latency_ok -- and the half-band runs,
+	// whose cascade kernels know the stages' skipped outputs)
 	const bool lat = latency_chain();
 	if (lat && !opt_.at("fuse_latency")) return 1;
 	if (fuse_with_next(s)) return 2;
 	const StageKind kind = plan_.stages[s].desc.kind;
-	if (lat && kind != kHBUp) return 1;
+	if (lat && kind != kHBUp && kind != kHBDown) return 1;
 	// Runs of decimators: one kernel saves two launches and the intermediate streams, but pays
 	// ~25 % of halo recomputation and holds 25 KB of LDS per workgroup; measured on sacd.cpp's
 	// 2822400 -> 176400 it wins on small batches (64 ch x 65536: 0.032 vs 0.037 ms) and loses on
@@ -2037,17 +2037,28 @@ long long Engine::stage_history(size_t s) const
 }
 
 void Engine::launch_dcascade(size_t s, int glen, long long fa, long long fb, const SrcView& src,
-	const DstView& dst, void* stream)
+	const DstView& dst_in, void* stream)
 {
 	HBCascadeLaunch L;
 	L.nst = glen;
-	L.has_skip = 0; // (the decimating run is not used in chains with a fractional latency: group_len)
+	L.has_skip = 0;
 	for (int g = 0; g < kMaxCascade; g++)
 	{
 		L.ntaps[g] = 0;
 		L.skip[g] = 0;
 		for (int k = 0; k < 14; k++) L.taps[g][k] = 0.0;
 	}
+	// (chains with a fractional latency: the stages' skipped outputs, as in launch_cascade)
+	for (int g = 0; g + 1 < glen; g++)
+	{
+		L.skip[g] = (int) plan_.stages[s + g].out_skip;
+		if (L.skip[g] != 0) L.has_skip = 1;
+	}
+	const long long sk_last = plan_.stages[s + glen - 1].out_skip;
+	fa += sk_last;
+	fb += sk_last;
+	DstView dst = dst_in;
+	dst.off -= sk_last;
 	for (int g = 0; g < glen; g++)
 	{
 		const StagePlan& sp = plan_.stages[s + g];

@@ -1421,17 +1421,22 @@ R8B_HD void hbd_ranges(const HBCascadeLaunch& L, long long q0, long long q1, HBC
 		R.hi[s] = hi;
 		const int T = L.ntaps[s];
 		const long long ilo = 2 * lo - (2 * T - 1), ihi = 2 * (hi - 1) + (2 * T - 1) + 1;
-		lo = ilo;
-		hi = ihi;
+		// (chains with a fractional latency: input n of stage s is output n + skip[s - 1] of the stage in front of it)
+		const long long sk = s > 0 ? L.skip[s - 1] : 0;
+		lo = ilo + sk;
+		hi = ihi + sk;
 	}
 	R.in_lo = lo;
 	R.in_hi = hi;
 }
 
+// (in_lo: the INPUT index of xin[0] -- the previous stage's first output less its skip)
 template<int TP>
 R8B_HD void hbd_stage_t(const HBCascadeLaunch& L, int s, const double* xin, long long in_lo,
 	long long lo, long long hi, double* yout, bool last, int ch, int tid, int nthr)
 {
+	// the stage's outputs below kz do not exist for the next stage (0; its out_skip in a chain with a fractional latency)
+	const long long kz = last || L.has_skip == 0 ? 0 : L.skip[s];
 	double f[TP];
 #pragma unroll
 	for (int k = 0; k < TP; k++) f[k] = L.taps[s][k];
@@ -1461,7 +1466,7 @@ R8B_HD void hbd_stage_t(const HBCascadeLaunch& L, int s, const double* xin, long
 			const int i = i0 + u * nthr;
 			if (i >= cnt) continue;
 			// a stage's stream starts at position 0: earlier outputs do not exist for the next stage
-			const double w = lo + i < 0 ? 0.0 : v[u];
+			const double w = lo + i < kz ? 0.0 : v[u];
 			if (last) dst_store(L.dst, ch, lo + i, w);
 			else yout[i] = w;
 		}

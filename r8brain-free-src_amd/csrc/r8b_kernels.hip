@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void k_hbdcascade(const HBCascadeLaunch L)
 		hbd_stage(L, s, (s & 1) ? odd : even, in_lo, R.lo[s], R.hi[s], (s & 1) ? even : odd,
 			s + 1 == L.nst, ch, tid, nthr);
 		__syncthreads();
-		in_lo = R.lo[s];
+		in_lo = R.lo[s] - (s + 1 < L.nst ? L.skip[s] : 0);
 	}
 }
 

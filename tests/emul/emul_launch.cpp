@@ -482,7 +482,7 @@ void launch_hbdcascade(const HBCascadeLaunch& L, void*)
 				for (int t = 0; t < nthr; t++)
 					hbd_stage(L, s, (s & 1) ? odd : even, in_lo, R.lo[s], R.hi[s],
 						(s & 1) ? even : odd, s + 1 == L.nst, ch, t, nthr);
-				in_lo = R.lo[s];
+				in_lo = R.lo[s] - (s + 1 < L.nst ? L.skip[s] : 0);
 			}
 		}
 }

@@ -52,7 +52,9 @@ for case in T._cases(n, seed):
             worst = max(worst, float(np.abs(ya - yb).max()))
             cnt += ya.shape[1]
         pos += l
-    if not ok or cnt == 0 or worst > 1e-13:
+    if ok and cnt == 0:
+        continue  # (the chain's latency is longer than the fuzz's stream: nothing to compare)
+    if not ok or worst > 1e-13:
         bad += 1
         print("FAIL", (src, dst, maxin, tb, att), cnt, worst, objs[0].describe().replace("\n", " | "), flush=True)
 print("minimum-phase fuse fuzz done", n, "fused chains", fused, "bad", bad, "skipped", skipped)
