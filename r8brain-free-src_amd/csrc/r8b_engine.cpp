@@ -1137,8 +1137,15 @@ int Engine::conv_once(size_t s, const DstView& dst) const
 // doubles per channel of a park buffer: what one block can hold, rounded up to whole 64-byte lines
 long long Engine::park_row_len(size_t s) const
 {
+	return park_len_of(s, true);
+}
+
+// (end_of_chain = false: the bound on what a stage in the MIDDLE of a chain writes ahead into the next ring -- one
+// block's outputs, whatever kernel runs it; load_state checks a blob's counters against it)
+long long Engine::park_len_of(size_t s, bool end_of_chain) const
+{
 	long long n;
-	if (s + 2 == plan_.stages.size() && fuse_with_next(s))
+	if ((!end_of_chain || s + 2 == plan_.stages.size()) && fuse_with_next(s))
 	{
 		long long S = 0, off = 0;
 		fused_blocking(s, &S, &off);
@@ -1150,7 +1157,7 @@ long long Engine::park_row_len(size_t s) const
 		const long long e0 = (long long) g.in_len + off - g.fl2 - w.fl2 - fused_shift(s).d;
 		if (e0 > 0) n = std::max(n, (e0 * w.out_step + w.in_step - 1) / w.in_step + 2);
 		// (output ring of the one-channel fused kernel: a call's outputs plus one block's, a power of two)
-		if (!use_pair_fused(plan_.stages[s].cg)) return pow2_at_least(plan_.max_out_len + n + 16);
+		if (end_of_chain && !use_pair_fused(plan_.stages[s].cg)) return pow2_at_least(plan_.max_out_len + n + 16);
 	}
 	else
 	{
@@ -1158,7 +1165,7 @@ long long Engine::park_row_len(size_t s) const
 		n = g.in_len / g.down + 2;
 		const int path = conv_path(g);
 		// (output ring of the one-channel fast path: a call's outputs plus one block's, a power of two)
-		if (path == kPathConvx || path == kPathConvx3) return pow2_at_least(plan_.max_out_len + n + 16);
+		if (end_of_chain && (path == kPathConvx || path == kPathConvx3)) return pow2_at_least(plan_.max_out_len + n + 16);
 	}
 	return (n + 7) / 8 * 8 + 8;
 }
@@ -1166,8 +1173,19 @@ long long Engine::park_row_len(size_t s) const
 void Engine::ensure_park(size_t s)
 {
 	StageDev& d = dev_[s];
-	if (d.park[0] != nullptr) return;
-	d.park_stride = park_row_len(s);
+	const long long len = park_row_len(s);
+	if (d.park[0] != nullptr && d.park_stride == len) return;
+	// (the row length follows the structural options -- pair_solo, pair_conv, align_groups ... --, which may change
+	// between clear() and the next process(): buffers of another length are replaced, and they hold nothing then)
+	if (d.park[0] != nullptr)
+	{
+		if (d.park_end > d.park_base) throw std::logic_error("park buffer resized while it holds outputs");
+		dev_free(d.park[0]);
+		dev_free(d.park[1]);
+		d.park[0] = d.park[1] = nullptr;
+		d.park_cur = 0;
+	}
+	d.park_stride = len;
 	const size_t bytes = (size_t) d.park_stride * (size_t) nch_ * sizeof(double);
 	d.park[0] = (double*) dev_alloc(bytes);
 	d.park[1] = (double*) dev_alloc(bytes);
@@ -1311,7 +1329,12 @@ void Engine::clear()
 	// ring contents need no reset: positions restart at 0 and every position >= 0 is rewritten
 	// before it is read again, positions < 0 read as zero by construction
 	plan_.clear();
-	for (StageDev& d : dev_) d.park_base = d.park_end = 0;
+	// (park_cur too: the output-ring use of the buffers -- launch_stage once = 4, launch_fused oring -- knows park[0] only)
+	for (StageDev& d : dev_)
+	{
+		d.park_base = d.park_end = 0;
+		d.park_cur = 0;
+	}
 }
 
 // ---- checkpoint -------------------------------------------------------------------------------
@@ -1407,7 +1430,8 @@ size_t Engine::save_state(void* buf, size_t cap, void* stream)
 		st.in_counter = sp.poly.in_counter; st.in_pos_int = sp.poly.in_pos_int;
 		st.ring_size = d.ring_size;
 		st.has_ring = stage_owns_ring(s) ? 1 : 0;
-		st.park_len = stage_parks(s) ? d.park_stride : 0;
+		st.park_len = stage_parks(s) ? park_row_len(s) : 0;
+		if (st.park_len != 0 && st.park_len != d.park_stride) throw std::logic_error("park buffer length");
 		st.park_base = d.park_base; st.park_end = d.park_end;
 		std::memcpy(p, &st, sizeof(st));
 		p += sizeof(st);
@@ -1419,11 +1443,13 @@ size_t Engine::save_state(void* buf, size_t cap, void* stream)
 		}
 		if (st.park_len > 0)
 		{
-			const size_t bytes = (size_t) d.park_stride * (size_t) nch_ * sizeof(double);
+			const size_t bytes = (size_t) st.park_len * (size_t) nch_ * sizeof(double);
+			if ((size_t) (p - static_cast<unsigned char*>(buf)) + bytes > need) throw std::logic_error("state size");
 			dev_download(p, d.park[d.park_cur], bytes, stream);
 			p += bytes;
 		}
 	}
+	if ((size_t) (p - static_cast<unsigned char*>(buf)) != need) throw std::logic_error("state size");
 	return need;
 }
 
@@ -1465,8 +1491,13 @@ void Engine::load_state(const void* buf, size_t size, void* stream)
 		}
 		if (st.park_len != (stage_parks(s) ? park_row_len(s) : 0))
 			throw std::runtime_error("state blob park layout mismatch");
-		// (a stage that writes its last block ahead into a ring has counters but no buffer)
+		// (a stage that writes its last block ahead into a ring has counters but no buffer: what lies between them is
+		// at most one block's outputs -- a larger park_end would make the next calls skip their blocks and hand out
+		// whatever the ring holds --, and only a convolver ever has any)
 		if (st.park_base < 0 || st.park_end < st.park_base || (st.park_len > 0 && st.park_end - st.park_base > st.park_len))
+			throw std::runtime_error("state blob holds impossible counters");
+		if (st.park_len == 0 && st.park_end - st.park_base >
+			(plan_.stages[s].desc.kind == kConv && s + 1 < dev_.size() ? park_len_of(s, false) : 0))
 			throw std::runtime_error("state blob holds impossible counters");
 		if (st.park_len > 0)
 		{
@@ -1492,10 +1523,16 @@ void Engine::load_state(const void* buf, size_t size, void* stream)
 			ensure_ring(s);
 			dev_upload(dev_[s].ring, rings[s], (size_t) dev_[s].ring_size * (size_t) nch_ * sizeof(double));
 		}
+		if (parks[s] != nullptr)
+		{
+			// (buffers of an earlier life under other options are replaced here -- while the old counters still say
+			// whether they may be)
+			dev_[s].park_base = dev_[s].park_end = 0;
+			ensure_park(s);
+		}
 		dev_[s].park_base = st.park_base; dev_[s].park_end = st.park_end;
 		if (parks[s] != nullptr)
 		{
-			ensure_park(s);
 			dev_upload(dev_[s].park[dev_[s].park_cur], parks[s], (size_t) dev_[s].park_stride * (size_t) nch_ * sizeof(double));
 		}
 	}

@@ -126,6 +126,7 @@ private:
 	bool stage_parks(size_t s) const;
 	int conv_once(size_t s, const DstView& dst) const;
 	long long park_row_len(size_t s) const;
+	long long park_len_of(size_t s, bool end_of_chain) const;
 	void ensure_park(size_t s);
 	void prepare_two_phase(size_t s);
 	int group_len(size_t s) const;

@@ -863,8 +863,10 @@ void R8B_LAUNCH(launch_whole)(const WholeLaunch& L, void* stream)
 	// A thread keeps one phase (whole_compute_t): no more waves than the phases fill (147 phases: three waves, not four
 	// with one idle but for its share of the staging -- 96000 -> 44100: 0.0838 -> 0.0777 ms; MORE waves, whole sets of
 	// phases on 448 / 512 threads, took 0.1256: profiles/r04_experiments.txt)
+	// (fewer phases than that: as many whole sets of phases as 256 threads hold, rounded up to whole waves -- a small
+	// Out keeps its four waves, which also share the tile's staging)
 	unsigned nthr = 256;
-	if (L.out_step <= 256) nthr = ((unsigned) L.out_step + 63u) & ~63u;
+	if (L.out_step <= 256) nthr = ((256u / (unsigned) L.out_step) * (unsigned) L.out_step + 63u) & ~63u;
 	hipLaunchKernelGGL(k_whole, dim3(tiles, (unsigned) L.nch), dim3(nthr),
 		(size_t) L.span_max * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_whole");

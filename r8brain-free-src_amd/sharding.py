@@ -90,11 +90,11 @@ def gather_channels(y_local, total_channels, dst=0, n=None, out=None):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             n = int(t.item())
     if rank == dst:
-        # (`out`: a preallocated [total_channels, >= n] buffer of the caller, e.g. RootPipeline's rotation)
-        if out is not None and out.shape[1] == n:
-            pass
-        elif out is not None and world == 1:
-            out = out[:, :n]
+        # (`out`: a preallocated contiguous buffer of the caller with room for [total_channels, n], e.g. RootPipeline's
+        # rotation of [total_channels, max_out_len] tensors: its storage is used as a DENSE [total_channels, n] result --
+        # a [:, :n] view of wider rows is not contiguous, and a receive wants contiguous rows)
+        if out is not None and out.is_contiguous() and out.numel() >= total_channels * n and out.dtype == y_local.dtype:
+            out = out.reshape(-1)[:total_channels * n].view(total_channels, n)
         else:
             out = torch.empty((total_channels, n), dtype=y_local.dtype, device=y_local.device)
         ops = []
@@ -198,15 +198,16 @@ class RootPipeline:
                 if self.cuda:
                     self.side.wait_event(done[i])
                 ob = None
-                if self.cuda and rank == self.root and hasattr(self.sh.local, "max_out_len"):
-                    # (three result buffers in rotation: the caller gets views; a result stays valid until the third
-                    # call after it has been gathered -- run() hands all of them back at its end, so callers that keep
-                    # more than three results alive copy them)
+                if self.keep_last_only and rank == self.root and hasattr(self.sh.local, "max_out_len"):
+                    # (three result buffers in rotation, only when the caller asked for them -- keep_last_only --: the
+                    # caller gets views; a result stays valid until the third call after it has been gathered.  Rows of
+                    # max_out_len, handed to the gather as the [:, :n] view of this call's length, so that the rotation
+                    # also holds when the per-call count changes -- 35666 / 35667 for 44100 -> 96000)
                     if self._obuf[i % 3] is None:
                         self._obuf[i % 3] = torch.empty((self.sh.total, self.sh.local.max_out_len), dtype=y.dtype,
                                                         device=self.device)
                     ob = self._obuf[i % 3]
-                outs[i] = gather_channels(y, self.sh.total, dst=self.root, out=ob if self.keep_last_only else None)
+                outs[i] = gather_channels(y, self.sh.total, dst=self.root, out=ob)
 
         if n:
             scatter(0)

@@ -91,6 +91,32 @@ def _worker(rank, world, port, q):
             assert torch.equal(got[i], whole2.process(batches[i]))
     else:
         assert all(g is None for g in got)
+    # ... and with the three result buffers in rotation (keep_last_only, what bench.py --e2e asks for): per-call counts
+    # that change from call to call (44100 -> 96000: 4457 / 4458 / ...) still land in the SAME three buffers, as dense
+    # [channels, n] results (a fresh tensor per call defeated the rotation whenever n != max_out_len)
+    class LocalMax(Local):
+        def __init__(self, nch):
+            super().__init__(nch)
+            self.max_out_len = self.rs.max_out_len
+    calls3 = 7
+    sh3 = r8b.ShardedBatchResampler(LocalMax, total_ch)
+    pipe3 = r8b.RootPipeline(sh3, L, root=0, device="cpu", keep_last_only=True)
+    if rank == 0:
+        xall3 = make_input(total_ch, L * calls3, 5)
+    whole3 = Local(total_ch) if rank == 0 else None
+    ptrs, lens3 = set(), set()
+    for i in range(calls3):
+        b3 = [torch.from_numpy(np.ascontiguousarray(xall3[:, i * L:(i + 1) * L])) if rank == 0 else None]
+        g3 = pipe3.run(b3)[0]
+        if rank == 0:
+            assert g3.is_contiguous() and torch.equal(g3, whole3.process(b3[0]))
+            ptrs.add(g3.data_ptr())
+            lens3.add(g3.shape[1])
+        else:
+            assert g3 is None
+    if rank == 0:
+        # (run() is called once per batch here, so every call uses buffer 0 of the rotation: one address)
+        assert len(lens3) > 1 and len(ptrs) == 1, (lens3, ptrs)
     tmax = t[2:3].clone()
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     if rank == 0:

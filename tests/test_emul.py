@@ -758,3 +758,65 @@ def test_emulated_fused_minimum_phase_equals_unfused(emul, src, dst, maxin, tb):
     assert [o.shape for o in ys[0]] == [o.shape for o in ys[1]]
     d = np.abs(np.concatenate(ys[0], axis=1) - np.concatenate(ys[1], axis=1))
     assert d.shape[1] > 1000 and d.max() <= 2e-14, d.max()
+
+
+@pytest.mark.parametrize("src,dst,knob", [(48000.0, 16000.0, "pair_solo"), (88200.0, 44100.0, "pair_solo"),
+                                          (44100.0, 96000.0, "pair_two"), (44100.0, 88200.0, "pair_conv")])
+@pytest.mark.parametrize("first", [1, 0])
+def test_emulated_park_buffers_follow_structural_options_after_clear(emul, src, dst, knob, first):
+    """clear() + a structural option that changes the park rows' length (one-channel / pair form, ...)
+    must not leave the old buffers, stride or buffer index behind: the checkpoint is exactly state_size() bytes and the
+    stream after the toggle equals that of an object created with the option (bit for bit), both ways."""
+    tb = 0.5 if knob == "pair_solo" else 2.0
+    nch, chunk = 2, 1500
+    x = make_input(nch, 6 * chunk, 23)
+
+    def fresh(v):
+        o = r8b.BatchResampler(src, dst, chunk, tb, 136.45, nch=nch, lib=emul)
+        o.set_option(knob, v)
+        return o
+
+    ref = fresh(1 - first)
+    y_ref = [ref.process_host(x[:, i:i + chunk]) for i in range(0, 6 * chunk, chunk)]
+    b = fresh(first)
+    for i in range(0, 3 * chunk, chunk):          # an odd number of parking calls: the buffer index may be 1
+        b.process_host(x[:, i:i + chunk])
+    b.clear()
+    b.set_option(knob, 1 - first)
+    size = emul.r8b_batch_state_size(b._h)
+    guard = np.full(size + 4096, 0xA5, dtype=np.uint8)
+    n = emul.r8b_batch_state_save(b._h, guard.ctypes.data, size, None)
+    assert n == size and np.all(guard[size:] == 0xA5)  # nothing written past the caller's buffer
+    ys = []
+    for k, i in enumerate(range(0, 6 * chunk, chunk)):
+        ys.append(b.process_host(x[:, i:i + chunk]))
+        if k == 2:
+            blob = b.state_dict()
+            assert blob.size == emul.r8b_batch_state_size(b._h)
+            c = fresh(1 - first)
+            c.load_state_dict(blob)
+            assert np.array_equal(c.process_host(x[:, 3 * chunk:4 * chunk]), y_ref[3])
+    for a, r in zip(ys, y_ref):
+        assert a.shape == r.shape and np.array_equal(a, r)
+
+
+def test_emulated_state_blob_with_too_much_written_ahead_is_refused(emul):
+    """ADVICE r4 (low): a stage that writes its call's last block AHEAD into the next ring has counters but no buffer;
+    a blob whose counters claim more than one block's outputs would make the next calls skip their blocks."""
+    import struct
+    b = r8b.BatchResampler(44100.0, 2822400.0, 1024, 2.0, 180.15, nch=2, lib=emul)  # convolver in front of a cascade
+    x = make_input(2, 2048, 29)
+    b.process_host(x[:, :1024])
+    blob = b.state_dict()
+    # StateHeader 32 bytes; StageState: m, done, rpos, ring_size, has_ring, pos_frac, pos_shift, in_counter, in_pos_int,
+    # park_len, park_base, park_end
+    st = list(struct.unpack_from("<5q2d5q", blob, 32))
+    assert st[9] == 0 and st[11] >= st[10]          # no buffer; something may be written ahead
+    bad = blob.copy()
+    st[11] = st[10] + 10 ** 6
+    struct.pack_into("<5q2d5q", bad, 32, *st)
+    keep = b.state_dict()
+    with pytest.raises(RuntimeError, match="impossible counters"):
+        b.load_state_dict(bad)
+    assert np.array_equal(b.state_dict(), keep)
+    b.load_state_dict(blob)
