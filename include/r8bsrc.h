@@ -264,6 +264,13 @@ R8BSRC_DECL int r8b_design_hbfilter(double ReqAtten, int SteepIndex, int IsThird
 R8BSRC_DECL int r8b_design_whole_stepping(double SSampleRate, double DSampleRate, int* InStep,
 	int* OutStep);
 
+/* The designer's caches are bounded like the reference's (r8bconf.h:90 R8B_FILTER_CACHE_MAX 96, :103
+ * R8B_FRACBANK_CACHE_MAX 12; CDSPFIRFilter.h:598-694, CDSPFracInterpolator.h:516): least recently used entries that no
+ * live object holds are dropped once a cache is full, so a host that sweeps ratios does not grow without limit; what a
+ * live resampler uses stays alive with it.  Writes the number of entries held right now: low-pass filters,
+ * fractional-delay banks, lane tables of the fused interpolator (one per ratio, at most 96). */
+R8BSRC_DECL void r8b_design_cache_counts(int* Filters, int* FracBanks, int* LaneTables);
+
 /* Host-only schedule object: the integer bookkeeping of a resampler without any device work.
  * r8b_plan_step feeds l input samples and returns how many output samples the reference's
  * process() returns for that call. */

@@ -62,6 +62,7 @@ PROTOTYPES = [
                                       C.c_int]),
     ("r8b_design_hbfilter", C.c_int, [C.c_double, C.c_int, C.c_int, dp, dp]),
     ("r8b_design_whole_stepping", C.c_int, [C.c_double, C.c_double, ip, ip]),
+    ("r8b_design_cache_counts", None, [ip, ip, ip]),
     ("r8b_plan_create", C.c_void_p, [C.c_double, C.c_double, C.c_int, C.c_double, C.c_double]),
     ("r8b_plan_delete", None, [C.c_void_p]),
     ("r8b_plan_clear", None, [C.c_void_p]),

@@ -221,6 +221,13 @@ R8BSRC_DECL CR8BBatch r8b_batch_create_stage(int kind, double a, double b, doubl
 	}
 }
 
+// (the entries that can report an error refuse a NULL handle; the plain getters, like the reference's, do not test it)
+static Batch* need(CR8BBatch b)
+{
+	if (b == nullptr) throw std::runtime_error("null handle");
+	return (Batch*) b;
+}
+
 R8BSRC_DECL void r8b_batch_delete(CR8BBatch b) { delete (Batch*) b; }
 
 R8BSRC_DECL void r8b_batch_clear(CR8BBatch b)
@@ -249,7 +256,7 @@ R8BSRC_DECL int r8b_batch_process(CR8BBatch b, const double* d_in, long long in_
 {
 	try
 	{
-		return ((Batch*) b)->eng->process(d_in, in_stride, l, d_out, out_stride, stream);
+		return need(b)->eng->process(d_in, in_stride, l, d_out, out_stride, stream);
 	}
 	catch (const std::exception& e)
 	{
@@ -263,7 +270,7 @@ R8BSRC_DECL int r8b_batch_process_host(CR8BBatch b, const double* in, long long 
 {
 	try
 	{
-		return batch_process_host((Batch*) b, in, in_stride, l, out, out_stride);
+		return batch_process_host(need(b), in, in_stride, l, out, out_stride);
 	}
 	catch (const std::exception& e)
 	{
@@ -278,7 +285,7 @@ R8BSRC_DECL int r8b_batch_process_pcm(CR8BBatch b, const void* d_in, int in_form
 {
 	try
 	{
-		return batch_process_pcm((Batch*) b, d_in, in_format, in_interleaved, in_stride, l, d_out,
+		return batch_process_pcm(need(b), d_in, in_format, in_interleaved, in_stride, l, d_out,
 			out_format, out_interleaved, out_stride, stream);
 	}
 	catch (const std::exception& e)
@@ -310,7 +317,7 @@ R8BSRC_DECL long long r8b_batch_state_save(CR8BBatch b, void* buf, long long cap
 {
 	try
 	{
-		return (long long) ((Batch*) b)->eng->save_state(buf, cap < 0 ? 0 : (size_t) cap, stream);
+		return (long long) need(b)->eng->save_state(buf, cap < 0 ? 0 : (size_t) cap, stream);
 	}
 	catch (const std::exception& e)
 	{
@@ -323,7 +330,7 @@ R8BSRC_DECL int r8b_batch_state_load(CR8BBatch b, const void* buf, long long siz
 {
 	try
 	{
-		((Batch*) b)->eng->load_state(buf, size < 0 ? 0 : (size_t) size, stream);
+		need(b)->eng->load_state(buf, size < 0 ? 0 : (size_t) size, stream);
 		return 0;
 	}
 	catch (const std::exception& e)
@@ -366,7 +373,7 @@ R8BSRC_DECL int r8b_batch_stage_timing(CR8BBatch b, int stage, double* ms_sum, i
 	try
 	{
 		std::string name;
-		if (!((Batch*) b)->eng->stage_timing((size_t) stage, ms_sum, launches, &name,
+		if (!need(b)->eng->stage_timing((size_t) stage, ms_sum, launches, &name,
 			in_samples, out_samples)) return -1;
 		copy_text(name, kernel, cap);
 		return 0;
@@ -438,7 +445,8 @@ R8BSRC_DECL int r8b_process(CR8BResampler rs, double* ip0, int l, double*& op0)
 R8BSRC_DECL int r8b_design_lpfilter(double ReqNormFreq, double ReqTransBand, double ReqAtten,
 	double ReqGain, int* BlockLenBits, int* Latency, double* taps, int cap)
 {
-	const LpFilter& f = design_lp(ReqNormFreq, ReqTransBand, ReqAtten, ReqGain);
+	const LpFilterRef fr = design_lp(ReqNormFreq, ReqTransBand, ReqAtten, ReqGain);
+	const LpFilter& f = *fr;
 	if (BlockLenBits) *BlockLenBits = f.block_len_bits;
 	if (Latency) *Latency = f.fl2;
 	if (taps)
@@ -450,7 +458,8 @@ R8BSRC_DECL int r8b_design_lpfilter_ex(double ReqNormFreq, double ReqTransBand, 
 	double ReqGain, int ReqPhase, int* BlockLenBits, int* Latency, double* LatencyFrac, double* taps,
 	int cap)
 {
-	const LpFilter& f = design_lp(ReqNormFreq, ReqTransBand, ReqAtten, ReqGain, ReqPhase != 0);
+	const LpFilterRef fr = design_lp(ReqNormFreq, ReqTransBand, ReqAtten, ReqGain, ReqPhase != 0);
+	const LpFilter& f = *fr;
 	if (BlockLenBits) *BlockLenBits = f.block_len_bits;
 	if (Latency) *Latency = f.fl2;
 	if (LatencyFrac) *LatencyFrac = f.lat_frac;
@@ -471,13 +480,23 @@ R8BSRC_DECL int r8b_design_fracbank(int FilterFracs, int ElementSize, int Interp
 {
 	if (!((ElementSize == 1 && InterpPoints == 2) || (ElementSize == 3 && InterpPoints == 8)))
 		return -1;
-	const FracBank& b = design_frac_bank(FilterFracs, ElementSize, InterpPoints, ReqAtten,
+	const FracBankRef br = design_frac_bank(FilterFracs, ElementSize, InterpPoints, ReqAtten,
 		IsThird != 0);
+	const FracBank& b = *br;
 	if (FilterLen) *FilterLen = b.filter_len;
 	if (Fracs) *Fracs = b.fracs;
 	const int n = (int) b.table.size();
 	if (table) memcpy(table, b.table.data(), sizeof(double) * (size_t) (n < cap ? n : cap));
 	return n;
+}
+
+R8BSRC_DECL void r8b_design_cache_counts(int* Filters, int* FracBanks, int* LaneTables)
+{
+	int c[3] = { 0, 0, 0 };
+	design_cache_counts(c);
+	if (Filters) *Filters = c[0];
+	if (FracBanks) *FracBanks = c[1];
+	if (LaneTables) *LaneTables = c[2];
 }
 
 R8BSRC_DECL int r8b_design_hbfilter(double ReqAtten, int SteepIndex, int IsThird, double* taps,

@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <complex>
+#include <list>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -152,7 +153,68 @@ void lp_fit(double trans_band, double atten_req, double* pwr_o, double* hl_o, do
 
 std::mutex g_cache_mutex;
 
+// Bounded cache in the manner of the reference's (CDSPFIRFilter.h:598-694): most recently used first; when a new
+// entry finds the cache full, entries nobody else holds go, oldest first -- the count exceeds the bound only while
+// that many different objects are in use at the same time.  (Callers hold g_cache_mutex.)
+template<class Key, class T>
+struct LruCache
+{
+	typedef std::shared_ptr<const T> Ref;
+	std::list<std::pair<Key, Ref>> items;
+	size_t max;
+	explicit LruCache(size_t m) : max(m) {}
+	Ref find(const Key& k)
+	{
+		for (auto it = items.begin(); it != items.end(); ++it)
+			if (it->first == k)
+			{
+				items.splice(items.begin(), items, it);
+				return items.front().second;
+			}
+		return Ref();
+	}
+	Ref insert(const Key& k, T&& v)
+	{
+		for (auto it = items.end(); items.size() >= max && it != items.begin();)
+		{
+			--it;
+			if (it->second.use_count() == 1) it = items.erase(it);
+		}
+		items.emplace_front(k, std::make_shared<const T>(std::move(v)));
+		return items.front().second;
+	}
+};
+
+typedef std::tuple<double, double, double, double, bool, int> LpKey;
+typedef std::tuple<int, int, int, double, bool> BankKey;
+LruCache<LpKey, LpFilter>& lp_cache()
+{
+	static LruCache<LpKey, LpFilter> c((size_t) kFilterCacheMax);
+	return c;
+}
+LruCache<BankKey, FracBank>& bank_cache()
+{
+	static LruCache<BankKey, FracBank> c((size_t) kFracBankCacheMax);
+	return c;
+}
+
 } // namespace
+
+namespace { int g_lane_deals = 0; }
+void lane_deal_cache_count(int delta_or_zero, int* count)
+{
+	std::lock_guard<std::mutex> lock(g_cache_mutex);
+	g_lane_deals += delta_or_zero;
+	if (count) *count = g_lane_deals;
+}
+
+void design_cache_counts(int counts[3])
+{
+	std::lock_guard<std::mutex> lock(g_cache_mutex);
+	counts[0] = (int) lp_cache().items.size();
+	counts[1] = (int) bank_cache().items.size();
+	counts[2] = g_lane_deals;
+}
 
 namespace {
 
@@ -261,10 +323,10 @@ void set_lp_provider(LpProvider p)
 }
 #endif
 
-const LpFilter& design_lp(double norm_freq, double trans_band, double atten, double gain, bool min_phase)
+LpFilterRef design_lp(double norm_freq, double trans_band, double atten, double gain, bool min_phase)
 {
-	typedef std::tuple<double, double, double, double, bool, int> Key;
-	static std::map<Key, LpFilter> cache;
+	typedef LpKey Key;
+	LruCache<LpKey, LpFilter>& cache = lp_cache();
 	std::unique_lock<std::mutex> lock(g_cache_mutex);
 	int gen = 0;
 #ifdef R8B_TEST_HOOKS
@@ -272,8 +334,7 @@ const LpFilter& design_lp(double norm_freq, double trans_band, double atten, dou
 	gen = provider != nullptr ? g_lp_provider_gen : 0;
 #endif
 	const Key key(norm_freq, trans_band, atten, gain, min_phase, gen);
-	auto it = cache.find(key);
-	if (it != cache.end()) return it->second;
+	if (LpFilterRef hit = cache.find(key)) return hit;
 #ifdef R8B_TEST_HOOKS
 	if (provider != nullptr)
 	{
@@ -286,8 +347,7 @@ const LpFilter& design_lp(double norm_freq, double trans_band, double atten, dou
 		const int n = provider(norm_freq, trans_band, atten, gain, min_phase ? 1 : 0, t.data(), (int) t.size(),
 			&lat, &lf, &bits);
 		lock.lock();
-		it = cache.find(key);
-		if (it != cache.end()) return it->second;
+		if (LpFilterRef hit = cache.find(key)) return hit;
 		if (n > 0)
 		{
 			LpFilter f;
@@ -297,7 +357,7 @@ const LpFilter& design_lp(double norm_freq, double trans_band, double atten, dou
 			f.lat_frac = lf;
 			f.zero_phase = !min_phase;
 			f.block_len_bits = bits;
-			return cache.emplace(key, std::move(f)).first->second;
+			return cache.insert(key, std::move(f));
 		}
 	}
 #endif
@@ -358,7 +418,7 @@ const LpFilter& design_lp(double norm_freq, double trans_band, double atten, dou
 	for (int i = 0; i < f.kernel_len; i++) s += f.taps[(size_t) i];
 	s = gain / s;
 	for (int i = 0; i < f.kernel_len; i++) f.taps[(size_t) i] *= s;
-	return cache.emplace(key, std::move(f)).first->second;
+	return cache.insert(key, std::move(f));
 }
 
 namespace {
@@ -430,15 +490,14 @@ void frac_filter(double fd, int flen, double beta, double power, double* op, int
 
 } // namespace
 
-const FracBank& design_frac_bank(int fracs, int element_size, int interp_points, double atten,
+FracBankRef design_frac_bank(int fracs, int element_size, int interp_points, double atten,
 	bool third)
 {
-	typedef std::tuple<int, int, int, double, bool> Key;
-	static std::map<Key, FracBank> cache;
+	typedef BankKey Key;
+	LruCache<BankKey, FracBank>& cache = bank_cache();
 	std::lock_guard<std::mutex> lock(g_cache_mutex);
 	const Key key(fracs, element_size, interp_points, atten, third);
-	auto it = cache.find(key);
-	if (it != cache.end()) return it->second;
+	if (FracBankRef hit = cache.find(key)) return hit;
 
 	double beta, power, att_r;
 	int flen;
@@ -484,7 +543,7 @@ const FracBank& design_frac_bank(int fracs, int element_size, int interp_points,
 					29.0 * (xm2 + x2) - 167.0 * x0) * k;
 			}
 	}
-	return cache.emplace(key, std::move(b)).first->second;
+	return cache.insert(key, std::move(b));
 }
 
 int select_hb_filter(double atten, int steep, bool third, const double** taps, double* att)

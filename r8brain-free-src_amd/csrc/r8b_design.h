@@ -13,6 +13,7 @@
 #ifndef R8B_DESIGN_H
 #define R8B_DESIGN_H
 
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -49,8 +50,17 @@ enum FilterPhase { kLinearPhase = 0, kMinPhase = 1 };
 
 // Kaiser-power-windowed sinc low-pass; min_phase: followed by the cepstral minimum-phase transform
 // (reference CDSPRealFFT.h:681-785 calcMinPhaseTransform, 16x oversampled).
-const LpFilter& design_lp(double norm_freq, double trans_band, double atten, double gain,
+// The result is shared with the designer's cache, which is bounded like the reference's (CDSPFIRFilter.h:598-694,
+// r8bconf.h:90 R8B_FILTER_CACHE_MAX 96 / :103 R8B_FRACBANK_CACHE_MAX 12): least recently used entries nobody holds
+// any more are dropped once the cache is full; what a live object holds stays alive through its shared_ptr.
+typedef std::shared_ptr<const LpFilter> LpFilterRef;
+LpFilterRef design_lp(double norm_freq, double trans_band, double atten, double gain,
 	bool min_phase = false);
+static const int kFilterCacheMax = 96, kFracBankCacheMax = 12, kLaneDealCacheMax = 96;
+// entries the caches hold right now: [0] low-pass filters, [1] fractional-delay banks, [2] lane tables of the fused
+// interpolator (Engine, one per ratio)
+void design_cache_counts(int counts[3]);
+void lane_deal_cache_count(int delta_or_zero, int* count); // (kept by r8b_engine.cpp; read through design_cache_counts)
 
 struct FracBank
 {
@@ -61,7 +71,8 @@ struct FracBank
 	std::vector<double> table; // (fracs+1) rows x filter_len*element_size
 };
 
-const FracBank& design_frac_bank(int fracs, int element_size, int interp_points, double atten,
+typedef std::shared_ptr<const FracBank> FracBankRef;
+FracBankRef design_frac_bank(int fracs, int element_size, int interp_points, double atten,
 	bool third);
 
 // Tap selection over the generated half-band tables.  Returns tap count, *taps points to

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <list>
 #include <mutex>
 #include <complex>
 #include <cstdio>
@@ -977,17 +978,21 @@ void Engine::prepare_two_phase(size_t s)
 	const int NQ = (NP + 3) / 4, NI = NQ * nsets;
 	std::vector<int> slot_item(64, -1); // [service group * 4 + rank] -> item = set * NQ + data quad
 	// (the table depends on the ratio alone: searched once per process and ratio)
+	// (bounded like the designer's caches -- kLaneDealCacheMax ratios, most recently used first; an entry is copied out,
+	// so dropping the oldest one costs a host that comes back to its ratio one more search, nothing else)
 	static std::mutex cache_mutex;
-	static std::map<std::pair<int, int>, std::vector<int>> cache;
+	static std::list<std::pair<std::pair<int, int>, std::vector<int>>> cache;
 	bool cached = false;
 	{
 		std::lock_guard<std::mutex> lock(cache_mutex);
-		auto it = cache.find(std::make_pair(In, Out));
-		if (it != cache.end())
-		{
-			slot_item = it->second;
-			cached = true;
-		}
+		for (auto it = cache.begin(); it != cache.end(); ++it)
+			if (it->first == std::make_pair(In, Out))
+			{
+				cache.splice(cache.begin(), cache, it);
+				slot_item = cache.front().second;
+				cached = true;
+				break;
+			}
 	}
 	if (!cached)
 	{
@@ -1053,7 +1058,19 @@ void Engine::prepare_two_phase(size_t s)
 		slot_item = best;
 		{
 			std::lock_guard<std::mutex> lock(cache_mutex);
-			cache[std::make_pair(In, Out)] = slot_item;
+			bool have = false; // (another thread may have searched the same ratio meanwhile: same table, one entry)
+			for (const auto& e : cache) have = have || e.first == std::make_pair(In, Out);
+			if (!have)
+			{
+				int dropped = 0;
+				while (cache.size() >= (size_t) kLaneDealCacheMax)
+				{
+					cache.pop_back();
+					dropped++;
+				}
+				cache.emplace_front(std::make_pair(In, Out), slot_item);
+				lane_deal_cache_count(1 - dropped, nullptr);
+			}
 		}
 		if (std::getenv("R8B_DEBUG_TWO")) fprintf(stderr, "two-phase tables: %d phase pairs in %d quads x %d sets, %d bank clashes over the 16 service groups\n", NP, NQ, nsets, best_cost);
 	}

@@ -15,8 +15,8 @@ StagePlan make_stage_plan(const StageDesc& d, double prev_lat)
 	{
 		// geometry, reference CDSPBlockConvolver.h:62-185 (linear phase, PrevLatency 0,
 		// DoConsumeLatency)
-		const LpFilter& f = design_lp(d.a, d.b, d.c, d.d, d.phase == kMinPhase);
-		s.lp = &f;
+		s.lp = design_lp(d.a, d.b, d.c, d.d, d.phase == kMinPhase);
+		const LpFilter& f = *s.lp;
 		ConvGeom& g = s.cg;
 		g.up = d.i0;
 		g.down = d.i1;
@@ -79,8 +79,8 @@ StagePlan make_stage_plan(const StageDesc& d, double prev_lat)
 		s.dsr = d.b;
 		s.whole = whole_stepping(d.a, d.b, &s.in_step, &s.out_step);
 		// reference CDSPFracInterpolator.h:736-760
-		s.bank = s.whole ? &design_frac_bank(s.out_step, 1, 2, d.c, d.i0 != 0) :
-			&design_frac_bank(-1, 3, 8, d.c, d.i0 != 0);
+		s.bank = s.whole ? design_frac_bank(s.out_step, 1, 2, d.c, d.i0 != 0) :
+			design_frac_bank(-1, 3, 8, d.c, d.i0 != 0);
 		s.flen = s.bank->filter_len;
 		s.fl2 = s.flen / 2;
 		s.fll = s.fl2 - 1;

