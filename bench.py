@@ -408,10 +408,14 @@ def main():
             run(calls, 8)
             calls += 8
 
-    # second pass, same steps, with per-kernel HIP events (kept out of the headline timing)
+    # second pass, same steps, with per-kernel HIP events (kept out of the headline timing); its own wall time is taken
+    # too: wall time per step minus the kernels' time per step = what a step spends BETWEEN kernels (launch gaps)
     rs.set_option("timing", 1)
+    torch.cuda.synchronize()
+    t_ev0 = time.perf_counter()
     run(calls, args.steps)
     torch.cuda.synchronize()
+    ev_wall_ms = (time.perf_counter() - t_ev0) / args.steps * 1e3
     timings = rs.stage_timings()
     rs.set_option("timing", 0)
 
@@ -459,6 +463,21 @@ def main():
                          "path_frac": round(path_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                                             4)},
         }
+        # `frac` above is the dominant kernel as the event pass saw it -- LATER than the value window, i.e. in another
+        # clock state when the value window lies in the power controller's dip.  The same fraction FOR the value window:
+        # the kernels' share of a step there = ms_per_step minus the launch gaps, the gaps taken from the window whose
+        # kernels were timed in the same state (the settled window when there is one, else the event pass itself, whose
+        # wall time carries the events' own overhead -- a slightly larger gap, never a smaller one)
+        ksum = sum(t[1] for t in timings) / args.steps
+        ref_ms = settled["ms_per_step"] if settled is not None else ev_wall_ms
+        gap_ms = max(0.0, ref_ms - ksum)
+        kern_vw = max(dt / args.steps * 1e3 - gap_ms, 1e-9)
+        res["roofline"]["launch_gap_ms_per_step"] = round(gap_ms, 4)
+        res["roofline"]["frac_value_window"] = round(achieved / HBM_PEAK_GBS * ksum / kern_vw, 4)
+        res["roofline"]["frac_clock_state"] = ("`frac`: per-kernel HIP events of a pass AFTER every timed window (settled "
+                                               "clock); `frac_value_window`: the same kernel in the window `value` is "
+                                               "quoted on = frac x (kernel ms per step of the event pass) / (ms_per_step "
+                                               "- launch_gap_ms_per_step)")
         res["value_window"] = "the %d steps timed straight after the %d warm-up calls" % (args.steps, args.warmup)
         if settled is not None:
             res["settle_calls"] = args.settle

@@ -48,11 +48,104 @@
 #define R8B_FORCE4(a, b, c, d)
 #endif
 // R8B_OUT_STORE16: a 16-byte store of an output pair to the caller's rows (the device build may mark it non-temporal)
+// R8B_OPAQUE2: the two values are produced HERE as far as the compiler can tell (device: an empty asm statement that
+// rewrites them) -- what is computed from them stays where it is written, e.g. inside a loop
+#ifndef R8B_OPAQUE2
+#define R8B_OPAQUE2(a, b)
+#endif
 #ifndef R8B_OUT_STORE16
 #define R8B_OUT_STORE16(ptr, v) { *reinterpret_cast<cd*>(ptr) = (v); }
 #endif
 
 namespace r8bhip {
+
+// ---- timing ablations (development builds only: tools/variant.sh ... -DR8B_ABL_TABLES=n; results are WRONG, the time says
+// what a resource costs; round 5, profiles/r05_ceiling.txt).  The shipped build expands every knob to the plain access.
+//   R8B_ABL_TABLES  1: every table fetch (twiddles, kernel constants, interpolator rows) reads one of four entries of its
+//                      row whatever the lane -- the same instructions, a handful of cache lines that stay in the CU's L1
+//                      (no L1 <- L2 fill traffic for tables);  2: no fetch at all, the value is made up in registers
+//                      (what a form that keeps every table in registers could reach at best);  3: the fetch is a
+//                      16-byte LDS read at lane-consecutive addresses (what a form that keeps the tables in LDS pays)
+//   R8B_ABL_SAMPLES 1: the block's sample loads read eight samples of the row whatever the lane (no HBM reads)
+//   R8B_ABL_STORES  1: the interpolator's output stores land in the first 64 outputs of the block's rows (no HBM writes)
+// (what the walk form keeps / overlaps -- development A/B, tools/variant.sh: R8B_WALK_ROWS the interpolator's rows in
+// registers across blocks, else fetched per block as in the one-block form; R8B_WALK_PREF the next block's samples
+// requested during this block's interpolator phase, else at the block's start)
+#ifndef R8B_WALK_ROWS
+#define R8B_WALK_ROWS 1
+#endif
+#ifndef R8B_WALK_PREF
+#define R8B_WALK_PREF 1
+#endif
+// (R8B_WALK_LEAN: development timing builds -- every block of the walk treated as an interior one: no history tail, no
+// parked outputs, the fast load path and the aligned interpolator loop only; results of a call's first and last blocks
+// are WRONG)
+#ifndef R8B_WALK_LEAN
+#define R8B_WALK_LEAN 0
+#endif
+// (R8B_WALK_HP: the thread's kernel constants of the middle pass kept across blocks too)
+#ifndef R8B_WALK_HP
+#define R8B_WALK_HP 0
+#endif
+#ifndef R8B_ABL_TABLES
+#define R8B_ABL_TABLES 0
+#endif
+#ifndef R8B_ABL_SAMPLES
+#define R8B_ABL_SAMPLES 0
+#endif
+#ifndef R8B_ABL_STORES
+#define R8B_ABL_STORES 0
+#endif
+// (per table class: R8B_ABL_T twiddles, R8B_ABL_H kernel constants, R8B_ABL_R interpolator rows; default R8B_ABL_TABLES)
+#ifndef R8B_ABL_T
+#define R8B_ABL_T R8B_ABL_TABLES
+#endif
+#ifndef R8B_ABL_H
+#define R8B_ABL_H R8B_ABL_TABLES
+#endif
+#ifndef R8B_ABL_R
+#define R8B_ABL_R R8B_ABL_TABLES
+#endif
+#if R8B_ABL_T || R8B_ABL_H || R8B_ABL_R
+R8B_HD cd abl_made_up(int uoff, int loff)
+{
+	cd v;
+	v.re = 0.7;
+	v.im = -0.7;
+	(void) uoff;
+	(void) loff;
+#ifdef __HIP_DEVICE_COMPILE__
+	asm volatile("" : "+v"(v.re), "+v"(v.im));
+#endif
+	return v;
+}
+R8B_HD cd abl_from_lds(int uoff, int loff)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+	typedef double abl_d2_t __attribute__((ext_vector_type(2)));
+	const abl_d2_t t = *(const __attribute__((address_space(3))) abl_d2_t*) (size_t) ((unsigned) (((uoff) + (loff)) & 4095) << 4);
+	cd v;
+	v.re = t.x;
+	v.im = t.y;
+	return v;
+#else
+	cd v;
+	v.re = v.im = 0.0;
+	(void) uoff;
+	(void) loff;
+	return v;
+#endif
+}
+#endif
+#define R8B_TAB_LD_0(base, uoff, loff) ((base)[(uoff) + (loff)])
+#define R8B_TAB_LD_1(base, uoff, loff) ((base)[(uoff) + ((loff) & 3)])
+#define R8B_TAB_LD_2(base, uoff, loff) abl_made_up((uoff), (loff))
+#define R8B_TAB_LD_3(base, uoff, loff) abl_from_lds((uoff), (loff))
+#define R8B_TAB_CAT2(a, b) a##b
+#define R8B_TAB_CAT(a, b) R8B_TAB_CAT2(a, b)
+#define R8B_TAB_LD_T R8B_TAB_CAT(R8B_TAB_LD_, R8B_ABL_T)
+#define R8B_TAB_LD_H R8B_TAB_CAT(R8B_TAB_LD_, R8B_ABL_H)
+#define R8B_TAB_LD_R R8B_TAB_CAT(R8B_TAB_LD_, R8B_ABL_R)
 
 static const int kConvpThreads = 256;
 
@@ -245,6 +338,7 @@ struct ConvpState
 	double tk[2];         // the thread's element of the history tail behind the last block's window (cp_tail_slice_*)
 	double* tka;
 	double er[16], ei[16]; // split 2x up-sampling form (modes 8 / 9 / 12 / 13): the even half's outputs while the odd half is transformed
+	cd twp[4];            // walk form (convp_walk): the thread's own twiddles, kept across blocks -- [0], [1] first pass (w, w^4), [2], [3] last backward pass
 };
 
 // (+ 64 bytes behind the array: one word per wave for the workgroup-wide "channel has a non-zero sample" bits)
@@ -253,7 +347,77 @@ template<int LN, int UL> constexpr int convp_array_bytes()
 {
 	return kSplit<LN, UL> ? ConvpGeom<LN, UL>::N * 16 : ConvpGeom<LN, UL>::SUB * ConvpGeom<LN, UL>::NA * 16;
 }
-template<int LN, int UL> constexpr int convp_lds_bytes() { return convp_array_bytes<LN, UL>() + kConvpFlagBytes; }
+
+// Twiddles of the wave-local passes through LDS (round 5).  The passes between the first forward and the last
+// backward one have few DISTINCT twiddles -- JM = 4 ... 32 entries per row (ptw_fetch), the same for every wave, block
+// and channel pair -- yet every thread fetched its 4 + 4 + 6 of them with vector loads of its own: 14 of the kernel's
+// ~50 table loads per thread, each a trip through the address unit and the L1 that the pass then waits for
+// (profiles/r05_ceiling.txt: the kernel gains more from a table load NOT ISSUED than from its bytes not moved).  Now
+// the workgroup's first NE threads fetch ONE entry each at kernel entry (NE <= 240: the whole table), leave it in LDS
+// behind the array and the flags before the first barrier, and a pass reads its base powers from there when it starts
+// (16-byte LDS reads of a few consecutive entries: conflict free, and no register is held across phases for them).
+// Forward pass I uses slot I (rows of JM = min(n / E1, NT) entries, n = N >> (I EB1)), the backward pass with sub-length
+// 256 slot 3 (16 entries per row).  Geometries with the mirrored backward side (decimating, 8192 points) keep their
+// global fetches.
+#ifndef R8B_TW_LDS
+#define R8B_TW_LDS 1
+#endif
+template<int LN, int UL>
+struct ConvpTwLds
+{
+	typedef ConvpGeom<LN, UL> G;
+	static constexpr bool ON = R8B_TW_LDS != 0 && !G::POST && !kSplit<LN, UL>;
+	static constexpr int NBF = G::E1 >= 16 ? 6 : (G::E1 >= 8 ? 4 : (G::E1 >= 4 ? 3 : 1)); // base powers of a forward pass
+	static constexpr int jm(int i) { return ((G::N >> (i * G::EB1)) / G::E1 < G::NT) ? (G::N >> (i * G::EB1)) / G::E1 : G::NT; }
+	static constexpr int JM1 = ON && G::NPRE > 1 ? jm(1) : 0;
+	static constexpr int JM2 = ON && G::NPRE > 2 ? jm(2) : 0;
+	static constexpr int JM3 = ON && G::B1 ? (16 < G::NT ? 16 : G::NT) : 0;
+	static constexpr int O1 = 0, O2 = O1 + NBF * JM1, O3 = O2 + NBF * JM2, NE = O3 + 6 * JM3;
+	static_assert(NE <= G::WT, "one entry per thread");
+	// entry e of the LDS table -> its index in the global table (rows of NT entries, 6 rows per slot)
+	static R8B_HD int src_index(int e)
+	{
+		int slot = 1, jmv = JM1, r = e;
+		if (e >= O3) { slot = 3; jmv = JM3; r = e - O3; }
+		else if (e >= O2) { slot = 2; jmv = JM2; r = e - O2; }
+		if (jmv == 0) return 0;
+		const int c = r / jmv, t = r - c * jmv;
+		return (slot * 6 + c) * G::NT + t;
+	}
+};
+template<int LN, int UL> constexpr int convp_lds_bytes()
+{
+	return convp_array_bytes<LN, UL>() + kConvpFlagBytes + (ConvpTwLds<LN, UL>::ON ? ConvpTwLds<LN, UL>::NE * 16 : 0);
+}
+// the table as the phases see it: ltw = the workgroup's LDS + convp_array_bytes + kConvpFlagBytes
+#if defined(R8B_LDS_ABS) && defined(__HIP_DEVICE_COMPILE__)
+R8B_HD cd twl_ld(const cd* ltw, int idx)
+{
+	const lds_d2_t t = *(const lds_d2a_t*) (size_t) ((unsigned) (size_t) (const lds_cd_t*) ltw + ((unsigned) idx << 4));
+	cd v;
+	v.re = t.x;
+	v.im = t.y;
+	return v;
+}
+R8B_HD void twl_st(cd* ltw, int idx, cd v)
+{
+	lds_d2_t t;
+	t.x = v.re;
+	t.y = v.im;
+	*(lds_d2a_t*) (size_t) ((unsigned) (size_t) (const lds_cd_t*) ltw + ((unsigned) idx << 4)) = t;
+}
+#else
+R8B_HD cd twl_ld(const cd* ltw, int idx) { return ltw[idx]; }
+R8B_HD void twl_st(cd* ltw, int idx, cd v) { ltw[idx] = v; }
+#endif
+// base powers of a pass from the LDS table: rows of JM entries starting at entry OFF
+template<int NB, int JM>
+R8B_HD void twl_fetch(cd* twr, const cd* ltw, int off, int lt)
+{
+	const int j = off + (lt & (JM - 1));
+#pragma unroll
+	for (int c = 0; c < NB; c++) twr[c] = twl_ld(ltw, j + c * JM);
+}
 
 // Silence stays silence.  Two channels share one complex transform, so each picks up rounding residue of the
 // order of 1e-16 of its PARTNER's amplitude; for a channel whose samples are all zero that residue would be the
@@ -310,9 +474,8 @@ R8B_HD void ptw_fetch(cd* twr, const cd* ptw, int slot, int lt)
 {
 	constexpr int NB = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
 	if constexpr (JM < NT) lt &= JM - 1;
-	const cd* p = ptw + (slot * 6 * NT + lt);
 #pragma unroll
-	for (int c = 0; c < NB; c++) twr[c] = p[c * NT];
+	for (int c = 0; c < NB; c++) twr[c] = R8B_TAB_LD_T(ptw, slot * 6 * NT + c * NT, lt);
 }
 
 // First forward / last backward pass: every thread has twiddles of its own (NT distinct rows: 16 KB ... 24 KB per pass and
@@ -331,9 +494,8 @@ R8B_HD void ptw_fetch_lean(cd* twr, const cd* ptw, int slot, int lt)
 	if constexpr (!R8B_TW_DERIVE) ptw_fetch<R, NT>(twr, ptw, slot, lt);
 	else
 	{
-		const cd* p = ptw + (slot * 6 * NT + lt);
-		twr[0] = p[0];
-		if constexpr (NB == 6) twr[3] = p[3 * NT];
+		twr[0] = R8B_TAB_LD_T(ptw, slot * 6 * NT, lt);
+		if constexpr (NB == 6) twr[3] = R8B_TAB_LD_T(ptw, slot * 6 * NT + 3 * NT, lt);
 	}
 }
 R8B_HD cd tw_sq(cd a)
@@ -482,9 +644,10 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 	// most blocks of a call lie entirely inside the caller's buffer: one uniform row pointer per channel
 	// and a 32-bit offset per load (the general form selects ring / buffer / zero per sample: ~12
 	// vector instructions per load)
-	if (L.src.cur_fmt == kPcmF64 && base - (G::N - iln) >= L.src.cur_base && base - (G::N - iln) >= 0)
+	if (R8B_WALK_LEAN || (L.src.cur_fmt == kPcmF64 && base - (G::N - iln) >= L.src.cur_base && base - (G::N - iln) >= 0))
 	{
-		const long long w0 = base - (G::N - iln) - L.src.cur_base;
+		long long w0 = base - (G::N - iln) - L.src.cur_base;
+		if (R8B_WALK_LEAN && w0 < 0) w0 = 0;
 		const double* const pa = L.src.cur + ((long long) chA * L.src.cur_stride + w0);
 		const double* const pb = L.src.cur + ((long long) chB * L.src.cur_stride + w0);
 		const unsigned l0 = (unsigned) (lt + wr);
@@ -492,8 +655,13 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 		for (int p = 0; p < R; p++)
 		{
 			const unsigned w = (l0 + (unsigned) (p * q)) & (unsigned) (G::N - 1);
+#if R8B_ABL_SAMPLES
+			st.pr[p] = pa[w & 7u];
+			st.pi[p] = pb[w & 7u];
+#else
 			st.pr[p] = pa[w];
 			st.pi[p] = pb[w];
+#endif
 		}
 		return;
 	}
@@ -810,11 +978,20 @@ struct ConvpPre
 	static constexpr int n = G::N >> (I * G::EB1);
 	static R8B_HD void prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 	{
-		ptw_fetch<G::E1, G::NT, (n / G::E1 < G::NT ? n / G::E1 : G::NT)>(st.tw, L.ptw, I, lt);
+		if constexpr (!ConvpTwLds<LN, UL>::ON)
+			ptw_fetch<G::E1, G::NT, (n / G::E1 < G::NT ? n / G::E1 : G::NT)>(st.tw, L.ptw, I, lt);
 	}
-	static R8B_HD void run(cd* buf, const ConvpState<LN, UL>& st, int lt)
+	// (ltw: the workgroup's twiddle table in LDS, ConvpTwLds)
+	static R8B_HD void run(cd* buf, const ConvpState<LN, UL>& st, int lt, const cd* ltw)
 	{
-		pdif<LN, UL, G::E1, true>(buf, n, lt, st.tw);
+		typedef ConvpTwLds<LN, UL> TL;
+		if constexpr (TL::ON)
+		{
+			cd twr[TL::NBF];
+			twl_fetch<TL::NBF, (I == 1 ? TL::JM1 : TL::JM2)>(twr, ltw, I == 1 ? TL::O1 : TL::O2, lt);
+			pdif<LN, UL, G::E1, true>(buf, n, lt, twr);
+		}
+		else pdif<LN, UL, G::E1, true>(buf, n, lt, st.tw);
 	}
 };
 
@@ -831,7 +1008,7 @@ R8B_HD void cp_hp_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 #pragma unroll
 	for (int c = 0; c < NHP; c++)
 	{
-		st.hp[c] = L.hp[c * ConvpGeom<LN, UL>::NT + lt];
+		st.hp[c] = R8B_TAB_LD_H(L.hp, (c * ConvpGeom<LN, UL>::NT), lt);
 	}
 }
 
@@ -925,14 +1102,23 @@ R8B_HD void cp_middle_write(cd* buf, const ConvpState<LN, UL>& st, int lt)
 // backward pass with sub-length 256 (radix 16); in place, or -- when it is the last one (N2 = 256: its
 // elements lt + 16 p are the thread's elements lt + NT p of the result) -- into st.vr / st.vi
 template<int LN, int UL>
-R8B_HD void cp_back1(cd* buf, ConvpState<LN, UL>& st, int lt)
+R8B_HD void cp_back1(cd* buf, ConvpState<LN, UL>& st, int lt, const cd* ltw)
 {
+	typedef ConvpTwLds<LN, UL> TL;
+	cd twl[6];
+	const cd* twr = st.tw;
+	if constexpr (TL::ON && ConvpGeom<LN, UL>::B1)
+	{
+		twl_fetch<6, TL::JM3>(twl, ltw, TL::O3, lt);
+		twr = twl;
+	}
+	(void) ltw;
 	if constexpr (!ConvpGeom<LN, UL>::B1) return; // (no such pass below 256 points)
-	else if constexpr (ConvpGeom<LN, UL>::R2 == 1) pdit_regs<16, true>(buf, 256, lt, st.tw, st.vr, st.vi);
+	else if constexpr (ConvpGeom<LN, UL>::R2 == 1) pdit_regs<16, true>(buf, 256, lt, twr, st.vr, st.vi);
 	else
 	{
 		double vr[16], vi[16];
-		pdit_regs<16, true>(buf, 256, lt, st.tw, vr, vi);
+		pdit_regs<16, true>(buf, 256, lt, twr, vr, vi);
 		const int e0 = (lt >> 4) * 256 + (lt & 15);
 		const SwBase bb = sw_base(buf, pswz(e0));
 #pragma unroll
@@ -1880,11 +2066,11 @@ R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int pt)
 	// sets with the same phase pairs find them in the CU's cache (idle lanes read pair 0)
 	const int q = pt < 0 ? 0 : pt & 0xff;
 	const int ctp = (((X.out_step + 1) >> 1) + 3) & ~3;
-	const cd* ct = reinterpret_cast<const cd*>(X.ctab) + q;
+	const cd* ct = reinterpret_cast<const cd*>(X.ctab);
 #pragma unroll
 	for (int i = 0; i < T2; i++)
 	{
-		const cd v = ct[i * ctp];
+		const cd v = R8B_TAB_LD_R(ct, i * ctp, q);
 		rows[2 * i] = v.re;
 		rows[2 * i + 1] = v.im;
 	}
@@ -1892,7 +2078,7 @@ R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int pt)
 
 // (wd: where the outputs go -- the launch's X.wdst, or the park buffer for the part of the call's last block that
 // belongs to the next call, ConvxLaunch::park_dst)
-template<int T2>
+template<int T2, bool ALIGNED_ONLY = false>
 R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const SpanInfo& Bm, const cd* y, const double* rows,
 	int pt, int chA, int chB, bool bvalid)
 {
@@ -1916,7 +2102,7 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 	const bool pair16 = (((size_t) pa0 | (size_t) pb0) & 15) == 0 && (out_step & 1) == 0;
 	constexpr int CH = T2 == 25 ? 5 : 3, NCH = T2 / CH;
 	static_assert(CH * NCH == T2, "chunks");
-	if (lo_mod == 0 && hi_mod == out_step && linear && pair16)
+	if (ALIGNED_ONLY || (lo_mod == 0 && hi_mod == out_step && linear && pair16))
 	{
 		// Whole groups only (every block of a call but those cut by its ends, when the blocks are aligned to
 		// groups -- Engine::launch_fused): nothing to mask, every output pair is one 16-byte store.
@@ -1952,7 +2138,11 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 			// multiply-adds behind it, away from the LDS reads they should overlap, and keeps the whole window live)
 			R8B_FORCE4(b0[0], b0[1], b1[0], b1[1]);
 			// (uniform row pointer + one 32-bit index: no 64-bit address arithmetic per store)
+#if R8B_ABL_STORES
+			const unsigned o = (unsigned) (out_step * gl + 2 * q) & 63u;
+#else
 			const unsigned o = (unsigned) (out_step * gl + 2 * q);
+#endif
 			cd va, vb;
 			va.re = a0[0] + a0[1];
 			va.im = a1[0] + a1[1];
@@ -1963,6 +2153,7 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 		}
 		return;
 	}
+	if constexpr (!ALIGNED_ONLY)
 	for (int gl = set; gl <= gmax; gl += nsets)
 	{
 		const cd* w = y + (u_lo + in_step * gl + rq);
@@ -2069,14 +2260,32 @@ struct ConvpItem
 	bool bvalid;
 };
 
+// Walk form (round 5; convp_walk): a workgroup takes SEVERAL consecutive blocks of its channel pair, one after the other,
+// and keeps across them what is the same for every block -- the interpolator's two rows and lane-table entry and the
+// thread's own twiddles in registers, the wave-local passes' twiddle table in LDS (ConvpTwLds) -- and requests block
+// k + 1's samples while block k is interpolated.  more: another block follows this one.
+struct ConvpWalk
+{
+	bool more;
+};
+template<int LN, int UL, int MODE> constexpr bool convp_walk_ok()
+{
+	// (two phases per thread, one block pair per workgroup, the plain backward side, two lean twiddles per pass at most)
+	return (MODE == 4 || MODE == 5 || MODE == 16 || MODE == 17) && ConvpGeom<LN, UL>::SUB == 1 && !ConvpGeom<LN, UL>::POST &&
+		ConvpGeom<LN, UL>::NB2 == 1 && ConvpTwLds<LN, UL>::ON;
+}
+
 
 // X: the launch descriptor as the phases read it -- on the GPU a copy whose hot scalars k_convp has pinned in
 // scalar registers (see there); XM: the descriptor in kernel-argument memory, for its per-block array only.
-template<int LN, int UL, int MODE, int FLENP, class Exec>
-R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd* buf, const ConvpItem& cur)
+template<int LN, int UL, int MODE, int FLENP, bool WALK = false, class Exec>
+R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd* buf, const ConvpItem& cur,
+	const ConvpWalk walk = ConvpWalk())
 {
 	typedef ConvpGeom<LN, UL> G;
 	typedef ConvpState<LN, UL> St;
+	static_assert(!WALK || convp_walk_ok<LN, UL, MODE>(), "walk form: fused two-phase modes of the 4096-point geometries");
+	(void) walk;
 	// modes 6 / 7: modes 0 / 3 with a complex kernel spectrum
 	// modes 16 / 17: modes 4 / 5 (fused interpolator, two phases per thread) with a complex kernel spectrum
 	constexpr bool CX = MODE == 6 || MODE == 7 || MODE == 16 || MODE == 17;
@@ -2100,6 +2309,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	// (they take part in every barrier) and store nothing
 	auto hp_prefetch = [&](St& st, int lt)
 	{
+		if constexpr (WALK && R8B_WALK_HP) { (void) st; (void) lt; } // (kept across blocks: convp_walk)
+		else
 		if constexpr (SOLO) { (void) st; (void) lt; } // (fetched behind the spectrum's write: cp_solo_mid_a)
 		else if constexpr (SP) cp_sp_hp_prefetch<LN, UL>(L, st, lt);
 		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
@@ -2107,6 +2318,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	auto sub_of = [&](int tid) { return convp_sub<LN, UL>(tid); };
 	auto lt_of = [&](int tid) { return convp_lt<LN, UL>(tid); };
 	auto buf_of = [&](int tid) { return buf + sub_of(tid) * G::NA; };
+	// (the workgroup's twiddle table in LDS, behind the array and the flag words: ConvpTwLds)
+	typedef ConvpTwLds<LN, UL> TL;
+	cd* const ltw = reinterpret_cast<cd*>(reinterpret_cast<unsigned char*>(buf) + convp_array_bytes<LN, UL>() + kConvpFlagBytes);
 	auto k_of = [&](int tid)
 	{
 		if constexpr (G::SUB == 1) return cur.k;
@@ -2121,14 +2335,41 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		if constexpr (G::SUB == 1) return true;
 		else return sub_of(tid) < cur.nvalid;
 	};
-	ex.phase([&](int tid, St& st)
+	auto front = [&](int tid, St& st, cd& twl_v)
 	{
 		const int lt = lt_of(tid);
+		twl_v.re = twl_v.im = 0.0;
+		if constexpr (WALK)
+		{
+			// (walk form: twiddles, table and this block's samples are there already -- convp_walk, or the previous
+			// block's interpolator phase)
+			// (opaque copies: the powers the pass derives from them are loop invariant, and hoisted out of the block loop
+			// they would stay live -- or spilled -- across all phases)
+			st.tw[0] = st.twp[0];
+			R8B_OPAQUE2(st.tw[0].re, st.tw[0].im);
+			if constexpr (G::E1 >= 16)
+			{
+				st.tw[3] = st.twp[1];
+				R8B_OPAQUE2(st.tw[3].re, st.tw[3].im);
+			}
+			if constexpr (!R8B_WALK_PREF) cp_load<LN, UL, BM, SP>(L, st, k_of(tid), chA, chB, lt);
+		}
+		else
+		{
 		// (the first pass's twiddles -- L2 -- requested ahead of the samples -- HBM --, not behind their wait)
 		ptw_fetch_lean<G::E1, G::NT>(st.tw, L.ptw, 0, lt);
+		// (... and this thread's entry of the wave-local passes' twiddle table)
+		if constexpr (TL::ON)
+		{
+			if (tid < TL::NE) twl_v = L.ptw[TL::src_index(tid)];
+		}
 		ex.stamp2();
 		if constexpr (SOLO) cp_load_solo<LN, UL, BM>(L, st, k_of(tid), chA, lt);
 		else cp_load<LN, UL, BM, SP>(L, st, k_of(tid), chA, chB, lt);
+		}
+		constexpr bool LEANW = WALK && R8B_WALK_LEAN;
+		if constexpr (LEANW) { st.tka = nullptr; st.pka = nullptr; st.pf = 0; }
+		else {
 		if ((L.tail_flags & 2) != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) > L.k0 + L.tail_bf)
 		{
 			// (the launch's last block: the samples behind its window -- read by no block of this call -- requested
@@ -2159,28 +2400,61 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				else if (cur.k == L.k0) cp_park_back<G::WT>(XM, X.wdst, chA, chB, bvalid, tid);
 			}
 		}
+		}
 		ex.stamp2();
 		ex.post_bits(tid, cp_nonzero_bits<LN, UL>(st));
 		ex.stamp2();
+	};
+	auto first_pass = [&](int tid, St& st, const cd& twl_v)
+	{
+		const int lt = lt_of(tid);
 		cp_first<LN, UL>(L, buf_of(tid), st, lt);
+		if constexpr (TL::ON && !WALK)
+		{
+			if (tid < TL::NE) twl_st(ltw, tid, twl_v);
+		}
+		(void) twl_v;
 		// (modes 4 / 5: the thread's entry of the interpolator's lane table, long before its rows are addressed with it)
-		if constexpr (BM == 4 || BM == 5) st.pt = cp_ptab_fetch(X, tid);
+		if constexpr ((BM == 4 || BM == 5) && !WALK) st.pt = cp_ptab_fetch(X, tid);
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
 		else hp_prefetch(st, lt);
+	};
+	if constexpr (WALK)
+	{
+		// (a barrier between the two: the slowest wave of the PREVIOUS block still reads its run from the array the first
+		// pass overwrites)
+		ex.phase([&](int tid, St& st)
+		{
+			cd twl_v;
+			front(tid, st, twl_v);
+		});
+		ex.phase([&](int tid, St& st)
+		{
+			cd twl_v;
+			twl_v.re = twl_v.im = 0.0;
+			first_pass(tid, st, twl_v);
+		});
+	}
+	else
+	ex.phase([&](int tid, St& st)
+	{
+		cd twl_v;
+		front(tid, st, twl_v);
+		first_pass(tid, st, twl_v);
 	});
 	// forward passes 1 .., the middle pass and the first backward pass stay inside each wave's own range
 	// of the array (ConvpGeom): wave-level ordering points instead of workgroup barriers between them
 	auto s_pre1 = [&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
-		ConvpPre<LN, UL, 1>::run(buf_of(tid), st, lt);
+		ConvpPre<LN, UL, 1>::run(buf_of(tid), st, lt, ltw);
 		if constexpr (G::NPRE > 2) ConvpPre<LN, UL, 2>::prefetch(L, st, lt);
 		else hp_prefetch(st, lt);
 	};
 	auto s_pre2 = [&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
-		ConvpPre<LN, UL, 2>::run(buf_of(tid), st, lt);
+		ConvpPre<LN, UL, 2>::run(buf_of(tid), st, lt, ltw);
 		hp_prefetch(st, lt);
 	};
 	// (two steps: every lane has read its forward data before any lane's backward data overwrites it --
@@ -2294,15 +2568,26 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	{
 		const int lt = lt_of(tid);
 		cp_middle_compute<LN, UL, CX>(buf_of(tid), st, lt);
-		if constexpr (G::B1) ptw_fetch<16, G::NT, (16 < G::NT ? 16 : G::NT)>(st.tw, L.ptw, 3, lt);
+		if constexpr (G::B1 && TL::ON) {} // (the pass fetches its twiddles from LDS itself)
+		else if constexpr (G::B1) ptw_fetch<16, G::NT, (16 < G::NT ? 16 : G::NT)>(st.tw, L.ptw, 3, lt);
 		else cp_back2_prefetch<LN, UL>(L, st, lt);
 	};
 	auto s_midw = [&](int tid, St& st) { cp_middle_write<LN, UL>(buf_of(tid), st, lt_of(tid)); };
 	auto s_b1 = [&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
-		cp_back1<LN, UL>(buf_of(tid), st, lt);
-		cp_back2_prefetch<LN, UL>(L, st, lt);
+		cp_back1<LN, UL>(buf_of(tid), st, lt, ltw);
+		if constexpr (WALK)
+		{
+			st.tw[0] = st.twp[2];
+			R8B_OPAQUE2(st.tw[0].re, st.tw[0].im);
+			if constexpr (G::R2 >= 16)
+			{
+				st.tw[3] = st.twp[3];
+				R8B_OPAQUE2(st.tw[3].re, st.tw[3].im);
+			}
+		}
+		else cp_back2_prefetch<LN, UL>(L, st, lt);
 	};
 	static_assert(G::NPRE >= 1 && G::NPRE <= 3, "pair kernel: one to three forward passes before the middle");
 #ifdef R8B_SPLIT_UP2
@@ -2361,7 +2646,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	// a round trip of 3 500-5 500 cycles per workgroup wherever the loads were put; from the registers: cfg2 -3.5 %,
 	// cfg3 -6 % again, the last block 5 000 cycles longer than the others -- the samples it fetches for the ring miss
 	// the caches like its own, and a CU's L1 keeps only so many misses in flight.)
-	if ((L.tail_flags & 5) != 0)
+	if (!(WALK && R8B_WALK_LEAN) && (L.tail_flags & 5) != 0)
 	{
 		const unsigned long long tn = (unsigned long long) (L.tail_p1 - L.tail_p0), nb = (unsigned long long) L.nblk;
 		const unsigned long long bi = (unsigned long long) (cur.k - L.k0), be = bi + (unsigned) (G::SUB == 1 ? 1 : cur.nvalid);
@@ -2495,7 +2780,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		{
 			if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
 			else cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
-			cp_rows2_fetch<T2>(X, st.rows2, st.pt);
+			if constexpr (!WALK || !R8B_WALK_ROWS) cp_rows2_fetch<T2>(X, st.rows2, st.pt);
 		});
 		ex.phase([&](int tid, St& st)
 		{
@@ -2503,8 +2788,19 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_final_store<LN, UL>(L, buf_of(tid), buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
 		});
 		// the interpolator: all 256 threads over the run of one block pair after the other
-		ex.each([&](int, St& st)
+		ex.each([&](int tid, St& st)
 		{
+			if constexpr (WALK && R8B_WALK_PREF)
+			{
+				// (the next block's samples, requested here: they travel while this block is interpolated)
+				if (walk.more) cp_load<LN, UL, BM, SP>(L, st, cur.k + 1, chA, chB, lt_of(tid));
+			}
+			(void) tid;
+			if constexpr (WALK && R8B_WALK_LEAN)
+			{
+				cp_whole2_compute<T2, true>(X, X.wdst, XM.blk[cur.k - L.k0], buf, st.rows2, st.pt, chA, chB, bvalid);
+				return;
+			}
 			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
 			cp_tail_slice_store(L, st, chA, chB, bvalid);
 			const int nv = G::SUB == 1 ? 1 : cur.nvalid;
@@ -2551,6 +2847,49 @@ template<int LN, int UL, int MODE, int FLENP, class Exec>
 R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, cd* buf, const ConvpItem& cur)
 {
 	convp_body<LN, UL, MODE, FLENP>(ex, X, X, buf, cur);
+}
+
+// Walk form: blocks cur.k ... cur.k + nit - 1 of the channel pair by one workgroup (ConvpWalk).  The prologue fetches
+// what every block needs once; results are those of the one-block form bit for bit (same arithmetic on the same values,
+// tests: option walk = 0 / 1).
+template<int LN, int UL, int MODE, int FLENP, class Exec>
+R8B_HD void convp_walk(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd* buf, ConvpItem cur, int nit)
+{
+	typedef ConvpGeom<LN, UL> G;
+	typedef ConvpState<LN, UL> St;
+	typedef ConvpTwLds<LN, UL> TL;
+	constexpr int BM = MODE == 16 ? 4 : (MODE == 17 ? 5 : MODE);
+	constexpr int T2 = BM == 4 ? 25 : 27;
+	const ConvLaunch& L = X.c;
+	cd* const ltw = reinterpret_cast<cd*>(reinterpret_cast<unsigned char*>(buf) + convp_array_bytes<LN, UL>() + kConvpFlagBytes);
+	ex.each([&](int tid, St& st)
+	{
+		const int lt = convp_lt<LN, UL>(tid);
+		cd t0[6], t4[6];
+		ptw_fetch_lean<G::E1, G::NT>(t0, L.ptw, 0, lt);
+		ptw_fetch_lean<G::R2, G::NT>(t4, L.ptw, 4, lt);
+		cd twl_v;
+		twl_v.re = twl_v.im = 0.0;
+		if (tid < TL::NE) twl_v = L.ptw[TL::src_index(tid)];
+		st.pt = cp_ptab_fetch(X, tid);
+		// (the first block's samples)
+		if constexpr (R8B_WALK_PREF) cp_load<LN, UL, BM, false>(L, st, cur.k, cur.chA, cur.chB, lt);
+		if constexpr (R8B_WALK_ROWS) cp_rows2_fetch<T2>(X, st.rows2, st.pt);
+		if constexpr (R8B_WALK_HP) cp_hp_prefetch<LN, UL, (MODE >= 16)>(L, st, lt);
+		st.twp[0] = t0[0];
+		st.twp[1] = t0[3];
+		st.twp[2] = t4[0];
+		st.twp[3] = t4[3];
+		if (tid < TL::NE) twl_st(ltw, tid, twl_v);
+	});
+	for (int it = 0; it < nit; it++)
+	{
+		ConvpWalk w;
+		w.more = it + 1 < nit;
+		ex.next_block();
+		convp_body<LN, UL, MODE, FLENP, true>(ex, X, XM, buf, cur, w);
+		cur.k++;
+	}
 }
 
 // What a launcher (r8b_kernels.hip, tests/emul) sets in its copy of the descriptor before the kernel runs: the

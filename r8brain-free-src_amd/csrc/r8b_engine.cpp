@@ -758,6 +758,10 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// the call's last block of a fused pair at the end of the chain is computed once: what it holds beyond the call
 	// is parked for the next one (launch_fused)
 	opt_["park"] = 1;
+	// fused two-phase pair kernel in its walk form (r8b_convp.h convp_walk): a workgroup per channel pair takes the call's
+	// blocks one after the other (0: a workgroup per block, as before round 5)
+	opt_["walk"] = 0;      // (1: by batch size; 2: whatever the batch size -- tests)
+	opt_["walk_len"] = 0;  // blocks per workgroup of the walk form (0: the launch's whole run of blocks)
 	stat_["conv_blocks"] = 0;
 	stat_["park_calls"] = 0;
 	stat_["park_only_calls"] = 0;
@@ -1598,6 +1602,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			return v <= 0 ? 0LL : (v + g.down - 1) / g.down;
 		};
 		X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
+		X.walk = 0;
 		X.park_src = nullptr; X.park_dst = nullptr;
 		X.park_blk = SpanInfo();
 		long long ca = a; // the first output this call has to compute
@@ -2480,6 +2485,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	};
 	auto block_jhi = [&](long long k) { return ceil_div_nonneg((k * S + off - fl2c + in_len - w.fl2 - D) * Out, In); };
 	X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
+	X.walk = 0;
 	X.park_src = nullptr; X.park_dst = nullptr;
 	X.park_blk = SpanInfo();
 	// Parked outputs (ConvxLaunch::park_*): the block that holds the call's last output is computed ONCE -- what it
@@ -2589,6 +2595,11 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 		X.park_n = k0 == kfirst ? park_n : 0;
 		X.c.k0 = k0;
 		X.c.nblk = (int) (k1 - k0 + 1);
+		// Walk form: enough channel pairs to fill the chip with one workgroup each (2 per CU on 256 CUs: from 128 pairs on
+		// a launch is worth it) and at least two blocks to walk; the launcher ignores it where the kernel has no walk form
+		X.walk = 0;
+		if (pair_two && (opt_.at("walk") == 2 || (opt_.at("walk") == 1 && nchw_ >= 256 && X.c.nblk >= 2)))
+			X.walk = opt_.at("walk_len") > 0 ? std::min(opt_.at("walk_len"), X.c.nblk) : X.c.nblk;
 		if (ch0_ == 0) stat_["conv_blocks"] += X.c.nblk;
 		for (int i = 0; i < X.c.nblk; i++)
 		{

@@ -100,6 +100,7 @@
 	}
 #endif
 #define R8B_FORCE4(a, b, c, d) asm volatile("" :: "v"(a), "v"(b), "v"(c), "v"(d))
+#define R8B_OPAQUE2(a, b) asm volatile("" : "+v"(a), "+v"(b))
 // the interpolator's 16-byte output stores (r8b_convp.h R8B_OUT_STORE16): R8B_NT_STORE = 1 marks them non-temporal
 // (streaming: the outputs are not read again by this kernel and need not displace tables and history in L2)
 #ifndef R8B_NT_STORE
@@ -624,6 +625,11 @@ struct GpuExecP
 		lds_barrier();
 		stamp();
 	}
+	// (walk form: nothing to reset -- the flag words are rewritten per block.  The thread index is made opaque once per
+	// block: everything a phase derives from it -- LDS addresses, table offsets, dozens of values -- is loop invariant,
+	// and hoisted out of the block loop it would stay live across ALL phases: 150 registers more than the one-block
+	// kernel needs, i.e. spills)
+	__device__ __forceinline__ void next_block() { asm volatile("" : "+v"(tid_)); }
 	template<class F>
 	__device__ __forceinline__ void each(F f) // no barrier
 	{
@@ -639,6 +645,34 @@ struct GpuExecP
 		stamp();
 	}
 };
+
+// the launch descriptor's hot scalars pinned in scalar registers (k_convp, below, says why)
+template<int MODE>
+__device__ __forceinline__ void convp_pin(ConvxLaunch& H, const ConvxLaunch& X)
+{
+	H.c = X.c;
+	H.in_step = X.in_step; H.out_step = X.out_step; H.flen = X.flen; H.fl2w = X.fl2w; H.fllw = X.fllw;
+	H.table = X.table; H.wtab = X.wtab; H.wa = X.wa; H.wb = X.wb; H.wdst = X.wdst;
+	H.run_off = X.run_off; H.ptab = X.ptab; H.ctab = X.ctab; H.nsets = X.nsets;
+	H.nblk_magic = X.nblk_magic;
+	H.park_n = X.park_n; H.park_out = X.park_out; H.park_slices = X.park_slices;
+	H.walk = X.walk;
+	// (integers are made opaque -- "+s" --, pointers are only USED here -- "s" --: a pointer that went through an asm
+	// output loses its kernel-argument provenance and would be dereferenced with flat instructions)
+	asm volatile("" : "+s"(H.c.k0), "+s"(H.c.blk_stride), "+s"(H.c.blk_offset), "+s"(H.c.in_len), "+s"(H.c.fl2),
+		"+s"(H.c.up_pow2), "+s"(H.c.src.cur_stride), "+s"(H.c.src.cur_base), "+s"(H.c.src.cur_fmt), "+s"(H.c.rot),
+		"+s"(H.c.fl2r), "+s"(H.c.tail_flags), "+s"(H.c.tail_bf)
+		: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
+	if constexpr (MODE == 4 || MODE == 5 || MODE == 16 || MODE == 17)
+		asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),
+			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt), "+s"(H.park_n), "+s"(H.park_out), "+s"(H.park_slices),
+			"+s"(H.c.t_zero)
+			: "s"(H.ptab), "s"(H.ctab), "s"(H.wdst.p));
+	else if constexpr (MODE == 1) {}
+	else
+		asm volatile("" : "+s"(H.c.a), "+s"(H.c.b), "+s"(H.c.dst.stride), "+s"(H.c.dst.mask), "+s"(H.c.dst.off),
+			"+s"(H.c.dst.fmt), "+s"(H.c.down), "+s"(H.c.down_pow2), "+s"(H.c.up) : "s"(H.c.dst.p));
+}
 
 // 64 KB of LDS per workgroup: two workgroups per CU, i.e. two waves per SIMD and 256 registers each
 #ifndef R8B_SPLIT_MINBLOCKS
@@ -687,28 +721,8 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLI
 	// and pinned in scalar registers HERE, all loads in flight together and one wait; the phases read the copy.
 	// (Pointers to rarely used data -- the history ring of a call's first blocks -- stay in memory.)
 	ConvxLaunch H;
-	H.c = X.c;
-	H.in_step = X.in_step; H.out_step = X.out_step; H.flen = X.flen; H.fl2w = X.fl2w; H.fllw = X.fllw;
-	H.table = X.table; H.wtab = X.wtab; H.wa = X.wa; H.wb = X.wb; H.wdst = X.wdst;
-	H.run_off = X.run_off; H.ptab = X.ptab; H.ctab = X.ctab; H.nsets = X.nsets;
-	H.nblk_magic = X.nblk_magic;
-	H.park_n = X.park_n; H.park_out = X.park_out; H.park_slices = X.park_slices;
+	convp_pin<MODE>(H, X);
 	ex.stamp();
-	// (integers are made opaque -- "+s" --, pointers are only USED here -- "s" --: a pointer that went through an asm
-	// output loses its kernel-argument provenance and would be dereferenced with flat instructions)
-	asm volatile("" : "+s"(H.c.k0), "+s"(H.c.blk_stride), "+s"(H.c.blk_offset), "+s"(H.c.in_len), "+s"(H.c.fl2),
-		"+s"(H.c.up_pow2), "+s"(H.c.src.cur_stride), "+s"(H.c.src.cur_base), "+s"(H.c.src.cur_fmt), "+s"(H.c.rot),
-		"+s"(H.c.fl2r), "+s"(H.c.tail_flags), "+s"(H.c.tail_bf)
-		: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
-	if constexpr (MODE == 4 || MODE == 5 || MODE == 16 || MODE == 17)
-		asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),
-			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt), "+s"(H.park_n), "+s"(H.park_out), "+s"(H.park_slices),
-			"+s"(H.c.t_zero)
-			: "s"(H.ptab), "s"(H.ctab), "s"(H.wdst.p));
-	else if constexpr (MODE == 1) {}
-	else
-		asm volatile("" : "+s"(H.c.a), "+s"(H.c.b), "+s"(H.c.dst.stride), "+s"(H.c.dst.mask), "+s"(H.c.dst.off),
-			"+s"(H.c.dst.fmt), "+s"(H.c.down), "+s"(H.c.down_pow2), "+s"(H.c.up) : "s"(H.c.dst.p));
 	// (One workgroup per item.  Persistent workgroups that take their items from per-XCD work queues -- no start-up
 	// between items -- were built and measured 25-30 % SLOWER, as was a 512-thread workgroup carrying two block pairs
 	// in step: DESIGN.md section 5; the code is in the history of this file, the round-3 commits "Pair kernel: persistent workgroups on per-XCD work queues" ... "twin-block experiment".)
@@ -748,6 +762,42 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLI
 	ex.dump();
 }
 
+// Walk form of the fused two-phase modes (r8b_convp.h convp_walk): workgroup wi takes blocks [slice walk, (slice + 1) walk)
+// of channel pair wi mod npair -- consecutive workgroups are consecutive pairs, so a pair's blocks (whose windows overlap)
+// meet in one XCD's L2 whatever the slice.
+template<int LN, int UL, int MODE, int FLENP>
+__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), 2) void k_convp_walk(const ConvxLaunch X)
+{
+	extern __shared__ __align__(256) unsigned char smem[];
+	if constexpr (convp_walk_ok<LN, UL, MODE>())
+	{
+		GpuExecP<LN, UL> ex(smem);
+		ConvxLaunch H;
+		convp_pin<MODE>(H, X);
+		const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
+		unsigned slice = blockIdx.x / npair, pr = blockIdx.x - slice * npair;
+		slice = (unsigned) __builtin_amdgcn_readfirstlane((int) slice);
+		pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
+		const int chA = (int) (2u * pr);
+		const bool bvalid = chA + 1 < X.c.nch;
+		ConvpItem cur;
+		const int b0 = (int) slice * X.walk;
+		cur.k = X.c.k0 + b0;
+		cur.nvalid = 1;
+		cur.chA = chA;
+		cur.chB = bvalid ? chA + 1 : chA;
+		cur.bvalid = bvalid;
+		const int nit = X.c.nblk - b0 < X.walk ? X.c.nblk - b0 : X.walk;
+#ifdef R8B_WALK_STAGGER
+		// (development: the workgroups that take a CU's second slot start R8B_WALK_STAGGER x 1024 cycles late, and stay out
+		// of phase with the first for the whole walk)
+		if (blockIdx.x >= gridDim.x / 2)
+			for (int i = 0; i < R8B_WALK_STAGGER * 16; i++) __builtin_amdgcn_s_sleep(1);
+#endif
+		convp_walk<LN, UL, MODE, FLENP>(ex, H, X, reinterpret_cast<cd*>(smem), cur, nit);
+	}
+}
+
 template<int LN, int UL, int MODE, int FLENP>
 void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 {
@@ -777,6 +827,18 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
 	const unsigned npair = convp_mode_solo(MODE) ? (unsigned) X.c.nch : ((unsigned) X.c.nch + 1u) >> 1;
 	unsigned grid = nbg * npair;
+	if constexpr (convp_walk_ok<LN, UL, MODE>())
+	{
+		if (X.walk > 0)
+		{
+			auto wkern = k_convp_walk<LN, UL, MODE, FLENP>;
+			lds_opt_in(reinterpret_cast<const void*>(wkern), "hipFuncSetAttribute(k_convp_walk)");
+			const unsigned nslice = ((unsigned) X.c.nblk + (unsigned) X.walk - 1u) / (unsigned) X.walk;
+			hipLaunchKernelGGL(wkern, dim3(nslice * npair), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
+			check(hipGetLastError(), "launch k_convp_walk");
+			return;
+		}
+	}
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
 	}

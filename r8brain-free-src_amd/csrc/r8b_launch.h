@@ -263,6 +263,9 @@ struct ConvxLaunch
 	// element per thread and channel, requested a phase ahead of the interpolator and stored at its start (no wait of
 	// its own); 0: the launch's first workgroup of the pair copies everything beside its sample loads (short calls)
 	int park_n, park_out, park_slices;
+	// walk form of the fused two-phase modes (r8b_convp.h convp_walk): blocks per workgroup (a workgroup takes `walk`
+	// consecutive blocks of its channel pair and keeps rows and twiddles across them); 0: one workgroup per block
+	int walk;
 	long long park_j0, park_stride;
 	const double* park_src;
 	double* park_dst;

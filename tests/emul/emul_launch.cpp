@@ -233,6 +233,7 @@ struct EmulExecP
 	void post_bits(int, unsigned v) { bits |= v; }
 	unsigned collect_bits() const { return bits; }
 	int uniform(int v) const { return v; }
+	void next_block() { bits = 0; }
 	template<class F>
 	void phase(F f)
 	{
@@ -270,6 +271,30 @@ void emul_convp_t(const ConvxLaunch& X0)
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
+	if constexpr (convp_walk_ok<LN, UL, MODE>())
+	{
+		if (X.walk > 0)
+		{
+			// walk form (r8b_convp.h convp_walk; the GPU's k_convp_walk): a workgroup per (slice, channel pair)
+			const int npair = (X.c.nch + 1) / 2, nslice = (X.c.nblk + X.walk - 1) / X.walk;
+			for (int wi = 0; wi < nslice * npair; wi++)
+			{
+				const int slice = wi / npair, pr = wi % npair, b0 = slice * X.walk;
+				EmulExecP<LN, UL> ex;
+				for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
+				for (auto& s : ex.st)
+					for (int j = 0; j < 16; j++) s.vr[j] = s.vi[j] = std::numeric_limits<double>::quiet_NaN();
+				ConvpItem cur;
+				cur.k = X.c.k0 + b0;
+				cur.nvalid = 1;
+				cur.chA = 2 * pr;
+				cur.bvalid = cur.chA + 1 < X.c.nch;
+				cur.chB = cur.bvalid ? cur.chA + 1 : cur.chA;
+				convp_walk<LN, UL, MODE, FLENP>(ex, X, X, reinterpret_cast<cd*>(base), cur, std::min(X.walk, X.c.nblk - b0));
+			}
+			return;
+		}
+	}
 	const long long items = (long long) ((X.c.nblk + SUB - 1) / SUB) * (SOLO ? X.c.nch : (X.c.nch + 1) / 2);
 	for (long long i = 0; i < items; i++)
 	{
