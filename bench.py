@@ -465,19 +465,19 @@ def main():
         }
         # `frac` above is the dominant kernel as the event pass saw it -- LATER than the value window, i.e. in another
         # clock state when the value window lies in the power controller's dip.  The same fraction FOR the value window:
-        # the kernels' share of a step there = ms_per_step minus the launch gaps, the gaps taken from the window whose
-        # kernels were timed in the same state (the settled window when there is one, else the event pass itself, whose
-        # wall time carries the events' own overhead -- a slightly larger gap, never a smaller one)
+        # a kernel's share of a step does not depend on the clock, so the kernel's time there is its time in the event pass
+        # scaled by the two windows' step times -- the settled window (same state as the event pass, which follows it)
+        # against the value window.  Without a settled window (--settle 0) the event pass follows the value window
+        # directly: one clock state, one fraction.
         ksum = sum(t[1] for t in timings) / args.steps
+        scale = settled["ms_per_step"] / (dt / args.steps * 1e3) if settled is not None else 1.0
+        res["roofline"]["frac_value_window"] = round(achieved / HBM_PEAK_GBS * scale, 4)
+        # (what a step spends between its kernels, where the events' own overhead does not drown it: informational)
         ref_ms = settled["ms_per_step"] if settled is not None else ev_wall_ms
-        gap_ms = max(0.0, ref_ms - ksum)
-        kern_vw = max(dt / args.steps * 1e3 - gap_ms, 1e-9)
-        res["roofline"]["launch_gap_ms_per_step"] = round(gap_ms, 4)
-        res["roofline"]["frac_value_window"] = round(achieved / HBM_PEAK_GBS * ksum / kern_vw, 4)
+        res["roofline"]["launch_gap_ms_per_step"] = round(ref_ms - ksum, 4) if ref_ms >= ksum else None
         res["roofline"]["frac_clock_state"] = ("`frac`: per-kernel HIP events of a pass AFTER every timed window (settled "
-                                               "clock); `frac_value_window`: the same kernel in the window `value` is "
-                                               "quoted on = frac x (kernel ms per step of the event pass) / (ms_per_step "
-                                               "- launch_gap_ms_per_step)")
+                                               "clock); `frac_value_window` = frac x settled.ms_per_step / ms_per_step: "
+                                               "the same kernel in the window `value` is quoted on")
         res["value_window"] = "the %d steps timed straight after the %d warm-up calls" % (args.steps, args.warmup)
         if settled is not None:
             res["settle_calls"] = args.settle

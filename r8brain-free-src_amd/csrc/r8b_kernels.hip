@@ -29,7 +29,7 @@
 // ... and, for the build's sake, in parts (Makefile: six compilations side by side instead of one of six minutes):
 //   -DR8B_TU_PAIR=k  the pair kernels (r8b_convp.h) of part k only -- the geometry lists R8B_CONVP_GEOMS* come from the
 //                    command line (with -DR8B_DEV_GEOMS) -- and their dispatcher launch_convp_part<k>_f64
-//   -DR8B_TU_NOPAIR=n everything else; launch_convp_f64 tries the n part dispatchers
+//   -DR8B_TU_NOPAIR=n everything else; launch_convp_f64 tries the n (= 8) part dispatchers
 //   neither          one object with everything (development builds: tools/variant.sh, tools/isa_dev.sh)
 // The PCM twin carries the streaming kernels and the generic convolver only: a fast-path convolver at a PCM edge is
 // fed through the staging rows (r8b_capi.cpp batch_process_pcm, Engine::pcm_fused_in / _out), so the hundreds of
@@ -1119,13 +1119,16 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 }
 #else // !R8B_HAS_PAIR: the pair kernels live in R8B_TU_NOPAIR part objects
 #define R8B_PAIR_DECL(k) bool launch_convp_part##k(const ConvxLaunch& X, int mode, void* stream);
-R8B_PAIR_DECL(1) R8B_PAIR_DECL(2) R8B_PAIR_DECL(3) R8B_PAIR_DECL(4)
+R8B_PAIR_DECL(1) R8B_PAIR_DECL(2) R8B_PAIR_DECL(3) R8B_PAIR_DECL(4) R8B_PAIR_DECL(5) R8B_PAIR_DECL(6) R8B_PAIR_DECL(7)
+R8B_PAIR_DECL(8)
 #undef R8B_PAIR_DECL
 void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 {
-	static_assert(R8B_TU_NOPAIR == 4, "the Makefile builds four pair-kernel parts");
+	static_assert(R8B_TU_NOPAIR == 8, "the Makefile builds eight pair-kernel parts");
 	if (launch_convp_part1(X, mode, stream) || launch_convp_part2(X, mode, stream) ||
-		launch_convp_part3(X, mode, stream) || launch_convp_part4(X, mode, stream)) return;
+		launch_convp_part3(X, mode, stream) || launch_convp_part4(X, mode, stream) ||
+		launch_convp_part5(X, mode, stream) || launch_convp_part6(X, mode, stream) ||
+		launch_convp_part7(X, mode, stream) || launch_convp_part8(X, mode, stream)) return;
 	throw std::runtime_error("launch_convp: geometry not instantiated");
 }
 #endif // R8B_HAS_PAIR

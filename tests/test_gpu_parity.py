@@ -476,18 +476,13 @@ def test_bench_contract(tmp_path):
     for side in (d["settled"], d["other_placement"]):
         assert side["value"] > 0 and abs(side["value"] - 1024 * 16384 / side["ms_per_step"] / 1e3) / side["value"] < 0.01
     assert d["other_placement"]["placement"] == "stream-aligned"
-    # `frac` (event pass, settled clock) has a twin for the window `value` is quoted on; the two agree
-    # with each other through the windows' own times: frac_value_window / frac == kernel time (event pass) / kernel
-    # time (value window), the latter = ms_per_step - launch gaps
-    ks = sum(r["kernels_ms_per_step"].values())
-    assert 0.0 <= r["launch_gap_ms_per_step"] < 0.5 * d["settled"]["ms_per_step"]
-    assert abs(r["launch_gap_ms_per_step"] - max(0.0, d["settled"]["ms_per_step"] - ks)) < 2e-3
-    kv = d["ms_per_step"] - r["launch_gap_ms_per_step"]
-    assert kv > 0 and abs(r["frac_value_window"] - r["frac"] * ks / kv) < 2e-3 + 0.01 * r["frac"]
-    # ... and with the algorithmic bytes: the value window's kernel rate is alg bytes / kernel time there (one launch
-    # per step on this workload)
-    if r["launches"] == d["steps"] and len(r["kernels_ms_per_step"]) == 1:
-        assert abs(r["frac_value_window"] - r["alg_bytes_per_launch"] / (kv * 1e-3) / 1e9 / 8000.0) < 2e-3 + 0.01 * r["frac"]
+    # `frac` (event pass, settled clock) has a twin for the window `value` is quoted on; the two differ by
+    # exactly the ratio of the windows' step times, and the twin never exceeds what the value window's own step time
+    # allows for the kernel's algorithmic bytes
+    assert abs(r["frac_value_window"] - r["frac"] * d["settled"]["ms_per_step"] / d["ms_per_step"]) < 1e-3
+    if r["launches"] == d["steps"]:
+        assert r["frac_value_window"] <= r["alg_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0 * 1.15 + 1e-3
+    assert r["launch_gap_ms_per_step"] is None or 0.0 <= r["launch_gap_ms_per_step"] < d["settled"]["ms_per_step"]
 
 
 @pytest.mark.gpu
