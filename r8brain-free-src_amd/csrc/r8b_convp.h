@@ -68,25 +68,6 @@ namespace r8bhip {
 //                      16-byte LDS read at lane-consecutive addresses (what a form that keeps the tables in LDS pays)
 //   R8B_ABL_SAMPLES 1: the block's sample loads read eight samples of the row whatever the lane (no HBM reads)
 //   R8B_ABL_STORES  1: the interpolator's output stores land in the first 64 outputs of the block's rows (no HBM writes)
-// (what the walk form keeps / overlaps -- development A/B, tools/variant.sh: R8B_WALK_ROWS the interpolator's rows in
-// registers across blocks, else fetched per block as in the one-block form; R8B_WALK_PREF the next block's samples
-// requested during this block's interpolator phase, else at the block's start)
-#ifndef R8B_WALK_ROWS
-#define R8B_WALK_ROWS 1
-#endif
-#ifndef R8B_WALK_PREF
-#define R8B_WALK_PREF 1
-#endif
-// (R8B_WALK_LEAN: development timing builds -- every block of the walk treated as an interior one: no history tail, no
-// parked outputs, the fast load path and the aligned interpolator loop only; results of a call's first and last blocks
-// are WRONG)
-#ifndef R8B_WALK_LEAN
-#define R8B_WALK_LEAN 0
-#endif
-// (R8B_WALK_HP: the thread's kernel constants of the middle pass kept across blocks too)
-#ifndef R8B_WALK_HP
-#define R8B_WALK_HP 0
-#endif
 #ifndef R8B_ABL_TABLES
 #define R8B_ABL_TABLES 0
 #endif
@@ -606,7 +587,7 @@ R8B_HD void pdit_regs(const cd* buf, int n, int b, const cd* twr, double* vr, do
 // circular block is sample i of channel A (real part) and of channel B (imaginary part).  A wave
 // reads 64 consecutive samples of each channel per load.
 // (SPU: the split 2x up-sampling form -- modes 8 / 9 on a 1:1 geometry: the block is loaded as a 2x up-sampling one)
-template<int LN, int UL, int MODE = 0, bool SPU = false>
+template<int LN, int UL, int MODE = 0, bool SPU = false, bool FAST = false>
 R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, int chA, int chB, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
@@ -644,10 +625,10 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 	// most blocks of a call lie entirely inside the caller's buffer: one uniform row pointer per channel
 	// and a 32-bit offset per load (the general form selects ring / buffer / zero per sample: ~12
 	// vector instructions per load)
-	if (R8B_WALK_LEAN || (L.src.cur_fmt == kPcmF64 && base - (G::N - iln) >= L.src.cur_base && base - (G::N - iln) >= 0))
+	// (FAST: the caller knows that the window lies inside the caller's fp64 buffer -- walk form, convp_walk_range)
+	if (FAST || (L.src.cur_fmt == kPcmF64 && base - (G::N - iln) >= L.src.cur_base && base - (G::N - iln) >= 0))
 	{
-		long long w0 = base - (G::N - iln) - L.src.cur_base;
-		if (R8B_WALK_LEAN && w0 < 0) w0 = 0;
+		const long long w0 = base - (G::N - iln) - L.src.cur_base;
 		const double* const pa = L.src.cur + ((long long) chA * L.src.cur_stride + w0);
 		const double* const pb = L.src.cur + ((long long) chB * L.src.cur_stride + w0);
 		const unsigned l0 = (unsigned) (lt + wr);
@@ -2148,8 +2129,22 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 			va.im = a1[0] + a1[1];
 			vb.re = b0[0] + b0[1];
 			vb.im = b1[0] + b1[1];
-			R8B_OUT_STORE16(pa0 + o, va);
-			if (bvalid) R8B_OUT_STORE16(pb0 + o, vb);
+			if (!ALIGNED_ONLY || pair16)
+			{
+				R8B_OUT_STORE16(pa0 + o, va);
+				if (bvalid) R8B_OUT_STORE16(pb0 + o, vb);
+			}
+			else
+			{
+				// (walk form in a call whose outputs start at an odd column of the rows: the same values, 8 bytes at a time)
+				pa0[o] = va.re;
+				pa0[o + 1] = va.im;
+				if (bvalid)
+				{
+					pb0[o] = vb.re;
+					pb0[o + 1] = vb.im;
+				}
+			}
 		}
 		return;
 	}
@@ -2309,8 +2304,6 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	// (they take part in every barrier) and store nothing
 	auto hp_prefetch = [&](St& st, int lt)
 	{
-		if constexpr (WALK && R8B_WALK_HP) { (void) st; (void) lt; } // (kept across blocks: convp_walk)
-		else
 		if constexpr (SOLO) { (void) st; (void) lt; } // (fetched behind the spectrum's write: cp_solo_mid_a)
 		else if constexpr (SP) cp_sp_hp_prefetch<LN, UL>(L, st, lt);
 		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
@@ -2352,7 +2345,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				st.tw[3] = st.twp[1];
 				R8B_OPAQUE2(st.tw[3].re, st.tw[3].im);
 			}
-			if constexpr (!R8B_WALK_PREF) cp_load<LN, UL, BM, SP>(L, st, k_of(tid), chA, chB, lt);
+			// (an interior block: its window lies inside the caller's fp64 buffer)
+			cp_load<LN, UL, BM, SP, true>(L, st, k_of(tid), chA, chB, lt);
 		}
 		else
 		{
@@ -2367,9 +2361,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		if constexpr (SOLO) cp_load_solo<LN, UL, BM>(L, st, k_of(tid), chA, lt);
 		else cp_load<LN, UL, BM, SP>(L, st, k_of(tid), chA, chB, lt);
 		}
-		constexpr bool LEANW = WALK && R8B_WALK_LEAN;
-		if constexpr (LEANW) { st.tka = nullptr; st.pka = nullptr; st.pf = 0; }
-		else {
+		// (walk form: interior blocks own no part of the history tail and never hold the call's last output -- the shared
+		// one-element copies are all they take part in)
+		if constexpr (!WALK)
 		if ((L.tail_flags & 2) != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) > L.k0 + L.tail_bf)
 		{
 			// (the launch's last block: the samples behind its window -- read by no block of this call -- requested
@@ -2391,15 +2385,14 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			// the call's range are parked, not computed again by the next call)?  The previous call's parked outputs:
 			// this thread's element requested here, behind the samples, and stored in the workgroup's last phase --
 			// or all of them by the launch's first workgroup of the pair (short calls).
-			st.pf = X.park_out != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) == L.k0 + L.nblk ? 1 : 0;
+			st.pf = !WALK && X.park_out != 0 && cur.k + (G::SUB == 1 ? 1 : cur.nvalid) == L.k0 + L.nblk ? 1 : 0;
 			st.pka = nullptr;
 			if (X.park_n > 0)
 			{
 				if (X.park_slices != 0)
 					cp_park_slice_load<G::WT>(XM, X.wdst, st, (int) (cur.k - L.k0) / G::SUB, chA, chB, tid);
-				else if (cur.k == L.k0) cp_park_back<G::WT>(XM, X.wdst, chA, chB, bvalid, tid);
+				else if (!WALK && cur.k == L.k0) cp_park_back<G::WT>(XM, X.wdst, chA, chB, bvalid, tid);
 			}
-		}
 		}
 		ex.stamp2();
 		ex.post_bits(tid, cp_nonzero_bits<LN, UL>(st));
@@ -2646,7 +2639,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	// a round trip of 3 500-5 500 cycles per workgroup wherever the loads were put; from the registers: cfg2 -3.5 %,
 	// cfg3 -6 % again, the last block 5 000 cycles longer than the others -- the samples it fetches for the ring miss
 	// the caches like its own, and a CU's L1 keeps only so many misses in flight.)
-	if (!(WALK && R8B_WALK_LEAN) && (L.tail_flags & 5) != 0)
+	if (!WALK && (L.tail_flags & 5) != 0)
 	{
 		const unsigned long long tn = (unsigned long long) (L.tail_p1 - L.tail_p0), nb = (unsigned long long) L.nblk;
 		const unsigned long long bi = (unsigned long long) (cur.k - L.k0), be = bi + (unsigned) (G::SUB == 1 ? 1 : cur.nvalid);
@@ -2780,7 +2773,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		{
 			if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
 			else cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
-			if constexpr (!WALK || !R8B_WALK_ROWS) cp_rows2_fetch<T2>(X, st.rows2, st.pt);
+			if constexpr (!WALK) cp_rows2_fetch<T2>(X, st.rows2, st.pt);
 		});
 		ex.phase([&](int tid, St& st)
 		{
@@ -2790,19 +2783,15 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		// the interpolator: all 256 threads over the run of one block pair after the other
 		ex.each([&](int tid, St& st)
 		{
-			if constexpr (WALK && R8B_WALK_PREF)
-			{
-				// (the next block's samples, requested here: they travel while this block is interpolated)
-				if (walk.more) cp_load<LN, UL, BM, SP>(L, st, cur.k + 1, chA, chB, lt_of(tid));
-			}
 			(void) tid;
-			if constexpr (WALK && R8B_WALK_LEAN)
+			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
+			cp_tail_slice_store(L, st, chA, chB, bvalid);
+			if constexpr (WALK)
 			{
+				// (an interior block: whole output groups only -- convp_walk_range)
 				cp_whole2_compute<T2, true>(X, X.wdst, XM.blk[cur.k - L.k0], buf, st.rows2, st.pt, chA, chB, bvalid);
 				return;
 			}
-			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
-			cp_tail_slice_store(L, st, chA, chB, bvalid);
 			const int nv = G::SUB == 1 ? 1 : cur.nvalid;
 			for (int sb = 0; sb < nv; sb++)
 				cp_whole2_compute<T2>(X, X.wdst, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
@@ -2872,10 +2861,7 @@ R8B_HD void convp_walk(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		twl_v.re = twl_v.im = 0.0;
 		if (tid < TL::NE) twl_v = L.ptw[TL::src_index(tid)];
 		st.pt = cp_ptab_fetch(X, tid);
-		// (the first block's samples)
-		if constexpr (R8B_WALK_PREF) cp_load<LN, UL, BM, false>(L, st, cur.k, cur.chA, cur.chB, lt);
-		if constexpr (R8B_WALK_ROWS) cp_rows2_fetch<T2>(X, st.rows2, st.pt);
-		if constexpr (R8B_WALK_HP) cp_hp_prefetch<LN, UL, (MODE >= 16)>(L, st, lt);
+		cp_rows2_fetch<T2>(X, st.rows2, st.pt);
 		st.twp[0] = t0[0];
 		st.twp[1] = t0[3];
 		st.twp[2] = t4[0];
@@ -2992,6 +2978,50 @@ inline void convp_prepare(ConvxLaunch& X, bool slices = true, bool spu = false, 
 			X.c.tail_flags |= 8;
 #endif
 	}
+}
+
+// Walk form: which of the launch's blocks are INTERIOR ones, i.e. may run on the lean walk body (convp_body<.., WALK>)?
+// Block i of the launch (k = k0 + i) qualifies when its window lies inside the caller's fp64 buffer (the fast load
+// path), it owns no part of the history tail and is not the call's last block (no parked outputs), and it holds whole
+// output groups only (SpanInfo of the two-phase interpolator: first phase 0, last group complete), the destination being
+// linear fp64 rows.  Returns the longest such run [*i0, *i1) (called after convp_prepare; false: no walk).
+template<int LN, int UL>
+inline bool convp_walk_range(const ConvxLaunch& X, int* i0, int* i1)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int US = UL > 0 ? UL : 0;
+	const ConvLaunch& L = X.c;
+	if (L.src.cur_fmt != kPcmF64 || X.wdst.fmt != kPcmF64 || X.wdst.mask != -1 || !L.up_pow2 || L.up != (1 << US)) return false;
+	if ((L.tail_flags & 5) != 0) return false; // (history copied in slices by every block: short calls)
+	if ((X.out_step & 1) != 0) return false;   // (phase pairs straddle the groups)
+	const long long iln = L.in_len >> US;
+	int best0 = 0, best1 = 0, run0 = -1;
+	for (int i = 0; i <= L.nblk; i++)
+	{
+		bool ok = i < L.nblk;
+		if (ok)
+		{
+			const long long k = L.k0 + i;
+			const long long bs = (k * (long long) L.blk_stride + L.blk_offset) >> US;
+			const long long w0 = bs - (G::N - iln);
+			ok = w0 >= L.src.cur_base && w0 >= 0;
+			if ((L.tail_flags & 2) != 0 && i >= L.tail_bf) ok = false;
+			if (i + 1 == L.nblk) ok = false;
+			const SpanInfo& B = X.blk[i];
+			if (B.jhi <= B.jlo || B.jlo_mod != 0 || B.pad != X.out_step) ok = false;
+			// (the stream's first blocks: zeros in front of the run, cp_final_store)
+			if (k * (long long) L.blk_stride + L.blk_offset - L.fl2 - L.t_zero <= 0) ok = false;
+		}
+		if (ok && run0 < 0) run0 = i;
+		if (!ok && run0 >= 0)
+		{
+			if (i - run0 > best1 - best0) { best0 = run0; best1 = i; }
+			run0 = -1;
+		}
+	}
+	*i0 = best0;
+	*i1 = best1;
+	return best1 > best0;
 }
 
 // workgroup i of a launch, pair major: the block groups of one channel pair are consecutive

@@ -760,7 +760,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["park"] = 1;
 	// fused two-phase pair kernel in its walk form (r8b_convp.h convp_walk): a workgroup per channel pair takes the call's
 	// blocks one after the other (0: a workgroup per block, as before round 5)
-	opt_["walk"] = 0;      // (1: by batch size; 2: whatever the batch size -- tests)
+	opt_["walk"] = 1;      // (0: a workgroup per block, as before round 5; 2: whatever the batch size -- tests)
 	opt_["walk_len"] = 0;  // blocks per workgroup of the walk form (0: the launch's whole run of blocks)
 	stat_["conv_blocks"] = 0;
 	stat_["park_calls"] = 0;
@@ -1282,6 +1282,7 @@ bool Engine::set_option(const std::string& name, int value)
 
 long long Engine::stat(const std::string& name) const
 {
+	if (name == "walk_blocks") return launch_walk_blocks();
 	auto it = stat_.find(name);
 	return it == stat_.end() ? -1 : it->second;
 }
@@ -1385,7 +1386,9 @@ unsigned long long Engine::config_hash() const
 	std::string key = plan_.describe();
 	key += "|maxin=" + std::to_string(plan_.max_in) + "|nch=" + std::to_string(nch_);
 	for (const auto& kv : opt_)
-		if (kv.first != "timing") key += "|" + kv.first + "=" + std::to_string(kv.second);
+		// (options that change neither the state nor a single bit of the stream stay out of it)
+		if (kv.first != "timing" && kv.first != "walk" && kv.first != "walk_len")
+			key += "|" + kv.first + "=" + std::to_string(kv.second);
 	unsigned long long h = 1469598103934665603ull;
 	for (unsigned char c : key)
 	{

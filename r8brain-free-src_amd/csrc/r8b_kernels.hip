@@ -8,6 +8,7 @@
 // and stay L2 resident.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <mutex>
 #include <set>
 #include <stdexcept>
@@ -762,9 +763,13 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLI
 	ex.dump();
 }
 
-// Walk form of the fused two-phase modes (r8b_convp.h convp_walk): workgroup wi takes blocks [slice walk, (slice + 1) walk)
-// of channel pair wi mod npair -- consecutive workgroups are consecutive pairs, so a pair's blocks (whose windows overlap)
-// meet in one XCD's L2 whatever the slice.
+// Walk form of the fused two-phase modes (r8b_convp.h convp_walk, convp_walk_range): ONE launch, two kinds of workgroups.
+// The first nslice x npair take the call's INTERIOR blocks [walk_i0, walk_i1) -- workgroup wi blocks [slice walk_len,
+// (slice + 1) walk_len) of them for channel pair wi mod npair -- on the lean walk body; the others one EDGE block each (a
+// call's first block, whose window reaches back into the history ring, and its last ones, which own the history tail
+// and the parked outputs) on the general body, exactly as k_convp runs it.  Consecutive workgroups are consecutive
+// pairs in both parts, so a pair's blocks (whose windows overlap) meet in one XCD's L2.  The walk workgroups come
+// first in the grid: they are resident before any edge workgroup is dispatched and all end together.
 template<int LN, int UL, int MODE, int FLENP>
 __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), 2) void k_convp_walk(const ConvxLaunch X)
 {
@@ -775,26 +780,41 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), 2) void k_convp_walk(const
 		ConvxLaunch H;
 		convp_pin<MODE>(H, X);
 		const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1;
-		unsigned slice = blockIdx.x / npair, pr = blockIdx.x - slice * npair;
-		slice = (unsigned) __builtin_amdgcn_readfirstlane((int) slice);
-		pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
-		const int chA = (int) (2u * pr);
-		const bool bvalid = chA + 1 < X.c.nch;
+		const unsigned nwi = (unsigned) (X.walk_i1 - X.walk_i0);
+		const unsigned nslice = (nwi + (unsigned) X.walk_len - 1u) / (unsigned) X.walk_len;
+		const unsigned nwalk = nslice * npair;
 		ConvpItem cur;
-		const int b0 = (int) slice * X.walk;
-		cur.k = X.c.k0 + b0;
 		cur.nvalid = 1;
-		cur.chA = chA;
-		cur.chB = bvalid ? chA + 1 : chA;
-		cur.bvalid = bvalid;
-		const int nit = X.c.nblk - b0 < X.walk ? X.c.nblk - b0 : X.walk;
-#ifdef R8B_WALK_STAGGER
-		// (development: the workgroups that take a CU's second slot start R8B_WALK_STAGGER x 1024 cycles late, and stay out
-		// of phase with the first for the whole walk)
-		if (blockIdx.x >= gridDim.x / 2)
-			for (int i = 0; i < R8B_WALK_STAGGER * 16; i++) __builtin_amdgcn_s_sleep(1);
-#endif
-		convp_walk<LN, UL, MODE, FLENP>(ex, H, X, reinterpret_cast<cd*>(smem), cur, nit);
+		if (blockIdx.x < nwalk)
+		{
+			unsigned slice = blockIdx.x / npair, pr = blockIdx.x - slice * npair;
+			slice = (unsigned) __builtin_amdgcn_readfirstlane((int) slice);
+			pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
+			const int chA = (int) (2u * pr);
+			const bool bvalid = chA + 1 < X.c.nch;
+			const int b0 = (int) slice * X.walk_len;
+			cur.k = X.c.k0 + X.walk_i0 + b0;
+			cur.chA = chA;
+			cur.chB = bvalid ? chA + 1 : chA;
+			cur.bvalid = bvalid;
+			const int left = (int) nwi - b0;
+			convp_walk<LN, UL, MODE, FLENP>(ex, H, X, reinterpret_cast<cd*>(smem), cur, left < X.walk_len ? left : X.walk_len);
+		}
+		else
+		{
+			const unsigned e = blockIdx.x - nwalk;
+			unsigned j = e / npair, pr = e - j * npair;
+			j = (unsigned) __builtin_amdgcn_readfirstlane((int) j);
+			pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
+			const int blk = (int) j < X.walk_i0 ? (int) j : X.walk_i1 + ((int) j - X.walk_i0);
+			const int chA = (int) (2u * pr);
+			const bool bvalid = chA + 1 < X.c.nch;
+			cur.k = X.c.k0 + blk;
+			cur.chA = chA;
+			cur.chB = bvalid ? chA + 1 : chA;
+			cur.bvalid = bvalid;
+			convp_body<LN, UL, MODE, FLENP>(ex, H, X, reinterpret_cast<cd*>(smem), cur);
+		}
 	}
 }
 
@@ -829,13 +849,21 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	unsigned grid = nbg * npair;
 	if constexpr (convp_walk_ok<LN, UL, MODE>())
 	{
-		if (X.walk > 0)
+		// (X.walk: the engine allows the walk form, at most that many blocks per workgroup; the launch's interior blocks
+		// decide whether it is taken)
+		int i0 = 0, i1 = 0;
+		if (X.walk > 0 && convp_walk_range<LN, UL>(X, &i0, &i1) && i1 - i0 >= 2)
 		{
+			X.walk_i0 = i0;
+			X.walk_i1 = i1;
+			X.walk_len = X.walk < i1 - i0 ? X.walk : i1 - i0;
 			auto wkern = k_convp_walk<LN, UL, MODE, FLENP>;
 			lds_opt_in(reinterpret_cast<const void*>(wkern), "hipFuncSetAttribute(k_convp_walk)");
-			const unsigned nslice = ((unsigned) X.c.nblk + (unsigned) X.walk - 1u) / (unsigned) X.walk;
-			hipLaunchKernelGGL(wkern, dim3(nslice * npair), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
+			const unsigned nwi = (unsigned) (i1 - i0), nslice = (nwi + (unsigned) X.walk_len - 1u) / (unsigned) X.walk_len;
+			hipLaunchKernelGGL(wkern, dim3((nslice + (unsigned) X.c.nblk - nwi) * npair), dim3(ConvpGeom<LN, UL>::WT), lds,
+				stream, X);
 			check(hipGetLastError(), "launch k_convp_walk");
+			launch_walk_blocks_add((long long) nwi);
 			return;
 		}
 	}
@@ -1199,6 +1227,10 @@ void launch_convx(const ConvxLaunch& X, int mode, void* stream)
 	if ((X.c.src.cur_fmt | X.c.dst.fmt | X.wdst.fmt) != kPcmF64) launch_convx_pcm(X, mode, stream);
 	else launch_convx_f64(X, mode, stream);
 }
+
+namespace { std::atomic<long long> g_walk_blocks{0}; }
+long long launch_walk_blocks() { return g_walk_blocks.load(); }
+void launch_walk_blocks_add(long long n) { g_walk_blocks += n; }
 
 void launch_convp(const ConvxLaunch& X, int mode, void* stream)
 {

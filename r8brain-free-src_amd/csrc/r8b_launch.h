@@ -266,6 +266,10 @@ struct ConvxLaunch
 	// walk form of the fused two-phase modes (r8b_convp.h convp_walk): blocks per workgroup (a workgroup takes `walk`
 	// consecutive blocks of its channel pair and keeps rows and twiddles across them); 0: one workgroup per block
 	int walk;
+	// ... set by the launcher (convp_walk_range): blocks [walk_i0, walk_i1) of the launch are interior ones and run on
+	// the walk body, walk_len of them per workgroup; the others -- a call's first and last blocks -- on the general body,
+	// a workgroup each, in the same launch
+	int walk_i0, walk_i1, walk_len;
 	long long park_j0, park_stride;
 	const double* park_src;
 	double* park_dst;
@@ -391,6 +395,10 @@ void launch_pcm_out(const PcmLaunch& L, void* stream); // planar fp64 -> PCM
 void launch_convx(const ConvxLaunch& X, int mode, void* stream);
 // the same work in pair form (modes 0, 1, 3, 4 ... 9; needs X.c.hp)
 void launch_convp(const ConvxLaunch& X, int mode, void* stream);
+// blocks the launchers have put on the walk body so far (process wide; Engine::stat("walk_blocks"): the launcher, not
+// the engine, decides per launch -- convp_walk_range)
+long long launch_walk_blocks();
+void launch_walk_blocks_add(long long n);
 
 // memory helpers; all throw std::runtime_error with the HIP error text on failure
 // Device selection.  dev_resolve: the ordinal an object created with `device` lives on (-1: the

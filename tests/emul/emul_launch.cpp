@@ -273,24 +273,43 @@ void emul_convp_t(const ConvxLaunch& X0)
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
 	if constexpr (convp_walk_ok<LN, UL, MODE>())
 	{
-		if (X.walk > 0)
+		int i0 = 0, i1 = 0;
+		if (X.walk > 0 && convp_walk_range<LN, UL>(X, &i0, &i1) && i1 - i0 >= 2)
 		{
-			// walk form (r8b_convp.h convp_walk; the GPU's k_convp_walk): a workgroup per (slice, channel pair)
-			const int npair = (X.c.nch + 1) / 2, nslice = (X.c.nblk + X.walk - 1) / X.walk;
-			for (int wi = 0; wi < nslice * npair; wi++)
+			// walk form (r8b_convp.h convp_walk; the GPU's k_convp_walk): walk workgroups over the interior blocks, then a
+			// workgroup per edge block on the general body
+			X.walk_i0 = i0;
+			X.walk_i1 = i1;
+			X.walk_len = std::min(X.walk, i1 - i0);
+			const int npair = (X.c.nch + 1) / 2, nwi = i1 - i0, nslice = (nwi + X.walk_len - 1) / X.walk_len;
+			const int nwalk = nslice * npair, ntot = (nslice + X.c.nblk - nwi) * npair;
+			launch_walk_blocks_add(nwi);
+			for (int wi = 0; wi < ntot; wi++)
 			{
-				const int slice = wi / npair, pr = wi % npair, b0 = slice * X.walk;
 				EmulExecP<LN, UL> ex;
 				for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
 				for (auto& s : ex.st)
 					for (int j = 0; j < 16; j++) s.vr[j] = s.vi[j] = std::numeric_limits<double>::quiet_NaN();
 				ConvpItem cur;
-				cur.k = X.c.k0 + b0;
 				cur.nvalid = 1;
-				cur.chA = 2 * pr;
-				cur.bvalid = cur.chA + 1 < X.c.nch;
-				cur.chB = cur.bvalid ? cur.chA + 1 : cur.chA;
-				convp_walk<LN, UL, MODE, FLENP>(ex, X, X, reinterpret_cast<cd*>(base), cur, std::min(X.walk, X.c.nblk - b0));
+				if (wi < nwalk)
+				{
+					const int slice = wi / npair, pr = wi % npair, b0 = slice * X.walk_len;
+					cur.k = X.c.k0 + i0 + b0;
+					cur.chA = 2 * pr;
+					cur.bvalid = cur.chA + 1 < X.c.nch;
+					cur.chB = cur.bvalid ? cur.chA + 1 : cur.chA;
+					convp_walk<LN, UL, MODE, FLENP>(ex, X, X, reinterpret_cast<cd*>(base), cur, std::min(X.walk_len, nwi - b0));
+				}
+				else
+				{
+					const int e = wi - nwalk, j = e / npair, pr = e % npair;
+					cur.k = X.c.k0 + (j < i0 ? j : i1 + (j - i0));
+					cur.chA = 2 * pr;
+					cur.bvalid = cur.chA + 1 < X.c.nch;
+					cur.chB = cur.bvalid ? cur.chA + 1 : cur.chA;
+					convp_body<LN, UL, MODE, FLENP>(ex, X, X, reinterpret_cast<cd*>(base), cur);
+				}
 			}
 			return;
 		}
@@ -338,6 +357,10 @@ void emul_convp_sp(const ConvxLaunch& X, int mode)
 		else emul_convp_t<LN, UL, 15, 24>(X);
 	}
 }
+
+static long long g_walk_blocks = 0;
+long long launch_walk_blocks() { return g_walk_blocks; }
+void launch_walk_blocks_add(long long n) { g_walk_blocks += n; }
 
 void launch_convp(const ConvxLaunch& X, int mode, void*)
 {

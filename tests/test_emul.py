@@ -875,3 +875,43 @@ def test_threading_contract_under_thread_sanitizer(tmp_path):
     exe = _build_cxx_threads(tmp_path, os.path.join(d, "_build", "tsan"), extra=("-g", "-fsanitize=thread"))
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert out.returncode == 0 and "ThreadSanitizer" not in out.stdout and out.stdout.strip().endswith("OK"), out.stdout[-3000:]
+
+
+# (the last field: the case is known to walk -- a 2048 -> 4096-point fused pair with an even number of phases)
+WALK_CASES = [(44100.0, 96000.0, 16384, 2.0, 180.15, 0, True), (44100.0, 96000.0, 6000, 2.0, 180.15, 1, False),
+              (22050.0, 48000.0, 16384, 2.0, 180.15, 0, True), (96000.0, 44100.0, 16384, 2.0, 180.15, 0, False),
+              (44100.0, 96000.0, 16384, 3.0, 150.0, 0, False)]
+
+
+def run_walk_form_case(lib_kw, case, walk_len, nch=5):
+    """the walk form of the fused pair kernel (r8b_convp.h convp_walk: a workgroup per channel pair takes the call's
+    interior blocks one after the other, rows and twiddles kept; a call's first and last blocks on the general body in
+    the same launch) against a workgroup per block: the same stream bit for bit, ragged calls, odd channel count"""
+    src, dst, maxin, tb, att, phase, _ = case
+
+    def mk(w):
+        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, phase=phase, **lib_kw)
+        b.set_option("walk", w)
+        b.set_option("walk_len", walk_len)
+        return b
+
+    a, b = mk(0), mk(2)
+    w0 = b.stat("walk_blocks")
+    x = make_input(nch, 6 * maxin, 37)
+    lens = [maxin, maxin, maxin // 3, 300, maxin, 17, 1, maxin - 5, 2500, maxin]
+    pos = 0
+    for l in lens:
+        if pos + l > x.shape[1]:
+            break
+        ya, yb = a.process_host(x[:, pos:pos + l]), b.process_host(x[:, pos:pos + l])
+        pos += l
+        assert ya.shape == yb.shape and np.array_equal(ya, yb), (case, walk_len, pos)
+    return b.stat("walk_blocks") - w0, a.stat("conv_blocks")
+
+
+@pytest.mark.parametrize("walk_len", [0, 1, 3])
+@pytest.mark.parametrize("case", WALK_CASES)
+def test_emulated_walk_form_equals_one_block_form(emul, case, walk_len):
+    walked, blocks = run_walk_form_case({"lib": emul}, case, walk_len)
+    if case[6]:
+        assert walked >= blocks // 3, (walked, blocks)   # (the long calls do walk: most of their blocks are interior ones)

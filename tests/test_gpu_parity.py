@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 
 import r8b_oracle as O
+import test_emul
 from cases import (STREAM_CASES, SHORT_CASES, REBLOCK_CASES, SPLIT_CASES, SOLO_CASES, MINPHASE_CASES, MINPHASE_LONG_CASES, PAIR_SCALE_CASES, PARK_CASES,
                    PARK_CASES_MINPHASE, RMS_TOL, PEAK_TOL, compare_stream, make_input, check_pair_scales,
                    check_parked_outputs)
@@ -528,6 +529,35 @@ def test_cxx_batch_device(tmp_path):
                     "-L" + libdir, "-lr8bsrc_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.returncode, out.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("walk_len", [0, 2])
+@pytest.mark.parametrize("case", test_emul.WALK_CASES)
+def test_hip_walk_form_equals_one_block_form(torch, case, walk_len):
+    """the GPU twin of test_emulated_walk_form_equals_one_block_form"""
+    walked, blocks = test_emul.run_walk_form_case({"device": 0}, case, walk_len)
+    if case[6]:
+        assert walked >= blocks // 3, (walked, blocks)
+
+
+@pytest.mark.gpu
+def test_hip_walk_form_full_batch(torch):
+    """BASELINE's cfg2 batch (1024 channels x 16384) with the engine's own choice (option walk = 1: by batch size) against
+    a workgroup per block: every channel bit for bit, calls whose outputs start at even and at odd columns"""
+    a = r8b.BatchResampler(44100.0, 96000.0, 16384, 2.0, 180.15, nch=1024, device=0)
+    b = r8b.BatchResampler(44100.0, 96000.0, 16384, 2.0, 180.15, nch=1024, device=0)
+    a.set_option("walk", 0)
+    b.set_option("walk", 1)
+    w0 = b.stat("walk_blocks")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    for _ in range(4):
+        x = torch.rand((1024, 16384), generator=g, dtype=torch.float64, device="cuda") * 2.0 - 1.0
+        ya = a.process(x).clone()
+        yb = b.process(x).clone()
+        assert ya.shape == yb.shape and torch.equal(ya, yb)
+    assert b.stat("walk_blocks") - w0 >= 4 * 8
 
 
 @pytest.mark.gpu
