@@ -149,7 +149,8 @@ R8B_HD int pswz(int e) { return e ^ ((e >> 4) & 15); }
 // kernel modes of the long-block forms on the 8192-point geometries (convp_body): split 2x up-sampling form 8 / 9
 // (12 / 13 with a complex kernel spectrum), one-channel form 10 / 11 (14 / 15)
 constexpr bool convp_mode_sp(int m) { return m == 8 || m == 9 || m == 12 || m == 13; }
-constexpr bool convp_mode_solo(int m) { return m == 10 || m == 11 || m == 14 || m == 15; }
+// (18: the one-channel form with the whole-step interpolator fused in -- round 5, cp_solo_final_store / cp_whole_compute_solo)
+constexpr bool convp_mode_solo(int m) { return m == 10 || m == 11 || m == 14 || m == 15 || m == 18; }
 
 template<int LN, int UL>
 struct ConvpGeom
@@ -2021,6 +2022,82 @@ R8B_HD void cp_whole_compute(const ConvxLaunch& X, const SpanInfo& B, const cd* 
 	}
 }
 
+// ---- one-channel form with the interpolator fused in (MODE 18; round 5) ------------------------------------------
+// The long blocks (16384 real points: transition bands of 0.5 ... 0.6 %) ran the interpolator as a launch of its own
+// (k_whole) behind the one-channel form, i.e. the convolver's whole 1x stream went to HBM and came back: 268 of the
+// 632 MB the 96000 -> 44100 path at a 0.5 % band moved per call.  Here the block's valid outputs
+// go to LDS as a linear run of REAL samples -- the run overlays the block's own array, as in the pair form -- and the
+// workgroup's 512 threads interpolate from it, one phase per thread, lanes sharing a phase in group sets
+// (reference CDSPFracInterpolator.h:861-922, 991-1060 behind CDSPBlockConvolver.h:252-354).
+// The thread's backward element i holds real samples 2 (lt + NT i) and + 1 of the circular block (st.vr / st.vi); sample c
+// is output u = (c + fl2r) mod 2N of the run when u < in_len (cf. cp_sp_store).
+template<int LN, int UL>
+R8B_HD void cp_solo_final_store(const ConvLaunch& L, double* y, const ConvpState<LN, UL>& st, long long k, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int mask = 2 * G::N - 1;
+	const long long t0 = cx_block_t0(L, k) - L.t_zero;
+	// (the interpolator's stream starts at this stage's output t_zero: earlier outputs do not exist for it)
+	const int nzero = t0 >= 0 ? 0 : (-t0 > L.in_len ? L.in_len : (int) -t0);
+	const int in_len = L.in_len;
+#pragma unroll
+	for (int i = 0; i < 16; i++)
+	{
+		const int c0 = 2 * (lt + G::NT * i);
+		const int uE = (c0 + L.fl2r) & mask, uO = (c0 + 1 + L.fl2r) & mask;
+		if (uE < in_len) y[uE] = uE < nzero ? 0.0 : st.vr[i];
+		if (uO < in_len) y[uO] = uO < nzero ? 0.0 : st.vi[i];
+	}
+	// zero extension read (times zero taps) by the padded polyphase rows
+	for (int i = lt; i < kConvxRunPad; i += G::NT) y[in_len + i] = 0.0;
+}
+
+// (cp_whole_compute on a run of real samples: every tap one 8-byte LDS read)
+template<int FLEN>
+R8B_HD void cp_whole_compute_solo(const ConvxLaunch& X, const DstView& wd, const SpanInfo& B, const double* y, double* row,
+	int* row_t, int ch, int tid, int wt)
+{
+	const long long jhi = B.jhi;
+	const int nsets = wt >= X.out_step ? wt / X.out_step : 1;
+	const int set = wt >= X.out_step ? tid / X.out_step : 0;
+	if (set >= nsets) return;
+	const int jstep = nsets * X.out_step, ustep = nsets * X.in_step;
+	for (int t = wt >= X.out_step ? tid - set * X.out_step : tid; t < X.out_step; t += wt)
+	{
+		if (t != *row_t)
+		{
+			cx_whole_row<FLEN>(X, row, t);
+			*row_t = t;
+		}
+		int d = t - B.jlo_mod;
+		if (d < 0) d += X.out_step;
+		long long j = B.jlo + d + (long long) set * X.out_step;
+		if (j >= jhi) continue;
+		int u = B.u_lo + (int) ((unsigned) (B.ph_lo + d * X.in_step) / (unsigned) X.out_step) + set * X.in_step;
+		for (; j < jhi; j += jstep, u += ustep)
+		{
+			double v[FLEN];
+			R8B_LDS_WINDOW(FLEN, v, y + u);
+			double s[2] = { 0.0, 0.0 };
+			R8B_LDS_ARRIVED(FLEN, v, 0);
+			cx_mac8(row, v, s);
+			R8B_SCHED_FENCE();
+			R8B_LDS_ARRIVED(FLEN, v, 8);
+			cx_mac8(row + 8, v + 8, s);
+			R8B_SCHED_FENCE();
+			R8B_LDS_ARRIVED(FLEN, v, 16);
+			cx_mac8(row + 16, v + 16, s);
+			if constexpr (FLEN > 24)
+			{
+				R8B_SCHED_FENCE();
+				R8B_LDS_ARRIVED(FLEN, v, 24);
+				cx_mac8(row + 24, v + 24, s);
+			}
+			dst_store(wd, ch, j, s[0] + s[1]);
+		}
+	}
+}
+
 // MODE 4: K8 on the vector ALU, two ADJACENT phases per thread.  With In <= Out the tap windows of
 // phases 2q and 2q+1 start 0 or 1 samples apart, so 25 (A, B) pairs read from LDS feed four outputs
 // (two phases x two channels): half the LDS reads per output of the one-phase form, and with
@@ -2293,7 +2370,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	constexpr bool CXL = MODE >= 12 && MODE <= 15;
 
 	constexpr int BM = MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 14 ? 0 :
-		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : (MODE == 16 ? 4 : (MODE == 17 ? 5 : MODE)));
+		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : (MODE == 16 ? 4 : (MODE == 17 ? 5 :
+		(MODE == 18 ? 1 : MODE))));
 	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
 	constexpr bool SPLIT = kSplit<LN, UL> && !CX && (BM == 0 || BM == 3);
 	(void) SPLIT;
@@ -2374,12 +2452,12 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			if constexpr (SOLO) cp_tail_owned_solo<LN, UL>(L, st, k_of(tid), chA, lt);
 			else if (live(tid)) cp_tail_owned<LN, UL, SP>(L, st, k_of(tid), chA, chB, bvalid, lt);
 		}
-		if constexpr (MODE != 1)
+		if constexpr (BM != 1)
 		{
 			st.tka = nullptr;
 			if ((L.tail_flags & 8) != 0) cp_tail_slice_load<G::WT>(L, st, (int) (cur.k - L.k0) / G::SUB, chA, chB, tid);
 		}
-		if constexpr (MODE != 1)
+		if constexpr (BM != 1 || SOLO)
 		{
 			// Parked outputs (ConvxLaunch::park_*): does this workgroup hold the call's last block (whose outputs behind
 			// the call's range are parked, not computed again by the next call)?  The previous call's parked outputs:
@@ -2820,12 +2898,38 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		});
 		ex.phase([&](int tid, St& st)
 		{
+			if constexpr (SOLO)
+			{
+				// (one-channel form: the element's two parts are one channel's samples)
+				cp_silence<LN, UL>(st, ex.collect_bits() != 0 ? 3u : 0u);
+				cp_solo_final_store<LN, UL>(L, reinterpret_cast<double*>(buf), st, k_of(tid), lt_of(tid));
+			}
+			else
+			{
 			cp_silence<LN, UL>(st, ex.collect_bits());
 			cp_final_store<LN, UL>(L, buf_of(tid), buf_of(tid), st, k_of(tid), lt_of(tid));
+			}
 		});
 		ex.each([&](int tid, St& st)
 		{
 			int row_t = cp_whole_phase(X, tid); // (what cx_whole_row fetched ahead)
+			if constexpr (SOLO)
+			{
+				cp_whole_compute_solo<FLENP>(X, X.wdst, XM.blk[cur.k - L.k0], reinterpret_cast<const double*>(buf), st.row, &row_t, chA, tid, G::WT);
+				if (ex.uniform(st.pf) != 0)
+				{
+					// (the call's last block: its outputs behind the call's range belong to the next call -- parked, not
+					// computed again there; cf. modes 4 / 5)
+					DstView pd;
+					pd.p = XM.park_dst;
+					pd.stride = XM.park_stride;
+					pd.mask = -1;
+					pd.off = -XM.wb;
+					pd.fmt = kPcmF64;
+					cp_whole_compute_solo<FLENP>(X, pd, XM.park_blk, reinterpret_cast<const double*>(buf), st.row, &row_t, chA, tid, G::WT);
+				}
+			}
+			else
 			for (int sb = 0; sb < (G::SUB == 1 ? 1 : cur.nvalid); sb++)
 				cp_whole_compute<FLENP>(X, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.row, &row_t, chA, chB, bvalid, tid, G::WT);
 		});

@@ -760,6 +760,9 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["park"] = 1;
 	// fused two-phase pair kernel in its walk form (r8b_convp.h convp_walk): a workgroup per channel pair takes the call's
 	// blocks one after the other (0: a workgroup per block, as before round 5)
+	// 16384-point 1:1 blocks (one-channel form of the pair kernel) with the whole-step interpolator behind them fused in
+	// (kernel mode 18; 0: the interpolator as a launch of its own, as before round 5)
+	opt_["solo_fuse"] = 1;
 	opt_["walk"] = 1;      // (0: a workgroup per block, as before round 5; 2: whatever the batch size -- tests)
 	opt_["walk_len"] = 0;  // blocks per workgroup of the walk form (0: the launch's whole run of blocks)
 	stat_["conv_blocks"] = 0;
@@ -1178,7 +1181,8 @@ long long Engine::park_len_of(size_t s, bool end_of_chain) const
 		const long long e0 = (long long) g.in_len + off - g.fl2 - w.fl2 - fused_shift(s).d;
 		if (e0 > 0) n = std::max(n, (e0 * w.out_step + w.in_step - 1) / w.in_step + 2);
 		// (output ring of the one-channel fused kernel: a call's outputs plus one block's, a power of two)
-		if (end_of_chain && !use_pair_fused(plan_.stages[s].cg)) return pow2_at_least(plan_.max_out_len + n + 16);
+		if (end_of_chain && !use_pair_fused(plan_.stages[s].cg) && !use_solo_fused(s))
+			return pow2_at_least(plan_.max_out_len + n + 16);
 	}
 	else
 	{
@@ -1270,7 +1274,7 @@ bool Engine::set_option(const std::string& name, int value)
 	// (unfused stages keep it in rings the fused kernels never write): once a stream has started they
 	// may only change after clear().
 	static const char* const structural[] = { "fuse", "fuse_hb", "fuse_hbd", "fold_tail", "fast_conv",
-		"pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park", "fuse_latency" };
+		"pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park", "fuse_latency", "solo_fuse" };
 	bool started = false;
 	for (const StagePlan& sp : plan_.stages) started = started || sp.m != 0;
 	for (const char* n : structural)
@@ -1331,7 +1335,7 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 		{
 		case kConv:
 			*kernel = fuse_with_next(stage) ?
-				(use_pair_fused(sp.cg) ? "k_convp_whole" : "k_convx_whole") :
+				(use_pair_fused(sp.cg) || use_solo_fused(stage) ? "k_convp_whole" : "k_convx_whole") :
 				conv_path(sp.cg) == kPathGeneric ? "k_conv" :
 				(conv_path(sp.cg) == kPathPair || conv_path(sp.cg) == kPathPair3 ? "k_convp" : "k_convx");
 			break;
@@ -2318,6 +2322,19 @@ bool Engine::fuse_latency_ok(size_t s) const
 	return off + c.cg.in_len + w.in_step + 32 + 16 <= c.cg.n_out;
 }
 
+// A 1:1 convolver on 16384-point blocks in front of a whole-step interpolator: the pair kernel's one-channel form with
+// the interpolator fused in (r8b_convp.h mode 18: real kernel spectrum, plain load)
+bool Engine::use_solo_fused(size_t s) const
+{
+	if (!opt_.at("solo_fuse") || !opt_.at("pair_solo") || !opt_.at("pair_conv") || s + 1 >= plan_.stages.size()) return false;
+	const StagePlan& c = plan_.stages[s];
+	const StagePlan& w = plan_.stages[s + 1];
+	if (c.desc.kind != kConv || w.desc.kind != kFrac || !w.whole) return false;
+	const ConvGeom& g = c.cg;
+	return !g.complex_h && g.up_pow2 && g.up == 1 && g.down == 1 && conv_path(g) == kPathPair &&
+		convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len);
+}
+
 bool Engine::fuse_with_next(size_t s) const
 {
 	if (latency_chain() && !fuse_latency_ok(s)) return false;
@@ -2325,7 +2342,9 @@ bool Engine::fuse_with_next(size_t s) const
 	const StagePlan& c = plan_.stages[s];
 	const StagePlan& w = plan_.stages[s + 1];
 	if (c.desc.kind != kConv || w.desc.kind != kFrac || !w.whole || c.cg.down != 1) return false;
-	// (8192 -> 16384-point blocks: the pair kernel's split form + the unfused interpolator beat the fused one-channel kernel)
+	// (8192 -> 16384-point blocks: the pair kernel's split form + the unfused interpolator beat the fused one-channel kernel;
+	// 16384-point 1:1 blocks: the pair kernel's one-channel form with the interpolator fused in -- use_solo_fused)
+	if (use_solo_fused(s)) return w.flen <= 32 && c.cg.in_len >= 4 * w.flen && c.cg.in_len + 64 <= c.cg.n_out;
 	if (conv_path(c.cg) == kPathPair && !use_pair(c.cg)) return false;
 	if (!convx_geometry_ok(c.cg.n_in, c.cg.n_out, c.cg.up, c.cg.down, c.cg.up_pow2) && !use_pair_fused(c.cg))
 		return false;
@@ -2497,7 +2516,10 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	StageDev& dp = dev_[s];
 	// (the one-channel kernel fused with the interpolator -- 16384-point blocks -- at the end of a chain: an output ring
 	// of the stage's own and a copy, as in launch_stage)
-	const bool oring = opt_.at("park") && !use_pair_fused(c.cg) && stage_parks(s) && dst.mask == -1 && dst.fmt == kPcmF64;
+	// (the one-channel form of the pair kernel fused with the interpolator -- use_solo_fused -- parks like the two-phase pair form)
+	const bool solo_fused = use_solo_fused(s);
+	const bool oring = opt_.at("park") && !use_pair_fused(c.cg) && !solo_fused && stage_parks(s) && dst.mask == -1 &&
+		dst.fmt == kPcmF64;
 	const bool parks = !oring && stage_parks(s) && dst.mask == -1 && dst.fmt == kPcmF64;
 	// ... and in the middle of a chain the same block writes what it holds beyond the call AHEAD into the next stage's
 	// ring (nobody reads it before it is due; the ring was sized for it -- Engine::Engine)
@@ -2571,7 +2593,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	if (oring ? wcut - wa > dp.park_stride :
 		ahead && (wcut < wb || dst.mask + 1 < stage_history(s + 2) + plan_.stage_max_in[s + 2] + (wcut - wb)))
 		throw std::logic_error("ring too small for a block written ahead");
-	if (X.c.tail_ring != nullptr && pair_two && c.cg.up_pow2)
+	if (X.c.tail_ring != nullptr && (pair_two || solo_fused) && c.cg.up_pow2)
 	{
 		// History for the next call, exactly: its first block is knext -- the first block whose outputs this call
 		// has not produced --, and no later block reads further back than that block's window (r8b_convp.h cp_load:
@@ -2620,6 +2642,22 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			B.u_lo = (int) (jlo * In / Out + D - w.fll - t0);
 			B.pad = 0;
 		}
+		if (solo_fused && parks && k1 == klast && block_jhi(klast) > wb)
+		{
+			// what the call's last block holds beyond the call: [wb, end of the block) into the other park buffer (one phase
+			// per thread: the span in the form of the loop above)
+			park_b = block_jhi(klast);
+			if (park_b - wb > dp.park_stride) throw std::logic_error("park buffer too small");
+			SpanInfo& P = X.park_blk;
+			P.jlo = wb; P.jhi = park_b;
+			P.jlo_mod = (int) (wb % Out);
+			P.ph_lo = (int) ((wb * In) % Out);
+			P.u_lo = (int) (wb * In / Out + D - w.fll - (klast * S + off - fl2c));
+			P.pad = 0;
+			X.park_out = 1;
+			X.park_dst = dp.park[dp.park_cur ^ 1] + (long long) ch0_ * dp.park_stride;
+			X.park_stride = dp.park_stride;
+		}
 		if (pair_two)
 		{
 			auto two_phase_span = [&](SpanInfo& B, long long k)
@@ -2653,6 +2691,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 			// (fuse_latency_ok admits a complex spectrum only where the two-phase tables exist)
 			throw std::logic_error("fused launch: complex kernel spectrum without the two-phase tables");
 		else if (use_pair_fused(c.cg)) launch_convp(X, 1, stream);
+		else if (use_solo_fused(s)) launch_convp(X, 18, stream);
 		else launch_convx(X, 1, stream);
 		if (X.c.tail_ring != nullptr) tail_done_ = true;
 	}

@@ -115,6 +115,7 @@ private:
 	void plan_transforms();
 	void ensure_ring(size_t s);
 	bool fuse_with_next(size_t s) const;
+	bool use_solo_fused(size_t s) const;
 	bool use_pair(const ConvGeom& g) const;
 	bool use_pair_fused(const ConvGeom& g) const;
 	bool fast_geometry(const ConvGeom& g) const;

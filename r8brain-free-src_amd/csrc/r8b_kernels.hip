@@ -669,6 +669,11 @@ __device__ __forceinline__ void convp_pin(ConvxLaunch& H, const ConvxLaunch& X)
 			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt), "+s"(H.park_n), "+s"(H.park_out), "+s"(H.park_slices),
 			"+s"(H.c.t_zero)
 			: "s"(H.ptab), "s"(H.ctab), "s"(H.wdst.p));
+	else if constexpr (MODE == 18)
+		// (one-channel form + one phase per thread: what its last two phases read)
+		asm volatile("" : "+s"(H.in_step), "+s"(H.out_step), "+s"(H.flen), "+s"(H.wdst.stride), "+s"(H.wdst.mask),
+			"+s"(H.wdst.off), "+s"(H.wdst.fmt), "+s"(H.park_n), "+s"(H.park_out), "+s"(H.park_slices), "+s"(H.c.t_zero)
+			: "s"(H.wtab), "s"(H.wdst.p));
 	else if constexpr (MODE == 1) {}
 	else
 		asm volatile("" : "+s"(H.c.a), "+s"(H.c.b), "+s"(H.c.dst.stride), "+s"(H.c.dst.mask), "+s"(H.c.dst.off),
@@ -837,7 +842,7 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 		if (nbg > 1 && imax * nbg >= 0x100000000ull)
 			throw std::runtime_error("launch_convp: too many blocks per call for the workgroup map (split the call)");
 	}
-	convp_prepare<LN, UL>(X, MODE != 1, convp_mode_sp(MODE), convp_mode_solo(MODE));
+	convp_prepare<LN, UL>(X, MODE != 1 && MODE != 18, convp_mode_sp(MODE), convp_mode_solo(MODE));
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
 #ifdef R8B_DEV_ONLY_MODE
@@ -900,6 +905,8 @@ void launch_convp_sp(const ConvxLaunch& X, int mode, hipStream_t stream)
 		else if (mode == 9) launch_convp_t<LN, UL, 9, 24>(X, stream);
 		else if (mode == 10) launch_convp_t<LN, UL, 10, 24>(X, stream);
 		else if (mode == 11) launch_convp_t<LN, UL, 11, 24>(X, stream);
+		else if (mode == 18 && X.flen > 24) launch_convp_t<LN, UL, 18, 32>(X, stream);
+		else if (mode == 18) launch_convp_t<LN, UL, 18, 24>(X, stream);
 		else if (mode == 12) launch_convp_t<LN, UL, 12, 24>(X, stream);
 		else if (mode == 13) launch_convp_t<LN, UL, 13, 24>(X, stream);
 		else if (mode == 14) launch_convp_t<LN, UL, 14, 24>(X, stream);

@@ -301,7 +301,8 @@ PARK_CASES = [
     # 16384-point blocks: the one-channel form of the pair kernel (modes 10 / 11)
     (48000.0, 16000.0, 8192, 0.5, 180.15, "park"),        # re-blocked 8 507-tap filter, 16384 points 1:1, strided store
     (176400.0, 44100.0, 16384, 0.5, 180.15, "park"),      # half-band decimator + 16384 -> 8192 points (decimating form)
-    (96000.0, 44100.0, 8192, 0.5, 180.15, "ahead"),       # 16384 points 1:1 in front of the (unfused) interpolator
+    (96000.0, 44100.0, 8192, 0.5, 180.15, "park"),        # 16384 points 1:1 with the interpolator fused in (mode 18, round 5)
+    (96000.0, 44100.0, 8192, 0.5, 180.15, "ahead", {"solo_fuse": 0}),   # ... in front of the unfused interpolator
     (44100.0, 132300.0, 3000, 0.5, 180.15, "park"),       # 3x zero stuffing into 16384 points
     (48000.0, 36000.0, 6000, 0.5, 180.15, "park"),        # 3x zero stuffing into 16384 points, decimated by 4
     # the one-channel KERNEL (what is left for it: option pair_solo = 0): at the end of a chain through an output ring of
@@ -309,7 +310,7 @@ PARK_CASES = [
     (48000.0, 36000.0, 6000, 0.5, 180.15, "ahead", {"pair_solo": 0}),
     (48000.0, 16000.0, 8192, 0.5, 180.15, "ahead", {"pair_solo": 0}),
     (96000.0, 44100.0, 8192, 0.5, 180.15, "ahead", {"pair_solo": 0}),   # fused with the interpolator (output ring)
-    (192000.0, 44100.0, 8192, 0.5, 180.15, "ahead"),      # half-band decimator + fused 16384 -> 16384 points
+    (192000.0, 44100.0, 8192, 0.5, 180.15, "park"),       # half-band decimator + fused 16384 -> 16384 points (mode 18)
 ]
 # Minimum-phase filters on the long blocks (transition band 0.5 ... 1 %): 8192 -> 16384 points on the split form, 16384
 # points 1:1 and decimating by 2 on the one-channel form, with a complex kernel spectrum (modes 12 ... 15) -- until round 4

@@ -266,7 +266,7 @@ void emul_convp_t(const ConvxLaunch& X0)
 {
 	ConvxLaunch X = X0;
 	constexpr bool SOLO = convp_mode_solo(MODE);
-	convp_prepare<LN, UL>(X, MODE != 1, convp_mode_sp(MODE), SOLO);
+	convp_prepare<LN, UL>(X, MODE != 1 && MODE != 18, convp_mode_sp(MODE), SOLO);
 	std::vector<double> lds((size_t) convp_lds_bytes<LN, UL>() / sizeof(double) + 2);
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
@@ -351,6 +351,8 @@ void emul_convp_sp(const ConvxLaunch& X, int mode)
 		else if (mode == 9) emul_convp_t<LN, UL, 9, 24>(X);
 		else if (mode == 10) emul_convp_t<LN, UL, 10, 24>(X);
 		else if (mode == 11) emul_convp_t<LN, UL, 11, 24>(X);
+		else if (mode == 18 && X.flen > 24) emul_convp_t<LN, UL, 18, 32>(X);
+		else if (mode == 18) emul_convp_t<LN, UL, 18, 24>(X);
 		else if (mode == 12) emul_convp_t<LN, UL, 12, 24>(X);
 		else if (mode == 13) emul_convp_t<LN, UL, 13, 24>(X);
 		else if (mode == 14) emul_convp_t<LN, UL, 14, 24>(X);
