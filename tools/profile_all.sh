@@ -67,4 +67,6 @@ prof solo --src 96000 --dst 44100 --tb 0.5
 prof solo13 --src 48000 --dst 16000 --tb 1
 prof pair13 --src 48000 --dst 16000 --tb 2
 prof minphase --src 44100 --dst 96000 --phase 1
+prof solo192 --src 192000 --dst 44100 --tb 0.5
+prof up3 --src 16000 --dst 48000
 ls $out/*

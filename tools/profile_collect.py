@@ -33,7 +33,8 @@ for cfg in sorted(os.listdir(src)):
     except Exception:
         pass
     for k, v in rec.items():
-        name = "k_convp_whole" if (k == "k_convp" and fused) else k
+        # (... also in its walk form, k_convp_walk; the one-channel form with the interpolator fused in is k_convp<13, 0, 18, .>)
+        name = "k_convp_whole" if (k in ("k_convp", "k_convp_walk") and fused) else k
         v["profile"] = "%s_%s_pmc_summary.txt" % (prefix, cfg)
         traffic["%s:%s" % (bench_cfg.get(cfg, cfg), name)] = v
 json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
