@@ -271,7 +271,7 @@ MINPHASE_FUSED_DRAWS = [
 def test_fuzz_minimum_phase_fused_equals_two_launches(emul, case):
     """minimum-phase chains: convolver + interpolator in one launch (Engine::fused_shift, kernel modes 16 / 17) against
     the two launches behind option fuse_latency = 0 -- same counts per call, same samples to rounding, ragged calls
-    (tools/minphase_fuse_fuzz.py is the one-off long form of this test)"""
+    (tools/attic/minphase_fuse_fuzz.py is the one-off long form of this test)"""
     src, dst, maxin, tb, att, seed = case
     objs = [r8b.BatchResampler(src, dst, maxin, tb, att, nch=3, phase=1, lib=emul) for _ in range(2)]
     objs[1].set_option("fuse_latency", 0)

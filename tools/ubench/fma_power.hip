@@ -1,4 +1,4 @@
-// micro-benchmark: a pure fp64 FMA loop on every SIMD for ~2.5 s per configuration while tools/fma_power.sh
+// micro-benchmark: a pure fp64 FMA loop on every SIMD for ~2.5 s per configuration while tools/attic/fma_power.sh
 // samples rocm-smi: the shader clock and board power the chip sustains under fp64 vector load
 #include <hip/hip_runtime.h>
 #include <cstdio>
