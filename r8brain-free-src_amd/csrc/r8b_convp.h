@@ -146,6 +146,8 @@ template<int LN, int UL> constexpr bool kSplit = false;
 // service group.
 R8B_HD int pswz(int e) { return e ^ ((e >> 4) & 15); }
 
+// mode 19: polyphase 3x form (cp_p3_*; geometries <10, 0> ... <12, 0>)
+constexpr bool convp_mode_p3(int m) { return m == 19; }
 // kernel modes of the long-block forms on the 8192-point geometries (convp_body): split 2x up-sampling form 8 / 9
 // (12 / 13 with a complex kernel spectrum), one-channel form 10 / 11 (14 / 15)
 constexpr bool convp_mode_sp(int m) { return m == 8 || m == 9 || m == 12 || m == 13; }
@@ -320,6 +322,8 @@ struct ConvpState
 	double tk[2];         // the thread's element of the history tail behind the last block's window (cp_tail_slice_*)
 	double* tka;
 	double er[16], ei[16]; // split 2x up-sampling form (modes 8 / 9 / 12 / 13): the even half's outputs while the odd half is transformed
+	double zr[16], zi[16];   // polyphase 3x form (mode 19): the block's spectrum, kept across the three backward transforms
+	double p3r[16], p3i[16]; // ... the second component's outputs (the first's wait in er / ei; kP3Keep of the sixteen)
 	cd twp[4];            // walk form (convp_walk): the thread's own twiddles, kept across blocks -- [0], [1] first pass (w, w^4), [2], [3] last backward pass
 };
 
@@ -2319,6 +2323,133 @@ R8B_HD void cp_park_view(const Exec& ex, const ConvxLaunch& XM, const St& st, lo
 	(void) cur;
 }
 
+// ---- polyphase 3x form (MODE 19; round 5) ---------------------------------------------------------------------------
+// A 3x up-sampling convolver on the zero-stuffing block transforms N points of which two thirds are zeros (reference
+// CDSPBlockConvolver.h:414-496 copyUpsample in front of :283-350).  The same outputs from the INPUT stream alone:
+// y[3 m + r] = sum_d x[m - d] g_r[d], g_r[d] = h[3 d + r + fl2] (ConvGeom::p3) -- three FIR filters over one window of
+// N input samples: ONE forward transform Z, then y_r = IDFT(Z G_r) for r = 0, 1, 2, one after the other in the same
+// array (1:1 geometry, complex products per position: G_r is the spectrum of a one-sided piece of h).  The three
+// components' outputs meet in registers and leave together (cp_p3_store).
+// Block k: window = input samples [t0 / 3 - rot, + N), t0 = k blk_stride + blk_offset - fl2 (a multiple of 3; rot = the
+// components' reach into the past), valid outputs = virtual times t0 ... t0 + in_len - 1 at circular positions 0 ...
+// in_len / 3 - 1 of each component (Engine::pair_constants_poly3 lays the components out for that).
+template<int LN, int UL>
+R8B_HD void cp_p3_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, int chA, int chB, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int R = G::E1, q = G::N / R;
+	const long long t0 = k * (long long) L.blk_stride + L.blk_offset - L.fl2;
+	// (exact: t0 is a multiple of 3, negative for the stream's first block)
+	const long long w0 = t0 / 3 - L.rot;
+	if (L.src.cur_fmt == kPcmF64 && w0 >= L.src.cur_base && w0 >= 0)
+	{
+		const double* const pa = L.src.cur + ((long long) chA * L.src.cur_stride + (w0 - L.src.cur_base));
+		const double* const pb = L.src.cur + ((long long) chB * L.src.cur_stride + (w0 - L.src.cur_base));
+#pragma unroll
+		for (int p = 0; p < R; p++)
+		{
+			st.pr[p] = pa[lt + p * q];
+			st.pi[p] = pb[lt + p * q];
+		}
+		return;
+	}
+	const SrcBlock sa = src_block(L.src, chA, w0), sb = src_block(L.src, chB, w0);
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		st.pr[p] = src_block_load1(sa, lt + p * q);
+		st.pi[p] = src_block_load1(sb, lt + p * q);
+	}
+}
+// the block's spectrum: the last forward butterflies over the thread's 16 consecutive positions
+template<int LN, int UL>
+R8B_HD void cp_p3_spectrum(const cd* buf, ConvpState<LN, UL>& st, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	static_assert(UL == 0 && G::E1 == 16 && !G::POST, "polyphase 3x form: 1:1 geometries up to 4096 points");
+	const SwBase bbf = sw_base(buf, fslot<LN, UL>(G::E1 * lt));
+#pragma unroll
+	for (int c = 0; c < 16; c++)
+	{
+		const cd v = sw_ld(bbf, fmap_c<LN, UL>(c));
+		st.zr[c] = v.re;
+		st.zi[c] = v.im;
+	}
+#pragma unroll
+	for (int f = 0; f < G::NBF; f++) dif_regs<G::RM>(st.zr + G::RM * f, st.zi + G::RM * f);
+}
+// component r: Z G_r and the first backward butterflies (results in st.vr / st.vi, as cp_middle_compute leaves them)
+// (the component's sixteen constants are fetched HERE, one product at a time: fetched a component ahead -- 64 registers
+// more across the backward passes -- the kernel measured slower, 0.335 against 0.313 ms; profiles/r05_experiments.txt)
+template<int LN, int UL>
+R8B_HD void cp_p3_product(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt, int r)
+{
+	typedef ConvpGeom<LN, UL> G;
+	const cd* const hr = L.hp + (size_t) r * 16 * G::NT + lt;
+#pragma unroll
+	for (int p = 0; p < 16; p++)
+	{
+		const cd h = hr[p * G::NT];
+		st.vr[p] = st.zr[p] * h.re - st.zi[p] * h.im;
+		st.vi[p] = st.zr[p] * h.im + st.zi[p] * h.re;
+	}
+	dit_regs<16>(st.vr, st.vi);
+}
+// The three components' outputs leave TOGETHER -- position i of the block is virtual times t0 + 3 i, + 1, + 2: three
+// consecutive doubles per channel, a wave's stores cover 1.5 KB of consecutive bytes back to back -- so the first two wait
+// in registers (st.er / st.ei, st.p3r / st.p3i) while the next one is transformed.  Measured against storing each component
+// straight from its last pass (8-byte stores 24 bytes apart, the three parts of a cache line microseconds apart; 221
+// registers instead of 256 + spills): 0.271 against 0.313 ms per call for 16000 -> 48000 (profiles/r05_experiments.txt).
+// Only the thread's first kP3Keep positions wait: a block's valid positions are i < in_len / 3 <= N - (the components'
+// reach), i.e. 10.5 of a thread's 16 for the 24-bit filter at 2 % -- the ones beyond 11 (short filters in a long window)
+// leave component by component (cp_p3_store_rest), and 40 registers are not held for values that are mostly never stored.
+static const int kP3Keep = 11;
+template<int LN, int UL>
+R8B_HD void cp_p3_store(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int chA, int chB, bool bvalid,
+	int lt, const DstView& pd, long long pend)
+{
+	typedef ConvpGeom<LN, UL> G;
+	const long long t0 = k * (long long) L.blk_stride + L.blk_offset - L.fl2;
+	const int m3 = L.in_len / 3;
+	auto run = [&](const CpStoreView& v)
+	{
+#pragma unroll
+		for (int p = 0; p < kP3Keep; p++)
+		{
+			const int i = lt + G::NT * p;
+			if (i < m3)
+			{
+				cp_store1(v, (unsigned) (3 * i), st.er[p], st.ei[p], bvalid);
+				cp_store1(v, (unsigned) (3 * i + 1), st.p3r[p], st.p3i[p], bvalid);
+				cp_store1(v, (unsigned) (3 * i + 2), st.vr[p], st.vi[p], bvalid);
+			}
+		}
+	};
+	run(cp_store_view(L.dst, chA, chB, t0, L.a, L.b, L.in_len));
+	if (pend > L.b) run(cp_store_view(pd, chA, chB, t0, L.b, pend, L.in_len));
+}
+// (component r of the positions that do not wait, straight from st.vr / st.vi)
+template<int LN, int UL>
+R8B_HD void cp_p3_store_rest(const ConvLaunch& L, const ConvpState<LN, UL>& st, int r, long long k, int chA, int chB,
+	bool bvalid, int lt, const DstView& pd, long long pend)
+{
+	typedef ConvpGeom<LN, UL> G;
+	const int m3 = L.in_len / 3;
+	if (m3 <= G::NT * kP3Keep) return; // (uniform: the usual case)
+	const long long t0 = k * (long long) L.blk_stride + L.blk_offset - L.fl2;
+	auto run = [&](const CpStoreView& v)
+	{
+#pragma unroll
+		for (int p = kP3Keep; p < 16; p++)
+		{
+			const int i = lt + G::NT * p;
+			if (i < m3) cp_store1(v, (unsigned) (3 * i + r), st.vr[p], st.vi[p], bvalid);
+		}
+	};
+	run(cp_store_view(L.dst, chA, chB, t0, L.a, L.b, L.in_len));
+	if (pend > L.b) run(cp_store_view(pd, chA, chB, t0, L.b, pend, L.in_len));
+}
+
 // ---- the kernel body ---------------------------------------------------------------------------------
 
 // one workgroup's work: blocks k0 .. k0 + nvalid - 1 (nvalid <= SUB) of the channel pair (chA, chB);
@@ -2371,7 +2502,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 
 	constexpr int BM = MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 14 ? 0 :
 		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : (MODE == 16 ? 4 : (MODE == 17 ? 5 :
-		(MODE == 18 ? 1 : MODE))));
+		(MODE == 18 ? 1 : (MODE == 19 ? 0 : MODE)))));
+	// mode 19: polyphase 3x form (cp_p3_*): a convolver-only mode with its own load, middle and store
+	constexpr bool P3 = convp_mode_p3(MODE);
 	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
 	constexpr bool SPLIT = kSplit<LN, UL> && !CX && (BM == 0 || BM == 3);
 	(void) SPLIT;
@@ -2382,6 +2515,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	// (they take part in every barrier) and store nothing
 	auto hp_prefetch = [&](St& st, int lt)
 	{
+		if constexpr (P3) { (void) st; (void) lt; } // (fetched where they are multiplied: cp_p3_product)
+		else
 		if constexpr (SOLO) { (void) st; (void) lt; } // (fetched behind the spectrum's write: cp_solo_mid_a)
 		else if constexpr (SP) cp_sp_hp_prefetch<LN, UL>(L, st, lt);
 		else cp_hp_prefetch<LN, UL, CX>(L, st, lt);
@@ -2436,7 +2571,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			if (tid < TL::NE) twl_v = L.ptw[TL::src_index(tid)];
 		}
 		ex.stamp2();
-		if constexpr (SOLO) cp_load_solo<LN, UL, BM>(L, st, k_of(tid), chA, lt);
+		if constexpr (P3) cp_p3_load<LN, UL>(L, st, k_of(tid), chA, chB, lt);
+		else if constexpr (SOLO) cp_load_solo<LN, UL, BM>(L, st, k_of(tid), chA, lt);
 		else cp_load<LN, UL, BM, SP>(L, st, k_of(tid), chA, chB, lt);
 		}
 		// (walk form: interior blocks own no part of the history tail and never hold the call's last output -- the shared
@@ -2699,6 +2835,85 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	}
 	else
 #endif
+	if constexpr (P3)
+	{
+		static_assert(!P3 || (G::NPRE == 2 && G::B1 && G::R2 > 1), "polyphase 3x form: 1024 ... 4096-point 1:1 geometries");
+		// the spectrum once, then the three components one after the other through the same backward passes; the first
+		// two components' outputs wait in registers (st.er / st.ei, st.p3r / st.p3i)
+		auto p_mid0 = [&](int tid, St& st)
+		{
+			const int lt = lt_of(tid);
+			cp_p3_spectrum<LN, UL>(buf_of(tid), st, lt);
+			cp_p3_product<LN, UL>(L, st, lt, 0);
+		};
+		auto p_mid1 = [&](int tid, St& st) { cp_p3_product<LN, UL>(L, st, lt_of(tid), 1); };
+		auto p_mid2 = [&](int tid, St& st) { cp_p3_product<LN, UL>(L, st, lt_of(tid), 2); };
+		ex.wave_steps(s_pre1, p_mid0, s_midw, s_b1);
+		auto p_rest = [&](int tid, St& st, int r)
+		{
+			// (the positions that do not wait for the other components: rare -- cp_p3_store_rest)
+			cp_silence<LN, UL>(st, ex.collect_bits());
+			if (live(tid))
+			{
+				DstView pd = L.dst;
+				long long pend = L.b;
+				cp_park_view(ex, XM, st, k_of(tid), cur, pd, pend);
+				cp_p3_store_rest<LN, UL>(L, st, r, k_of(tid), chA, chB, bvalid, lt_of(tid), pd, pend);
+			}
+		};
+		ex.phase([&](int tid, St& st)
+		{
+			cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
+			if (L.in_len / 3 > G::NT * kP3Keep) p_rest(tid, st, 0);
+#pragma unroll
+			for (int p = 0; p < kP3Keep; p++)
+			{
+				st.er[p] = st.vr[p];
+				st.ei[p] = st.vi[p];
+			}
+		});
+		ex.wave_steps(p_mid1, s_midw, s_b1);
+		ex.phase([&](int tid, St& st)
+		{
+			cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
+			if (L.in_len / 3 > G::NT * kP3Keep) p_rest(tid, st, 1);
+#pragma unroll
+			for (int p = 0; p < kP3Keep; p++)
+			{
+				st.p3r[p] = st.vr[p];
+				st.p3i[p] = st.vi[p];
+			}
+		});
+		ex.wave_steps(p_mid2, s_midw, s_b1);
+		ex.each([&](int tid, St& st)
+		{
+			const int lt = lt_of(tid);
+			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
+			cp_tail_slice_store(L, st, chA, chB, bvalid);
+			cp_back2<LN, UL>(buf_of(tid), st, lt);
+			const unsigned nzb = ex.collect_bits();
+			cp_silence<LN, UL>(st, nzb);
+			if (nzb != 3u)
+			{
+				// (the first two components' outputs too)
+#pragma unroll
+				for (int p = 0; p < kP3Keep; p++)
+				{
+					if (!(nzb & 1u)) st.er[p] = st.p3r[p] = 0.0;
+					if (!(nzb & 2u)) st.ei[p] = st.p3i[p] = 0.0;
+				}
+			}
+			if (live(tid))
+			{
+				DstView pd = L.dst;
+				long long pend = L.b;
+				cp_park_view(ex, XM, st, k_of(tid), cur, pd, pend);
+				cp_p3_store<LN, UL>(L, st, k_of(tid), chA, chB, bvalid, lt, pd, pend);
+				cp_p3_store_rest<LN, UL>(L, st, 2, k_of(tid), chA, chB, bvalid, lt, pd, pend);
+			}
+		});
+	}
+	else
 	if constexpr (G::NPRE == 3) ex.wave_steps(s_pre1, s_pre2, s_midc, s_midw, s_b1);
 	else if constexpr (G::NPRE == 2 && G::B1) ex.wave_steps(s_pre1, s_midc, s_midw, s_b1);
 	else if constexpr (G::NPRE == 2) ex.wave_steps(s_pre1, s_midc, s_midw);
@@ -2825,6 +3040,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			}
 		});
 	}
+	else if constexpr (P3) {} // (stored component by component, above)
 	else if constexpr (BM == 0 || BM == 3)
 	{
 		ex.each([&](int tid, St& st)
@@ -3023,14 +3239,17 @@ inline void convp_tail_owners(ConvLaunch& L)
 // (spu: the split 2x up-sampling form on a 1:1 geometry -- modes 8 / 9)
 // (solo: the one-channel form on that geometry -- modes 10 / 11: the window is 2N samples, rotated by pairs)
 template<int LN, int UL>
-inline void convp_prepare(ConvxLaunch& X, bool slices = true, bool spu = false, bool solo = false)
+inline void convp_prepare(ConvxLaunch& X, bool slices = true, bool spu = false, bool solo = false, bool p3 = false)
 {
-	X.c.rot = 0;
+	// (p3 -- polyphase 3x form, mode 19: rot carries the components' reach into the past, set by the engine; the
+	// history tail is copied in slices)
+	if (!p3) X.c.rot = 0;
 	X.c.fl2r = X.c.fl2;
 	X.c.tail_flags = X.c.tail_ring != nullptr ? 1 : 0;
 	X.c.tail_bf = 0;
 	X.c.tail_c0 = X.c.tail_c1 = 0;
-	if (solo && UL < 0)
+	if (p3) {}
+	else if (solo && UL < 0)
 	{
 		// (decimation in the spectrum: no rotation)
 		if (X.c.up == 1 && (X.c.in_len & 1) == 0) convp_tail_owners<2 * ConvpGeom<LN, UL>::N, 0>(X.c);

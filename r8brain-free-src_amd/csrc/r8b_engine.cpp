@@ -587,6 +587,63 @@ std::vector<double> pair_constants_complex(const std::vector<double>& Hc, int n_
 	return out;
 }
 
+// Polyphase 3x form (ConvGeom::p3; r8b_convp.h mode 19): the spectra of the filter's three polyphase components
+// g_r[d] = h[3 d + r + fl2], d in [-a, b], each laid out circularly so that the block's first valid output comes out at
+// circular position 0 -- gc_r[(d - b) mod N] = g_r[d] --, scaled by 1 / N (unnormalised transforms both ways), one
+// complex value per backward position: hp3[((r * 16 + c) * NT + t)] = G_r[bitrev(16 t + c)] (cf. pair_constants_complex).
+std::vector<double> pair_constants_poly3(const LpFilter& f, int fl2, int N, int a, int b)
+{
+	const int NT = N / 16, K = (int) f.taps.size();
+	int ln = 0;
+	while ((1 << ln) < N) ln++;
+	auto rev = [](int v, int bits)
+	{
+		int r = 0;
+		for (int q = 0; q < bits; q++)
+			if (v & (1 << q)) r |= 1 << (bits - 1 - q);
+		return r;
+	};
+	const std::vector<double> tw = make_twiddles(N); // exp(-2 pi i e / N)
+	std::vector<double> out((size_t) 3 * 16 * NT * 2, 0.0);
+	for (int r = 0; r < 3; r++)
+	{
+		// (the component's taps with their circular positions)
+		std::vector<std::pair<int, double>> taps;
+		for (int d = -a; d <= b; d++)
+		{
+			const long long i = 3LL * d + r + fl2;
+			if (i >= 0 && i < K) taps.emplace_back(((d - b) % N + N) % N, f.taps[(size_t) i]);
+		}
+		std::vector<long double> Gr((size_t) N), Gi((size_t) N);
+		for (int k = 0; k <= N / 2; k++)
+		{
+			long double re = 0.0L, im = 0.0L;
+			for (const auto& t : taps)
+			{
+				const long long e = ((long long) k * t.first) & (N - 1);
+				re += (long double) t.second * tw[(size_t) e * 2];
+				im += (long double) t.second * tw[(size_t) e * 2 + 1];
+			}
+			Gr[(size_t) k] = re / N;
+			Gi[(size_t) k] = im / N;
+			if (k > 0 && k < N / 2)
+			{
+				Gr[(size_t) (N - k)] = re / N;
+				Gi[(size_t) (N - k)] = -im / N;
+			}
+		}
+		for (int t = 0; t < NT; t++)
+			for (int c = 0; c < 16; c++)
+			{
+				const int k = rev(16 * t + c, ln);
+				const size_t o = (((size_t) r * 16 + c) * NT + t) * 2;
+				out[o] = (double) Gr[(size_t) k];
+				out[o + 1] = (double) Gi[(size_t) k];
+			}
+	}
+	return out;
+}
+
 std::vector<double> pair_twiddles(const std::vector<double>& tw, int tw_len, int n_in, int n_out)
 {
 	// rows of NT entries (r8b_convp.h ptw_fetch): 6 per slot; slots 0-2 forward passes (radix e1); then,
@@ -763,6 +820,9 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// 16384-point 1:1 blocks (one-channel form of the pair kernel) with the whole-step interpolator behind them fused in
 	// (kernel mode 18; 0: the interpolator as a launch of its own, as before round 5)
 	opt_["solo_fuse"] = 1;
+	// 3x up-sampling convolvers in the polyphase form -- one forward transform of the INPUT samples, three backward ones,
+	// no stuffed zeros transformed (r8b_convp.h mode 19, ConvGeom::p3); 0: the zero-stuffing block, as before round 5
+	opt_["up3_poly"] = 1;
 	opt_["walk"] = 1;      // (0: a workgroup per block, as before round 5; 2: whatever the batch size -- tests)
 	opt_["walk_len"] = 0;  // blocks per workgroup of the walk form (0: the launch's whole run of blocks)
 	stat_["conv_blocks"] = 0;
@@ -781,8 +841,10 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 			// (+ one block of the convolver in front of it: the block that holds a call's last output is written whole,
 			// ahead of what the call owes -- launch_stage, conv_once)
 			// (the same behind a fused convolver + whole-step interpolator: a block's interpolated outputs -- launch_fused)
+			// (the larger of the blocks the convolver may run on: the plan's, or its polyphase 3x block -- ConvGeom::p3)
 			long long ahead = s > 0 && plan_.stages[s - 1].desc.kind == kConv ?
-				plan_.stages[s - 1].cg.in_len / plan_.stages[s - 1].cg.down + 2 : 0;
+				std::max(plan_.stages[s - 1].cg.in_len, plan_.stages[s - 1].cg.p3 ? 3 * plan_.stages[s - 1].cg.p3_m : 0) /
+					plan_.stages[s - 1].cg.down + 2 : 0;
 			if (s > 1 && plan_.stages[s - 1].desc.kind == kFrac && plan_.stages[s - 1].whole &&
 				plan_.stages[s - 2].desc.kind == kConv)
 				ahead = (long long) plan_.stages[s - 2].cg.in_len * plan_.stages[s - 1].out_step / plan_.stages[s - 1].in_step +
@@ -795,6 +857,18 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 				const ConvGeom& g = sp.cg;
 				if (g.n_in < 32 || g.n_out < 32)
 					throw std::runtime_error("block convolver transform too short");
+				if (g.p3)
+				{
+					// polyphase 3x form: the three component spectra and the twiddles of its own geometry (beside the tables of
+					// the zero-stuffing block, which option up3_poly = 0 falls back to)
+					const std::vector<double> h3 = pair_constants_poly3(*sp.lp, g.fl2, g.p3_n, g.p3_a, g.p3_b);
+					d.hp3 = (cd*) dev_alloc(h3.size() * sizeof(double));
+					dev_upload(d.hp3, h3.data(), h3.size() * sizeof(double));
+					const std::vector<double> tw3 = make_twiddles(g.p3_n);
+					const std::vector<double> pt3 = pair_twiddles(tw3, g.p3_n, g.p3_n, g.p3_n);
+					d.ptw3 = (cd*) dev_alloc(pt3.size() * sizeof(double));
+					dev_upload(d.ptw3, pt3.data(), pt3.size() * sizeof(double));
+				}
 				// the generic kernel keeps both transforms' arrays in LDS, the fast path works in place
 				const bool m3 = convx_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
 				const bool fast_ok = (m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2)) &&
@@ -1143,9 +1217,9 @@ bool Engine::stage_parks(size_t s) const
 	if (s + 2 == plan_.stages.size() && fuse_with_next(s))
 		return use_pair_two(s, nullptr) || !use_pair_fused(plan_.stages[s].cg); // (the latter: an output ring)
 	if (s + 1 != plan_.stages.size()) return false;
-	const int path = conv_path(plan_.stages[s].cg);
+	const int path = conv_path(eff_geom(s));
 	// (the one-channel fast path at the end of a chain keeps an output ring in the same buffer: launch_stage)
-	return path == kPathPair || path == kPathPair3 || path == kPathConvx || path == kPathConvx3;
+	return path == kPathPair || path == kPathPair3 || path == kPathPairP3 || path == kPathConvx || path == kPathConvx3;
 }
 
 // How an unfused pair-kernel convolver treats the block that holds a call's last output (launch_stage): 0 -- computed
@@ -1186,7 +1260,7 @@ long long Engine::park_len_of(size_t s, bool end_of_chain) const
 	}
 	else
 	{
-		const ConvGeom& g = plan_.stages[s].cg;
+		const ConvGeom g = eff_geom(s);
 		n = g.in_len / g.down + 2;
 		const int path = conv_path(g);
 		// (output ring of the one-channel fast path: a call's outputs plus one block's, a power of two)
@@ -1243,6 +1317,8 @@ void Engine::release()
 		dev_free(d.spec2);
 		dev_free(d.hp);
 		dev_free(d.ptw);
+		dev_free(d.hp3);
+		dev_free(d.ptw3);
 		dev_free(d.table);
 		dev_free(d.wtab);
 		dev_free(d.ptab);
@@ -1274,7 +1350,7 @@ bool Engine::set_option(const std::string& name, int value)
 	// (unfused stages keep it in rings the fused kernels never write): once a stream has started they
 	// may only change after clear().
 	static const char* const structural[] = { "fuse", "fuse_hb", "fuse_hbd", "fold_tail", "fast_conv",
-		"pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park", "fuse_latency", "solo_fuse" };
+		"pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park", "fuse_latency", "solo_fuse", "up3_poly" };
 	bool started = false;
 	for (const StagePlan& sp : plan_.stages) started = started || sp.m != 0;
 	for (const char* n : structural)
@@ -1336,8 +1412,9 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 		case kConv:
 			*kernel = fuse_with_next(stage) ?
 				(use_pair_fused(sp.cg) || use_solo_fused(stage) ? "k_convp_whole" : "k_convx_whole") :
-				conv_path(sp.cg) == kPathGeneric ? "k_conv" :
-				(conv_path(sp.cg) == kPathPair || conv_path(sp.cg) == kPathPair3 ? "k_convp" : "k_convx");
+				conv_path(eff_geom(stage)) == kPathGeneric ? "k_conv" :
+				(conv_path(eff_geom(stage)) == kPathPair || conv_path(eff_geom(stage)) == kPathPair3 ||
+					conv_path(eff_geom(stage)) == kPathPairP3 ? "k_convp" : "k_convx");
 			break;
 		case kFrac: *kernel = sp.whole ? "k_whole" : "k_poly"; break;
 		case kHBUp: *kernel = group_len(stage) > 1 ? "k_hbcascade" : "k_hbup"; break;
@@ -1582,10 +1659,20 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 	{
 	case kConv:
 	{
-		const ConvGeom& g = sp.cg;
+		const ConvGeom g = eff_geom(s);
 		ConvxLaunch X;
 		ConvLaunch& L = X.c;
 		fill_conv(s, L, src);
+		if (g.poly3)
+		{
+			// polyphase 3x form (ConvGeom::p3; r8b_convp.h mode 19): a block is a window of p3_n INPUT samples, its valid
+			// outputs the 3 p3_m virtual samples from k in_len + blk_off - fl2 (a multiple of 3) on; rot carries the
+			// components' reach into the past
+			L.bl2 = g.bl2; L.in_len = g.in_len; L.n_in = L.n_out = g.n_in;
+			L.blk_stride = g.in_len; L.blk_offset = g.blk_off;
+			L.rot = g.p3_b;
+			L.hp = d.hp3; L.ptw = d.ptw3;
+		}
 		const int path = conv_path(g);
 		// Every block once (pair kernels): the block that holds the call's last output is computed whole -- what it
 		// holds beyond b goes ahead into the next stage's ring (once = 3: nobody reads it before it is due) or, at the
@@ -1598,14 +1685,15 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		// own (once = 4: the park buffer used as a ring of max_out_len + one block's outputs) and copying the call's
 		// outputs from there to the caller's rows (k_tail: 2 x 8 bytes per output more, for one block in 5.2 less at
 		// 48000 -> 32000 with a 0.5 % transition band)
-		int once = (path == kPathPair || path == kPathPair3) ? conv_once(s, dst) : 0;
+		int once = (path == kPathPair || path == kPathPair3 || path == kPathPairP3) ? conv_once(s, dst) : 0;
 		if ((path == kPathConvx || path == kPathConvx3) && opt_.at("park") && dst.fmt == kPcmF64)
 			once = s + 1 == plan_.stages.size() ? (dst.mask == -1 && stage_parks(s) ? 4 : 0) : (dst.mask != -1 ? 3 : 0);
 		StageDev& dd = dev_[s];
-		auto blk_of = [&](long long q) { return ((long long) g.down * q + g.fl2) / g.in_len; };
+		// (blk_off: 0 but for the polyphase 3x form, whose blocks start on multiples of 3 -- <= 0, so the sum stays >= 0)
+		auto blk_of = [&](long long q) { return ((long long) g.down * q + g.fl2 - g.blk_off) / g.in_len; };
 		auto blk_end = [&](long long k) // the first output block k does not hold
 		{
-			const long long v = (k + 1) * (long long) g.in_len - g.fl2;
+			const long long v = (k + 1) * (long long) g.in_len + g.blk_off - g.fl2;
 			return v <= 0 ? 0LL : (v + g.down - 1) / g.down;
 		};
 		X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
@@ -1707,6 +1795,15 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 				X.park_blk.jlo = b;
 				X.park_blk.jhi = pend;
 			}
+			if (path == kPathPairP3 && L.tail_ring != nullptr)
+			{
+				// (history for the next call, exactly: its first block is the one behind this call's last -- or the one that
+				// holds output b --, whose window starts p3_b input samples before its first output's input position)
+				const long long kn = once != 0 ? k1 + 1 : blk_of(b);
+				const long long wstart = (kn * (long long) g.in_len + g.blk_off - g.fl2) / 3 - g.p3_b;
+				const long long p0 = std::min(std::max(L.tail_p0, wstart - 8), L.tail_p1);
+				L.tail_p0 = p0 < 0 ? 0 : (p0 & ~1LL);
+			}
 			if ((path == kPathPair || path == kPathPair3) && L.tail_ring != nullptr && g.up_pow2)
 			{
 				// (history for the next call, exactly -- cf. launch_fused: the next call's first block is the one that
@@ -1726,7 +1823,8 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 					convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len));
 			// (long-block forms: + 4 with a complex kernel spectrum)
 			const int cxl = g.complex_h ? 4 : 0;
-			if (path == kPathPair3) launch_convp(X, solo ? 11 + cxl : (sp ? 9 + cxl : (g.complex_h ? 7 : 3)), stream);
+			if (path == kPathPairP3) launch_convp(X, 19, stream);
+			else if (path == kPathPair3) launch_convp(X, solo ? 11 + cxl : (sp ? 9 + cxl : (g.complex_h ? 7 : 3)), stream);
 			else if (path == kPathConvx3) launch_convx(X, 3, stream);
 			else if (path == kPathPair) launch_convp(X, solo ? 10 + cxl : (sp ? 8 + cxl : (g.complex_h ? 6 : 0)), stream);
 			else launch_convx(X, 0, stream);
@@ -2212,8 +2310,23 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 }
 
 // which kernel family runs a (not fused) convolver stage
+ConvGeom Engine::eff_geom(size_t s) const
+{
+	ConvGeom g = plan_.stages[s].cg;
+	if (g.p3 && opt_.at("up3_poly") && opt_.at("pair_conv") && opt_.at("fast_conv"))
+	{
+		g.poly3 = true;
+		g.in_len = 3 * g.p3_m;
+		g.bl2 = 3 * g.p3_n;
+		g.n_in = g.n_out = g.p3_n;
+		g.blk_off = g.p3_off;
+	}
+	return g;
+}
+
 int Engine::conv_path(const ConvGeom& g) const
 {
+	if (g.poly3) return kPathPairP3;
 	if (!(opt_.at("fast_conv") || !generic_conv_fits(g))) return kPathGeneric;
 	// (8192 -> 16384-point blocks: the split 2x up-sampling form of the pair kernel, two channels per workgroup, instead
 	// of the one-channel kernel)

@@ -75,6 +75,8 @@ private:
 		cd* spec2 = nullptr; // the same per backward position (up 1 or 2)
 		cd* hp = nullptr;    // pair kernel: kernel constants of the middle pass (r8b_convp.h)
 		cd* ptw = nullptr;   // pair kernel: twiddle base powers per pass and thread
+		cd* hp3 = nullptr;   // polyphase 3x form (ConvGeom::p3, r8b_convp.h mode 19): spectra of the three components
+		cd* ptw3 = nullptr;  // ... and the twiddles of its 4096-point 1:1 geometry
 		int tw_len = 0;
 		double* table = nullptr;
 		double* wtab = nullptr; // whole-step bank, transposed per residue class (fused kernel)
@@ -119,7 +121,9 @@ private:
 	bool use_pair(const ConvGeom& g) const;
 	bool use_pair_fused(const ConvGeom& g) const;
 	bool fast_geometry(const ConvGeom& g) const;
-	enum { kPathGeneric, kPathConvx, kPathConvx3, kPathPair, kPathPair3 };
+	enum { kPathGeneric, kPathConvx, kPathConvx3, kPathPair, kPathPair3, kPathPairP3 };
+	// the geometry stage s runs with: the plan's, or its polyphase 3x block (ConvGeom::p3, option up3_poly)
+	ConvGeom eff_geom(size_t s) const;
 	int conv_path(const ConvGeom& g) const;
 	bool latency_chain() const; // some stage carries fractional-latency state (minimum phase): no fusing
 	bool use_pair_two(size_t s, int* run_off) const;

@@ -842,7 +842,7 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 		if (nbg > 1 && imax * nbg >= 0x100000000ull)
 			throw std::runtime_error("launch_convp: too many blocks per call for the workgroup map (split the call)");
 	}
-	convp_prepare<LN, UL>(X, MODE != 1 && MODE != 18, convp_mode_sp(MODE), convp_mode_solo(MODE));
+	convp_prepare<LN, UL>(X, MODE != 1 && MODE != 18, convp_mode_sp(MODE), convp_mode_solo(MODE), convp_mode_p3(MODE));
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
 #ifdef R8B_DEV_ONLY_MODE
@@ -875,6 +875,14 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
 	}
+}
+
+// (the polyphase 3x form: 1:1 geometries of 1024 ... 4096 points)
+template<int LN, int UL>
+void launch_convp_p3(const ConvxLaunch& X, hipStream_t stream)
+{
+	if constexpr (UL == 0 && LN >= 10 && LN <= 12) launch_convp_t<LN, UL, 19, 24>(X, stream);
+	else throw std::runtime_error("launch_convp: polyphase 3x form on a geometry it is not built for");
 }
 
 // (the one-channel form decimating by 2: geometry <13, -1>)
@@ -1083,6 +1091,7 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 	if (ln == LN && up == (1 << UL)) \
 	{ \
 		if (mode == 0) launch_convp_t<LN, UL, 0, 24>(X, (hipStream_t) stream); \
+		else if (mode == 19) launch_convp_p3<LN, UL>(X, (hipStream_t) stream); \
 		else if (mode == 3) launch_convp_t<LN, UL, 3, 24>(X, (hipStream_t) stream); \
 		else if (mode == 6) launch_convp_t<LN, UL, 6, 24>(X, (hipStream_t) stream); \
 		else if (mode == 7) launch_convp_t<LN, UL, 7, 24>(X, (hipStream_t) stream); \

@@ -67,6 +67,39 @@ StagePlan make_stage_plan(const StageDesc& d, double prev_lat)
 			g.complex_h = !f.zero_phase || extra != 0;
 			s.lat_frac = lf / g.down;
 		}
+		if (!g.up_pow2 && g.up == 3 && g.down == 1)
+		{
+			// polyphase form of the 3x zero-stuffing convolver (ConvGeom::p3): reach of the three components into the
+			// future (a) and the past (b) of the input stream
+			auto fdiv = [](long long a, long long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+			int a3 = 0, b3 = 0;
+			for (int r = 0; r < 3; r++)
+			{
+				const long long dmin = -fdiv((long long) r + g.fl2, 3);                    // ceil((-r - fl2) / 3)
+				const long long dmax = fdiv((long long) f.kernel_len - 1 - r - g.fl2, 3);
+				if (dmax < dmin) continue;
+				a3 = std::max(a3, (int) std::max(-dmin, 0LL));
+				b3 = std::max(b3, (int) std::max(dmax, 0LL));
+			}
+			g.p3_a = a3;
+			g.p3_b = b3;
+			g.p3_off = -((3 - g.fl2 % 3) % 3);
+			// The window: the largest power of two whose block has its COMPLETE input when the reference owes the block's
+			// first output -- the reference answers in_len + fl2 virtual samples late (CDSPBlockConvolver.h:94-101), so a
+			// block may reach p3_m + p3_a input samples past its first output's position only while that stays below the
+			// latency --, at least half of it valid.
+			const int lat_in = (g.in_len + g.fl2) / 3;
+			for (int n = 4096; n >= 1024 && !g.p3; n /= 2)
+			{
+				const int m3 = (n - a3 - b3) & ~1;
+				if (g.fl2 >= 0 && m3 >= n / 2 && m3 + a3 + 2 <= lat_in)
+				{
+					g.p3 = true;
+					g.p3_n = n;
+					g.p3_m = m3;
+				}
+			}
+		}
 		g.latency = g.in_len + g.fl2; // reference: InputLen (after the divisibility adjustment) + latency
 		g.ref_bl2 = g.bl2; g.ref_in_len = g.in_len; g.ref_n_in = g.n_in; g.ref_n_out = g.n_out;
 		// transforms longer than 16384 points do not fit a workgroup's LDS: shorter blocks, same filter
@@ -232,7 +265,10 @@ int StagePlan::history() const
 		// (+ up to one interpolator filter length when the next stage is fused in and starts a
 		// little earlier than this stage's own next output)
 		// (re-blocked geometry: the outputs due still lag the input by the REFERENCE's latency)
-		return (std::max(cg.in_len, cg.ref_in_len + cg.fl2) + cg.bl2) / cg.up + 64;
+		// (polyphase 3x form, ConvGeom::p3: the next call's first block starts at most one block stride + the reference's
+		// latency before the stream's end and reaches p3_b further back)
+		return std::max((std::max(cg.in_len, cg.ref_in_len + cg.fl2) + cg.bl2) / cg.up,
+			cg.p3 ? (cg.ref_in_len + cg.fl2) / cg.up + cg.p3_m + cg.p3_b + 8 : 0) + 64;
 	case kFrac:
 		return 2 * flen + 4;
 	case kHBUp:

@@ -46,6 +46,21 @@ struct ConvGeom
 	bool complex_h = false;
 	bool up_pow2 = true;   // up-sampling by spectrum replication (else explicit zero stuffing)
 	bool down_pow2 = false; // decimation by spectrum truncation (else strided pick)
+	// 3x up-sampling WITHOUT transforming the stuffed zeros (round 5; r8b_convp.h mode 19, reference
+	// CDSPBlockConvolver.h:414-496 copyUpsample + :283-350): output 3 m + r of the stage is the r-th polyphase component
+	// of the filter applied to the INPUT stream, y[3 m + r] = sum_d x[m - d] g_r[d], g_r[d] = h[3 d + r + fl2], d in
+	// [-p3_a, p3_b]; a block is a window of p3_n input samples -- ONE forward transform, three backward ones -- with
+	// p3_m = p3_n - p3_a - p3_b valid outputs per component, block k holding stage outputs [k 3 p3_m + p3_off - fl2,
+	// + 3 p3_m), a multiple of 3 at its start.  p3: the form applies (3x, no decimation, the filter's components short
+	// enough for a window of 1024 ... 4096 points that the reference's latency covers to be at least half valid); the fields
+	// above keep describing the zero-stuffing
+	// block, which the engine falls back to (option up3_poly = 0).
+	bool p3 = false;
+	int p3_n = 0, p3_a = 0, p3_b = 0, p3_m = 0, p3_off = 0;
+	// (engine, Engine::eff_geom: the geometry above replaced by the polyphase block -- in_len = 3 p3_m, bl2 = 3 p3_n,
+	// n_in = n_out = p3_n -- and the offset of block 0's first fresh virtual sample)
+	bool poly3 = false;
+	int blk_off = 0;
 };
 
 // State of a CDSPFracInterpolator's non-whole-stepping position counter

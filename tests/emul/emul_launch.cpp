@@ -266,7 +266,7 @@ void emul_convp_t(const ConvxLaunch& X0)
 {
 	ConvxLaunch X = X0;
 	constexpr bool SOLO = convp_mode_solo(MODE);
-	convp_prepare<LN, UL>(X, MODE != 1 && MODE != 18, convp_mode_sp(MODE), SOLO);
+	convp_prepare<LN, UL>(X, MODE != 1 && MODE != 18, convp_mode_sp(MODE), SOLO, convp_mode_p3(MODE));
 	std::vector<double> lds((size_t) convp_lds_bytes<LN, UL>() / sizeof(double) + 2);
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
@@ -360,6 +360,13 @@ void emul_convp_sp(const ConvxLaunch& X, int mode)
 	}
 }
 
+template<int LN, int UL>
+void emul_convp_p3(const ConvxLaunch& X)
+{
+	if constexpr (UL == 0 && LN >= 10 && LN <= 12) emul_convp_t<LN, UL, 19, 24>(X);
+	else throw std::runtime_error("launch_convp: polyphase 3x form on a geometry it is not built for");
+}
+
 static long long g_walk_blocks = 0;
 long long launch_walk_blocks() { return g_walk_blocks; }
 void launch_walk_blocks_add(long long n) { g_walk_blocks += n; }
@@ -374,6 +381,7 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 	if (ln == LN && up == (1 << UL)) \
 	{ \
 		if (mode == 0) emul_convp_t<LN, UL, 0, 24>(X); \
+		else if (mode == 19) emul_convp_p3<LN, UL>(X); \
 		else if (mode == 3) emul_convp_t<LN, UL, 3, 24>(X); \
 		else if (mode == 6) emul_convp_t<LN, UL, 6, 24>(X); \
 		else if (mode == 7) emul_convp_t<LN, UL, 7, 24>(X); \

@@ -12,6 +12,17 @@ wide = len(sys.argv) > 3
 rng = np.random.default_rng(seed)
 # (R8B_FUZZ_TB=lo,hi narrows the transition band range, as in tools/wide_fuzz.py)
 TB = [float(v) for v in os.environ.get("R8B_FUZZ_TB", "0.5,45").split(",")]
+# (R8B_FUZZ_OPTS="walk=2 solo_fuse=0": engine options set on every object the fuzz creates -- e.g. the walk form forced
+# on the fuzz's three-channel batches, which the engine would not walk by itself)
+OPTS = [o.split("=") for o in os.environ.get("R8B_FUZZ_OPTS", "").split()]
+if OPTS:
+    _orig = T.r8b.BatchResampler
+    def _with_opts(*a, **kw):
+        b = _orig(*a, **kw)
+        for k, v in OPTS:
+            b.set_option(k, int(v))
+        return b
+    T.r8b.BatchResampler = _with_opts
 bad = 0; done = 0; skipped = 0; known = 0
 for case in [c for c in T._cases(3 * n, seed) if c[2] >= 300][:n]:
     if wide:
@@ -27,7 +38,7 @@ for case in [c for c in T._cases(3 * n, seed) if c[2] >= 300][:n]:
         # (the two known differences, as in tools/wide_fuzz.py: a one-tap half-band up-sampler's first odd output, where
         # the reference's own value is indeterminate; truncated 32768-point reference blocks within 1e-10)
         desc = T.r8b.BatchResampler(case[0], case[1], case[2], case[3], case[4], nch=1).describe()
-        a = e.args[0] if e.args and isinstance(e.args[0], tuple) and len(e.args[0]) == 3 else None
+        a = e.args[0] if e.args and isinstance(e.args[0], tuple) and len(e.args[0]) in (3, 4) else None
         if "taps=1 " in desc or ("fft=32768/" in desc and a is not None and a[1] <= 1e-10 and a[2] <= 5e-10):
             known += 1
         else:
