@@ -915,3 +915,85 @@ def test_emulated_walk_form_equals_one_block_form(emul, case, walk_len):
     walked, blocks = run_walk_form_case({"lib": emul}, case, walk_len)
     if case[6]:
         assert walked >= blocks // 3, (walked, blocks)   # (the long calls do walk: most of their blocks are interior ones)
+
+
+UP3_CASES = [(16000.0, 48000.0, 3000, 2.0, 180.15, 0), (16000.0, 48000.0, 16384, 2.0, 180.15, 0),
+             (8000.0, 48000.0, 2000, 2.0, 180.15, 0),     # ... in front of a half-band up-sampler (written ahead into its ring)
+             (32000.0, 96000.0, 4096, 1.0, 180.15, 0),    # 4253 taps
+             (44100.0, 132300.0, 2500, 3.0, 140.0, 0),    # a shorter filter: another window length
+             (16000.0, 48000.0, 3000, 2.0, 180.15, 1)]    # minimum phase: one-sided components of a causal filter
+
+
+def run_polyphase_up3_case(lib_kw, refwrap, case, nch=3):
+    """3x up-sampling convolvers in the polyphase form (r8b_convp.h mode 19: one forward transform of the INPUT samples,
+    three backward ones) against the zero-stuffing block (option up3_poly = 0): same counts per call, samples to
+    rounding (another block anchoring), ragged calls, odd channel count; linear phase also against the oracle"""
+    src, dst, maxin, tb, att, phase = case
+    objs = []
+    for v in (1, 0):
+        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, phase=phase, **lib_kw)
+        b.set_option("up3_poly", v)
+        objs.append(b)
+    x = make_input(nch, 45000, 41)
+    lens = [maxin, maxin // 3, 300, maxin, 17, 1, maxin - 5] * 30
+    pos, worst, n = 0, 0.0, 0
+    for l in lens:
+        if pos + l > x.shape[1]:
+            break
+        ya, yb = objs[0].process_host(x[:, pos:pos + l]), objs[1].process_host(x[:, pos:pos + l])
+        pos += l
+        assert ya.shape == yb.shape, (case, pos)
+        if ya.shape[1]:
+            worst = max(worst, float(np.abs(ya - yb).max()))
+            n += ya.shape[1]
+    assert n > 10000 and worst <= 1e-14, (case, n, worst)
+    # (more blocks of the shorter window for the same stream: the form is the one that ran)
+    assert objs[0].stat("conv_blocks") > objs[1].stat("conv_blocks"), case
+    if phase == 0:
+        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, **lib_kw)
+        r, p = compare_stream(b, src, dst, maxin, min(maxin, 1500), 30000, tb, att, 2)
+        assert r <= RMS_TOL and p <= PEAK_TOL, (case, r, p)
+
+
+@pytest.mark.parametrize("case", UP3_CASES)
+def test_emulated_polyphase_up3_equals_zero_stuffing(emul, refwrap, case):
+    run_polyphase_up3_case({"lib": emul}, refwrap, case)
+
+
+SOLO_FUSE_CASES = [(96000.0, 44100.0, 3000, 0.5), (96000.0, 44100.0, 16384, 0.5), (192000.0, 44100.0, 5000, 0.5),
+                   (96000.0, 44100.0, 8192, 0.6)]
+
+
+def run_solo_fused_case(lib_kw, case, nch=3):
+    """16384-point 1:1 blocks with the whole-step interpolator fused in (mode 18) against the two launches (option
+    solo_fuse = 0): same counts per call, samples to rounding; fused: ragged calls == whole calls bit for bit"""
+    src, dst, maxin, tb = case
+    x = make_input(nch, 70000, 43)
+
+    def run(fuse, lens):
+        b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=nch, **lib_kw)
+        b.set_option("solo_fuse", fuse)
+        b.set_option("timing", 1)
+        names = [t[0] for t in b.stage_timings()]
+        b.set_option("timing", 0)
+        pos, ys = 0, []
+        for l in lens:
+            if pos + l > x.shape[1]:
+                break
+            ys.append(b.process_host(x[:, pos:pos + l]))
+            pos += l
+        return np.concatenate(ys, axis=1), names
+
+    ragged = [maxin, maxin // 3, 300, maxin, 17, 1, maxin - 5] * 40
+    y1, n1 = run(1, ragged)
+    y0, n0 = run(0, ragged)
+    assert "k_convp_whole" in n1 and "k_convp_whole" not in n0, (n1, n0)
+    assert y1.shape == y0.shape and y1.shape[1] > 5000 and float(np.abs(y1 - y0).max()) <= 1e-14, (case, y1.shape)
+    y2, _ = run(1, [maxin] * 60)
+    n = min(y1.shape[1], y2.shape[1])
+    assert np.array_equal(y1[:, :n], y2[:, :n]), case
+
+
+@pytest.mark.parametrize("case", SOLO_FUSE_CASES)
+def test_emulated_one_channel_form_fused_with_the_interpolator(emul, case):
+    run_solo_fused_case({"lib": emul}, case)

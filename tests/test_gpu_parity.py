@@ -542,6 +542,20 @@ def test_hip_walk_form_equals_one_block_form(torch, case, walk_len):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", test_emul.UP3_CASES)
+def test_hip_polyphase_up3_equals_zero_stuffing(torch, refwrap, case):
+    """the GPU twin of test_emulated_polyphase_up3_equals_zero_stuffing"""
+    test_emul.run_polyphase_up3_case({"device": 0}, refwrap, case)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", test_emul.SOLO_FUSE_CASES)
+def test_hip_one_channel_form_fused_with_the_interpolator(torch, case):
+    """the GPU twin of test_emulated_one_channel_form_fused_with_the_interpolator"""
+    test_emul.run_solo_fused_case({"device": 0}, case)
+
+
+@pytest.mark.gpu
 def test_hip_walk_form_full_batch(torch):
     """BASELINE's cfg2 batch (1024 channels x 16384) with the engine's own choice (option walk = 1: by batch size) against
     a workgroup per block: every channel bit for bit, calls whose outputs start at even and at odd columns"""
