@@ -2384,7 +2384,7 @@ bool Engine::pcm_fused_in() const
 {
 	if (plan_.stages.empty()) return false;
 	const StagePlan& sp = plan_.stages[0];
-	return !(sp.desc.kind == kConv && conv_path(sp.cg) != kPathGeneric);
+	return !(sp.desc.kind == kConv && conv_path(eff_geom(0)) != kPathGeneric);
 }
 
 bool Engine::pcm_fused_out() const
@@ -2393,7 +2393,7 @@ bool Engine::pcm_fused_out() const
 	if (ns == 0) return false;
 	if (ns >= 2 && fuse_with_next(ns - 2)) return false; // (convolver + whole-step interpolator as one fast-path kernel)
 	const StagePlan& sp = plan_.stages[ns - 1];
-	return !(sp.desc.kind == kConv && conv_path(sp.cg) != kPathGeneric);
+	return !(sp.desc.kind == kConv && conv_path(eff_geom(ns - 1)) != kPathGeneric);
 }
 
 // The interpolator of a chain with a fractional latency emits sample j as sample q = j + out_skip of its stream, whose
