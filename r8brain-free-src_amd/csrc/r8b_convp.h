@@ -2473,9 +2473,12 @@ struct ConvpWalk
 };
 template<int LN, int UL, int MODE> constexpr bool convp_walk_ok()
 {
-	// (two phases per thread, one block pair per workgroup, the plain backward side, two lean twiddles per pass at most)
-	return (MODE == 4 || MODE == 5 || MODE == 16 || MODE == 17) && ConvpGeom<LN, UL>::SUB == 1 && !ConvpGeom<LN, UL>::POST &&
-		ConvpGeom<LN, UL>::NB2 == 1 && ConvpTwLds<LN, UL>::ON;
+	// (two phases per thread, one block pair per workgroup, the plain backward side, two lean twiddles per pass at most.
+	// UL >= 1: the 2x up-sampling convolver in front of the interpolator -- every up-sampling ratio's first stage.  The 1:1
+	// geometry <12, 0> qualifies by structure, but its walk body keeps 280 bytes per lane in scratch and no ratio of the
+	// rate table takes it: not instantiated)
+	return (MODE == 4 || MODE == 5 || MODE == 16 || MODE == 17) && UL >= 1 && ConvpGeom<LN, UL>::SUB == 1 &&
+		!ConvpGeom<LN, UL>::POST && ConvpGeom<LN, UL>::NB2 == 1 && ConvpTwLds<LN, UL>::ON;
 }
 
 

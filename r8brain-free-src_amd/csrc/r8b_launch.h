@@ -229,7 +229,13 @@ struct SpanInfo
 	int pad;
 };
 
-static const int kConvxMaxBlocks = 64; // blocks per fused launch (longer calls are split)
+#ifndef R8B_CONVX_MAX_BLOCKS
+#define R8B_CONVX_MAX_BLOCKS 104
+#endif
+// blocks per fused launch (longer calls are split).  104: the launch descriptor is a kernel argument, 672 + 32 x 104 =
+// 4000 of the 4096 bytes a launch can carry; 44100 -> 96000 at a 10 % transition band has 99 blocks per 16384-sample
+// call (0.253 -> 0.242 ms as one launch instead of two, profiles/r05_experiments.txt)
+static const int kConvxMaxBlocks = R8B_CONVX_MAX_BLOCKS;
 
 struct ConvxLaunch
 {
@@ -275,6 +281,7 @@ struct ConvxLaunch
 	double* park_dst;
 	SpanInfo park_blk;
 };
+static_assert(sizeof(ConvxLaunch) <= 4096, "ConvxLaunch is passed by value: 4096 bytes of kernel arguments");
 
 // geometries the fast path is instantiated for: (log2 of the forward complex length, up shift), and
 // for the 2x-decimating convolver (log2 of the forward complex length, down shift)
