@@ -10,9 +10,9 @@ r8b = importlib.import_module("r8brain-free-src_amd")
 src, dst, nch, L = 44100.0, 96000.0, 1024, 16384
 if len(sys.argv) > 2:
     src, dst = float(sys.argv[1]), float(sys.argv[2])
-# (BLOCK / TB in the environment: input samples per call, transition band)
+# (BLOCK / TB / ATTEN in the environment: input samples per call, transition band, stop-band attenuation)
 L = int(os.environ.get("BLOCK", L))
-rs = r8b.BatchResampler(src, dst, L, float(os.environ.get("TB", "2.0")), 180.15, nch=nch, device=0)
+rs = r8b.BatchResampler(src, dst, L, float(os.environ.get("TB", "2.0")), float(os.environ.get("ATTEN", "180.15")), nch=nch, device=0)
 x = torch.rand((nch, L), dtype=torch.float64, device="cuda:0") * 2 - 1
 out = torch.empty((nch, rs.max_out_len), dtype=torch.float64, device="cuda:0")
 for i in range(int(os.environ.get("NCALLS", "30"))):
