@@ -56,6 +56,12 @@
 #ifndef R8B_OUT_STORE16
 #define R8B_OUT_STORE16(ptr, v) { *reinterpret_cast<cd*>(ptr) = (v); }
 #endif
+// R8B_OUT_STORE16U: the same pair to an address that is only 8-byte aligned (a call whose outputs start at an odd column
+// of the caller's rows).  Device: ONE 16-byte store instruction -- global memory takes vector accesses at element
+// alignment --; host: two doubles.
+#ifndef R8B_OUT_STORE16U
+#define R8B_OUT_STORE16U(ptr, v) { (ptr)[0] = (v).re; (ptr)[1] = (v).im; }
+#endif
 
 namespace r8bhip {
 
@@ -1731,18 +1737,23 @@ R8B_HD void cp_solo_store_down(const ConvLaunch& L, const ConvpState<LN, UL>& st
 	const long long q0 = ((k * (long long) L.blk_stride + L.blk_offset) >> G::DL) - fl2;
 	auto run = [&](const CpStoreView& v)
 	{
-		const bool al = ((v.qoff + (unsigned) fl2) & 1u) == 0 && v.fmt == kPcmF64 && (v.m & 1u) != 0 &&
+		// (al: the pairs start at 16-byte aligned addresses; otherwise -- fp64 rows at an odd column -- still one store
+		// instruction per pair, R8B_OUT_STORE16U, unless the pair wraps around a ring's end)
+		const bool fp = v.fmt == kPcmF64;
+		const bool al = ((v.qoff + (unsigned) fl2) & 1u) == 0 && fp && (v.m & 1u) != 0 &&
 			(reinterpret_cast<unsigned long long>(v.pa) & 15ull) == 0;
 #pragma unroll
 		for (int p = 0; p < G::E2; p++)
 		{
 			const unsigned iE = (unsigned) ((2 * (lt + G::NT * p) + fl2) & mask), iO = (unsigned) ((iE + 1u) & mask);
-			if (al && iO == iE + 1 && iE - v.ulo < v.uhi - v.ulo && iO < v.uhi)
+			const unsigned e = (v.qoff + iE) & v.m;
+			if (fp && (al || e != v.m) && iO == iE + 1 && iE - v.ulo < v.uhi - v.ulo && iO < v.uhi)
 			{
 				cd va;
 				va.re = st.vr[p];
 				va.im = st.vi[p];
-				R8B_OUT_STORE16(v.pa + ((v.qoff + iE) & v.m), va);
+				if (al) { R8B_OUT_STORE16(v.pa + e, va); }
+				else { R8B_OUT_STORE16U(v.pa + e, va); }
 			}
 			else
 			{
@@ -1935,21 +1946,32 @@ R8B_HD void cp_sp_store(const ConvLaunch& L, const double* ea, const double* oa,
 		// of 16-byte aligned fp64 rows (the launch's property: the rotation leaves fl2r = 0 or 1, blocks start in_len --
 		// even -- apart); the two 8-byte stores otherwise.  (Separately they are two half-written 32-byte pieces per lane
 		// pair on the way to the L2s: measured 403 MB written for 268 MB of outputs.)
-		const bool al = ((v.qoff + (unsigned) L.fl2r) & 1u) == 0 && v.fmt == kPcmF64 && (v.m & 1u) != 0 &&
+		// (... and at an odd column of fp64 rows the pair is still one instruction, R8B_OUT_STORE16U, unless it wraps around a
+		// ring's end)
+		const bool fp = v.fmt == kPcmF64;
+		const bool al = ((v.qoff + (unsigned) L.fl2r) & 1u) == 0 && fp && (v.m & 1u) != 0 &&
 			((reinterpret_cast<unsigned long long>(v.pa) | reinterpret_cast<unsigned long long>(v.pb)) & 15ull) == 0;
 #pragma unroll
 		for (int i = 0; i < 16; i++)
 		{
 			const int c0 = 2 * (lt + G::NT * i);
 			const unsigned iE = (unsigned) ((c0 + L.fl2r) & mask), iO = (unsigned) ((c0 + 1 + L.fl2r) & mask);
-			if (al && iO == iE + 1 && iE - v.ulo < v.uhi - v.ulo && iO < v.uhi)
+			const unsigned e = (v.qoff + iE) & v.m;
+			if (fp && (al || e != v.m) && iO == iE + 1 && iE - v.ulo < v.uhi - v.ulo && iO < v.uhi)
 			{
-				const unsigned e = (v.qoff + iE) & v.m;
 				cd va, vb;
 				va.re = ea[i]; va.im = oa[i];
 				vb.re = eb[i]; vb.im = ob[i];
-				R8B_OUT_STORE16(v.pa + e, va);
-				if (bvalid) R8B_OUT_STORE16(v.pb + e, vb);
+				if (al)
+				{
+					R8B_OUT_STORE16(v.pa + e, va);
+					if (bvalid) R8B_OUT_STORE16(v.pb + e, vb);
+				}
+				else
+				{
+					R8B_OUT_STORE16U(v.pa + e, va);
+					if (bvalid) R8B_OUT_STORE16U(v.pb + e, vb);
+				}
 			}
 			else
 			{
@@ -2161,10 +2183,15 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 	double* const pb0 = wd.p + ((long long) chB * wd.stride + (jg0 + wd.off));
 	double* const pa = pa0 + 2 * q;
 	double* const pb = pb0 + 2 * q;
-	const bool pair16 = (((size_t) pa0 | (size_t) pb0) & 15) == 0 && (out_step & 1) == 0;
+	// (pairu: a thread's two outputs are neighbours in the row in every group -- an even number of phases; pair16: and the
+	// pairs start at 16-byte aligned addresses.  Without the latter -- a call whose outputs start at an odd column of the
+	// caller's rows -- the pair is still ONE store instruction: R8B_OUT_STORE16U.  As two 8-byte stores the odd calls of a
+	// column-0 caller cost 4.4 % more than the even ones: tools/placement_probe.py, profiles/r05_experiments.txt.)
+	const bool pairu = (out_step & 1) == 0;
+	const bool pair16 = (((size_t) pa0 | (size_t) pb0) & 15) == 0 && pairu;
 	constexpr int CH = T2 == 25 ? 5 : 3, NCH = T2 / CH;
 	static_assert(CH * NCH == T2, "chunks");
-	if (ALIGNED_ONLY || (lo_mod == 0 && hi_mod == out_step && linear && pair16))
+	if (ALIGNED_ONLY || (lo_mod == 0 && hi_mod == out_step && linear && pairu))
 	{
 		// Whole groups only (every block of a call but those cut by its ends, when the blocks are aligned to
 		// groups -- Engine::launch_fused): nothing to mask, every output pair is one 16-byte store.
@@ -2210,21 +2237,16 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 			va.im = a1[0] + a1[1];
 			vb.re = b0[0] + b0[1];
 			vb.im = b1[0] + b1[1];
-			if (!ALIGNED_ONLY || pair16)
+			if (pair16)
 			{
 				R8B_OUT_STORE16(pa0 + o, va);
 				if (bvalid) R8B_OUT_STORE16(pb0 + o, vb);
 			}
 			else
 			{
-				// (walk form in a call whose outputs start at an odd column of the rows: the same values, 8 bytes at a time)
-				pa0[o] = va.re;
-				pa0[o + 1] = va.im;
-				if (bvalid)
-				{
-					pb0[o] = vb.re;
-					pb0[o + 1] = vb.im;
-				}
+				// (a call whose outputs start at an odd column of the rows: the same values, the same single instruction)
+				R8B_OUT_STORE16U(pa0 + o, va);
+				if (bvalid) R8B_OUT_STORE16U(pb0 + o, vb);
 			}
 		}
 		return;
@@ -2268,15 +2290,23 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 			// channel as one 16-byte store when the pair is aligned (the same for every thread: pairs
 			// start at even output indices of a group)
 			const int o = out_step * gl;
-			if (v0 && v1 && pair16)
+			if (v0 && v1 && pairu)
 			{
 				cd va, vb;
 				va.re = a0[0] + a0[1];
 				va.im = a1[0] + a1[1];
 				vb.re = b0[0] + b0[1];
 				vb.im = b1[0] + b1[1];
-				R8B_OUT_STORE16(pa + o, va);
-				if (bvalid) R8B_OUT_STORE16(pb + o, vb);
+				if (pair16)
+				{
+					R8B_OUT_STORE16(pa + o, va);
+					if (bvalid) R8B_OUT_STORE16(pb + o, vb);
+				}
+				else
+				{
+					R8B_OUT_STORE16U(pa + o, va);
+					if (bvalid) R8B_OUT_STORE16U(pb + o, vb);
+				}
 				continue;
 			}
 			if (v0)
@@ -2403,6 +2433,8 @@ R8B_HD void cp_p3_product(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt, i
 // Only the thread's first kP3Keep positions wait: a block's valid positions are i < in_len / 3 <= N - (the components'
 // reach), i.e. 10.5 of a thread's 16 for the 24-bit filter at 2 % -- the ones beyond 11 (short filters in a long window)
 // leave component by component (cp_p3_store_rest), and 40 registers are not held for values that are mostly never stored.
+// (The first two of the three as one 16-byte store at element alignment -- R8B_OUT_STORE16U -- measured slower: 0.251
+// against 0.227 ms; a wave's three 8-byte stores cover its 1.5 KB evenly, a 16- and an 8-byte one do not.)
 static const int kP3Keep = 11;
 template<int LN, int UL>
 R8B_HD void cp_p3_store(const ConvLaunch& L, const ConvpState<LN, UL>& st, long long k, int chA, int chB, bool bvalid,

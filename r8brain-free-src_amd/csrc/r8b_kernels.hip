@@ -112,6 +112,10 @@ typedef double r8b_d2_t __attribute__((ext_vector_type(2)));
 #define R8B_OUT_STORE16(ptr, v) { r8b_d2_t t_; t_.x = (v).re; t_.y = (v).im; \
 	__builtin_nontemporal_store(t_, reinterpret_cast<r8b_d2_t*>(ptr)); }
 #endif
+#ifndef R8B_NO_STORE16U
+struct __attribute__((aligned(8))) r8b_cd8_t { double re, im; };
+#define R8B_OUT_STORE16U(ptr, v) { r8b_cd8_t t_; t_.re = (v).re; t_.im = (v).im; *reinterpret_cast<r8b_cd8_t*>(ptr) = t_; }
+#endif
 // nothing is scheduled across this point (no instruction is emitted)
 #ifndef R8B_NO_SCHED_FENCE
 #define R8B_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)

@@ -997,3 +997,54 @@ def run_solo_fused_case(lib_kw, case, nch=3):
 @pytest.mark.parametrize("case", SOLO_FUSE_CASES)
 def test_emulated_one_channel_form_fused_with_the_interpolator(emul, case):
     run_solo_fused_case({"lib": emul}, case)
+
+
+# (src, dst, MaxInLen, transition band, attenuation, phase): a chain per form that stores output PAIRS -- the fused
+# two-phase pair form (even and odd phase counts), the walk form, the split 2x and the decimating one-channel forms, the
+# polyphase 3x form -- and neighbours that do not (one-channel form with the interpolator, half-band cascade)
+COLUMN_CASES = [(44100.0, 96000.0, 6000, 2.0, 180.15, 0), (44100.0, 96000.0, 16384, 2.0, 180.15, 0),
+                (96000.0, 44100.0, 6000, 2.0, 180.15, 0), (44100.0, 88200.0, 9000, 0.5, 180.15, 0),
+                (88200.0, 44100.0, 12000, 0.5, 180.15, 0), (16000.0, 48000.0, 6000, 2.0, 180.15, 0),
+                (96000.0, 44100.0, 9000, 0.5, 180.15, 0), (44100.0, 176400.0, 3000, 2.0, 180.15, 0),
+                (44100.0, 96000.0, 6000, 2.0, 180.15, 1)]
+
+
+def run_output_columns_case(lib_kw, case, device_buffers, nch=3):
+    """Every call's outputs at column 4 + c, c = 0 ... 3, of rows filled with NaN: the same values as a column-0 caller
+    gets, bit for bit (a pair of outputs at an odd column is ONE 16-byte store at element alignment -- R8B_OUT_STORE16U,
+    r8b_convp.h -- instead of two 8-byte ones), and not a byte outside the call's n outputs.  device_buffers(x, rows,
+    cols) -> (input pointer, input row stride, output buffer object, its pointer, read-back function)."""
+    src, dst, maxin, tb, att, phase = case
+
+    def mk():
+        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, phase=phase, **lib_kw)
+        b.set_option("walk", 2)
+        return b
+
+    ref, objs = mk(), [mk() for _ in range(4)]
+    cap = ref.max_out_len
+    pitch = cap + 16
+    x = make_input(nch, 6 * maxin, 23)
+    pos = 0
+    for l in [maxin, maxin // 3, maxin, 301, maxin - 5, maxin]:
+        xa = np.ascontiguousarray(x[:, pos:pos + l])
+        pos += l
+        yref = ref.process_host(xa)
+        for c, o in enumerate(objs):
+            col = 4 + c
+            ip, istride, obuf, op, back = device_buffers(xa, nch, pitch)
+            n = o.process_ptr(ip, istride, l, op + 8 * col, pitch)
+            got = back(obuf)
+            assert n == yref.shape[1], (case, l, c)
+            assert np.array_equal(got[:, col:col + n], yref), (case, l, c)
+            assert np.isnan(got[:, :col]).all() and np.isnan(got[:, col + n:]).all(), (case, l, c)
+
+
+def _host_buffers(xa, rows, cols):
+    obuf = np.full((rows, cols), np.nan)
+    return xa.ctypes.data, xa.shape[1], obuf, obuf.ctypes.data, lambda b: b
+
+
+@pytest.mark.parametrize("case", COLUMN_CASES)
+def test_emulated_output_columns_are_bitwise_alike(emul, case):
+    run_output_columns_case({"lib": emul}, case, _host_buffers)

@@ -708,3 +708,22 @@ def test_cxx_batch_sharded(torch, tmp_path):
                     "-L" + libdir, "-lr8bsrc_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
     out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), (out.returncode, out.stdout)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", test_emul.COLUMN_CASES)
+def test_hip_output_columns_are_bitwise_alike(torch, case):
+    """the GPU twin of test_emulated_output_columns_are_bitwise_alike: here the odd columns take the 16-byte store at
+    element alignment (one global_store_dwordx4 at an address that is 8 mod 16)"""
+    def device_buffers(xa, rows, cols):
+        xin = torch.from_numpy(xa).to("cuda:0")
+        obuf = torch.full((rows, cols), float("nan"), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        keep.append(xin)
+
+        def back(b):
+            torch.cuda.synchronize()
+            return b.cpu().numpy()
+        return xin.data_ptr(), xin.stride(0), obuf, obuf.data_ptr(), back
+    keep = []
+    test_emul.run_output_columns_case({"device": 0}, case, device_buffers)
