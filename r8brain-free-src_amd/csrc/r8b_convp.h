@@ -2183,15 +2183,17 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 	double* const pb0 = wd.p + ((long long) chB * wd.stride + (jg0 + wd.off));
 	double* const pa = pa0 + 2 * q;
 	double* const pb = pb0 + 2 * q;
-	// (pairu: a thread's two outputs are neighbours in the row in every group -- an even number of phases; pair16: and the
-	// pairs start at 16-byte aligned addresses.  Without the latter -- a call whose outputs start at an odd column of the
-	// caller's rows -- the pair is still ONE store instruction: R8B_OUT_STORE16U.  As two 8-byte stores the odd calls of a
+	// (A thread's two outputs are neighbours in the row; pair16: the pairs of every group start at 16-byte aligned
+	// addresses.  Without that -- a call whose outputs start at an odd column of the caller's rows, or an odd number of
+	// phases -- the pair is still ONE store instruction: R8B_OUT_STORE16U.  As two 8-byte stores the odd calls of a
 	// column-0 caller cost 4.4 % more than the even ones: tools/placement_probe.py, profiles/r05_experiments.txt.)
-	const bool pairu = (out_step & 1) == 0;
-	const bool pair16 = (((size_t) pa0 | (size_t) pb0) & 15) == 0 && pairu;
+	// (An odd number of phases -- cfg3's 147: the thread's two outputs are neighbours all the same, at an alignment that
+	// alternates from group to group, and only the LAST pair has no second phase: p1ok.)
+	const bool p1ok = 2 * q + 1 < out_step;
+	const bool pair16 = (((size_t) pa0 | (size_t) pb0) & 15) == 0 && (out_step & 1) == 0;
 	constexpr int CH = T2 == 25 ? 5 : 3, NCH = T2 / CH;
 	static_assert(CH * NCH == T2, "chunks");
-	if (ALIGNED_ONLY || (lo_mod == 0 && hi_mod == out_step && linear && pairu))
+	if (ALIGNED_ONLY || (lo_mod == 0 && hi_mod == out_step && linear))
 	{
 		// Whole groups only (every block of a call but those cut by its ends, when the blocks are aligned to
 		// groups -- Engine::launch_fused): nothing to mask, every output pair is one 16-byte store.
@@ -2242,11 +2244,17 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 				R8B_OUT_STORE16(pa0 + o, va);
 				if (bvalid) R8B_OUT_STORE16(pb0 + o, vb);
 			}
-			else
+			else if (ALIGNED_ONLY || p1ok)
 			{
 				// (a call whose outputs start at an odd column of the rows: the same values, the same single instruction)
 				R8B_OUT_STORE16U(pa0 + o, va);
 				if (bvalid) R8B_OUT_STORE16U(pb0 + o, vb);
+			}
+			else
+			{
+				// (the last phase of an odd number of them)
+				pa0[o] = va.re;
+				if (bvalid) pb0[o] = vb.re;
 			}
 		}
 		return;
@@ -2290,7 +2298,7 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 			// channel as one 16-byte store when the pair is aligned (the same for every thread: pairs
 			// start at even output indices of a group)
 			const int o = out_step * gl;
-			if (v0 && v1 && pairu)
+			if (v0 && v1)
 			{
 				cd va, vb;
 				va.re = a0[0] + a0[1];
