@@ -1737,23 +1737,18 @@ R8B_HD void cp_solo_store_down(const ConvLaunch& L, const ConvpState<LN, UL>& st
 	const long long q0 = ((k * (long long) L.blk_stride + L.blk_offset) >> G::DL) - fl2;
 	auto run = [&](const CpStoreView& v)
 	{
-		// (al: the pairs start at 16-byte aligned addresses; otherwise -- fp64 rows at an odd column -- still one store
-		// instruction per pair, R8B_OUT_STORE16U, unless the pair wraps around a ring's end)
-		const bool fp = v.fmt == kPcmF64;
-		const bool al = ((v.qoff + (unsigned) fl2) & 1u) == 0 && fp && (v.m & 1u) != 0 &&
+		const bool al = ((v.qoff + (unsigned) fl2) & 1u) == 0 && v.fmt == kPcmF64 && (v.m & 1u) != 0 &&
 			(reinterpret_cast<unsigned long long>(v.pa) & 15ull) == 0;
 #pragma unroll
 		for (int p = 0; p < G::E2; p++)
 		{
 			const unsigned iE = (unsigned) ((2 * (lt + G::NT * p) + fl2) & mask), iO = (unsigned) ((iE + 1u) & mask);
-			const unsigned e = (v.qoff + iE) & v.m;
-			if (fp && (al || e != v.m) && iO == iE + 1 && iE - v.ulo < v.uhi - v.ulo && iO < v.uhi)
+			if (al && iO == iE + 1 && iE - v.ulo < v.uhi - v.ulo && iO < v.uhi)
 			{
 				cd va;
 				va.re = st.vr[p];
 				va.im = st.vi[p];
-				if (al) { R8B_OUT_STORE16(v.pa + e, va); }
-				else { R8B_OUT_STORE16U(v.pa + e, va); }
+				R8B_OUT_STORE16(v.pa + ((v.qoff + iE) & v.m), va);
 			}
 			else
 			{
@@ -1946,32 +1941,21 @@ R8B_HD void cp_sp_store(const ConvLaunch& L, const double* ea, const double* oa,
 		// of 16-byte aligned fp64 rows (the launch's property: the rotation leaves fl2r = 0 or 1, blocks start in_len --
 		// even -- apart); the two 8-byte stores otherwise.  (Separately they are two half-written 32-byte pieces per lane
 		// pair on the way to the L2s: measured 403 MB written for 268 MB of outputs.)
-		// (... and at an odd column of fp64 rows the pair is still one instruction, R8B_OUT_STORE16U, unless it wraps around a
-		// ring's end)
-		const bool fp = v.fmt == kPcmF64;
-		const bool al = ((v.qoff + (unsigned) L.fl2r) & 1u) == 0 && fp && (v.m & 1u) != 0 &&
+		const bool al = ((v.qoff + (unsigned) L.fl2r) & 1u) == 0 && v.fmt == kPcmF64 && (v.m & 1u) != 0 &&
 			((reinterpret_cast<unsigned long long>(v.pa) | reinterpret_cast<unsigned long long>(v.pb)) & 15ull) == 0;
 #pragma unroll
 		for (int i = 0; i < 16; i++)
 		{
 			const int c0 = 2 * (lt + G::NT * i);
 			const unsigned iE = (unsigned) ((c0 + L.fl2r) & mask), iO = (unsigned) ((c0 + 1 + L.fl2r) & mask);
-			const unsigned e = (v.qoff + iE) & v.m;
-			if (fp && (al || e != v.m) && iO == iE + 1 && iE - v.ulo < v.uhi - v.ulo && iO < v.uhi)
+			if (al && iO == iE + 1 && iE - v.ulo < v.uhi - v.ulo && iO < v.uhi)
 			{
+				const unsigned e = (v.qoff + iE) & v.m;
 				cd va, vb;
 				va.re = ea[i]; va.im = oa[i];
 				vb.re = eb[i]; vb.im = ob[i];
-				if (al)
-				{
-					R8B_OUT_STORE16(v.pa + e, va);
-					if (bvalid) R8B_OUT_STORE16(v.pb + e, vb);
-				}
-				else
-				{
-					R8B_OUT_STORE16U(v.pa + e, va);
-					if (bvalid) R8B_OUT_STORE16U(v.pb + e, vb);
-				}
+				R8B_OUT_STORE16(v.pa + e, va);
+				if (bvalid) R8B_OUT_STORE16(v.pb + e, vb);
 			}
 			else
 			{

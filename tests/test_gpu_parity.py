@@ -481,7 +481,9 @@ def test_bench_contract(tmp_path):
     # exactly the ratio of the windows' step times, and the twin never exceeds what the value window's own step time
     # allows for the kernel's algorithmic bytes
     assert abs(r["frac_value_window"] - r["frac"] * d["settled"]["ms_per_step"] / d["ms_per_step"]) < 1e-3
-    if r["launches"] == d["steps"]:
+    # (... checked where the two windows ran at one clock: with 2 + 5 calls the value window can lie BEFORE the power
+    # controller's dip and the settled one inside it, and the event pass in neither)
+    if r["launches"] == d["steps"] and abs(d["settled"]["ms_per_step"] / d["ms_per_step"] - 1.0) < 0.05:
         assert r["frac_value_window"] <= r["alg_bytes_per_launch"] / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0 * 1.15 + 1e-3
     assert r["launch_gap_ms_per_step"] is None or 0.0 <= r["launch_gap_ms_per_step"] < d["settled"]["ms_per_step"]
 
