@@ -1208,6 +1208,11 @@ R8B_HD void hbc_point(const double (&f)[TP], LdsWin x, double& ev, double& od, d
 
 // (kz: the stage's outputs below kz do not exist for the next stage -- 0, or the stage's out_skip in a chain with a
 // fractional latency --: they are stored as zeros)
+#ifndef R8B_HBC_SLACK
+#define R8B_HBC_SLACK 1 // (0: the edge inputs of every stage through the general loop, as before -- development A/B)
+#endif
+// elements the cascade's LDS buffers keep free in front of their first stream element (and as many behind the last)
+static const int kHbcSlack = 2;
 template<int TP, bool LAST>
 R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, const double (&taps)[14], const double* xin, long long in_lo,
 	long long lo, long long hi, double* yout, int ch, int tid, int nthr, int kz)
@@ -1239,7 +1244,15 @@ R8B_HD void hbc_stage_t(const HBCascadeLaunch& L, const double (&taps)[14], cons
 	const int mode = !LAST ? 0 : (!linear ? -1 : L.pair_ok);
 	if (ineg == 0 && mode >= 0)
 	{
-		if (mode == 2)
+		if (!LAST && R8B_HBC_SLACK)
+		{
+			// (a stage that feeds the next one through LDS: EVERY input is interior -- the two outputs that fall just outside
+			// [lo, hi) land in the slack element in front of / behind the stream's buffer (kHbcSlack, k_hbcascade) and nobody
+			// reads them.  The general loop below was a second, dependent LDS round trip per stage for two inputs.)
+			ia = 0;
+			ib = cnt;
+		}
+		else if (mode == 2)
 		{
 			// the pair (odd output of i, even output of i + 1) ends inside the tile; input 0 also owns the
 			// tile's first even output: general loop

@@ -335,8 +335,9 @@ __global__ __launch_bounds__(256) void k_hbcascade(const HBCascadeLaunch L)
 	extern __shared__ __align__(16) unsigned char smem[];
 	// two buffers, alternating; the last stage's input (tile/2 samples) lands in the big one, so
 	// the other never holds more than tile/4
-	double* const big = reinterpret_cast<double*>(smem);
-	double* const small = big + L.buf;
+	// (kHbcSlack free elements in front of each and behind the second: hbc_stage_t)
+	double* const big = reinterpret_cast<double*>(smem) + kHbcSlack;
+	double* const small = big + L.buf + kHbcSlack;
 	const int tid = threadIdx.x, nthr = blockDim.x;
 	const int ch = blockIdx.y;
 	const long long q0 = L.a + (long long) blockIdx.x * L.tile;
@@ -1190,7 +1191,7 @@ void R8B_LAUNCH(launch_hbcascade)(const HBCascadeLaunch& L, void* stream)
 	if (n <= 0) return;
 	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
 	hipLaunchKernelGGL(k_hbcascade, dim3(tiles, (unsigned) L.nch), dim3(256),
-		(size_t) (L.buf + L.buf2) * sizeof(double), (hipStream_t) stream, L);
+		(size_t) (L.buf + L.buf2 + 3 * kHbcSlack) * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_hbcascade");
 }
 

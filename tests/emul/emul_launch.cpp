@@ -476,7 +476,7 @@ void launch_convx(const ConvxLaunch& X, int mode, void*)
 void launch_hbcascade(const HBCascadeLaunch& L, void*)
 {
 	const int nthr = 256;
-	std::vector<double> lds((size_t) (L.buf + L.buf2));
+	std::vector<double> lds((size_t) (L.buf + L.buf2 + 3 * kHbcSlack));
 	const long long n = L.b - L.a;
 	if (n <= 0) return;
 	const int tiles = (int) ((n + L.tile - 1) / L.tile);
@@ -490,8 +490,8 @@ void launch_hbcascade(const HBCascadeLaunch& L, void*)
 			HBCRanges R;
 			hbc_ranges(L, q0, q1, R);
 			// big / small buffer as in k_hbcascade; every stream must fit the one it lands in
-			double* const big = lds.data();
-			double* const small = big + L.buf;
+			double* const big = lds.data() + kHbcSlack;
+			double* const small = big + L.buf + kHbcSlack;
 			double* xin = ((L.nst - 1) & 1) ? small : big;
 			double* yout = ((L.nst - 1) & 1) ? big : small;
 			if (R.in_hi - R.in_lo > (xin == big ? L.buf : L.buf2))

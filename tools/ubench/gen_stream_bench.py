@@ -74,7 +74,7 @@ int main()
 		{
 			L.tile = tile; L.buf = tile / 2 + 96; L.buf2 = tile / 4 + 96;
 			const unsigned tiles = (unsigned) ((L.b - L.a + tile - 1) / tile);
-			const size_t lds = (size_t) (L.buf + L.buf2) * sizeof(double);
+			const size_t lds = (size_t) (L.buf + L.buf2 + 3 * kHbcSlack) * sizeof(double);
 			CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_hbcascade), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 			const float ms = time_ms([&] { hipLaunchKernelGGL(k_hbcascade, dim3(tiles, nch), dim3(256), lds, 0, L); }, 50);
 			CK(hipGetLastError());
@@ -91,7 +91,7 @@ int main()
 			M.src.cur_stride = in_per * calls; // (x holds 6144 samples per channel: only the first tiles' spans are real; timing only)
 			M.tile = 8192; M.buf = M.tile / 2 + 96; M.buf2 = M.tile / 4 + 96;
 			const unsigned tiles = (unsigned) ((M.b - M.a + M.tile - 1) / M.tile);
-			const size_t lds = (size_t) (M.buf + M.buf2) * sizeof(double);
+			const size_t lds = (size_t) (M.buf + M.buf2 + 3 * kHbcSlack) * sizeof(double);
 			const float ms = time_ms([&] { hipLaunchKernelGGL(k_hbcascade, dim3(tiles, nch), dim3(256), lds, 0, M); }, 50);
 			CK(hipGetLastError());
 			printf("k_hbcascade %d stages, tile 8192: %.4f ms  %.2f TB/s\n", nst, ms, 8.0 * nch * (out_per + (out_per >> nst)) / ms * 1e-9);
@@ -101,7 +101,7 @@ int main()
 		for (int tile : { 1024, 2048, 4096, 8192 })
 		{
 			L.tile = tile; L.buf = L.tile / 2 + 96; L.buf2 = L.tile / 4 + 96;
-			const size_t lds = (size_t) (L.buf + L.buf2) * sizeof(double);
+			const size_t lds = (size_t) (L.buf + L.buf2 + 3 * kHbcSlack) * sizeof(double);
 			const float ms = time_ms([&] { hipLaunchKernelGGL(k_hbcascade, dim3(32768 / tile, 64), dim3(256), lds, 0, L); }, 200);
 			CK(hipGetLastError());
 			printf("k_hbcascade 64 ch x 32768, tile %d: %.4f ms\n", tile, ms);
