@@ -1,8 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: batched 44100->96000 fp64 resampling on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W            (N = 1)
+  python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Started WITHOUT a launcher (no WORLD_SIZE in the environment) and with --gpus N > 1 the script starts its own N ranks --
+it re-executes itself through `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port <free port>` --, forwards rank 0's ONE JSON line and exits non-zero if any rank failed; started by
+torch.distributed.run (the driver's multi-GPU shape) it is a rank.
 
 A "step" is one process() call of the whole hot path (r8b::CDSPResampler::process semantics) over
 one batch of synthetic input: 1024 channels x 16384 samples per GPU (BASELINE.json configs[1];
@@ -193,6 +198,34 @@ def cpu_baseline(src, dst, L, gpu_sample=None, budget_s=24.0):
                       "(oracle/_ref not present)" % L}
 
 
+def spawn_ranks(n):
+    """--gpus N > 1 without a launcher: run this very command line as N ranks of one node under
+    torch.distributed.run (RCCL rendezvous on 127.0.0.1, a free port), pass rank 0's JSON line through, return the
+    launcher's exit status (non-zero when any rank failed)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL across processes needs it on these hosts)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    other = [ln for ln in r.stdout.splitlines() if ln not in lines]
+    if other:
+        sys.stderr.write("\n".join(other) + "\n")
+    if r.returncode == 0 and len(lines) != 1:
+        sys.stderr.write("bench.py: %d JSON lines from %d ranks (expected one, from rank 0)\n" % (len(lines), n))
+        return 1
+    for ln in lines:
+        print(ln, flush=True)
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,6 +267,14 @@ def main():
     ap.add_argument("--pcm", choices=["s16", "s24", "s32", "f32"], default=None,
                     help="side measurement: interleaved PCM in/out through the ingest/egress "
                          "kernels (r8b_batch_process_pcm) instead of planar fp64; not the headline")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the barrier / MAX-over-ranks.  nccl (= RCCL; default): the "
+                         "product on GPUs.  gloo: the CPU tier's side door -- needs --lib with a library that exports "
+                         "the same C ABI over HOST memory (tests/emul: the engine's schedule over a host emulation of "
+                         "the kernels); tensors stay on the CPU, there is no HIP-event pass and no CPU-baseline leg.  "
+                         "It exists so that the N-rank control flow of this script runs where there is no GPU "
+                         "(tests/test_dist.py); its numbers mean nothing")
+    ap.add_argument("--lib", default=None, help="with --backend gloo: the library to bind instead of the HIP one")
     ap.add_argument("--planar", action="store_true",
                     help="with --pcm: planar [channel][frame] buffers, decoded/encoded inside the "
                          "first/last stage kernels")
@@ -245,6 +286,20 @@ def main():
     cfg_name = args.config or ("cfg2" if (args.src, args.dst, args.block, args.channels, args.tb, args.atten) ==
                                (44100.0, 96000.0, 16384, 1024, 2.0, 180.15) else "custom")
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not started by a launcher: start the N ranks ourselves (the driver's `python3 bench.py --gpus N` shape)
+        sys.exit(spawn_ranks(args.gpus))
+    host_side = args.backend == "gloo"
+    if host_side and not args.lib:
+        raise SystemExit("--backend gloo is the CPU tier's side door and needs --lib (an emulation library); the "
+                         "product has no CPU path")
+    if args.lib and not host_side:
+        raise SystemExit("--lib goes with --backend gloo only (kernel variants of the HIP library: R8B_HIP_LIB)")
+    if host_side and (args.pcm or args.e2e):
+        raise SystemExit("--backend gloo: fp64 rows only")
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -253,21 +308,37 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE %d (launch with torch.distributed.run)" %
+        raise SystemExit("--gpus %d but WORLD_SIZE %d (the launcher's --nproc-per-node must equal --gpus)" %
                          (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
     r8b = importlib.import_module("r8brain-free-src_amd")
+    if host_side:
+        dev = torch.device("cpu")
+        lib = r8b.bind(args.lib)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU path)"
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("rank %d: --gpus %d but this node shows %d GPU(s)" %
+                             (rank, args.gpus, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        lib = None
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=dev)
+
+    def dev_sync():
+        if not host_side:
+            torch.cuda.synchronize()
+
     # weak scaling: --channels per GPU; the global batch is channels*world, rank r owns
     # channel_shard(channels*world, r, world)
     lo, hi = channel_shard(args.channels * world, rank, world)
     C, L = hi - lo, args.block
-    rs = r8b.BatchResampler(args.src, args.dst, L, args.tb, args.atten, nch=C, device=local_rank, phase=args.phase)
+    rs = r8b.BatchResampler(args.src, args.dst, L, args.tb, args.atten, nch=C, device=-1 if host_side else local_rank,
+                            phase=args.phase, lib=lib)
     for o in args.opt:
         k, v = o.split("=")
         rs.set_option(k, int(v))
@@ -279,8 +350,9 @@ def main():
     host_x = np.stack([splitmix_uniform(1 + lo + c, L * nbuf) for c in range(C)])
     xin = [torch.from_numpy(np.ascontiguousarray(host_x[:, i * L:(i + 1) * L])).to(dev)
            for i in range(nbuf)]
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
+    if args.pcm:
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
     # (output rows on a 64-byte pitch: the interpolator stores pairs of outputs as 16 bytes when both rows of a
     # channel pair are 16-byte aligned; max_out_len itself is odd for this conversion)
     # ... and the caller -- this script -- places a call's outputs at column (outputs produced so far) mod 8 of those
@@ -298,10 +370,17 @@ def main():
         return outs_full[i % 2][:, off:off + rs.max_out_len]
 
     def barrier():
-        torch.cuda.synchronize()
+        dev_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        dev_sync()
+
+    def process(x, out):
+        if not host_side:
+            return rs.process(x, out=out)
+        # (the side door: the same entry point, r8b_batch_process, over host memory)
+        n = rs.process_ptr(x.data_ptr(), x.stride(0), x.shape[1], out.data_ptr(), out.stride(0), 0)
+        return out[:, :n]
 
     if args.pcm:
         fmt = {"s16": r8b.PCM_S16, "s24": r8b.PCM_S24, "s32": r8b.PCM_S32, "f32": r8b.PCM_F32}[args.pcm]
@@ -327,7 +406,7 @@ def main():
                 n_out += rs.process_pcm(pin[i % nbuf], out_format=fmt, out=pouts[i % 2],
                                         planar=args.planar).shape[1 if args.planar else 0]
             else:
-                y = rs.process(xin[i % nbuf], out=out_view(i))
+                y = process(xin[i % nbuf], out_view(i))
                 produced[0] += y.shape[1]
                 n_out += y.shape[1]
                 if capture and i < nbuf:
@@ -383,7 +462,7 @@ def main():
                 "out_msamples_per_s": round(n * C * world / d / 1e6, 3), "what": what}
 
     # THE measurement: W untimed warm-up calls, then exactly K timed steps, barrier + synchronize on both sides
-    run(0, args.warmup, capture=not args.pcm and not args.no_cpu and world == 1 and args.phase == 0)
+    run(0, args.warmup, capture=not args.pcm and not args.no_cpu and world == 1 and args.phase == 0 and not host_side)
     n_out, dt = timed(args.warmup)
     calls = args.warmup + args.steps
     settled = other = None
@@ -411,12 +490,13 @@ def main():
     # second pass, same steps, with per-kernel HIP events (kept out of the headline timing); its own wall time is taken
     # too: wall time per step minus the kernels' time per step = what a step spends BETWEEN kernels (launch gaps)
     rs.set_option("timing", 1)
-    torch.cuda.synchronize()
+    dev_sync()
     t_ev0 = time.perf_counter()
     run(calls, args.steps)
-    torch.cuda.synchronize()
+    dev_sync()
     ev_wall_ms = (time.perf_counter() - t_ev0) / args.steps * 1e3
     timings = rs.stage_timings()
+    symbols = rs.stage_symbols()
     rs.set_option("timing", 0)
 
     if rank == 0:
@@ -429,11 +509,15 @@ def main():
         tmax = max(t[1] for t in timings)
         dom = max((i for i in range(len(timings)) if timings[i][1] >= 0.9 * tmax),
                   key=lambda i: timings[i][3] + timings[i][4])
-        name, ms_sum, launches, s_in, s_out = timings[dom]
+        label, ms_sum, launches, s_in, s_out = timings[dom]
+        # `kernel`: the device symbol as rocprofv3 prints it (profiles/*_kernel_stats.csv, profiles/traffic.json);
+        # `label`: the engine's name for the stage's form (k_convp_whole = convolver + interpolator in one launch)
+        name = symbols[dom] or label
         avg_ms = ms_sum / max(launches, 1)
         plan_out = n_out / args.steps  # average final outputs per channel per step
         alg_bytes = 8.0 * C * (s_in + s_out) / max(launches, 1)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # (the emulation library's events read 0: no kernel time, no fraction)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         path_bytes = 8.0 * (C * L + C * plan_out)
         res = {
             "metric": "Msamples/sec 44.1k\u219296k, N-channel batch, 1/2/4/8 GPU; RMS err vs ref",
@@ -454,30 +538,26 @@ def main():
                        "out_msamples_per_s":
                            round(n_out * C * world / dt / 1e6, 3),
                        "chain": rs.describe().strip().split("\n")},
-            "roofline": {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm", "kernel": name, "label": label, "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(name, cfg_name),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(name, cfg_name) or measured_traffic(label, cfg_name),
                          "alg_bytes_per_launch": alg_bytes, "avg_kernel_ms": round(avg_ms, 4),
                          "launches": launches,
                          "kernels_ms_per_step": kernel_ms(timings, args.steps),
+                         "kernel_symbols": [sym for sym in symbols if sym],
                          "path_frac": round(path_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
                                             4)},
         }
-        # `frac` above is the dominant kernel as the event pass saw it -- LATER than the value window, i.e. in another
-        # clock state when the value window lies in the power controller's dip.  The same fraction FOR the value window:
-        # a kernel's share of a step does not depend on the clock, so the kernel's time there is its time in the event pass
-        # scaled by the two windows' step times -- the settled window (same state as the event pass, which follows it)
-        # against the value window.  Without a settled window (--settle 0) the event pass follows the value window
-        # directly: one clock state, one fraction.
+        # `frac` is the dominant kernel as the event pass saw it -- AFTER every timed window, i.e. at the settled clock;
+        # `path_frac` is the whole call in the window `value` is quoted on (algorithmic bytes of the call / ms_per_step).
+        # (Round 5's derived `frac_value_window` is gone: path_frac is the measured figure of that window.)
         ksum = sum(t[1] for t in timings) / args.steps
-        scale = settled["ms_per_step"] / (dt / args.steps * 1e3) if settled is not None else 1.0
-        res["roofline"]["frac_value_window"] = round(achieved / HBM_PEAK_GBS * scale, 4)
         # (what a step spends between its kernels, where the events' own overhead does not drown it: informational)
         ref_ms = settled["ms_per_step"] if settled is not None else ev_wall_ms
         res["roofline"]["launch_gap_ms_per_step"] = round(ref_ms - ksum, 4) if ref_ms >= ksum else None
         res["roofline"]["frac_clock_state"] = ("`frac`: per-kernel HIP events of a pass AFTER every timed window (settled "
-                                               "clock); `frac_value_window` = frac x settled.ms_per_step / ms_per_step: "
-                                               "the same kernel in the window `value` is quoted on")
+                                               "clock); `path_frac`: the whole call, measured in the window `value` is "
+                                               "quoted on")
         res["value_window"] = "the %d steps timed straight after the %d warm-up calls" % (args.steps, args.warmup)
         if settled is not None:
             res["settle_calls"] = args.settle
@@ -487,7 +567,9 @@ def main():
         if e2e is not None:
             # (kernel-only = the line's own `value`: shards at rest; end-to-end beside it)
             res["e2e"] = e2e
-        if not args.no_cpu and world == 1 and args.phase == 0:
+        if host_side:
+            res["data"] = "synthetic; HOST EMULATION of the kernels (--backend gloo --lib): control flow only, not a measurement"
+        if not args.no_cpu and world == 1 and args.phase == 0 and not host_side:
             # (N = 1 only: the CPU leg is a per-box baseline, not part of the scaling runs)
             # error report: rows {0, C/2, C-1} of the timed batch's own output (what the object produced for its
             # first calls, captured during warm-up) against the reference on the same samples

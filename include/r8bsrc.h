@@ -212,6 +212,11 @@ R8BSRC_DECL int r8b_batch_stage_count(CR8BBatch b);
 R8BSRC_DECL long long r8b_batch_stat(CR8BBatch b, const char* name);
 R8BSRC_DECL int r8b_batch_stage_timing(CR8BBatch b, int stage, double* ms_sum, int* launches,
 	long long* in_samples, long long* out_samples, char* kernel, int cap);
+/* The device symbol of `stage`'s most recent launch made with "timing" = 1, as rocprofv3 prints it without namespace
+ * and argument list ("k_convp_walk<11, 1, 4, 24>"; r8b_batch_stage_timing's `kernel` is the engine's label for the
+ * stage's form, e.g. "k_convp_whole" = convolver + interpolator in one launch).  "" before the first such launch.
+ * 0 on success. */
+R8BSRC_DECL int r8b_batch_stage_symbol(CR8BBatch b, int stage, char* symbol, int cap);
 
 /* Last error message of the calling thread ("" if none). */
 R8BSRC_DECL const char* r8b_last_error(void);

@@ -52,6 +52,7 @@ PROTOTYPES = [
     ("r8b_batch_latency_frac", C.c_double, [C.c_void_p]),
     ("r8b_batch_stage_timing", C.c_int, [C.c_void_p, C.c_int, dp, ip, C.POINTER(C.c_longlong),
                                 C.POINTER(C.c_longlong), C.c_char_p, C.c_int]),
+    ("r8b_batch_stage_symbol", C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     ("r8b_last_error", C.c_char_p, []),
     ("r8b_design_lpfilter", C.c_int, [C.c_double, C.c_double, C.c_double, C.c_double, ip, ip, dp,
                                       C.c_int]),

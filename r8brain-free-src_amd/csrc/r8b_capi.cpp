@@ -385,6 +385,22 @@ R8BSRC_DECL int r8b_batch_stage_timing(CR8BBatch b, int stage, double* ms_sum, i
 	}
 }
 
+R8BSRC_DECL int r8b_batch_stage_symbol(CR8BBatch b, int stage, char* symbol, int cap)
+{
+	try
+	{
+		Batch* B = need(b);
+		if (stage < 0 || stage >= (int) B->eng->plan().stages.size()) return -1;
+		copy_text(B->eng->stage_symbol((size_t) stage), symbol, cap);
+		return 0;
+	}
+	catch (const std::exception& e)
+	{
+		set_err("r8b_batch_stage_symbol", e);
+		return -1;
+	}
+}
+
 // ---------------------------------------------------------------- drop-in single-stream ABI
 
 R8BSRC_DECL CR8BResampler r8b_create(double SrcSampleRate, double DstSampleRate, int MaxInLen,

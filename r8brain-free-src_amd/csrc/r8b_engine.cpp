@@ -826,6 +826,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["walk"] = 1;      // (0: a workgroup per block, as before round 5; 2: whatever the batch size -- tests)
 	opt_["walk_len"] = 0;  // blocks per workgroup of the walk form (0: the launch's whole run of blocks)
 	stat_["conv_blocks"] = 0;
+	stat_["walk_blocks"] = 0; // blocks of the fused pair kernel's launches that ran on the walk body (per channel, like conv_blocks)
 	stat_["park_calls"] = 0;
 	stat_["park_only_calls"] = 0;
 	stat_["pcm_staged_sides"] = 0; // planar PCM sides that went through the staging rows (r8b_capi.cpp)
@@ -1362,7 +1363,6 @@ bool Engine::set_option(const std::string& name, int value)
 
 long long Engine::stat(const std::string& name) const
 {
-	if (name == "walk_blocks") return launch_walk_blocks();
 	auto it = stat_.find(name);
 	return it == stat_.end() ? -1 : it->second;
 }
@@ -1425,6 +1425,11 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 	d.launches = 0;
 	d.t_in = d.t_out = 0;
 	return true;
+}
+
+std::string Engine::stage_symbol(size_t stage) const
+{
+	return stage < dev_.size() ? dev_[stage].symbol : std::string();
 }
 
 void Engine::clear()
@@ -2082,6 +2087,8 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 			{
 				dev_event_record(e1, stream);
 				dev_[s].pending.emplace_back(e0, e1);
+				// (what the launcher really started for this stage: rocprofv3's name for it)
+				if (const char* sym = launch_symbol_last()) dev_[s].symbol = sym;
 				// (one (in, out) count per call, however many channel windows it is launched in)
 				if (ch0_ == 0)
 				{
@@ -2798,7 +2805,10 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 				X.park_dst = dp.park[dp.park_cur ^ 1] + (long long) ch0_ * dp.park_stride;
 				X.park_stride = dp.park_stride;
 			}
+			// (blocks the launcher put on the walk body: counted per engine, once per call like conv_blocks)
+			const long long w0 = launch_walk_blocks();
 			launch_convp(X, (dw.taps2 == 27 ? 5 : 4) + (c.cg.complex_h ? 12 : 0), stream);
+			if (ch0_ == 0) stat_["walk_blocks"] += launch_walk_blocks() - w0;
 		}
 		else if (c.cg.complex_h)
 			// (fuse_latency_ok admits a complex spectrum only where the two-phase tables exist)

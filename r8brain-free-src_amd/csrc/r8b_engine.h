@@ -48,6 +48,11 @@ public:
 	bool stage_timing(size_t stage, double* ms_sum, int* launches, std::string* kernel,
 		long long* in_samples, long long* out_samples);
 
+	// device symbol of the stage's most recent launch made while option "timing" was 1, as rocprofv3 prints it without
+	// namespace and argument list ("k_convp_walk<11, 1, 4, 24>"); empty before the first one.  stage_timing's name is
+	// the engine's LABEL for the stage's form ("k_convp_whole": convolver + interpolator in one launch)
+	std::string stage_symbol(size_t stage) const;
+
 	// Checkpoint of the streaming state of all channels: the plan's counters
 	// and the contents of every history ring, as one host blob.  load_state() accepts only a blob
 	// saved by an object of the same configuration (rates, filter parameters, MaxInLen, channel
@@ -98,6 +103,7 @@ private:
 		double ms_sum = 0.0;
 		int launches = 0;
 		long long t_in = 0, t_out = 0; // per-channel samples in/out over the timed launches
+		std::string symbol; // device symbol of the stage's most recent timed launch (launch_symbol_last)
 	};
 	void* get_event(StageDev& d);
 	// Convolver + whole-step interpolator of a chain with a fractional latency (minimum phase) as ONE launch: the shifts

@@ -135,6 +135,13 @@ void check(hipError_t e, const char* what)
 		throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// "k_convp_walk<11, 1, 4, 24>": a kernel template's instance as rocprofv3 names it (launch_symbol_note)
+[[maybe_unused]] std::string symbol4(const char* base, int a, int b, int c, int d)
+{
+	return std::string(base) + "<" + std::to_string(a) + ", " + std::to_string(b) + ", " + std::to_string(c) + ", " +
+		std::to_string(d) + ">";
+}
+
 // Opt-in to more than 64 KB of dynamic LDS.  Function attributes are per DEVICE, so the memo is keyed
 // by (function, device ordinal): a process that drives several GPUs opts in on each of them.
 void lds_opt_in(const void* fn, const char* what)
@@ -873,12 +880,16 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 			hipLaunchKernelGGL(wkern, dim3((nslice + (unsigned) X.c.nblk - nwi) * npair), dim3(ConvpGeom<LN, UL>::WT), lds,
 				stream, X);
 			check(hipGetLastError(), "launch k_convp_walk");
+			static const std::string wsym = symbol4("k_convp_walk", LN, UL, MODE, FLENP);
+			launch_symbol_note(wsym.c_str());
 			launch_walk_blocks_add((long long) nwi);
 			return;
 		}
 	}
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(ConvpGeom<LN, UL>::WT), lds, stream, X);
 	check(hipGetLastError(), "launch k_convp");
+	static const std::string sym = symbol4("k_convp", LN, UL, MODE, FLENP);
+	launch_symbol_note(sym.c_str());
 	}
 }
 
@@ -940,6 +951,8 @@ void launch_convx_t(const ConvxLaunch& X, hipStream_t stream)
 	hipLaunchKernelGGL(kern, dim3((unsigned) X.c.nblk * (unsigned) X.c.nch), dim3(kConvxThreads),
 		lds, stream, X);
 	check(hipGetLastError(), "launch k_convx");
+	static const std::string sym = symbol4("k_convx", LOGN, UPLOG, MODE, FLENP);
+	launch_symbol_note(sym.c_str());
 }
 
 #endif // R8B_HAS_REST && R8B_HAS_FAST
@@ -963,6 +976,7 @@ void R8B_LAUNCH(launch_conv)(const ConvLaunch& L, void* stream)
 	hipLaunchKernelGGL(k_conv, dim3((unsigned) L.nblk, (unsigned) L.nch), dim3((unsigned) L.threads),
 		lds, (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_conv");
+	launch_symbol_note("k_conv");
 }
 
 void R8B_LAUNCH(launch_whole)(const WholeLaunch& L, void* stream)
@@ -980,6 +994,7 @@ void R8B_LAUNCH(launch_whole)(const WholeLaunch& L, void* stream)
 	hipLaunchKernelGGL(k_whole, dim3(tiles, (unsigned) L.nch), dim3(nthr),
 		(size_t) L.span_max * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_whole");
+	launch_symbol_note("k_whole");
 }
 
 void R8B_LAUNCH(launch_poly)(const PolyLaunch& L, void* stream)
@@ -992,11 +1007,13 @@ void R8B_LAUNCH(launch_poly)(const PolyLaunch& L, void* stream)
 		hipLaunchKernelGGL(k_poly_tiled, dim3((unsigned) ((n + kPolyTO - 1) / kPolyTO),
 			(unsigned) ((L.nch + kPolyTC - 1) / kPolyTC)), dim3(256), lds, (hipStream_t) stream, L);
 		check(hipGetLastError(), "launch k_poly_tiled");
+		launch_symbol_note("k_poly_tiled");
 		return;
 	}
 	hipLaunchKernelGGL(k_poly, dim3((unsigned) ((n + 255) / 256), (unsigned) L.nch), dim3(256), 0,
 		(hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_poly");
+	launch_symbol_note("k_poly");
 }
 
 void R8B_LAUNCH(launch_hbup)(const HBLaunch& L, void* stream)
@@ -1006,6 +1023,7 @@ void R8B_LAUNCH(launch_hbup)(const HBLaunch& L, void* stream)
 	hipLaunchKernelGGL(k_hbup, dim3(tiles, (unsigned) L.nch), dim3(256),
 		(size_t) (L.tile + 2 * L.ntaps) * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_hbup");
+	launch_symbol_note("k_hbup");
 }
 
 void R8B_LAUNCH(launch_hbdown)(const HBLaunch& L, void* stream)
@@ -1015,6 +1033,7 @@ void R8B_LAUNCH(launch_hbdown)(const HBLaunch& L, void* stream)
 	hipLaunchKernelGGL(k_hbdown, dim3(tiles, (unsigned) L.nch), dim3(256),
 		(size_t) hbdown_lds_doubles(L.tile, L.ntaps) * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_hbdown");
+	launch_symbol_note("k_hbdown");
 }
 
 #if !R8B_HAS_FAST
@@ -1193,6 +1212,7 @@ void R8B_LAUNCH(launch_hbcascade)(const HBCascadeLaunch& L, void* stream)
 	hipLaunchKernelGGL(k_hbcascade, dim3(tiles, (unsigned) L.nch), dim3(256),
 		(size_t) (L.buf + L.buf2 + 3 * kHbcSlack) * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_hbcascade");
+	launch_symbol_note("k_hbcascade");
 }
 
 void R8B_LAUNCH(launch_hbdcascade)(const HBCascadeLaunch& L, void* stream)
@@ -1204,6 +1224,7 @@ void R8B_LAUNCH(launch_hbdcascade)(const HBCascadeLaunch& L, void* stream)
 	hipLaunchKernelGGL(k_hbdcascade, dim3(tiles, (unsigned) L.nch), dim3(256),
 		(size_t) (L.buf + L.buf2) * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_hbdcascade");
+	launch_symbol_note("k_hbdcascade");
 }
 
 void R8B_LAUNCH(launch_tail)(const TailLaunch& L, void* stream)
@@ -1213,6 +1234,7 @@ void R8B_LAUNCH(launch_tail)(const TailLaunch& L, void* stream)
 	hipLaunchKernelGGL(k_tail, dim3((unsigned) ((n + 255) / 256), (unsigned) L.nch), dim3(256), 0,
 		(hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_tail");
+	launch_symbol_note("k_tail");
 }
 
 #ifndef R8B_PCM_VARIANT
@@ -1249,9 +1271,14 @@ void launch_convx(const ConvxLaunch& X, int mode, void* stream)
 	else launch_convx_f64(X, mode, stream);
 }
 
-namespace { std::atomic<long long> g_walk_blocks{0}; }
-long long launch_walk_blocks() { return g_walk_blocks.load(); }
-void launch_walk_blocks_add(long long n) { g_walk_blocks += n; }
+// (per THREAD: an engine counts what its own launches walked as the difference around them -- Engine::launch_pair)
+namespace { thread_local long long t_walk_blocks = 0; }
+long long launch_walk_blocks() { return t_walk_blocks; }
+void launch_walk_blocks_add(long long n) { t_walk_blocks += n; }
+
+namespace { thread_local const char* t_last_symbol = nullptr; }
+void launch_symbol_note(const char* symbol) { t_last_symbol = symbol; }
+const char* launch_symbol_last() { return t_last_symbol; }
 
 void launch_convp(const ConvxLaunch& X, int mode, void* stream)
 {

@@ -275,7 +275,7 @@ struct ConvxLaunch
 	// ... set by the launcher (convp_walk_range): blocks [walk_i0, walk_i1) of the launch are interior ones and run on
 	// the walk body, walk_len of them per workgroup; the others -- a call's first and last blocks -- on the general body,
 	// a workgroup each, in the same launch
-	int walk_i0, walk_i1, walk_len;
+	int walk_i0 = 0, walk_i1 = 0, walk_len = 0;
 	long long park_j0, park_stride;
 	const double* park_src;
 	double* park_dst;
@@ -402,10 +402,15 @@ void launch_pcm_out(const PcmLaunch& L, void* stream); // planar fp64 -> PCM
 void launch_convx(const ConvxLaunch& X, int mode, void* stream);
 // the same work in pair form (modes 0, 1, 3, 4 ... 9; needs X.c.hp)
 void launch_convp(const ConvxLaunch& X, int mode, void* stream);
-// blocks the launchers have put on the walk body so far (process wide; Engine::stat("walk_blocks"): the launcher, not
-// the engine, decides per launch -- convp_walk_range)
+// blocks the calling THREAD's launches have put on the walk body so far (the launcher, not the engine, decides per
+// launch -- convp_walk_range; an engine counts its own as the difference around its launches: Engine::stat("walk_blocks"))
 long long launch_walk_blocks();
 void launch_walk_blocks_add(long long n);
+// the device symbol of the calling thread's most recent kernel launch, as rocprofv3 prints it without namespace and
+// argument list ("k_convp_walk<11, 1, 4, 24>"); nullptr before the first launch.  The launchers note it, the engine
+// reads it behind a stage's launch when option "timing" is on (Engine::stage_symbol, r8b_batch_stage_symbol)
+void launch_symbol_note(const char* symbol);
+const char* launch_symbol_last();
 
 // memory helpers; all throw std::runtime_error with the HIP error text on failure
 // Device selection.  dev_resolve: the ordinal an object created with `device` lives on (-1: the

@@ -113,6 +113,16 @@ class BatchResampler(_Base):
             res.append((name.value.decode(), ms.value, n.value, si.value, so.value))
         return res
 
+    def stage_symbols(self):
+        """device symbol of every stage's most recent timed launch, as rocprofv3 names it (r8b_batch_stage_symbol)"""
+        res = []
+        for s in range(self._lib.r8b_batch_stage_count(self._h)):
+            buf = C.create_string_buffer(96)
+            if self._lib.r8b_batch_stage_symbol(self._h, s, buf, 96) != 0:
+                raise RuntimeError(self._err())
+            res.append(buf.value.decode())
+        return res
+
     def process_ptr(self, d_in, in_stride, l, d_out, out_stride, stream=0):
         """Raw device-pointer entry (r8b_batch_process)."""
         n = self._lib.r8b_batch_process(self._h, C.c_void_p(d_in), in_stride, int(l),

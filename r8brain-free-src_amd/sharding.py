@@ -81,7 +81,14 @@ def gather_channels(y_local, total_channels, dst=0, n=None, out=None):
     A rank WITHOUT channels (fewer channel pairs than ranks) has no resampler and so no n of its own:
     whenever some shard is empty -- every rank can tell from (total_channels, world) alone -- the ranks
     agree on n with one all_reduce(MAX) first (or the caller passes n), so that a channel-less `dst`
-    still allocates the full result and posts a receive for every sender."""
+    still allocates the full result and posts a receive for every sender.
+
+    `out` (optional, `dst` only): STORAGE for the result, not a tensor to read the result through.  A contiguous
+    tensor with room for total_channels * n elements of y_local's dtype; its first total_channels * n elements are
+    used as a DENSE [total_channels, n] tensor, which is what is returned -- row c starts at element c * n of the
+    storage, NOT at c * out.shape[1].  A caller that passes rows wider than n must read the RETURNED tensor; reading
+    its own `out` through its original shape yields scrambled rows.  An `out` that cannot hold the
+    result (too small, another dtype, not contiguous) is a ValueError rather than a silent fresh allocation."""
     rank, world = _rank_world()
     if n is None:
         n = y_local.shape[1]
@@ -93,7 +100,10 @@ def gather_channels(y_local, total_channels, dst=0, n=None, out=None):
         # (`out`: a preallocated contiguous buffer of the caller with room for [total_channels, n], e.g. RootPipeline's
         # rotation of [total_channels, max_out_len] tensors: its storage is used as a DENSE [total_channels, n] result --
         # a [:, :n] view of wider rows is not contiguous, and a receive wants contiguous rows)
-        if out is not None and out.is_contiguous() and out.numel() >= total_channels * n and out.dtype == y_local.dtype:
+        if out is not None:
+            if not (out.is_contiguous() and out.numel() >= total_channels * n and out.dtype == y_local.dtype):
+                raise ValueError("gather_channels: `out` must be contiguous storage for %d x %d elements of %s"
+                                 % (total_channels, n, y_local.dtype))
             out = out.reshape(-1)[:total_channels * n].view(total_channels, n)
         else:
             out = torch.empty((total_channels, n), dtype=y_local.dtype, device=y_local.device)
@@ -200,9 +210,11 @@ class RootPipeline:
                 ob = None
                 if self.keep_last_only and rank == self.root and hasattr(self.sh.local, "max_out_len"):
                     # (three result buffers in rotation, only when the caller asked for them -- keep_last_only --: the
-                    # caller gets views; a result stays valid until the third call after it has been gathered.  Rows of
-                    # max_out_len, handed to the gather as the [:, :n] view of this call's length, so that the rotation
-                    # also holds when the per-call count changes -- 35666 / 35667 for 44100 -> 96000)
+                    # caller gets the tensors the gather RETURNS; a result stays valid until the third call after it has
+                    # been gathered.  Each buffer is sized for max_out_len per channel and handed to the gather as
+                    # STORAGE: the result is the dense [total, n] tensor over its first total * n elements (not a
+                    # [:, :n] view of max_out_len-wide rows), so the rotation also holds when the per-call count
+                    # changes -- 35666 / 35667 for 44100 -> 96000 -- and nobody reads the buffer through its own shape)
                     if self._obuf[i % 3] is None:
                         self._obuf[i % 3] = torch.empty((self.sh.total, self.sh.local.max_out_len), dtype=y.dtype,
                                                         device=self.device)

@@ -367,9 +367,12 @@ void emul_convp_p3(const ConvxLaunch& X)
 	else throw std::runtime_error("launch_convp: polyphase 3x form on a geometry it is not built for");
 }
 
-static long long g_walk_blocks = 0;
-long long launch_walk_blocks() { return g_walk_blocks; }
-void launch_walk_blocks_add(long long n) { g_walk_blocks += n; }
+static thread_local long long t_walk_blocks = 0;
+long long launch_walk_blocks() { return t_walk_blocks; }
+void launch_walk_blocks_add(long long n) { t_walk_blocks += n; }
+static thread_local const char* t_last_symbol = nullptr;
+void launch_symbol_note(const char* symbol) { t_last_symbol = symbol; }
+const char* launch_symbol_last() { return t_last_symbol; }
 
 void launch_convp(const ConvxLaunch& X, int mode, void*)
 {

@@ -143,6 +143,63 @@ def test_channel_sharding_two_ranks(emul_built):
     assert shard0 == (0, 1024)
 
 
+def _bench_cmd(gpus, extra=()):
+    return [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "2",
+            "--settle", "0", "--channels", "6", "--block", "2048", "--backend", "gloo",
+            "--lib", os.path.join(ROOT, "tests", "emul", "_build", "libr8bsrc_emul.so")] + list(extra)
+
+
+def _bench_env():
+    return {k: v for k, v in os.environ.items()
+            if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_bench_starts_its_own_ranks(emul_built, gpus):
+    """`python3 bench.py --gpus N` with WORLD_SIZE unset -- the driver's command shape -- starts its N
+    ranks itself (torch.distributed.run, 127.0.0.1, a free port) and prints ONE line from rank 0 with n_gpus = N.  Run
+    here on gloo over the host emulation of the kernels (the --backend gloo --lib side door): the control flow of the
+    N-rank bench, not a measurement."""
+    import json
+    import subprocess
+    r = subprocess.run(_bench_cmd(gpus), env=_bench_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == gpus and d["steps"] == 3 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["channels_per_gpu"] == 6
+    # whole-job value: N ranks x 6 channels x 2048 samples x 3 steps over the MAX-over-ranks time
+    assert abs(d["value"] - gpus * 6 * 2048 / d["ms_per_step"] / 1e3) / d["value"] < 0.01
+    assert "HOST EMULATION" in d["data"] and "cpu_baseline" not in d
+
+
+def test_bench_under_a_launcher_is_a_rank(emul_built):
+    """... and launched by torch.distributed.run (the contract's other shape) it must not spawn again"""
+    import json
+    import subprocess
+    cmd = _bench_cmd(2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + cmd[1:]
+    r = subprocess.run(cmd, env=_bench_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_bench_exits_nonzero_when_a_rank_fails(emul_built):
+    """a rank that cannot start (here: the product path without a GPU) fails the whole command, no JSON line"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       env=_bench_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and not [l for l in r.stdout.split("\n") if l.startswith("{")]
+    # mismatched launcher: --gpus 2 inside a one-rank world is refused, not silently run as one rank
+    env = dict(_bench_env(), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run(_bench_cmd(2), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE 1" in r.stderr
+
+
 def test_channel_shard_function():
     sys.path.insert(0, ROOT)
     import bench

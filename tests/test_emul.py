@@ -761,13 +761,16 @@ def test_emulated_fused_minimum_phase_equals_unfused(emul, src, dst, maxin, tb):
 
 
 @pytest.mark.parametrize("src,dst,knob", [(48000.0, 16000.0, "pair_solo"), (88200.0, 44100.0, "pair_solo"),
-                                          (44100.0, 96000.0, "pair_two"), (44100.0, 88200.0, "pair_conv")])
+                                          (44100.0, 96000.0, "pair_two"), (44100.0, 88200.0, "pair_conv"),
+                                          # (round 5's two structural options -- the one-channel long-block
+                                          # form with the interpolator fused in, 0.5 % band; the polyphase 3x form)
+                                          (96000.0, 44100.0, "solo_fuse"), (16000.0, 48000.0, "up3_poly")])
 @pytest.mark.parametrize("first", [1, 0])
 def test_emulated_park_buffers_follow_structural_options_after_clear(emul, src, dst, knob, first):
     """clear() + a structural option that changes the park rows' length (one-channel / pair form, ...)
     must not leave the old buffers, stride or buffer index behind: the checkpoint is exactly state_size() bytes and the
     stream after the toggle equals that of an object created with the option (bit for bit), both ways."""
-    tb = 0.5 if knob == "pair_solo" else 2.0
+    tb = 0.5 if knob in ("pair_solo", "solo_fuse") else 2.0
     nch, chunk = 2, 1500
     x = make_input(nch, 6 * chunk, 23)
 

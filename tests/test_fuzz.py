@@ -96,8 +96,10 @@ def test_fuzz_emulated_engine_vs_reference(emul, reference, case):
                 cnt += len(yr)
         pos += l
     assert cnt > 0, case
-    rms, k = (sq / cnt) ** 0.5, tol_scale(rsq, cnt)
-    assert rms <= RMS_TOL * k and pk <= PEAK_TOL * k, (case, rms, pk, k)
+    # (narrow-range draws, 60 ... 200 dB / 0.7 ... 6 %: the ABSOLUTE bound, as before round 5 -- ADVICE r5; the scaled
+    # bound of cases.tol_scale is for the whole-filter-range draws only)
+    rms = (sq / cnt) ** 0.5
+    assert rms <= RMS_TOL and pk <= PEAK_TOL, (case, rms, pk, tol_scale(rsq, cnt))
 
 
 def _differential(b, refs, case, nch, lo_frac=0.0):
@@ -178,8 +180,8 @@ def test_fuzz_kernel_options_vs_reference(emul, reference, idx):
                 pk = max(pk, float(np.abs(d).max()))
                 cnt += len(yr)
         pos += l
-    rms, k = (sq / max(cnt, 1)) ** 0.5, tol_scale(rsq, cnt)
-    assert cnt > 0 and rms <= RMS_TOL * k and pk <= PEAK_TOL * k, (case, opts, rms, pk, k)
+    rms = (sq / max(cnt, 1)) ** 0.5   # (absolute bound: narrow-range draws)
+    assert cnt > 0 and rms <= RMS_TOL and pk <= PEAK_TOL, (case, opts, rms, pk, tol_scale(rsq, cnt))
 
 
 @pytest.mark.gpu
@@ -231,8 +233,8 @@ def test_fuzz_gpu_vs_reference(reference, case):
                 pk = max(pk, float(np.abs(d).max()))
                 cnt += len(yr)
         pos += l
-    rms, k = (sq / max(cnt, 1)) ** 0.5, tol_scale(rsq, cnt)
-    assert cnt > 0 and rms <= RMS_TOL * k and pk <= PEAK_TOL * k, (case, rms, pk, k)
+    rms = (sq / max(cnt, 1)) ** 0.5   # (absolute bound: narrow-range draws)
+    assert cnt > 0 and rms <= RMS_TOL and pk <= PEAK_TOL, (case, rms, pk, tol_scale(rsq, cnt))
 
 
 # Random (ratio, MaxInLen, filter) draws whose minimum-phase chain has a convolver + interpolator pair in ONE launch: the
