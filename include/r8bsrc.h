@@ -75,16 +75,31 @@ typedef void* CR8BBatch;
  * `device` (-1 = current).  ReqAtten is the reference constructor's ReqAtten in dB
  * (CDSPResampler.h:117-120).  NULL + message in r8b_last_error() on failure.
  *
- * Channel independence and accuracy.  The output of every channel equals the reference's for that channel's
- * samples within RMS 1e-15 / peak 1e-13 of FULL SCALE (+-1.0), and is bitwise independent of how the stream is cut
- * into calls.  Channels 2c and 2c+1 are convolved as the real and imaginary part of one complex transform
- * (the filter kernels are real), so the rounding error of a channel is of the order of 1e-16 of the LOUDER of
- * the two: a channel at -120 dBFS beside a full-scale partner still meets the absolute bound, i.e. 1e-9 of its
- * own level.  A channel whose samples are all zero comes out as exact zeros whatever its partner carries
- * (silence is detected per transform block).  Callers that need rounding errors scaled to each channel's own
- * level -- e.g. impulse responses of very different magnitude in one batch -- put channels of similar level
- * into a pair, leave the partner silent, or select the one-channel kernels (r8b_batch_set_option "pair_conv" = 0
- * before the first sample; slower). */
+ * Channel independence and accuracy.  The output of every channel equals the reference's for that channel's samples
+ * within RMS 1e-15 / peak 1e-13 OF THAT CHANNEL'S OWN LEVEL (for full-scale +-1.0 noise: the absolute figures; measured
+ * RMS 2-4e-16, the reference's own noise between two of its builds), and is bitwise independent of how the stream is
+ * cut into calls.  Channels 2c and 2c+1 are convolved as the real and imaginary part of one complex transform (the
+ * filter kernels are real); per transform block the quieter of the two is brought to its partner's binary order of
+ * magnitude by an exact power of two and taken back afterwards, so a channel at -240 dBFS beside a full-scale partner
+ * keeps its error at 1e-16 of its own level, as in the reference's one-object-per-channel use (README.md:52-55).  A
+ * channel whose samples are all zero comes out as exact zeros whatever its partner carries (silence is detected per
+ * transform block); an Inf / NaN in one channel of a pair reaches its partner's samples of that block (the reference
+ * keeps it to its own object).  "pair_conv" = 0 (r8b_batch_set_option, before the first sample) selects the one-channel
+ * kernels (slower).
+ *
+ * STATED EXCEPTIONS to the tolerance -- all of them conversions whose REFERENCE block is 32768 points (a radix-3 ratio
+ * with a transition band of 0.5 ... 0.6 %: 8 507 - 13 633 taps), which this library runs on 16384-point blocks of the
+ * same filter.  Where such a convolver also DECIMATES BY 2 OR 4 IN THE SPECTRUM the reference's output contains the
+ * residue of truncating the block's spectrum (-219 dB of the signal, CDSPBlockConvolver.h:329-344), and that residue
+ * depends on the block length:
+ *     ratio 3/2 (e.g. 32000 -> 48000) at tb 0.5 %:  RMS <= 1e-13 / peak <= 5e-12 against the reference
+ *     ratio 3/4 (e.g. 64000 -> 48000) at tb 0.5 %:  RMS <= 1e-10 / peak <= 5e-10
+ * The other re-blocked ratios (3/1, 1/3, 2/3) meet 1e-15.  Both are far inside the filters' own stop band (-180 dB);
+ * per-call output counts, latency queries and chunk invariance are the reference's in every case (tests/cases.py
+ * REBLOCK_CASES).  Minimum phase (r8b_batch_create_ex): see DESIGN.md section 6 -- the bound there is
+ * the reference's own run-to-run noise of its cepstral designer, the kernels meet 1e-15 on the reference's taps.
+ * One sample the reference leaves undefined (a ONE-tap half-band up-sampler, >= 32x up-sampling below 55 dB: the
+ * stream's first odd output reads an unwritten ring slot, CDSPHBUpsampler.h:606-693) is the filter's value here. */
 R8BSRC_DECL CR8BBatch r8b_batch_create(double SrcSampleRate, double DstSampleRate, int MaxInLen,
 	double ReqTransBand, double ReqAtten, int nch, int device);
 
@@ -134,7 +149,10 @@ R8BSRC_DECL int r8b_batch_process_host(CR8BBatch b, const double* in, long long 
  *   interleaved == 0: planar, element c*stride + f
  * Strides are in samples.  Integer formats decode as value / 2^(bits-1) and encode as
  * round-to-nearest-even of v * 2^(bits-1), saturated, without dither; R8B_PCM_S24 is packed
- * 3-byte little-endian.  Returns the output frames produced, or -1 on error. */
+ * 3-byte little-endian.  THIS CONVENTION IS THIS LIBRARY'S DEFINITION: the reference's converter (CWaveFile, from the
+ * author's libvox) is not part of the reference sources, so its scale (2^(bits-1) vs 2^(bits-1) - 1), rounding and
+ * dither cannot be pinned to it; the codec is bit-exact against its own specification (tests/test_pcm.py) and the fp64
+ * core between the two conversions is pinned to the reference.  Returns the output frames produced, or -1 on error. */
 enum r8b_pcm_format
 {
 	R8B_PCM_F64 = 0,

@@ -330,11 +330,15 @@ struct ConvpState
 	double er[16], ei[16]; // split 2x up-sampling form (modes 8 / 9 / 12 / 13): the even half's outputs while the odd half is transformed
 	double zr[16], zi[16];   // polyphase 3x form (mode 19): the block's spectrum, kept across the three backward transforms
 	double p3r[16], p3i[16]; // ... the second component's outputs (the first's wait in er / ei; kP3Keep of the sixteen)
+	cd twlv;              // the thread's entry of the wave-local passes' twiddle table on its way to LDS (front -> first pass)
 	cd twp[4];            // walk form (convp_walk): the thread's own twiddles, kept across blocks -- [0], [1] first pass (w, w^4), [2], [3] last backward pass
 };
 
-// (+ 64 bytes behind the array: one word per wave for the workgroup-wide "channel has a non-zero sample" bits)
-static const int kConvpFlagBytes = 64;
+// (+ 64 bytes behind the array: one word per wave for the workgroup-wide "channel has a non-zero sample" bits; + 256 bytes:
+// the blocks' level words -- cp_level_words --, one per wave or, where a wave carries several blocks, one per block;
+// ... and the blocks' shift words -- cp_level_shift, what the end of the body reads)
+static const int kConvpLevelWords = 64;
+static const int kConvpFlagBytes = 64 + 8 * kConvpLevelWords;
 template<int LN, int UL> constexpr int convp_array_bytes()
 {
 	return kSplit<LN, UL> ? ConvpGeom<LN, UL>::N * 16 : ConvpGeom<LN, UL>::SUB * ConvpGeom<LN, UL>::NA * 16;
@@ -449,6 +453,90 @@ R8B_HD void cp_silence(ConvpState<LN, UL>& st, unsigned nzbits)
 	{
 		if (za) st.vr[p] = 0.0;
 		if (zb) st.vi[p] = 0.0;
+	}
+}
+
+// Partners at their own level (round 6).  Two channels share one complex transform, so each carries rounding residue of
+// the order of 1e-16 of the LOUDER one: a channel at -120 dBFS beside a full-scale partner came out with an error of 1e-9
+// of its own level, where the reference -- one object per channel (README.md:52-55, CDSPResampler.h:559-575) -- keeps
+// every channel's error at 1e-16 of that channel.  Each block therefore brings its two channels to the same binary
+// order of magnitude before they are packed: every thread reports the largest exponent field among its samples of A and
+// of B (cp_level_words), the block's threads combine them (Exec::post_levels / collect_levels, across a workgroup
+// barrier in front of the first pass), the QUIETER channel's samples are multiplied by 2^d, d = the difference of the
+// two exponents, and its outputs by 2^-d behind the last backward pass.  Multiplying by a power of two is exact (no
+// result is subnormal that was not before: the scaled channel only moves UP to its partner's exponent; the way back
+// is exact unless the output itself is subnormal), so the quiet channel's result is what a transform with a partner of
+// its own level gives, the loud one's is unchanged, and partners of equal level (d = 0: one scalar branch) are
+// computed exactly as before.  d is a function of the block's window alone -- blocks are anchored at absolute stream
+// positions --, so the output stays bitwise independent of how the stream is cut into calls.  A channel without a
+// normal sample (zeros, subnormals) or with an Inf / NaN takes part unscaled.  The one-channel forms have no partner.
+// (a thread's levels: the larger of its samples' high words without the sign, per channel -- non-negative doubles order
+// like their bit patterns; packed levels: A's exponent field in bits 16-26, B's in bits 0-10)
+struct CpLevels { unsigned a, b; };
+template<int LN, int UL>
+R8B_HD CpLevels cp_level_words(const ConvpState<LN, UL>& st)
+{
+	CpLevels v;
+	v.a = v.b = 0;
+#pragma unroll
+	for (int p = 0; p < ConvpGeom<LN, UL>::E1; p++)
+	{
+		unsigned long long ua, ub;
+		__builtin_memcpy(&ua, &st.pr[p], 8);
+		__builtin_memcpy(&ub, &st.pi[p], 8);
+		const unsigned ha = (unsigned) (ua >> 32) & 0x7fffffffu, hb = (unsigned) (ub >> 32) & 0x7fffffffu;
+		v.a = ha > v.a ? ha : v.a;
+		v.b = hb > v.b ? hb : v.b;
+	}
+	return v;
+}
+R8B_HD unsigned cp_level_pack(CpLevels v) { return ((v.a >> 20) << 16) | (v.b >> 20); }
+R8B_HD unsigned cp_level_max(unsigned x, unsigned y)
+{
+	const unsigned xa = x & 0xffff0000u, ya = y & 0xffff0000u, xb = x & 0xffffu, yb = y & 0xffffu;
+	return (xa > ya ? xa : ya) | (xb > yb ? xb : yb);
+}
+// d > 0: channel B is the quieter one, by d binary orders of magnitude; d < 0: channel A, by -d
+R8B_HD int cp_level_shift(unsigned lv)
+{
+#ifdef R8B_NO_LEVELS
+	return 0; // (development: timing without the equalisation's arithmetic)
+#endif
+	const int la = (int) (lv >> 16), lb = (int) (lv & 0xffffu);
+	if (la == 0 || lb == 0 || la == 2047 || lb == 2047) return 0;
+	const int d = la - lb;
+	return d > 1000 ? 1000 : (d < -1000 ? -1000 : d);
+}
+R8B_HD double cp_pow2(int n)
+{
+	const unsigned long long u = (unsigned long long) (1023 + n) << 52;
+	double v;
+	__builtin_memcpy(&v, &u, 8);
+	return v;
+}
+template<int LN, int UL>
+R8B_HD void cp_scale_in(ConvpState<LN, UL>& st, int d)
+{
+	if (d == 0) return;
+	const double s = cp_pow2(d > 0 ? d : -d);
+#pragma unroll
+	for (int p = 0; p < ConvpGeom<LN, UL>::E1; p++)
+	{
+		if (d > 0) st.pi[p] *= s;
+		else st.pr[p] *= s;
+	}
+}
+// (vr: channel A's outputs, vi: channel B's)
+template<int N>
+R8B_HD void cp_scale_out(double* vr, double* vi, int d)
+{
+	if (d == 0) return;
+	const double s = cp_pow2(d > 0 ? -d : d);
+#pragma unroll
+	for (int p = 0; p < N; p++)
+	{
+		if (d > 0) vi[p] *= s;
+		else vr[p] *= s;
 	}
 }
 
@@ -2535,6 +2623,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
 	constexpr bool SPLIT = kSplit<LN, UL> && !CX && (BM == 0 || BM == 3);
 	(void) SPLIT;
+	// the pair's two channels are brought to one binary order of magnitude per block (cp_level_words; the one-channel
+	// forms have no partner)
+	constexpr bool LEVELS = !SOLO;
 	const ConvLaunch& L = X.c;
 	const int chA = cur.chA, chB = cur.chB;
 	const bool bvalid = cur.bvalid;
@@ -2637,11 +2728,25 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		}
 		ex.stamp2();
 		ex.post_bits(tid, cp_nonzero_bits<LN, UL>(st));
+		if constexpr (LEVELS) ex.post_levels(tid, sub_of(tid), cp_level_words<LN, UL>(st));
 		ex.stamp2();
+	};
+	// (the block's level shift as the end of the body sees it: read back from the block's shift word -- one LDS word, left
+	// there by the first pass --, not kept in registers across the phases)
+	auto level_shift = [&](int tid)
+	{
+		if constexpr (LEVELS) return ex.collect_shift(sub_of(tid));
+		else { (void) tid; return 0; }
 	};
 	auto first_pass = [&](int tid, St& st, const cd& twl_v)
 	{
 		const int lt = lt_of(tid);
+		if constexpr (LEVELS)
+		{
+			const int lsh = cp_level_shift(ex.collect_levels(sub_of(tid)));
+			ex.post_shift(tid, sub_of(tid), lt, lsh);
+			cp_scale_in<LN, UL>(st, lsh);
+		}
 		cp_first<LN, UL>(L, buf_of(tid), st, lt);
 		if constexpr (TL::ON && !WALK)
 		{
@@ -2668,6 +2773,12 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			twl_v.re = twl_v.im = 0.0;
 			first_pass(tid, st, twl_v);
 		});
+	}
+	else if constexpr (LEVELS)
+	{
+		// (a barrier between the two: the block's levels come from all of its threads)
+		ex.phase([&](int tid, St& st) { front(tid, st, st.twlv); });
+		ex.phase([&](int tid, St& st) { first_pass(tid, st, st.twlv); });
 	}
 	else
 	ex.phase([&](int tid, St& st)
@@ -2891,6 +3002,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.phase([&](int tid, St& st)
 		{
 			cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
+			cp_scale_out<16>(st.vr, st.vi, level_shift(tid));
 			if (L.in_len / 3 > G::NT * kP3Keep) p_rest(tid, st, 0);
 #pragma unroll
 			for (int p = 0; p < kP3Keep; p++)
@@ -2903,6 +3015,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.phase([&](int tid, St& st)
 		{
 			cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
+			cp_scale_out<16>(st.vr, st.vi, level_shift(tid));
 			if (L.in_len / 3 > G::NT * kP3Keep) p_rest(tid, st, 1);
 #pragma unroll
 			for (int p = 0; p < kP3Keep; p++)
@@ -2918,6 +3031,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
 			cp_tail_slice_store(L, st, chA, chB, bvalid);
 			cp_back2<LN, UL>(buf_of(tid), st, lt);
+			cp_scale_out<16>(st.vr, st.vi, level_shift(tid)); // (the first two components' outputs: where they were computed)
 			const unsigned nzb = ex.collect_bits();
 			cp_silence<LN, UL>(st, nzb);
 			if (nzb != 3u)
@@ -3015,6 +3129,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
 			cp_tail_slice_store(L, st, chA, chB, bvalid);
 			cp_split_last<LN, UL>(buf_of(tid), st.tw, st.vr + 8, st.vi + 8, lt);
+			cp_scale_out<16>(st.vr, st.vi, level_shift(tid));
 			cp_silence<LN, UL>(st, ex.collect_bits());
 			if (live(tid))
 			{
@@ -3035,6 +3150,12 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
 			cp_tail_slice_store(L, st, chA, chB, bvalid);
 			ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
+			if constexpr (LEVELS)
+			{
+				const int lsh = level_shift(tid);
+				cp_scale_out<16>(st.vr, st.vi, lsh);
+				if constexpr (SP) cp_scale_out<16>(st.er, st.ei, lsh); // (the even half's outputs too)
+			}
 			unsigned nzb = ex.collect_bits();
 			// (one-channel form: the element's two parts are one channel's samples)
 			if constexpr (SOLO) nzb = nzb != 0 ? 3u : 0u;
@@ -3076,6 +3197,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
 			cp_tail_slice_store(L, st, chA, chB, bvalid);
 			cp_back2<LN, UL>(buf_of(tid), st, lt);
+			cp_scale_out<16>(st.vr, st.vi, level_shift(tid));
 			cp_silence<LN, UL>(st, ex.collect_bits());
 			if (live(tid))
 			{
@@ -3098,6 +3220,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		});
 		ex.phase([&](int tid, St& st)
 		{
+			cp_scale_out<16>(st.vr, st.vi, level_shift(tid));
 			cp_silence<LN, UL>(st, ex.collect_bits());
 			cp_final_store<LN, UL>(L, buf_of(tid), buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
 		});
@@ -3149,6 +3272,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			}
 			else
 			{
+			cp_scale_out<16>(st.vr, st.vi, level_shift(tid));
 			cp_silence<LN, UL>(st, ex.collect_bits());
 			cp_final_store<LN, UL>(L, buf_of(tid), buf_of(tid), st, k_of(tid), lt_of(tid));
 			}

@@ -581,8 +581,9 @@ struct GpuExecP
 	ConvpState<LN, UL> st;
 	int tid_ = (int) threadIdx.x;
 	unsigned* flags_; // one word per wave behind the array (r8b_convp.h kConvpFlagBytes)
+	unsigned* lv_;    // ... and the blocks' level words behind them (kConvpLevelWords)
 	__device__ __forceinline__ explicit GpuExecP(unsigned char* smem)
-		: flags_(reinterpret_cast<unsigned*>(smem + convp_array_bytes<LN, UL>())) {}
+		: flags_(reinterpret_cast<unsigned*>(smem + convp_array_bytes<LN, UL>())), lv_(flags_ + 16) {}
 	// workgroup-wide OR of a small bit set: every thread posts before a barrier, anybody collects after it
 	__device__ __forceinline__ void post_bits(int, unsigned v)
 	{
@@ -596,6 +597,73 @@ struct GpuExecP
 #pragma unroll
 		for (int w = 0; w < ConvpGeom<LN, UL>::WT / 64; w++) r |= flags_[w];
 		return (unsigned) __builtin_amdgcn_readfirstlane((int) r);
+	}
+	// The levels of a block's two channels (r8b_convp.h cp_level_words), combined over the block's threads with a
+	// maximum per channel: every thread posts before a barrier, anybody collects after it.  A block of whole waves: inside
+	// a wave by DPP -- lane pairs, quads (quad_perm), the two quads of eight lanes (row_half_mirror), the two halves of a
+	// row (row_mirror) --, across its four rows through scalar registers, one packed word per wave; several blocks in a
+	// wave (short transforms): lane exchanges over the block's lanes, one word per block.
+	template<int CTRL>
+	static __device__ __forceinline__ unsigned lv_dpp_max(unsigned v)
+	{
+		const unsigned o = (unsigned) __builtin_amdgcn_update_dpp((int) v, (int) v, CTRL, 0xf, 0xf, false);
+		return o > v ? o : v;
+	}
+	static __device__ __forceinline__ unsigned lv_wave_max(unsigned v)
+	{
+		v = lv_dpp_max<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+		v = lv_dpp_max<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+		v = lv_dpp_max<0x141>(v);  // row_half_mirror
+		v = lv_dpp_max<0x140>(v);  // row_mirror
+		const unsigned r0 = (unsigned) __builtin_amdgcn_readlane((int) v, 0), r1 = (unsigned) __builtin_amdgcn_readlane((int) v, 16);
+		const unsigned r2 = (unsigned) __builtin_amdgcn_readlane((int) v, 32), r3 = (unsigned) __builtin_amdgcn_readlane((int) v, 48);
+		const unsigned m0 = r0 > r1 ? r0 : r1, m1 = r2 > r3 ? r2 : r3;
+		return m0 > m1 ? m0 : m1;
+	}
+	__device__ __forceinline__ void post_levels(int tid, int sub, CpLevels v)
+	{
+		typedef ConvpGeom<LN, UL> G;
+		if constexpr (G::NT >= 64)
+		{
+			CpLevels w;
+			w.a = lv_wave_max(v.a);
+			w.b = lv_wave_max(v.b);
+			if ((threadIdx.x & 63u) == 0) lv_[threadIdx.x >> 6] = cp_level_pack(w);
+		}
+		else
+		{
+			unsigned u = cp_level_pack(v);
+#pragma unroll
+			for (int m = 1; m < G::NT; m <<= 1) u = cp_level_max(u, (unsigned) __shfl_xor((int) u, m, 64));
+			if ((tid & (G::NT - 1)) == 0) lv_[sub] = u;
+		}
+	}
+	__device__ __forceinline__ unsigned collect_levels(int sub) const
+	{
+		typedef ConvpGeom<LN, UL> G;
+		if constexpr (G::NT >= 64)
+		{
+			constexpr int NWB = G::NT / 64; // waves per block
+			unsigned r = 0;
+#pragma unroll
+			for (int w = 0; w < NWB; w++) r = cp_level_max(r, lv_[sub * NWB + w]);
+			// (one block per workgroup: the same in every lane)
+			if constexpr (G::SUB == 1) r = (unsigned) __builtin_amdgcn_readfirstlane((int) r);
+			return r;
+		}
+		else return lv_[sub];
+	}
+	// the block's level shift (cp_level_shift), left in a word of its own by the first pass for the body's last phases
+	// (workgroup barriers lie in between)
+	__device__ __forceinline__ void post_shift(int, int sub, int lt, int d)
+	{
+		if (lt == 0) lv_[kConvpLevelWords + sub] = (unsigned) d;
+	}
+	__device__ __forceinline__ int collect_shift(int sub) const
+	{
+		const int d = (int) lv_[kConvpLevelWords + sub];
+		if constexpr (ConvpGeom<LN, UL>::SUB == 1) return __builtin_amdgcn_readfirstlane(d);
+		else return d;
 	}
 	// a value that is the same in every lane, kept in a vector register across phases: back to the scalar unit
 	__device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
@@ -699,7 +767,15 @@ __device__ __forceinline__ void convp_pin(ConvxLaunch& H, const ConvxLaunch& X)
 template<int LN, int UL, int MODE, int FLENP>
 __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLIT_MINBLOCKS : (ConvpGeom<LN, UL>::WT) > 256 ? 1 : 2)) void k_convp(const ConvxLaunch X)
 {
-	extern __shared__ __align__(256) unsigned char smem[];
+	extern __shared__ __align__(256) unsigned char smem_[];
+	// (development builds, the control of the occupancy experiment with a truncated array -- R8B_FAKE_LDS --: the array
+	// starts R8B_DEV_LDS_SHIFT bytes into a FULL-size allocation, so the same share of its accesses falls outside the
+	// allocation while the workgroups per CU stay what they are; timing only, results are wrong)
+#ifdef R8B_DEV_LDS_SHIFT
+	unsigned char* const smem = smem_ + R8B_DEV_LDS_SHIFT;
+#else
+	unsigned char* const smem = smem_;
+#endif
 #ifdef R8B_TIMELINE
 	const long long tl_t0 = (long long) __builtin_readcyclecounter();
 #endif

@@ -228,12 +228,24 @@ struct EmulExecP
 	static constexpr int WT = ConvpGeom<LN, UL>::WT;
 	std::vector<ConvpState<LN, UL>> st;
 	unsigned bits = 0;
-	EmulExecP() : st((size_t) WT) {}
+	// the blocks' level words (r8b_convp.h cp_level_bits): field-wise maximum over a block's threads
+	unsigned lv[ConvpGeom<LN, UL>::SUB];
+	EmulExecP() : st((size_t) WT) { next_block(); }
 	void stamp2() {}
 	void post_bits(int, unsigned v) { bits |= v; }
 	unsigned collect_bits() const { return bits; }
+	int shift[ConvpGeom<LN, UL>::SUB];
+	void post_levels(int, int sub, CpLevels v) { lv[sub] = cp_level_max(lv[sub], cp_level_pack(v)); }
+	unsigned collect_levels(int sub) const { return lv[sub]; }
+	void post_shift(int, int sub, int, int d) { shift[sub] = d; }
+	int collect_shift(int sub) const { return shift[sub]; }
 	int uniform(int v) const { return v; }
-	void next_block() { bits = 0; }
+	void next_block()
+	{
+		bits = 0;
+		for (unsigned& v : lv) v = 0;
+		for (int& v : shift) v = 0;
+	}
 	template<class F>
 	void phase(F f)
 	{

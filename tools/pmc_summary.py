@@ -103,8 +103,8 @@ for k in acc:
     if "FETCH_SIZE" in acc[k] and "WRITE_SIZE" in acc[k]:
         f = sum(acc[k]["FETCH_SIZE"]) / len(acc[k]["FETCH_SIZE"])
         w = sum(acc[k]["WRITE_SIZE"]) / len(acc[k]["WRITE_SIZE"])
-        short = "k_convx_whole" if k.startswith("k_convx<") and ", 1, 24>" in k or k.startswith("k_convx<") and ", 2, 24>" in k else k.split("<")[0]
-        rec[short] = {"kernel": k, "fetch_kb": f, "write_kb": w,
+        # (keyed by the device symbol, as bench.py's roofline.kernel and profiles/traffic.json are)
+        rec[k] = {"kernel": k, "fetch_kb": f, "write_kb": w,
                       "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0}
 with open(os.path.join(root, "traffic.json"), "w") as fh:
     json.dump(rec, fh, indent=1, sort_keys=True)

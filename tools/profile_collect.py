@@ -25,17 +25,11 @@ for cfg in sorted(os.listdir(src)):
         rec = json.load(open(os.path.join(d, "traffic.json")))
     except (OSError, ValueError):
         continue
-    # bench.py names the fused pair kernel k_convp_whole
-    fused = False
-    try:
-        line = json.loads(open(os.path.join(d, "bench_400.json")).read().strip().split("\n")[-1])
-        fused = "k_convp_whole" in line["roofline"]["kernels_ms_per_step"]
-    except Exception:
-        pass
+    ckey = bench_cfg.get(cfg, cfg)
+    for key in [key for key in traffic if key.startswith(ckey + ":")]:
+        del traffic[key]
     for k, v in rec.items():
-        # (... also in its walk form, k_convp_walk; the one-channel form with the interpolator fused in is k_convp<13, 0, 18, .>)
-        name = "k_convp_whole" if (k in ("k_convp", "k_convp_walk") and fused) else k
         v["profile"] = "%s_%s_pmc_summary.txt" % (prefix, cfg)
-        traffic["%s:%s" % (bench_cfg.get(cfg, cfg), name)] = v
+        traffic["%s:%s" % (ckey, v.get("kernel", k))] = v
 json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
 print("profiles/traffic.json:", sorted(traffic))
