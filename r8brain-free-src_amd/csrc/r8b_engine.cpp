@@ -823,6 +823,9 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// 3x up-sampling convolvers in the polyphase form -- one forward transform of the INPUT samples, three backward ones,
 	// no stuffed zeros transformed (r8b_convp.h mode 19, ConvGeom::p3); 0: the zero-stuffing block, as before round 5
 	opt_["up3_poly"] = 1;
+	// eight elements per thread (r8b_convq.h): the 2048 -> 4096-point convolver-only block pair on 512 threads (four waves
+	// per SIMD instead of two); same blocks, same state, results differ from the 256-thread form by rounding
+	opt_["quad"] = 0;
 	opt_["walk"] = 1;      // (0: a workgroup per block, as before round 5; 2: whatever the batch size -- tests)
 	opt_["walk_len"] = 0;  // blocks per workgroup of the walk form (0: the launch's whole run of blocks)
 	stat_["conv_blocks"] = 0;
@@ -1703,6 +1706,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		};
 		X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
 		X.walk = 0;
+		X.quad = opt_.at("quad") != 0 ? 1 : 0;
 		X.park_src = nullptr; X.park_dst = nullptr;
 		X.park_blk = SpanInfo();
 		long long ca = a; // the first output this call has to compute

@@ -123,6 +123,7 @@ struct __attribute__((aligned(8))) r8b_cd8_t { double re, im; };
 #include "r8b_kernel_phases.h"
 #include "r8b_convx.h"
 #include "r8b_convp.h"
+#include "r8b_convq.h"
 #include "r8b_pcm.h"
 
 namespace r8bhip {
@@ -911,6 +912,107 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), 2) void k_convp_walk(const
 	}
 }
 
+// ---- eight elements per thread (r8b_convq.h): the 2048 -> 4096-point block pair on 512 threads
+struct GpuExecQ
+{
+	ConvqState st;
+	int tid_ = (int) threadIdx.x;
+	unsigned* flags_;
+	unsigned* lv_;
+	__device__ __forceinline__ explicit GpuExecQ(unsigned char* smem)
+		: flags_(reinterpret_cast<unsigned*>(smem + kConvqN2 * 16)), lv_(flags_ + 16) {}
+	__device__ __forceinline__ void post_bits(int, unsigned v)
+	{
+		const unsigned w = (__builtin_amdgcn_ballot_w64((v & 1u) != 0) != 0 ? 1u : 0u) |
+			(__builtin_amdgcn_ballot_w64((v & 2u) != 0) != 0 ? 2u : 0u);
+		if ((threadIdx.x & 63u) == 0) flags_[threadIdx.x >> 6] = w;
+	}
+	__device__ __forceinline__ unsigned collect_bits() const
+	{
+		unsigned r = 0;
+#pragma unroll
+		for (int w = 0; w < kConvqThreads / 64; w++) r |= flags_[w];
+		return (unsigned) __builtin_amdgcn_readfirstlane((int) r);
+	}
+	__device__ __forceinline__ void post_levels(int, int, CpLevels v)
+	{
+		CpLevels w;
+		w.a = GpuExecP<11, 1>::lv_wave_max(v.a);
+		w.b = GpuExecP<11, 1>::lv_wave_max(v.b);
+		if ((threadIdx.x & 63u) == 0) lv_[threadIdx.x >> 6] = cp_level_pack(w);
+	}
+	__device__ __forceinline__ unsigned collect_levels(int) const
+	{
+		unsigned r = 0;
+#pragma unroll
+		for (int w = 0; w < kConvqThreads / 64; w++) r = cp_level_max(r, lv_[w]);
+		return (unsigned) __builtin_amdgcn_readfirstlane((int) r);
+	}
+	__device__ __forceinline__ void post_shift(int, int, int lt, int d)
+	{
+		if (lt == 0) lv_[kConvpLevelWords] = (unsigned) d;
+	}
+	__device__ __forceinline__ int collect_shift(int) const
+	{
+		return __builtin_amdgcn_readfirstlane((int) lv_[kConvpLevelWords]);
+	}
+	__device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+	__device__ __forceinline__ void wave_sync()
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+	}
+	template<class F0, class... F>
+	__device__ __forceinline__ void wave_steps(F0 f0, F... f)
+	{
+		f0(tid_, st);
+		((wave_sync(), f(tid_, st)), ...);
+		lds_barrier();
+	}
+	template<class F>
+	__device__ __forceinline__ void each(F f) { f(tid_, st); }
+	template<class F>
+	__device__ __forceinline__ void phase(F f)
+	{
+		f(tid_, st);
+		lds_barrier();
+	}
+};
+
+// one workgroup per block pair, the workgroup map of k_convp (pair-major over the launch's blocks, XCD-interleaved)
+__global__ __launch_bounds__(kConvqThreads, 2) void k_convq(const ConvxLaunch X)
+{
+	extern __shared__ __align__(256) unsigned char smem[];
+	const unsigned npair = ((unsigned) X.c.nch + 1u) >> 1, nbg = (unsigned) X.c.nblk;
+	unsigned bg, pr;
+	const unsigned wi = blockIdx.x;
+	if (nbg == 1) { bg = 0; pr = wi; }
+	else if ((npair & 7u) == 0)
+	{
+		const unsigned i = wi >> 3, qd = convp_div(i, X.nblk_magic);
+		bg = i - qd * nbg;
+		pr = (qd << 3) + (wi & 7u);
+	}
+	else
+	{
+		pr = convp_div(wi, X.nblk_magic);
+		bg = wi - pr * nbg;
+	}
+	bg = (unsigned) __builtin_amdgcn_readfirstlane((int) bg);
+	pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
+	GpuExecQ ex(smem);
+	ConvxLaunch H;
+	convp_pin<0>(H, X);
+	ConvpItem cur;
+	cur.k = X.c.k0 + (int) bg;
+	cur.nvalid = 1;
+	cur.chA = (int) (2u * pr);
+	cur.bvalid = cur.chA + 1 < X.c.nch;
+	cur.chB = cur.bvalid ? cur.chA + 1 : cur.chA;
+	convq_body(ex, H, X, reinterpret_cast<cd*>(smem), cur);
+}
+
 template<int LN, int UL, int MODE, int FLENP>
 void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 {
@@ -959,6 +1061,18 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 			static const std::string wsym = symbol4("k_convp_walk", LN, UL, MODE, FLENP);
 			launch_symbol_note(wsym.c_str());
 			launch_walk_blocks_add((long long) nwi);
+			return;
+		}
+	}
+	if constexpr (LN == 11 && UL == 1 && MODE == 0)
+	{
+		// eight elements per thread (r8b_convq.h): the same work on 512 threads per block pair, four waves per SIMD
+		if (X.quad != 0)
+		{
+			lds_opt_in(reinterpret_cast<const void*>(k_convq), "hipFuncSetAttribute(k_convq)");
+			hipLaunchKernelGGL(k_convq, dim3(grid), dim3(kConvqThreads), (size_t) convq_lds_bytes(), stream, X);
+			check(hipGetLastError(), "launch k_convq");
+			launch_symbol_note("k_convq");
 			return;
 		}
 	}

@@ -276,6 +276,9 @@ struct ConvxLaunch
 	// the walk body, walk_len of them per workgroup; the others -- a call's first and last blocks -- on the general body,
 	// a workgroup each, in the same launch
 	int walk_i0 = 0, walk_i1 = 0, walk_len = 0;
+	// eight elements per thread (r8b_convq.h: the 2048 -> 4096-point block pair on 512 threads, four waves per SIMD);
+	// the engine sets it where that form exists (option "quad") and the launcher takes it
+	int quad = 0;
 	long long park_j0, park_stride;
 	const double* park_src;
 	double* park_dst;

@@ -22,6 +22,7 @@
 #include "r8b_kernel_phases.h"
 #include "r8b_convx.h"
 #include "r8b_convp.h"
+#include "r8b_convq.h"
 #include "r8b_pcm.h"
 
 namespace r8bhip {
@@ -273,9 +274,77 @@ struct EmulExecP
 	}
 };
 
+// eight elements per thread (r8b_convq.h): 512 threads per block pair; waves of 64 run their wave-local steps one wave
+// after the other, like EmulExecP
+struct EmulExecQ
+{
+	static constexpr int WT = kConvqThreads;
+	std::vector<ConvqState> st;
+	unsigned bits = 0, lv = 0;
+	int shift = 0;
+	EmulExecQ() : st((size_t) WT) {}
+	void post_bits(int, unsigned v) { bits |= v; }
+	unsigned collect_bits() const { return bits; }
+	void post_levels(int, int, CpLevels v) { lv = cp_level_max(lv, cp_level_pack(v)); }
+	unsigned collect_levels(int) const { return lv; }
+	void post_shift(int, int, int, int d) { shift = d; }
+	int collect_shift(int) const { return shift; }
+	int uniform(int v) const { return v; }
+	template<class F>
+	void phase(F f)
+	{
+		for (int t = 0; t < WT; t++) f(t, st[(size_t) t]);
+	}
+	template<class F>
+	void each(F f)
+	{
+		for (int t = 0; t < WT; t++) f(t, st[(size_t) t]);
+	}
+	template<class F>
+	void run_step(F& f, int w)
+	{
+		// (lanes in DESCENDING order in every second wave: read-before-write inside a step is exercised)
+		if (w & 1)
+			for (int t = 64 * w + 63; t >= 64 * w; t--) f(t, st[(size_t) t]);
+		else
+			for (int t = 64 * w; t < 64 * w + 64; t++) f(t, st[(size_t) t]);
+	}
+	template<class... F>
+	void wave_steps(F... f)
+	{
+		for (int w = 0; w < WT / 64; w++) (run_step(f, w), ...);
+	}
+};
+
+void emul_convq(const ConvxLaunch& X0)
+{
+	ConvxLaunch X = X0;
+	convp_prepare<11, 1>(X, true, false, false, false);
+	std::vector<double> lds((size_t) convq_lds_bytes() / sizeof(double) + 2);
+	double* base = lds.data();
+	if (((size_t) base & 15) != 0) base++;
+	const long long items = (long long) X.c.nblk * ((X.c.nch + 1) / 2);
+	for (long long i = 0; i < items; i++)
+	{
+		EmulExecQ ex;
+		for (double& v : lds) v = std::numeric_limits<double>::quiet_NaN();
+		for (auto& s : ex.st)
+			for (int j = 0; j < 8; j++) s.vr[j] = s.vi[j] = std::numeric_limits<double>::quiet_NaN();
+		convq_body(ex, X, X, reinterpret_cast<cd*>(base), convp_item<1>(X.c, i, false));
+	}
+}
+
 template<int LN, int UL, int MODE, int FLENP>
 void emul_convp_t(const ConvxLaunch& X0)
 {
+	if constexpr (LN == 11 && UL == 1 && MODE == 0)
+	{
+		if (X0.quad != 0)
+		{
+			emul_convq(X0);
+			return;
+		}
+	}
 	ConvxLaunch X = X0;
 	constexpr bool SOLO = convp_mode_solo(MODE);
 	convp_prepare<LN, UL>(X, MODE != 1 && MODE != 18, convp_mode_sp(MODE), SOLO, convp_mode_p3(MODE));

@@ -1053,3 +1053,90 @@ def _host_buffers(xa, rows, cols):
 @pytest.mark.parametrize("case", COLUMN_CASES)
 def test_emulated_output_columns_are_bitwise_alike(emul, case):
     run_output_columns_case({"lib": emul}, case, _host_buffers)
+
+
+# ---- eight elements per thread (r8b_convq.h, engine option "quad"; round 6) ------------------------------------------------
+def _qswz(e):
+    return e ^ (((e >> 4) & 1) * 2) ^ (((e >> 5) & 1) * 13) ^ (((e >> 6) & 1) * 9)
+
+
+def _qfmap(p):
+    return ((p >> 8) << 9) | (p & 255)
+
+
+def test_convq_swizzle_is_conflict_free():
+    """r8b_convq.h qswz(): in every pass of the 512-thread form the sixteen lanes LDS serves together (16-byte accesses)
+    touch sixteen different 16-byte bank groups -- forward passes address forward positions through qfmap()"""
+    def check(name, elems_of_lane):
+        # elems_of_lane(b) -> the element indices lane b touches, one per access of the pass (same order in every lane)
+        for g0 in range(0, 512, 16):
+            per_access = list(zip(*[elems_of_lane(b) for b in range(g0, g0 + 16)]))
+            for acc in per_access:
+                banks = {_qswz(e) & 15 for e in acc}
+                assert len(banks) == 16, (name, g0, acc)
+
+    for n in (2048, 512, 128, 32, 8):        # forward DIF passes, radix 4
+        q = n // 4
+        check("fwd %d" % n, lambda b: [_qfmap((b // q) * n + b % q + p * q) for p in range(4)])
+    check("middle read", lambda b: [_qfmap(4 * b + c) for c in range(4)])
+    check("middle write", lambda b: [8 * b + p for p in range(8)])
+    for n in (64, 512, 4096):                # backward DIT passes, radix 8
+        q = n // 8
+        check("bwd %d" % n, lambda b: [(b // q) * n + b % q + p * q for p in range(8)])
+    # ... and the map is a permutation of the array
+    assert sorted(_qswz(e) for e in range(4096)) == list(range(4096))
+
+
+QUAD_CASES = [(44100.0, 88200.0, 6000, 2.0, 180.15, {}),
+              (44100.0, 88200.0, 6000, 2.0, 180.15, {"park": 0}),
+              (44100.0, 88200.0, 2500, 2.0, 180.15, {"fold_tail": 0}),
+              (44100.0, 2822400.0, 1024, 2.0, 180.15, {}),       # in front of the half-band cascade (written ahead into its ring)
+              (44100.0, 44101.0, 3000, 2.0, 180.15, {})]         # ... of the polynomial interpolator
+
+
+def run_quad_case(lib_kw, case, nch=5):
+    """the 2048 -> 4096-point convolver-only block pair on 512 threads (eight elements per thread, r8b_convq.h) against
+    the 256-thread form: same counts per call, samples to rounding (other radices), ragged calls, odd channel count,
+    history tail and parked outputs through the same mechanisms; channel 0 against the oracle"""
+    src, dst, maxin, tb, att, opts = case
+    x = make_input(nch, 5 * maxin, 41)
+    lens = [maxin, maxin, maxin // 5, 17, 1, maxin - 1, maxin // 2]
+    outs = []
+    for q in (0, 1):
+        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, **lib_kw)
+        for k, v in opts.items():
+            b.set_option(k, v)
+        b.set_option("quad", q)
+        ys, pos = [], 0
+        for l in lens:
+            ys.append(b.process_host(x[:, pos:pos + l]))
+            pos += l
+        outs.append(ys)
+    assert [y.shape for y in outs[0]] == [y.shape for y in outs[1]]
+    y0, y1 = np.concatenate(outs[0], axis=1), np.concatenate(outs[1], axis=1)
+    assert y1.shape[1] > 1000
+    d = y0 - y1
+    assert np.sqrt((d * d).mean()) <= RMS_TOL and np.abs(d).max() <= PEAK_TOL
+    assert d.any()   # (another rounding: the 512-thread kernel really ran)
+    o = O.OracleResampler(src, dst, maxin, tb, att)
+    yo, pos = [], 0
+    for l in lens:
+        yo.append(o.process(x[0, pos:pos + l]))
+        pos += l
+    do = y1[0] - np.concatenate(yo)
+    assert np.sqrt((do * do).mean()) <= RMS_TOL and np.abs(do).max() <= PEAK_TOL
+
+
+@pytest.mark.parametrize("case", QUAD_CASES)
+def test_emulated_eight_elements_per_thread_form(emul, case):
+    run_quad_case({"lib": emul}, case)
+
+
+def test_emulated_eight_elements_per_thread_levels_and_silence(emul):
+    """... with partners of very different level and silent channels (cases.check_pair_scales)"""
+    case = PAIR_SCALE_CASES[2]   # 44100 -> 88200, convolver alone
+    src, dst, maxin, chunk, n, tb, att = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=9, lib=emul)
+    b.set_option("quad", 1)
+    rel_rms, rel_pk = check_pair_scales(b, case)
+    assert rel_rms <= RMS_TOL and rel_pk <= PEAK_TOL

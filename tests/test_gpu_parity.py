@@ -451,6 +451,20 @@ def test_gpu_checkpoint_resume(src, dst):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [0, 1, 3])
+def test_hip_eight_elements_per_thread_form(torch, case):
+    """r8b_convq.h (engine option "quad": the 2048 -> 4096-point convolver-only block pair on 512 threads) against the
+    256-thread form and the oracle -- the measured E = 8 experiment of round 6 (profiles/r06_experiments.txt) stays correct"""
+    from test_emul import QUAD_CASES, run_quad_case
+    run_quad_case({"device": 0}, QUAD_CASES[case], nch=37)
+    b = r8b.BatchResampler(44100.0, 88200.0, 4096, 2.0, 180.15, nch=4, device=0)
+    b.set_option("quad", 1)
+    b.set_option("timing", 1)
+    b.process_host(make_input(4, 4096, 3))
+    assert "k_convq" in b.stage_symbols(), b.stage_symbols()
+
+
+@pytest.mark.gpu
 def test_bench_contract(tmp_path):
     """bench.py prints ONE JSON line carrying the driver's contract fields plus `roofline` (live
     HIP-event timing of the dominant kernel) -- a short run of the real script."""
