@@ -714,6 +714,14 @@ static bool generic_conv_fits(const ConvGeom& g)
 	return generic_conv_two_arrays(g) ||
 		(g.n_in == g.n_out && (size_t) g.n_in * sizeof(double) <= 160 * 1024);
 }
+// ... blocks of the reference's own length where the plan keeps them although the forward array does not fit (2^k
+// decimation in the spectrum on 32768-point blocks, r8b_plan.cpp): forward array in global memory, backward array in
+// LDS (k_conv_big)
+static bool generic_conv_big(const ConvGeom& g)
+{
+	return !generic_conv_fits(g) && g.down_pow2 && g.down > 1 && g.n_in <= 32768 &&
+		(size_t) g.n_out * sizeof(double) <= 128 * 1024;
+}
 
 std::vector<int> plan_radices(int N, int max_radix)
 {
@@ -877,7 +885,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 				const bool m3 = convx_mode3_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2);
 				const bool fast_ok = (m3 || convx_geometry_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2)) &&
 					convx_work_bytes(std::max(g.n_in, g.n_out) / 2) <= 160 * 1024;
-				if (!generic_conv_fits(g) && !fast_ok)
+				if (!generic_conv_fits(g) && !fast_ok && !generic_conv_big(g))
 					throw std::runtime_error("low-pass filter too long for the LDS-resident "
 						"block convolver (transition band too narrow)");
 				if (g.complex_h)
@@ -890,7 +898,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 						convp_solo_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len);
 					const bool down_cx = g.down == 2 &&
 						convp_solo_down_ok(g.n_in, g.n_out, g.up, g.down, g.up_pow2, g.down_pow2, g.in_len);
-					if (!generic_conv_fits(g) && !split_cx && !solo_cx && !down_cx)
+					if (!generic_conv_fits(g) && !split_cx && !solo_cx && !down_cx && !generic_conv_big(g))
 						throw std::runtime_error("minimum-phase filter too long for the generic block convolver");
 					const std::vector<double> hc = kernel_spectrum_complex(*sp.lp, g.bl2, g.fl2, 1.0 / g.bl2);
 					d.Hc = (cd*) dev_alloc(hc.size() * sizeof(double));
@@ -1329,6 +1337,7 @@ void Engine::release()
 		dev_free(d.ctab);
 		dev_free(d.park[0]);
 		dev_free(d.park[1]);
+		dev_free(d.work);
 	}
 	dev_.clear();
 }
@@ -1339,7 +1348,8 @@ void Engine::plan_transforms()
 	{
 		const StagePlan& sp = plan_.stages[s];
 		if (sp.desc.kind != kConv) continue;
-		dev_[s].fwd_radix = plan_radices(sp.cg.n_in / 2, opt_["conv_radix"]);
+		// (forward array in global memory: as few passes as there can be)
+		dev_[s].fwd_radix = plan_radices(sp.cg.n_in / 2, generic_conv_big(sp.cg) ? 16 : opt_["conv_radix"]);
 		std::vector<int> inv = plan_radices(sp.cg.n_out / 2, opt_["conv_radix"]);
 		// backward passes run with growing sub-transform length: smallest radix group first
 		dev_[s].inv_radix.assign(inv.rbegin(), inv.rend());
@@ -1377,6 +1387,22 @@ void Engine::ensure_ring(size_t s)
 	const size_t bytes = (size_t) d.ring_size * (size_t) nch_ * sizeof(double);
 	d.ring = (double*) dev_alloc(bytes);
 	if (s == 0) d.ring_alt = (double*) dev_alloc(bytes);
+}
+
+// forward arrays of the long-block generic convolver (k_conv_big): grown, never shrunk; growing waits for the device
+// (the arrays may be in use by an earlier launch), which happens on an object's first calls only
+void Engine::ensure_work(size_t s, int slots, void* stream)
+{
+	StageDev& d = dev_[s];
+	if (d.work != nullptr && d.work_slots >= slots) return;
+	if (d.work != nullptr)
+	{
+		dev_sync(stream); // (hipFree waits for the device besides)
+		dev_free(d.work);
+		d.work = nullptr;
+	}
+	d.work = (double*) dev_alloc((size_t) slots * (size_t) plan_.stages[s].cg.n_in * sizeof(double));
+	d.work_slots = slots;
 }
 
 void* Engine::get_event(StageDev& d)
@@ -1850,6 +1876,18 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		else
 		{
 			L.tail_ring = nullptr;
+			if (generic_conv_big(g))
+			{
+				// (the reference's 32768-point block in front of a decimation in the spectrum: forward arrays in global
+				// memory, one per workgroup of a launch that walks the (block, channel) items -- two workgroups per CU at
+				// most, so that the arrays in use stay within the Infinity Cache)
+				const long long items = (long long) L.nblk * L.nch;
+				const int slots = (int) std::min<long long>(items, 512);
+				ensure_work(s, slots, stream);
+				L.work = dev_[s].work;
+				L.work_slots = slots;
+				L.threads = 1024;
+			}
 			launch_conv(L, stream);
 		}
 		break;
@@ -2492,7 +2530,8 @@ void Engine::fill_conv(size_t s, ConvLaunch& L, const SrcView& src) const
 	L.vec_ok = src.cur_fmt == kPcmF64 && (src.cur == nullptr || (((size_t) src.cur & 15) == 0 &&
 		(src.cur_stride & 1) == 0 && (src.cur_base & 1) == 0)) && (src.ring_stride & 1) == 0 &&
 		((g.in_len / g.up) & 1) == 0 ? 1 : 0;
-	L.inplace = generic_conv_two_arrays(g) ? 0 : 1;
+	L.inplace = generic_conv_two_arrays(g) || generic_conv_big(g) ? 0 : 1;
+	L.work = nullptr; L.work_slots = 0;
 	L.up_pow2 = g.up_pow2 ? 1 : 0;
 	L.down_pow2 = g.down_pow2 ? 1 : 0;
 	L.n_fwd = (int) d.fwd_radix.size();

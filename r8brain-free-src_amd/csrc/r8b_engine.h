@@ -97,6 +97,10 @@ private:
 		long long park_stride = 0;
 		long long park_base = 0, park_end = 0;
 		int park_cur = 0;
+		// generic convolver on the reference's 32768-point blocks (k_conv_big): forward arrays in global memory, one per
+		// workgroup slot of the launch
+		double* work = nullptr;
+		int work_slots = 0;
 		std::vector<int> fwd_radix, inv_radix;
 		std::vector<std::pair<void*, void*>> pending; // (start, stop) events not yet read
 		std::vector<void*> free_events;
@@ -122,6 +126,7 @@ private:
 
 	void plan_transforms();
 	void ensure_ring(size_t s);
+	void ensure_work(size_t s, int slots, void* stream);
 	bool fuse_with_next(size_t s) const;
 	bool use_solo_fused(size_t s) const;
 	bool use_pair(const ConvGeom& g) const;

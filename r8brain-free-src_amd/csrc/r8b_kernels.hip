@@ -195,6 +195,50 @@ __global__ __launch_bounds__(256) void k_conv(const ConvLaunch L)
 	conv_store(L, rb, k, ch, tid, nthr);
 }
 
+// ... blocks whose forward array does not fit LDS (the reference's 32768-point blocks in front of a decimation in the
+// spectrum, which has to be taken on the reference's own block length -- r8b_plan.cpp): the same phases with the
+// forward array in global memory -- one array per workgroup, which walks the launch's (block, channel) items; its 256 KB
+// stay in the L2 / Infinity Cache between the passes -- and the backward array (<= 128 KB) in LDS.  Global memory is
+// coherent inside a workgroup across __syncthreads().
+__global__ __launch_bounds__(1024) void k_conv_big(const ConvLaunch L)
+{
+	extern __shared__ __align__(16) unsigned char smem[];
+	double* const ra = L.work + (size_t) blockIdx.x * (size_t) L.n_in;
+	cd* const za = reinterpret_cast<cd*>(ra);
+	double* const rb = reinterpret_cast<double*>(smem);
+	cd* const zb = reinterpret_cast<cd*>(smem);
+	const int tid = threadIdx.x, nthr = blockDim.x;
+	const long long items = (long long) L.nblk * L.nch;
+	for (long long it = blockIdx.x; it < items; it += gridDim.x)
+	{
+		// (a channel's blocks side by side: their windows overlap)
+		const int ch = (int) (it / L.nblk);
+		const long long k = L.k0 + (it - (long long) ch * L.nblk);
+		conv_load(L, ra, k, ch, tid, nthr);
+		__syncthreads();
+		const int N = L.n_in / 2;
+		int n = N;
+		for (int p = 0; p < L.n_fwd; p++)
+		{
+			fft_pass(za, N, n, L.fwd_radix[p], false, L.tw, L.tw_len, tid, nthr);
+			n /= L.fwd_radix[p];
+			__syncthreads();
+		}
+		conv_spectral(L, za, zb, tid, nthr);
+		__syncthreads();
+		const int N2 = L.n_out / 2;
+		n = 1;
+		for (int p = 0; p < L.n_inv; p++)
+		{
+			n *= L.inv_radix[p];
+			fft_pass(zb, N2, n, L.inv_radix[p], true, L.tw, L.tw_len, tid, nthr);
+			__syncthreads();
+		}
+		conv_store(L, rb, k, ch, tid, nthr);
+		__syncthreads();
+	}
+}
+
 // ------------------------------------------------------------------ whole-step polyphase FIR
 __global__ __launch_bounds__(256) void k_whole(const WholeLaunch L)
 {
@@ -1151,6 +1195,7 @@ void launch_convx_t(const ConvxLaunch& X, hipStream_t stream)
 void set_lds_attrs()
 {
 	lds_opt_in(reinterpret_cast<const void*>(k_conv), "hipFuncSetAttribute(k_conv)");
+	lds_opt_in(reinterpret_cast<const void*>(k_conv_big), "hipFuncSetAttribute(k_conv_big)");
 	lds_opt_in(reinterpret_cast<const void*>(k_whole), "hipFuncSetAttribute(k_whole)");
 	lds_opt_in(reinterpret_cast<const void*>(k_hbdcascade), "hipFuncSetAttribute(k_hbdcascade)");
 }
@@ -1162,6 +1207,14 @@ void set_lds_attrs()
 void R8B_LAUNCH(launch_conv)(const ConvLaunch& L, void* stream)
 {
 	set_lds_attrs();
+	if (L.work != nullptr)
+	{
+		hipLaunchKernelGGL(k_conv_big, dim3((unsigned) L.work_slots), dim3((unsigned) L.threads),
+			(size_t) L.n_out * sizeof(double), (hipStream_t) stream, L);
+		check(hipGetLastError(), "launch k_conv_big");
+		launch_symbol_note("k_conv_big");
+		return;
+	}
 	const size_t lds = (size_t) (L.inplace ? L.n_in : L.n_in + L.n_out) * sizeof(double);
 	hipLaunchKernelGGL(k_conv, dim3((unsigned) L.nblk, (unsigned) L.nch), dim3((unsigned) L.threads),
 		lds, (hipStream_t) stream, L);

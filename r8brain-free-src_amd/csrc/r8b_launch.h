@@ -59,6 +59,11 @@ struct ConvLaunch
 	// fast path: the source admits aligned 16-byte loads of sample pairs (even positions)
 	int vec_ok;
 	int inplace; // generic kernel: backward transform in the forward array (n_in == n_out only)
+	// generic kernel, blocks of the reference's longest filters (32768 points in front of a decimation in the spectrum:
+	// k_conv_big): the forward array does not fit LDS and lives in global memory, one array of n_in doubles per
+	// workgroup SLOT (the launch's workgroups walk the (block, channel) items); null: both arrays in LDS
+	double* work;
+	int work_slots;
 	// fast path at stage 0: the workgroups of the first block also copy stream positions
 	// [tail_p0, tail_p1) into the history ring the NEXT call reads (null: nothing to copy)
 	double* tail_ring;

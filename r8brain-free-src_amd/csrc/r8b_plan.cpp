@@ -102,8 +102,13 @@ StagePlan make_stage_plan(const StageDesc& d, double prev_lat)
 		}
 		g.latency = g.in_len + g.fl2; // reference: InputLen (after the divisibility adjustment) + latency
 		g.ref_bl2 = g.bl2; g.ref_in_len = g.in_len; g.ref_n_in = g.n_in; g.ref_n_out = g.n_out;
-		// transforms longer than 16384 points do not fit a workgroup's LDS: shorter blocks, same filter
-		while ((g.n_in > 16384 || g.n_out > 16384) && g.bl2 / 2 - (f.kernel_len - 1) - g.down >= 64)
+		// transforms longer than 16384 points do not fit a workgroup's LDS: shorter blocks, same filter -- exact for plain
+		// overlap-save and strided decimation.  NOT where the reference decimates by truncating the BLOCK's spectrum
+		// (2^k down factors, CDSPBlockConvolver.h:329-344): the truncation residue (-219 dB) depends on the block length,
+		// so those stages keep the reference's own 32768-point block and run on the generic kernel with its forward
+		// array in global memory (r8b_kernels.hip k_conv_big; ratios 3/2 and 3/4 at a 0.5 % transition band)
+		const bool exact_block = g.down_pow2 && g.down > 1 && g.n_in <= 32768 && g.n_out <= 16384;
+		while (!exact_block && (g.n_in > 16384 || g.n_out > 16384) && g.bl2 / 2 - (f.kernel_len - 1) - g.down >= 64)
 			shape(g.bl2 / 2);
 	}
 	else if (d.kind == kFrac)

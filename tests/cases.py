@@ -131,8 +131,8 @@ REBLOCK_CASES = [
     (48000.0, 32000.0, 4096, 3000, 90000, 0.5, 180.15, RMS_TOL, PEAK_TOL),    # 2/3
     (44100.0, 132300.0, 2048, 1000, 50000, 0.5, 180.15, RMS_TOL, PEAK_TOL),   # 3/1
     (96000.0, 32000.0, 4096, 4096, 120000, 0.5, 180.15, RMS_TOL, PEAK_TOL),   # 1/3
-    (32000.0, 48000.0, 2048, 2048, 60000, 0.5, 180.15, 1e-13, 5e-12),         # 3/2 (truncated spectrum)
-    (64000.0, 48000.0, 2048, 777, 70000, 0.5, 180.15, 1e-10, 5e-10),          # 3/4 (truncated spectrum)
+    (32000.0, 48000.0, 2048, 2048, 60000, 0.5, 180.15, RMS_TOL, PEAK_TOL),    # 3/2 (truncated spectrum: the reference's own 32768-point block)
+    (64000.0, 48000.0, 2048, 777, 70000, 0.5, 180.15, RMS_TOL, PEAK_TOL),     # 3/4 (truncated spectrum: ...)
 ]
 
 
@@ -157,8 +157,8 @@ SOLO_CASES = [
     (44100.0, 132300.0, 2048, 2048, 40000, 0.5, 180.15),      # 3x zero stuffing load (mode 11)
     (88200.0, 44100.0, 8192, 3000, 90000, 0.5, 180.15),       # decimating by 2 in the spectrum
     (176400.0, 44100.0, 16384, 16384, 200000, 0.55, 206.91),  # ... behind a half-band decimator (input from a ring)
-    (32000.0, 48000.0, 2048, 2048, 60000, 0.5, 180.15, 1e-13, 5e-12),   # 3x zero stuffing + decimating (REBLOCK_CASES' bound)
-    (64000.0, 48000.0, 2048, 777, 70000, 0.5, 180.15, 1e-10, 5e-10),    # ... decimating by 4 (REBLOCK_CASES' bound)
+    (32000.0, 48000.0, 2048, 2048, 60000, 0.6, 180.15),       # 3x zero stuffing + decimating (at 0.5 % the reference's block is 32768 points: REBLOCK_CASES)
+    (64000.0, 48000.0, 2048, 777, 70000, 0.7, 180.15),        # ... decimating by 4 (32768 points up to 0.6 %)
     (192000.0, 44100.0, 8192, 8192, 150000, 0.5, 180.15),     # half-band decimator + 16384 points 1:1 + interpolator
 ]
 
@@ -319,10 +319,10 @@ PARK_CASES = [
     (96000.0, 44100.0, 8192, 0.5, 180.15, "park"),        # 16384 points 1:1 with the interpolator fused in (mode 18, round 5)
     (96000.0, 44100.0, 8192, 0.5, 180.15, "ahead", {"solo_fuse": 0}),   # ... in front of the unfused interpolator
     (44100.0, 132300.0, 3000, 0.5, 180.15, "park"),       # 3x zero stuffing into 16384 points
-    (48000.0, 36000.0, 6000, 0.5, 180.15, "park"),        # 3x zero stuffing into 16384 points, decimated by 4
+    (48000.0, 36000.0, 6000, 0.7, 180.15, "park"),        # 3x zero stuffing into 16384 points, decimated by 4
     # the one-channel KERNEL (what is left for it: option pair_solo = 0): at the end of a chain through an output ring of
     # its own and a copy
-    (48000.0, 36000.0, 6000, 0.5, 180.15, "ahead", {"pair_solo": 0}),
+    (48000.0, 36000.0, 6000, 0.7, 180.15, "ahead", {"pair_solo": 0}),
     (48000.0, 16000.0, 8192, 0.5, 180.15, "ahead", {"pair_solo": 0}),
     (96000.0, 44100.0, 8192, 0.5, 180.15, "ahead", {"pair_solo": 0}),   # fused with the interpolator (output ring)
     (192000.0, 44100.0, 8192, 0.5, 180.15, "park"),       # half-band decimator + fused 16384 -> 16384 points (mode 18)

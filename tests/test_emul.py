@@ -82,13 +82,22 @@ def test_emulated_poly_channel_groups(emul):
     run_poly_channel_groups({"lib": emul})
 
 
+def exact_block_ratio(src, dst):
+    """the ratios whose convolver decimates by 2^k in the SPECTRUM (reference CDSPBlockConvolver.h:329-344): the
+    truncation residue depends on the block length, so they keep the reference's own 32768-point block (k_conv_big:
+    forward array in global memory) instead of running the filter on 16384-point blocks"""
+    return (src, dst) in ((32000.0, 48000.0), (64000.0, 48000.0))
+
+
 @pytest.mark.parametrize("case", REBLOCK_CASES)
 def test_emulated_long_filters_on_shorter_blocks(emul, refwrap, case):
-    """radix-3 convolvers whose reference block is 32768 points: same filter,
-    16384-point blocks; per-call counts equal the reference's, samples to the stated tolerance"""
+    """radix-3 convolvers whose reference block is 32768 points: same filter on 16384-point
+    blocks where overlap-save is exact for any block length (3/1, 1/3, 2/3), the reference's own block where it
+    decimates in the spectrum (3/2, 3/4); per-call counts equal the reference's, samples to the usual tolerance"""
     src, dst, maxin, chunk, n, tb, att, rtol, ptol = case
     b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, lib=emul)
     assert "fft=32768" in b.describe() or "/32768" in b.describe()   # describes the reference's block
+    b.set_option("timing", 1)
     x = make_input(2, n, 5)
     lens, ys, counts, pos = [], [], [], 0
     while pos < n:
@@ -100,6 +109,37 @@ def test_emulated_long_filters_on_shorter_blocks(emul, refwrap, case):
         pos += l
     r, p = refwrap.batch_check(src, dst, maxin, lens, x, np.concatenate(ys, axis=1), counts, tb, att)
     assert r.max() <= rtol and p.max() <= ptol, (r.max(), p.max())
+    names = [t[0] for t in b.stage_timings()]
+    assert (names == ["k_conv"]) == exact_block_ratio(src, dst), names
+
+
+def run_exact_block_chunk_invariance(lib_kw, src, dst, maxin, tb):
+    """the reference's 32768-point blocks (generic kernel, forward array in global memory; history by the copy kernel):
+    ragged calls and checkpoints into fresh objects equal MaxInLen calls bit for bit, odd channel count"""
+    n = maxin * 9 + 777
+    x = make_input(3, n, 33)
+    a = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, **lib_kw)
+    ya = np.concatenate([a.process_host(x[:, i:i + maxin]) for i in range(0, n, maxin)], axis=1)
+    lens = [maxin, 1, 3, maxin // 2 + 7, 1, maxin, 17, maxin - 9, 40, maxin, 1, maxin // 3]
+    b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, **lib_kw)
+    ys, pos, k = [], 0, 0
+    while pos < n:
+        l = min(lens[k % len(lens)], n - pos)
+        ys.append(b.process_host(x[:, pos:pos + l]))
+        pos += l
+        k += 1
+        if k in (2, 5, 9):
+            blob = b.state_dict()
+            b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, **lib_kw)
+            b.process_host(x[:, :333] * 0.25)
+            b.load_state_dict(blob)
+    yb = np.concatenate(ys, axis=1)
+    assert ya.shape == yb.shape and ya.shape[1] > 0 and np.array_equal(ya, yb)
+
+
+@pytest.mark.parametrize("src,dst,maxin,tb", [(32000.0, 48000.0, 5000, 0.5), (64000.0, 48000.0, 7000, 0.6)])
+def test_emulated_exact_block_chunk_invariance(emul, src, dst, maxin, tb):
+    run_exact_block_chunk_invariance({"lib": emul}, src, dst, maxin, tb)
 
 
 def run_split_form_case(lib_kw, case, split, nch=3):

@@ -295,6 +295,7 @@ def test_hip_long_filters_on_shorter_blocks(torch, refwrap, case):
     r8b_batch_create succeeds, counts equal the reference's, samples to the stated tolerance"""
     src, dst, maxin, chunk, n, tb, att, rtol, ptol = case
     b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=2, device=0)
+    b.set_option("timing", 1)
     x = make_input(2, n, 5)
     lens, ys, counts, pos = [], [], [], 0
     while pos < n:
@@ -306,6 +307,31 @@ def test_hip_long_filters_on_shorter_blocks(torch, refwrap, case):
         pos += l
     r, p = refwrap.batch_check(src, dst, maxin, lens, x, np.concatenate(ys, axis=1), counts, tb, att)
     assert r.max() <= rtol and p.max() <= ptol, (r.max(), p.max())
+    from test_emul import exact_block_ratio
+    assert ([t[0] for t in b.stage_timings()] == ["k_conv"]) == exact_block_ratio(src, dst)
+    if exact_block_ratio(src, dst):
+        assert b.stage_symbols() == ["k_conv_big"], b.stage_symbols()
+
+
+@pytest.mark.parametrize("src,dst,maxin,tb", [(32000.0, 48000.0, 5000, 0.5), (64000.0, 48000.0, 7000, 0.6)])
+def test_hip_exact_block_chunk_invariance(torch, src, dst, maxin, tb):
+    """k_conv_big: ragged calls and checkpoints == MaxInLen calls bit for bit"""
+    from test_emul import run_exact_block_chunk_invariance
+    run_exact_block_chunk_invariance({"device": 0}, src, dst, maxin, tb)
+
+
+def test_hip_exact_block_many_items(torch, refwrap):
+    """k_conv_big with more (block, channel) items than workgroup slots (512): every channel against the reference"""
+    src, dst, maxin, tb, att, nch = 32000.0, 48000.0, 16384, 0.5, 180.15, 300
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, device=0)
+    x = make_input(nch, 3 * maxin, 11)
+    ys, counts = [], []
+    for i in range(3):
+        y = b.process_host(x[:, i * maxin:(i + 1) * maxin])
+        ys.append(y)
+        counts.append(y.shape[1])
+    r, p = refwrap.batch_check(src, dst, maxin, [maxin] * 3, x, np.concatenate(ys, axis=1), counts, tb, att)
+    assert r.max() <= RMS_TOL and p.max() <= PEAK_TOL, (r.max(), p.max())
 
 
 @pytest.mark.parametrize("case", MINPHASE_CASES)
