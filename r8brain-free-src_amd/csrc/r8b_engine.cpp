@@ -715,8 +715,8 @@ static bool generic_conv_fits(const ConvGeom& g)
 		(g.n_in == g.n_out && (size_t) g.n_in * sizeof(double) <= 160 * 1024);
 }
 // ... blocks of the reference's own length where the plan keeps them although the forward array does not fit (2^k
-// decimation in the spectrum on 32768-point blocks, r8b_plan.cpp): forward array in global memory, backward array in
-// LDS (k_conv_big)
+// decimation in the spectrum on 32768-point blocks, r8b_plan.cpp): the forward transform in two halves through LDS
+// (k_conv_big)
 static bool generic_conv_big(const ConvGeom& g)
 {
 	return !generic_conv_fits(g) && g.down_pow2 && g.down > 1 && g.n_in <= 32768 &&
@@ -1348,9 +1348,16 @@ void Engine::plan_transforms()
 	{
 		const StagePlan& sp = plan_.stages[s];
 		if (sp.desc.kind != kConv) continue;
-		// (forward array in global memory: as few passes as there can be)
-		dev_[s].fwd_radix = plan_radices(sp.cg.n_in / 2, generic_conv_big(sp.cg) ? 16 : opt_["conv_radix"]);
-		std::vector<int> inv = plan_radices(sp.cg.n_out / 2, opt_["conv_radix"]);
+		const bool big = generic_conv_big(sp.cg);
+		dev_[s].fwd_radix = plan_radices(sp.cg.n_in / 2, opt_["conv_radix"]);
+		std::vector<int> inv = plan_radices(sp.cg.n_out / 2, big ? 16 : opt_["conv_radix"]);
+		if (big)
+		{
+			// (k_conv_big: a radix-2 stage in the load, then the two sub-blocks of half the length on their own, on 512
+			// threads -- one radix-16 butterfly each)
+			dev_[s].fwd_radix = plan_radices(sp.cg.n_in / 4, 16);
+			dev_[s].fwd_radix.insert(dev_[s].fwd_radix.begin(), 2);
+		}
 		// backward passes run with growing sub-transform length: smallest radix group first
 		dev_[s].inv_radix.assign(inv.rbegin(), inv.rend());
 	}
@@ -1389,8 +1396,9 @@ void Engine::ensure_ring(size_t s)
 	if (s == 0) d.ring_alt = (double*) dev_alloc(bytes);
 }
 
-// forward arrays of the long-block generic convolver (k_conv_big): grown, never shrunk; growing waits for the device
-// (the arrays may be in use by an earlier launch), which happens on an object's first calls only
+// backward-spectrum arrays of the long-block generic convolver (k_conv_big), one per workgroup of its launch: grown,
+// never shrunk; growing waits for the device (the arrays may be in use by an earlier launch), which happens on an
+// object's first calls only
 void Engine::ensure_work(size_t s, int slots, void* stream)
 {
 	StageDev& d = dev_[s];
@@ -1401,7 +1409,7 @@ void Engine::ensure_work(size_t s, int slots, void* stream)
 		dev_free(d.work);
 		d.work = nullptr;
 	}
-	d.work = (double*) dev_alloc((size_t) slots * (size_t) plan_.stages[s].cg.n_in * sizeof(double));
+	d.work = (double*) dev_alloc((size_t) slots * (size_t) plan_.stages[s].cg.n_out * sizeof(double));
 	d.work_slots = slots;
 }
 
@@ -1878,15 +1886,15 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			L.tail_ring = nullptr;
 			if (generic_conv_big(g))
 			{
-				// (the reference's 32768-point block in front of a decimation in the spectrum: forward arrays in global
-				// memory, one per workgroup of a launch that walks the (block, channel) items -- two workgroups per CU at
-				// most, so that the arrays in use stay within the Infinity Cache)
+				// (the reference's 32768-point block in front of a decimation in the spectrum: the launch's workgroups --
+				// one per CU, 128 KB of LDS each -- walk the (block, channel) items; a workgroup's packed backward spectrum
+				// passes through its own array in global memory)
 				const long long items = (long long) L.nblk * L.nch;
-				const int slots = (int) std::min<long long>(items, 512);
+				const int slots = (int) std::min<long long>(items, 256);
 				ensure_work(s, slots, stream);
 				L.work = dev_[s].work;
 				L.work_slots = slots;
-				L.threads = 1024;
+				L.threads = 512;
 			}
 			launch_conv(L, stream);
 		}

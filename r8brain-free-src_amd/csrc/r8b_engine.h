@@ -97,8 +97,8 @@ private:
 		long long park_stride = 0;
 		long long park_base = 0, park_end = 0;
 		int park_cur = 0;
-		// generic convolver on the reference's 32768-point blocks (k_conv_big): forward arrays in global memory, one per
-		// workgroup slot of the launch
+		// generic convolver on the reference's 32768-point blocks (k_conv_big): the packed backward spectra on their way
+		// between the two forward halves and the backward transform, one array of n_out doubles per workgroup of the launch
 		double* work = nullptr;
 		int work_slots = 0;
 		std::vector<int> fwd_radix, inv_radix;

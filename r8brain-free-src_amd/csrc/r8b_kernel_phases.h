@@ -459,12 +459,30 @@ R8B_HD void conv_load(const ConvLaunch& L, double* a, long long k, int ch, int t
 	}
 }
 
+// where the forward result's bins are: the whole transform bit-reversed in one array (bin k at bitrev(k)) ...
+struct ZFull
+{
+	const cd* za;
+	int logN;
+	R8B_HD cd operator()(int k) const { return za[bitrev_n(k, logN)]; }
+};
+// ... or ONE of the two sub-blocks the first radix-2 DIF stage leaves -- bins k = h (mod 2) --, transformed as an array
+// of its own (k_conv_big): bin k at bitrev(k >> 1) of N / 2 positions.  Bins k and N - k, kp and N2 - kp have the same
+// parity (N, N2 even), so the spectral stage of a parity class needs its own sub-block only.
+struct ZHalf
+{
+	const cd* zl;
+	int logN;
+	R8B_HD cd operator()(int k) const { return zl[bitrev_n(k >> 1, logN - 1)]; }
+};
+
 // spectrum bin k (0 <= k <= N) of the 2N-point real sequence whose packed N-point complex DFT
-// sits bit-reversed in `za`
-R8B_HD cd real_bin(const cd* za, int k, int N, int logN, const cd* tw, int tw_len)
+// sits bit-reversed behind `z`
+template<class Z>
+R8B_HD cd real_bin(const Z& z, int k, int N, const cd* tw, int tw_len)
 {
 	const int k1 = k & (N - 1), k2 = (N - k) & (N - 1);
-	const cd z1 = za[bitrev_n(k1, logN)], z2 = za[bitrev_n(k2, logN)];
+	const cd z1 = z(k1), z2 = z(k2);
 	const double er = 0.5 * (z1.re + z2.re), ei = 0.5 * (z1.im - z2.im);
 	// O = (Z1 - conj Z2) / (2i)
 	const double dr = z1.re - z2.re, di = z1.im + z2.im;
@@ -478,11 +496,12 @@ R8B_HD cd real_bin(const cd* za, int k, int N, int logN, const cd* tw, int tw_le
 
 // bin m (0 <= m <= bl2/2) of the spectrum of the zero-stuffed block: the 2N-point spectrum
 // repeated with period 2N (K3, reference CDSPBlockConvolver.h:606-629)
-R8B_HD cd stuffed_bin(const cd* za, int m, int N, int logN, const cd* tw, int tw_len)
+template<class Z>
+R8B_HD cd stuffed_bin(const Z& z, int m, int N, const cd* tw, int tw_len)
 {
 	const int mm = m & (2 * N - 1);
-	if (mm <= N) return real_bin(za, mm, N, logN, tw, tw_len);
-	cd r = real_bin(za, 2 * N - mm, N, logN, tw, tw_len);
+	if (mm <= N) return real_bin(z, mm, N, tw, tw_len);
+	cd r = real_bin(z, 2 * N - mm, N, tw, tw_len);
 	r.im = -r.im;
 	return r;
 }
@@ -491,9 +510,10 @@ R8B_HD cd stuffed_bin(const cd* za, int m, int N, int logN, const cd* tw, int tw
 // multiply by the real zero-phase kernel (reference CDSPRealFFT.h:289-385); when decimating by
 // 2^k the Nyquist bin of the shortened transform is the reference's fix-up
 // (reference CDSPBlockConvolver.h:329-342).
-R8B_HD cd product_bin(const ConvLaunch& L, const cd* za, int m, int N, int logN, int N2)
+template<class Z>
+R8B_HD cd product_bin(const ConvLaunch& L, const Z& z, int m, int N, int N2)
 {
-	cd r = stuffed_bin(za, m, N, logN, L.tw, L.tw_len);
+	cd r = stuffed_bin(z, m, N, L.tw, L.tw_len);
 	if (L.Hc != nullptr)
 	{
 		// complex kernel spectrum (minimum phase; reference CDSPRealFFT.h:186-274 multiplyBlocks)
@@ -516,16 +536,18 @@ R8B_HD cd product_bin(const ConvLaunch& L, const cd* za, int m, int N, int logN,
 }
 
 // K3+K4+K5 and the packing for the half-length complex backward transform: reads the forward
-// result (bit-reversed, buffer za, N complex), writes N2 complex values bit-reversed into zb.
-R8B_HD void conv_spectral(const ConvLaunch& L, const cd* za, cd* zb, int tid, int nthr)
+// result (bit-reversed behind `z`, N complex), writes N2 complex values bit-reversed into zb -- the slots
+// kp = first, first + step, ... <= N2 / 2 (a slot is the pair of backward bins kp, N2 - kp).
+template<class Z>
+R8B_HD void conv_spectral_z(const ConvLaunch& L, const Z& z, cd* zb, int first, int step, int tid, int nthr)
 {
 	const int N = L.n_in / 2, N2 = L.n_out / 2;
-	const int logN = ilog2(N), logN2 = ilog2(N2);
+	const int logN2 = ilog2(N2);
 	const int tsh = L.tw_len / (2 * N2);
-	for (int kp = tid; kp <= N2 / 2; kp += nthr)
+	for (int kp = first + step * tid; kp <= N2 / 2; kp += step * nthr)
 	{
-		const cd sa = product_bin(L, za, kp, N, logN, N2);
-		const cd sb = product_bin(L, za, N2 - kp, N, logN, N2);
+		const cd sa = product_bin(L, z, kp, N, N2);
+		const cd sb = product_bin(L, z, N2 - kp, N, N2);
 		// Z'[k] = (Sa + conj Sb) + i * conj(w^k) * (Sa - conj Sb),  w = exp(-2 pi i / (2 N2))
 		{
 			const cd w = L.tw[(long) kp * tsh];
@@ -533,10 +555,10 @@ R8B_HD void conv_spectral(const ConvLaunch& L, const cd* za, cd* zb, int tid, in
 			const double dr = sa.re - sb.re, di = sa.im + sb.im;
 			// conj(w) * D
 			const double pr = w.re * dr + w.im * di, pi = w.re * di - w.im * dr;
-			cd z;
-			z.re = er - pi;
-			z.im = ei + pr;
-			zb[bitrev_n(kp, logN2)] = z;
+			cd zz;
+			zz.re = er - pi;
+			zz.im = ei + pr;
+			zb[bitrev_n(kp, logN2)] = zz;
 		}
 		const int k2 = N2 - kp;
 		if (kp != 0 && k2 != kp)
@@ -545,12 +567,103 @@ R8B_HD void conv_spectral(const ConvLaunch& L, const cd* za, cd* zb, int tid, in
 			const double er = sb.re + sa.re, ei = sb.im - sa.im;
 			const double dr = sb.re - sa.re, di = sb.im + sa.im;
 			const double pr = w.re * dr + w.im * di, pi = w.re * di - w.im * dr;
-			cd z;
-			z.re = er - pi;
-			z.im = ei + pr;
-			zb[bitrev_n(k2, logN2)] = z;
+			cd zz;
+			zz.re = er - pi;
+			zz.im = ei + pr;
+			zb[bitrev_n(k2, logN2)] = zz;
 		}
 	}
+}
+
+R8B_HD void conv_spectral(const ConvLaunch& L, const cd* za, cd* zb, int tid, int nthr)
+{
+	ZFull z;
+	z.za = za;
+	z.logN = ilog2(L.n_in / 2);
+	conv_spectral_z(L, z, zb, 0, 1, tid, nthr);
+}
+
+// ---- blocks whose forward array does not fit LDS (k_conv_big: the reference's 32768-point blocks in front of a
+// decimation in the spectrum).  The forward transform's first radix-2 DIF stage is taken in the load -- every sample of
+// the block is a function of the source alone --, which leaves two independent sub-blocks of N / 2 complex: each is
+// loaded, transformed and multiplied into its parity class of backward bins (ZHalf) in LDS, one after the other; only
+// the packed backward spectrum (n_out doubles) goes through global memory.
+
+// sample i of block k's circular input (conv_load's element).  Zero stuffing: virtual time t = base + d, d = i or
+// i - bl2, in 32-bit arithmetic relative to the block's base (q0 = floor(base / up), r0 = base mod up, once per block):
+// t is a source sample's time iff (r0 + d) mod up == 0, the sample q0 + floor((r0 + d) / up)
+struct ConvBlockBase
+{
+	long long q0;
+	int r0;
+};
+R8B_HD ConvBlockBase conv_block_base(const ConvLaunch& L, long long k)
+{
+	ConvBlockBase B;
+	if (L.up_pow2)
+	{
+		B.q0 = k * (L.in_len / L.up);
+		B.r0 = 0;
+	}
+	else
+	{
+		const long long base = k * (long long) L.in_len;
+		B.q0 = base / L.up;
+		B.r0 = (int) (base - B.q0 * L.up);
+	}
+	return B;
+}
+R8B_HD double conv_sample(const ConvLaunch& L, const ConvBlockBase& B, int ch, int i)
+{
+	if (L.up_pow2)
+	{
+		const int iln = L.in_len / L.up;
+		return src_load(L.src, ch, i < iln ? B.q0 + i : B.q0 + i - L.n_in);
+	}
+	const int d = i < L.in_len ? i : i - L.bl2; // (>= -bl2)
+	const int bias = (L.bl2 / L.up + 1) * L.up;   // a multiple of up that makes the dividend positive
+	const unsigned e = (unsigned) (B.r0 + d + bias);
+	const unsigned q = L.up == 3 ? e / 3u : e / (unsigned) L.up;
+	if (e - q * (unsigned) L.up != 0u) return 0.0;
+	const long long pos = B.q0 + (long long) q - bias / L.up;
+	return pos >= 0 ? src_load(L.src, ch, pos) : 0.0;
+}
+
+// sub-block h (0 / 1) of block k behind the first radix-2 DIF stage (dif_pass_one<2> at n = N, in the same order of
+// operations), N / 2 complex into zl
+R8B_HD void conv_load_r2(const ConvLaunch& L, cd* zl, long long k, int ch, int h, int tid, int nthr)
+{
+	const int N = L.n_in / 2, Nh = N / 2;
+	const int ts = L.tw_len / N;
+	const ConvBlockBase B = conv_block_base(L, k);
+	for (int j = tid; j < Nh; j += nthr)
+	{
+		const double ar = conv_sample(L, B, ch, 2 * j), ai = conv_sample(L, B, ch, 2 * j + 1);
+		const double br = conv_sample(L, B, ch, 2 * (j + Nh)), bi = conv_sample(L, B, ch, 2 * (j + Nh) + 1);
+		cd o;
+		if (h == 0)
+		{
+			o.re = ar + br;
+			o.im = ai + bi;
+		}
+		else
+		{
+			const double dr = ar - br, di = ai - bi;
+			const cd w = L.tw[(long) ts * j];
+			o.re = dr * w.re - di * w.im;
+			o.im = dr * w.im + di * w.re;
+		}
+		zl[j] = o;
+	}
+}
+
+// the spectral stage of sub-block h: backward bins kp = h (mod 2) from the sub-block's transform in zl
+R8B_HD void conv_spectral_half(const ConvLaunch& L, const cd* zl, cd* zb, int h, int tid, int nthr)
+{
+	ZHalf z;
+	z.zl = zl;
+	z.logN = ilog2(L.n_in / 2);
+	conv_spectral_z(L, z, zb, h, 2, tid, nthr);
 }
 
 // K7: emit the valid part of block k that falls into the call's output range [L.a, L.b)

@@ -196,38 +196,45 @@ __global__ __launch_bounds__(256) void k_conv(const ConvLaunch L)
 }
 
 // ... blocks whose forward array does not fit LDS (the reference's 32768-point blocks in front of a decimation in the
-// spectrum, which has to be taken on the reference's own block length -- r8b_plan.cpp): the same phases with the
-// forward array in global memory -- one array per workgroup, which walks the launch's (block, channel) items; its 256 KB
-// stay in the L2 / Infinity Cache between the passes -- and the backward array (<= 128 KB) in LDS.  Global memory is
+// spectrum, which has to be taken on the reference's own block length -- r8b_plan.cpp).  The first radix-2 DIF stage of
+// the forward transform is taken in the load, which leaves two independent sub-blocks of N / 2 = 8192 complex (128 KB):
+// each is loaded, transformed and multiplied into its parity class of backward bins IN LDS, one after the other
+// (r8b_kernel_phases.h conv_load_r2 / conv_spectral_half); only the packed backward spectrum (n_out doubles, one array
+// per workgroup, which walks the launch's (block, channel) items) passes through global memory -- written in
+// bit-reversed slots, read back as a run -- before the backward transform runs in the same LDS.  Global memory is
 // coherent inside a workgroup across __syncthreads().
-__global__ __launch_bounds__(1024) void k_conv_big(const ConvLaunch L)
+__global__ __launch_bounds__(512) void k_conv_big(const ConvLaunch L)
 {
 	extern __shared__ __align__(16) unsigned char smem[];
-	double* const ra = L.work + (size_t) blockIdx.x * (size_t) L.n_in;
-	cd* const za = reinterpret_cast<cd*>(ra);
+	cd* const zl = reinterpret_cast<cd*>(smem);
 	double* const rb = reinterpret_cast<double*>(smem);
 	cd* const zb = reinterpret_cast<cd*>(smem);
+	cd* const zg = reinterpret_cast<cd*>(L.work + (size_t) blockIdx.x * (size_t) L.n_out);
 	const int tid = threadIdx.x, nthr = blockDim.x;
 	const long long items = (long long) L.nblk * L.nch;
+	const int Nh = L.n_in / 4, N2 = L.n_out / 2;
 	for (long long it = blockIdx.x; it < items; it += gridDim.x)
 	{
 		// (a channel's blocks side by side: their windows overlap)
 		const int ch = (int) (it / L.nblk);
 		const long long k = L.k0 + (it - (long long) ch * L.nblk);
-		conv_load(L, ra, k, ch, tid, nthr);
-		__syncthreads();
-		const int N = L.n_in / 2;
-		int n = N;
-		for (int p = 0; p < L.n_fwd; p++)
+		for (int h = 0; h < 2; h++)
 		{
-			fft_pass(za, N, n, L.fwd_radix[p], false, L.tw, L.tw_len, tid, nthr);
-			n /= L.fwd_radix[p];
+			conv_load_r2(L, zl, k, ch, h, tid, nthr);
+			__syncthreads();
+			int n = Nh;
+			for (int p = 1; p < L.n_fwd; p++)
+			{
+				fft_pass(zl, Nh, n, L.fwd_radix[p], false, L.tw, L.tw_len, tid, nthr);
+				n /= L.fwd_radix[p];
+				__syncthreads();
+			}
+			conv_spectral_half(L, zl, zg, h, tid, nthr);
 			__syncthreads();
 		}
-		conv_spectral(L, za, zb, tid, nthr);
+		for (int i = tid; i < N2; i += nthr) zb[i] = zg[i];
 		__syncthreads();
-		const int N2 = L.n_out / 2;
-		n = 1;
+		int n = 1;
 		for (int p = 0; p < L.n_inv; p++)
 		{
 			n *= L.inv_radix[p];
@@ -1209,8 +1216,10 @@ void R8B_LAUNCH(launch_conv)(const ConvLaunch& L, void* stream)
 	set_lds_attrs();
 	if (L.work != nullptr)
 	{
+		// (LDS: a forward sub-block of n_in / 4 complex, then the backward array of n_out doubles)
+		const size_t lds_big = (size_t) std::max(L.n_in / 2, L.n_out) * sizeof(double);
 		hipLaunchKernelGGL(k_conv_big, dim3((unsigned) L.work_slots), dim3((unsigned) L.threads),
-			(size_t) L.n_out * sizeof(double), (hipStream_t) stream, L);
+			lds_big, (hipStream_t) stream, L);
 		check(hipGetLastError(), "launch k_conv_big");
 		launch_symbol_note("k_conv_big");
 		return;

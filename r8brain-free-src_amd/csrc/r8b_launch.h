@@ -60,8 +60,10 @@ struct ConvLaunch
 	int vec_ok;
 	int inplace; // generic kernel: backward transform in the forward array (n_in == n_out only)
 	// generic kernel, blocks of the reference's longest filters (32768 points in front of a decimation in the spectrum:
-	// k_conv_big): the forward array does not fit LDS and lives in global memory, one array of n_in doubles per
-	// workgroup SLOT (the launch's workgroups walk the (block, channel) items); null: both arrays in LDS
+	// k_conv_big): the forward transform runs in two halves through LDS, the packed backward spectrum of a block passes
+	// through global memory -- one array of n_out doubles per workgroup SLOT (the launch's workgroups walk the (block,
+	// channel) items); null: the ordinary generic kernel, both arrays in LDS.  fwd_radix[0] is then the radix-2 stage
+	// taken in the load, the rest the passes of a sub-block (n_in / 4 complex)
 	double* work;
 	int work_slots;
 	// fast path at stage 0: the workgroups of the first block also copy stream positions

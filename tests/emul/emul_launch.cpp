@@ -27,8 +27,45 @@
 
 namespace r8bhip {
 
+// the long-block form (k_conv_big): the same phases in the kernel's order
+static void launch_conv_big(const ConvLaunch& L)
+{
+	const int Nh = L.n_in / 4, N2 = L.n_out / 2, nthr = L.threads;
+	std::vector<cd> zl((size_t) std::max(Nh, N2)), zg((size_t) N2);
+	for (int ch = 0; ch < L.nch; ch++)
+		for (int bx = 0; bx < L.nblk; bx++)
+		{
+			const long long k = L.k0 + bx;
+			for (int h = 0; h < 2; h++)
+			{
+				for (int t = 0; t < nthr; t++) conv_load_r2(L, zl.data(), k, ch, h, t, nthr);
+				int n = Nh;
+				for (int p = 1; p < L.n_fwd; p++)
+				{
+					for (int t = 0; t < nthr; t++) fft_pass(zl.data(), Nh, n, L.fwd_radix[p], false, L.tw, L.tw_len, t, nthr);
+					n /= L.fwd_radix[p];
+				}
+				for (int t = 0; t < nthr; t++) conv_spectral_half(L, zl.data(), zg.data(), h, t, nthr);
+			}
+			for (int i = 0; i < N2; i++) zl[(size_t) i] = zg[(size_t) i];
+			int n = 1;
+			for (int p = 0; p < L.n_inv; p++)
+			{
+				n *= L.inv_radix[p];
+				for (int t = 0; t < nthr; t++) fft_pass(zl.data(), N2, n, L.inv_radix[p], true, L.tw, L.tw_len, t, nthr);
+			}
+			for (int t = 0; t < nthr; t++)
+				conv_store(L, reinterpret_cast<const double*>(zl.data()), k, ch, t, nthr);
+		}
+}
+
 void launch_conv(const ConvLaunch& L, void*)
 {
+	if (L.work != nullptr)
+	{
+		launch_conv_big(L);
+		return;
+	}
 	std::vector<double> lds((size_t) (L.n_in + L.n_out) + 2);
 	// 16-byte alignment for the cd views
 	double* base = lds.data();
