@@ -838,6 +838,7 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	opt_["walk_len"] = 0;  // blocks per workgroup of the walk form (0: the launch's whole run of blocks)
 	stat_["conv_blocks"] = 0;
 	stat_["walk_blocks"] = 0; // blocks of the fused pair kernel's launches that ran on the walk body (per channel, like conv_blocks)
+	stat_["tail_launches"] = 0; // history copies that needed a launch of their own (k_tail)
 	stat_["park_calls"] = 0;
 	stat_["park_only_calls"] = 0;
 	stat_["pcm_staged_sides"] = 0; // planar PCM sides that went through the staging rows (r8b_capi.cpp)
@@ -1413,6 +1414,17 @@ void Engine::ensure_work(size_t s, int slots, void* stream)
 	d.work_slots = slots;
 }
 
+// a half-band launch takes the call's pending history copy with it (Engine::process)
+void Engine::take_carried_tail(TailLaunch& T, int* carry)
+{
+	*carry = 0;
+	T = carry_tail_;
+	if (!carry_) return;
+	carry_ = false;
+	tail_done_ = true;
+	if (carry_tail_.p1 > carry_tail_.p0) *carry = 1;
+}
+
 void* Engine::get_event(StageDev& d)
 {
 	if (!d.free_events.empty())
@@ -1964,6 +1976,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		L.tile = opt_.at("hb_tile");
 		L.nch = nchw_;
 		L.src = src; L.dst = dst;
+		take_carried_tail(L.tail, &L.carry_tail);
 		if (sp.desc.kind == kHBUp) launch_hbup(L, stream);
 		else launch_hbdown(L, stream);
 		break;
@@ -2118,7 +2131,26 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 			dst.off = 0;
 			dst.fmt = kPcmF64;
 		}
-		if (s == 0) tail_done_ = false;
+		if (s == 0)
+		{
+			tail_done_ = false;
+			// History for the next call: the last history() samples of the stream go into the OTHER ring (this call's
+			// kernels may still be reading the current one).  The fast convolver does the copy itself (tail_done_);
+			// otherwise it is CARRIED by the call's next half-band launch -- stage 0's own or a later one's: extra
+			// workgroups of that grid, nobody reads the other ring in this call -- and only when the call has none by
+			// the copy kernel (k_tail, below and behind the stage loop).  (fp64 caller rows, the whole batch in one
+			// launch: a later stage's kernel is the fp64 build, a channel window has its own tail.)
+			carry_ = false;
+			carry_tail_.src = src;
+			carry_tail_.p1 = sp.m;
+			carry_tail_.p0 = sp.m - stage_history(0);
+			if (carry_tail_.p0 < 0) carry_tail_.p0 = 0;
+			carry_tail_.ring = dev_[0].ring_alt + (long long) ch0_ * dev_[0].ring_size;
+			carry_tail_.ring_stride = dev_[0].ring_size;
+			carry_tail_.ring_mask = dev_[0].ring_size - 1;
+			carry_tail_.nch = nchw_;
+			carry_ = opt_.at("fold_tail") != 0 && src.cur_fmt == kPcmF64 && nchw_ == nch_;
+		}
 		if (r.work)
 		{
 			const bool timing = opt_.at("timing") != 0;
@@ -2147,21 +2179,11 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 				}
 			}
 		}
-		if (s == 0 && !tail_done_)
+		if (s == 0 && tail_done_) carry_ = false;
+		if (s == 0 && !tail_done_ && !carry_)
 		{
-			// History for the next call: the last history() samples of the stream go into the
-			// OTHER ring (this call's kernels may still be reading the current one).  The fast
-			// convolver does the copy itself (tail_done_); otherwise a copy kernel.
-			TailLaunch T;
-			T.src = src;
-			T.p1 = sp.m;
-			T.p0 = sp.m - stage_history(0);
-			if (T.p0 < 0) T.p0 = 0;
-			T.ring = dev_[0].ring_alt + (long long) ch0_ * dev_[0].ring_size;
-			T.ring_stride = dev_[0].ring_size;
-			T.ring_mask = dev_[0].ring_size - 1;
-			T.nch = nchw_;
-			launch_tail(T, stream);
+			launch_tail(carry_tail_, stream);
+			if (ch0_ == 0) stat_["tail_launches"]++;
 		}
 	};
 	for (const Rec& r : recs)
@@ -2208,6 +2230,13 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 		ch0_ = 0;
 		nchw_ = nch_;
 		i++;
+	}
+	if (carry_)
+	{
+		// (no launch of this call could carry the history copy)
+		carry_ = false;
+		launch_tail(carry_tail_, stream);
+		stat_["tail_launches"]++;
 	}
 	if (ns > 0) std::swap(dev_[0].ring, dev_[0].ring_alt);
 	return n;
@@ -2308,6 +2337,7 @@ void Engine::launch_dcascade(size_t s, int glen, long long fa, long long fb, con
 	L.in_end = plan_.stages[s].m;
 	L.nch = nchw_;
 	L.src = src; L.dst = dst;
+	take_carried_tail(L.tail, &L.carry_tail);
 	launch_hbdcascade(L, stream);
 }
 
@@ -2363,6 +2393,7 @@ void Engine::launch_cascade(size_t s, int glen, long long fa, long long fb, cons
 	// index is even when the offset is (1); with an odd offset the aligned pairs are (odd, next even) (2)
 	L.pair_ok = dst.fmt == kPcmF64 && ((size_t) dst.p & 15) == 0 && (dst.stride & 1) == 0 ?
 		((dst.off & 1) == 0 ? 1 : 2) : 0;
+	take_carried_tail(L.tail, &L.carry_tail);
 	launch_hbcascade(L, stream);
 }
 

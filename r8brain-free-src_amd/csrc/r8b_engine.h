@@ -127,6 +127,7 @@ private:
 	void plan_transforms();
 	void ensure_ring(size_t s);
 	void ensure_work(size_t s, int slots, void* stream);
+	void take_carried_tail(TailLaunch& T, int* carry);
 	bool fuse_with_next(size_t s) const;
 	bool use_solo_fused(size_t s) const;
 	bool use_pair(const ConvGeom& g) const;
@@ -168,6 +169,9 @@ private:
 	std::map<std::string, long long> stat_;
 	int io_in_fmt_ = kPcmF64, io_out_fmt_ = kPcmF64; // formats of the current call's buffers
 	bool tail_done_ = false; // stage-0 history already written by the convolver kernel
+	// the call's history copy while it waits for a launch to carry it (Engine::process, take_carried_tail)
+	TailLaunch carry_tail_{};
+	bool carry_ = false;
 };
 
 // complex twiddle table exp(-2 pi i e / len), exact on the axes; interleaved (re, im)

@@ -430,6 +430,14 @@ R8B_HD void fft_pass(cd* buf, int N, int n, int radix, bool inverse, const cd* t
 	}
 }
 
+// history copy (k_tail; carried by a half-band launch's second grid layer): workgroup w of nw of channel ch copies its
+// share of the stream positions into the ring the next call reads
+R8B_HD void tail_copy(const TailLaunch& T, int w, int nw, int ch, int tid, int nthr)
+{
+	for (long long i = T.p0 + (long long) w * nthr + tid; i < T.p1; i += (long long) nw * nthr)
+		T.ring[(long long) ch * T.ring_stride + (i & T.ring_mask)] = src_load(T.src, ch, i);
+}
+
 // ------------------------------------------------------------------------------------ convolver
 
 // K1: assemble the circular input block k of channel ch as n_in reals in LDS.

@@ -360,6 +360,12 @@ __global__ __launch_bounds__(256) void k_hbup(const HBLaunch L)
 	const int tid = threadIdx.x, nthr = blockDim.x;
 	const int ch = blockIdx.y;
 	const int T = L.ntaps;
+	if (blockIdx.z != 0)
+	{
+		// (a carried history copy: HBLaunch::tail)
+		tail_copy(L.tail, (int) blockIdx.x, (int) gridDim.x, ch, tid, nthr);
+		return;
+	}
 	const long long nb = L.a / 2, ne = (L.b + 1) / 2;
 	const long long n0 = nb + (long long) blockIdx.x * L.tile;
 	long long n1 = n0 + L.tile;
@@ -380,6 +386,12 @@ __global__ __launch_bounds__(256) void k_hbdown(const HBLaunch L)
 	double* const xs = reinterpret_cast<double*>(smem);
 	const int tid = threadIdx.x, nthr = blockDim.x;
 	const int ch = blockIdx.y;
+	if (blockIdx.z != 0)
+	{
+		// (a carried history copy: HBLaunch::tail)
+		tail_copy(L.tail, (int) blockIdx.x, (int) gridDim.x, ch, tid, nthr);
+		return;
+	}
 	const long long n0 = L.a + (long long) blockIdx.x * L.tile;
 	long long n1 = n0 + L.tile;
 	if (n1 > L.b) n1 = L.b;
@@ -399,6 +411,12 @@ __global__ __launch_bounds__(256) void k_hbcascade(const HBCascadeLaunch L)
 	double* const small = big + L.buf + kHbcSlack;
 	const int tid = threadIdx.x, nthr = blockDim.x;
 	const int ch = blockIdx.y;
+	if (blockIdx.z != 0)
+	{
+		// (a carried history copy: HBLaunch::tail)
+		tail_copy(L.tail, (int) blockIdx.x, (int) gridDim.x, ch, tid, nthr);
+		return;
+	}
 	const long long q0 = L.a + (long long) blockIdx.x * L.tile;
 	long long q1 = q0 + L.tile;
 	if (q1 > L.b) q1 = L.b;
@@ -457,6 +475,12 @@ __global__ __launch_bounds__(256) void k_hbdcascade(const HBCascadeLaunch L)
 	double* const odd = even + L.buf;
 	const int tid = threadIdx.x, nthr = blockDim.x;
 	const int ch = blockIdx.y;
+	if (blockIdx.z != 0)
+	{
+		// (a carried history copy: HBLaunch::tail)
+		tail_copy(L.tail, (int) blockIdx.x, (int) gridDim.x, ch, tid, nthr);
+		return;
+	}
 	const long long q0 = L.a + (long long) blockIdx.x * L.tile;
 	long long q1 = q0 + L.tile;
 	if (q1 > L.b) q1 = L.b;
@@ -484,10 +508,7 @@ __global__ __launch_bounds__(256) void k_hbdcascade(const HBCascadeLaunch L)
 // ------------------------------------------------------------------ history tail of the caller's buffer
 __global__ __launch_bounds__(256) void k_tail(const TailLaunch L)
 {
-	const long long i = L.p0 + (long long) blockIdx.x * blockDim.x + threadIdx.x;
-	const int ch = blockIdx.y;
-	if (i < L.p1)
-		L.ring[(long long) ch * L.ring_stride + (i & L.ring_mask)] = src_load(L.src, ch, i);
+	tail_copy(L, (int) blockIdx.x, (int) gridDim.x, (int) blockIdx.y, (int) threadIdx.x, (int) blockDim.x);
 }
 
 // ------------------------------------------------------------------ PCM ingest / egress (r8b_pcm.h)
@@ -1272,7 +1293,7 @@ void R8B_LAUNCH(launch_hbup)(const HBLaunch& L, void* stream)
 {
 	const long long n = (L.b + 1) / 2 - L.a / 2;
 	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
-	hipLaunchKernelGGL(k_hbup, dim3(tiles, (unsigned) L.nch), dim3(256),
+	hipLaunchKernelGGL(k_hbup, dim3(tiles, (unsigned) L.nch, L.carry_tail ? 2u : 1u), dim3(256),
 		(size_t) (L.tile + 2 * L.ntaps) * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_hbup");
 	launch_symbol_note("k_hbup");
@@ -1282,7 +1303,7 @@ void R8B_LAUNCH(launch_hbdown)(const HBLaunch& L, void* stream)
 {
 	const long long n = L.b - L.a;
 	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
-	hipLaunchKernelGGL(k_hbdown, dim3(tiles, (unsigned) L.nch), dim3(256),
+	hipLaunchKernelGGL(k_hbdown, dim3(tiles, (unsigned) L.nch, L.carry_tail ? 2u : 1u), dim3(256),
 		(size_t) hbdown_lds_doubles(L.tile, L.ntaps) * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_hbdown");
 	launch_symbol_note("k_hbdown");
@@ -1459,9 +1480,13 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 void R8B_LAUNCH(launch_hbcascade)(const HBCascadeLaunch& L, void* stream)
 {
 	const long long n = L.b - L.a;
-	if (n <= 0) return;
+	if (n <= 0)
+	{
+		if (L.carry_tail) throw std::logic_error("launch_hbcascade: a history copy on a launch without tiles");
+		return;
+	}
 	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
-	hipLaunchKernelGGL(k_hbcascade, dim3(tiles, (unsigned) L.nch), dim3(256),
+	hipLaunchKernelGGL(k_hbcascade, dim3(tiles, (unsigned) L.nch, L.carry_tail ? 2u : 1u), dim3(256),
 		(size_t) (L.buf + L.buf2 + 3 * kHbcSlack) * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_hbcascade");
 	launch_symbol_note("k_hbcascade");
@@ -1471,9 +1496,13 @@ void R8B_LAUNCH(launch_hbdcascade)(const HBCascadeLaunch& L, void* stream)
 {
 	set_lds_attrs();
 	const long long n = L.b - L.a;
-	if (n <= 0) return;
+	if (n <= 0)
+	{
+		if (L.carry_tail) throw std::logic_error("launch_hbdcascade: a history copy on a launch without tiles");
+		return;
+	}
 	const unsigned tiles = (unsigned) ((n + L.tile - 1) / L.tile);
-	hipLaunchKernelGGL(k_hbdcascade, dim3(tiles, (unsigned) L.nch), dim3(256),
+	hipLaunchKernelGGL(k_hbdcascade, dim3(tiles, (unsigned) L.nch, L.carry_tail ? 2u : 1u), dim3(256),
 		(size_t) (L.buf + L.buf2) * sizeof(double), (hipStream_t) stream, L);
 	check(hipGetLastError(), "launch k_hbdcascade");
 	launch_symbol_note("k_hbdcascade");

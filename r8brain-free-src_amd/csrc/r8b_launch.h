@@ -141,6 +141,16 @@ struct PolyLaunch
 	DstView dst;
 };
 
+struct TailLaunch
+{
+	SrcView src;        // where the stream is read (history ring and/or the caller's buffer)
+	long long p0, p1;   // positions [p0, p1) to copy into the ring
+	double* ring;
+	long long ring_stride;
+	long long ring_mask;
+	int nch;
+};
+
 struct HBLaunch
 {
 	int ntaps;
@@ -150,6 +160,11 @@ struct HBLaunch
 	int nch;
 	SrcView src;
 	DstView dst;
+	// a history copy carried by this launch (Engine::process: the stream's tail for the next call, when no convolver
+	// keeps it): with carry_tail set the grid has a second z layer whose workgroups copy `tail` instead of computing a
+	// tile (the layer is known from the workgroup id alone: the tiles' workgroups do not look at these fields)
+	int carry_tail;
+	TailLaunch tail;
 };
 
 // A run of consecutive 2x half-band up-samplers executed by one kernel: every intermediate stream
@@ -180,6 +195,8 @@ struct HBCascadeLaunch
 	int nch;
 	SrcView src;                   // input stream of the first stage
 	DstView dst;
+	int carry_tail;                // a carried history copy, as in HBLaunch
+	TailLaunch tail;
 };
 
 inline void hbc_fill_ranges(HBCascadeLaunch& L)
@@ -199,15 +216,6 @@ inline void hbc_fill_ranges(HBCascadeLaunch& L)
 	L.rhi[L.nst] = ch;
 }
 
-struct TailLaunch
-{
-	SrcView src;        // where the stream is read (history ring and/or the caller's buffer)
-	long long p0, p1;   // positions [p0, p1) to copy into the ring
-	double* ring;
-	long long ring_stride;
-	long long ring_mask;
-	int nch;
-};
 
 struct PcmLaunch
 {

@@ -178,12 +178,21 @@ void launch_poly(const PolyLaunch& L, void*)
 		for (long long i = 0; L.a + i < L.b; i++) dst_store(L.dst, ch, L.a + i, poly_one(L, ch, i));
 }
 
+// the second grid layer of a launch that carries a history copy (HBLaunch::tail), or k_tail's own grid
+static void emul_carried_tail(const TailLaunch& T, int blocks, int nch)
+{
+	for (int ch = 0; ch < nch; ch++)
+		for (int w = 0; w < blocks; w++)
+			for (int t = 0; t < 256; t++) tail_copy(T, w, blocks, ch, t, 256);
+}
+
 void launch_hbup(const HBLaunch& L, void*)
 {
 	const int nthr = 256, T = L.ntaps;
 	std::vector<double> xs((size_t) (L.tile + 2 * T));
 	const long long nb = L.a / 2, ne = (L.b + 1) / 2;
 	const int tiles = (int) ((ne - nb + L.tile - 1) / L.tile);
+	if (L.carry_tail) emul_carried_tail(L.tail, tiles, L.nch);
 	for (int ch = 0; ch < L.nch; ch++)
 		for (int bx = 0; bx < tiles; bx++)
 		{
@@ -203,6 +212,7 @@ void launch_hbdown(const HBLaunch& L, void*)
 	std::vector<double> xs((size_t) hbdown_lds_doubles(L.tile, T));
 	const long long n = L.b - L.a;
 	const int tiles = (int) ((n + L.tile - 1) / L.tile);
+	if (L.carry_tail) emul_carried_tail(L.tail, tiles, L.nch);
 	for (int ch = 0; ch < L.nch; ch++)
 		for (int bx = 0; bx < tiles; bx++)
 		{
@@ -599,8 +609,13 @@ void launch_hbcascade(const HBCascadeLaunch& L, void*)
 	const int nthr = 256;
 	std::vector<double> lds((size_t) (L.buf + L.buf2 + 3 * kHbcSlack));
 	const long long n = L.b - L.a;
-	if (n <= 0) return;
+	if (n <= 0)
+	{
+		if (L.carry_tail) throw std::logic_error("emul: a history copy on a cascade launch without tiles");
+		return;
+	}
 	const int tiles = (int) ((n + L.tile - 1) / L.tile);
+	if (L.carry_tail) emul_carried_tail(L.tail, tiles, L.nch);
 	for (int ch = 0; ch < L.nch; ch++)
 		for (int bx = 0; bx < tiles; bx++)
 		{
@@ -637,8 +652,13 @@ void launch_hbdcascade(const HBCascadeLaunch& L, void*)
 	const int nthr = 256;
 	std::vector<double> lds((size_t) (L.buf + L.buf2));
 	const long long n = L.b - L.a;
-	if (n <= 0) return;
+	if (n <= 0)
+	{
+		if (L.carry_tail) throw std::logic_error("emul: a history copy on a cascade launch without tiles");
+		return;
+	}
 	const int tiles = (int) ((n + L.tile - 1) / L.tile);
+	if (L.carry_tail) emul_carried_tail(L.tail, tiles, L.nch);
 	for (int ch = 0; ch < L.nch; ch++)
 		for (int bx = 0; bx < tiles; bx++)
 		{
@@ -668,9 +688,8 @@ void launch_hbdcascade(const HBCascadeLaunch& L, void*)
 
 void launch_tail(const TailLaunch& L, void*)
 {
-	for (int ch = 0; ch < L.nch; ch++)
-		for (long long i = L.p0; i < L.p1; i++)
-			L.ring[(long long) ch * L.ring_stride + (i & L.ring_mask)] = src_load(L.src, ch, i);
+	const int blocks = (int) ((L.p1 - L.p0 + 255) / 256);
+	emul_carried_tail(L, blocks, L.nch);
 }
 
 static void emul_pcm(const PcmLaunch& L, bool in)

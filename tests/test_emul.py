@@ -674,7 +674,10 @@ def test_one_tap_halfband_start_of_stream(emul, refwrap, src, dst, att):
 TAIL_TOPOLOGIES = [(44100.0, 96000.0, 8192, 2.0), (96000.0, 44100.0, 16384, 2.0), (88200.0, 44100.0, 12000, 2.0),
                    (44100.0, 88200.0, 6000, 2.0), (48000.0, 32000.0, 16384, 2.0),
                    (44100.0, 88200.0, 9000, 0.5), (96000.0, 44100.0, 16384, 0.5), (88200.0, 44100.0, 12000, 0.5),
-                   (48000.0, 16000.0, 30000, 0.5)]
+                   (48000.0, 16000.0, 30000, 0.5),
+                   # (a half-band stage carries the copy: stage 0's own launch, or a later stage's in calls without a block)
+                   (176400.0, 44100.0, 16384, 2.0), (192000.0, 44100.0, 8192, 0.5), (44100.0, 2822400.0, 1024, 2.0),
+                   (2822400.0, 176400.0, 8192, 2.0)]
 
 
 @pytest.mark.parametrize("src,dst,maxin,tb", TAIL_TOPOLOGIES)
@@ -683,15 +686,48 @@ def test_emulated_history_from_registers_equals_the_copy_kernel(emul, src, dst, 
     block's fetch (long calls, r8b_convp.h convp_tail_owners), copied in slices by every block (calls shorter than a
     window) and by a kernel of its own (option fold_tail = 0) -- the outputs are the same BIT FOR BIT, with an odd channel
     count (a block pair without a partner) and calls of every length in between"""
-    lens = [maxin, maxin, maxin // 3, 300, maxin, 17, 1, maxin - 5, 2500, maxin]
-    a = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, lib=emul)
-    b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, lib=emul)
+    run_history_three_ways({"lib": emul}, src, dst, maxin, tb)
+
+
+def run_history_three_ways(lib_kw, src, dst, maxin, tb):
+    lens = [min(l, maxin) for l in (maxin, maxin, maxin // 3, 300, maxin, 17, 1, maxin - 5, 2500, maxin)]
+    a = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, **lib_kw)
+    b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=3, **lib_kw)
     b.set_option("fold_tail", 0)
     rng = np.random.default_rng(5)
     for i, l in enumerate(lens):
         x = rng.uniform(-1.0, 1.0, (3, l))
         ya, yb = a.process_host(x), b.process_host(x)
         assert ya.shape == yb.shape and np.array_equal(ya, yb), (i, l)
+    assert b.stat("tail_launches") == len(lens) and a.stat("tail_launches") < len(lens)
+
+
+HB_CARRY_TOPOLOGIES = [(176400.0, 44100.0, 16384, 2.0), (192000.0, 44100.0, 8192, 0.5), (44100.0, 2822400.0, 1024, 2.0),
+                       (2822400.0, 176400.0, 8192, 2.0), (352800.0, 44100.0, 4096, 2.0)]
+
+
+def run_history_copy_carried(lib_kw, src, dst, maxin, tb):
+    """chains whose first stage is a half-band decimator, and the SACD chain in calls without a convolver block: the
+    history copy rides on a half-band launch of the call -- no k_tail launch in whole calls --, same samples as with the
+    copy kernel bit for bit"""
+    a = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=5, **lib_kw)
+    b = r8b.BatchResampler(src, dst, maxin, tb, 180.15, nch=5, **lib_kw)
+    b.set_option("fold_tail", 0)
+    rng = np.random.default_rng(9)
+    n = 0
+    for i in range(12):
+        x = rng.uniform(-1.0, 1.0, (5, maxin))
+        ya, yb = a.process_host(x), b.process_host(x)
+        assert ya.shape == yb.shape and np.array_equal(ya, yb), i
+        n += ya.shape[1]
+    assert n > 0 and b.stat("tail_launches") == 12
+    # (the first calls of a stream may have no half-band work yet)
+    assert a.stat("tail_launches") <= 2, a.stat("tail_launches")
+
+
+@pytest.mark.parametrize("src,dst,maxin,tb", HB_CARRY_TOPOLOGIES)
+def test_emulated_history_copy_carried_by_a_half_band_launch(emul, src, dst, maxin, tb):
+    run_history_copy_carried({"lib": emul}, src, dst, maxin, tb)
 
 
 def run_parked_outputs(lib_kw, case, phase=0):

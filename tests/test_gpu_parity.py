@@ -669,6 +669,19 @@ def test_hip_history_from_registers_equals_the_copy_kernel(torch, src, dst, maxi
         assert ya.shape == yb.shape and np.array_equal(ya, yb), (i, l)
 
 
+def _hb_carry_topologies():
+    from test_emul import HB_CARRY_TOPOLOGIES
+    return HB_CARRY_TOPOLOGIES
+
+
+@pytest.mark.parametrize("src,dst,maxin,tb", _hb_carry_topologies())
+def test_hip_history_copy_carried_by_a_half_band_launch(torch, src, dst, maxin, tb):
+    """the history copy as extra workgroups of a half-band launch (k_hbdown, k_hbcascade, k_hbdcascade) == k_tail"""
+    from test_emul import run_history_copy_carried, run_history_three_ways
+    run_history_copy_carried({"device": 0}, src, dst, maxin, tb)
+    run_history_three_ways({"device": 0}, src, dst, maxin, tb)
+
+
 @pytest.mark.parametrize("case", PARK_CASES)
 def test_hip_parked_outputs_equal_recomputation(torch, case):
     """every block once -- the call's last block parks what it holds of the next call (r8b_convp.h cp_park_*, the second
