@@ -62,6 +62,10 @@
 #ifndef R8B_OUT_STORE16U
 #define R8B_OUT_STORE16U(ptr, v) { (ptr)[0] = (v).re; (ptr)[1] = (v).im; }
 #endif
+// R8B_IN_LOAD16U: two neighbouring doubles from an address that is only 8-byte aligned, as ONE load on the device
+#ifndef R8B_IN_LOAD16U
+#define R8B_IN_LOAD16U(ptr, a, b) { (a) = (ptr)[0]; (b) = (ptr)[1]; }
+#endif
 
 namespace r8bhip {
 
@@ -753,6 +757,182 @@ R8B_HD void cp_load(const ConvLaunch& L, ConvpState<LN, UL>& st, long long k, in
 		const int rel = i < iln ? i : i - G::N;
 		st.pr[p] = src_block_load1(sa, rel);
 		st.pi[p] = src_block_load1(sb, rel);
+	}
+}
+
+// ---- mode 20: a half-band decimator in front of the block, taken in the block's load (geometry <12, -1>) -------------
+// MEASURED AND NOT THE DEFAULT (engine option fuse_hbconv = 0; profiles/r06_experiments.txt item 10): correct -- the
+// fused launch equals k_hbdown + k_convp bit for bit -- and 20 % slower than the two launches.
+// The block's window is N = 4096 consecutive CONVOLVER inputs n = w0 .. w0 + N - 1, each the decimator's output
+//   y[n] = x[2n] + sum_k f[k] (x[2n + 1 + 2k] + x[2n - 1 - 2k])     (reference CDSPHBDownsampler.h:282-295; hbdown_compute)
+// of the raw stream x.  Two rounds of kHbfRound = 2048 outputs: the round's 2 * 2048 + 4 TP - 3 raw samples of both
+// channels are staged in LDS over the (still unused) array, de-interleaved -- tap samples (odd raw positions) and centre
+// samples (even ones) in rows of their own, one pad slot per eight so that lanes eight outputs apart meet different
+// banks --, and thread t computes outputs 8 t .. 8 t + 7 of the round from a sliding window of 2 TP + 7 tap samples in
+// registers (5 LDS reads per output instead of 2 TP + 1).  Sums in k_hbdown's order: the fused chain equals the two
+// launches bit for bit.  The sixteen values per thread and channel then go through the array once (element = window
+// sample rotated as cp_load lays it out) and the first pass reads its strided sixteen as if cp_load had fetched them.
+static const int kHbfRow = 2352;
+static const int kHbfLdsBytes = 4 * kHbfRow * 8;
+static_assert(kHbfRound + 2 * kHbfTapsMax + ((kHbfRound + 2 * kHbfTapsMax) >> 3) < kHbfRow, "staging rows of the half-band front");
+R8B_HD constexpr int hbf_pad(int j) { return j + (j >> 3); }
+struct SlotHbf
+{
+	// raw index i of a round (0 = an odd raw position): tap sample i / 2 or centre sample i / 2 of the channel's rows
+	R8B_HD int operator()(int i) const { return ((i & 1) ? kHbfRow : 0) + hbf_pad(i >> 1); }
+};
+
+// round r of block k: the raw samples of both channels into LDS.  Every load of the round is issued before the first
+// LDS store (one trip to memory per round: the workgroup has nothing else to do meanwhile, and as loops of eight loads
+// the two channels' staging was six dependent trips -- 15 000 cycles per round on a block of 34 000); a span inside the
+// caller's fp64 buffer is read as 16-byte (tap, centre) pairs through a uniform row pointer.
+template<int LN, int UL>
+R8B_HD void cp_hbf_stage(const ConvLaunch& L, const ConvxLaunch& XM, double* xs, long long k, int r, int chA, int chB, int tid)
+{
+	typedef ConvpGeom<LN, UL> G;
+	static_assert(UL < 0 && G::SUB == 1 && G::N == 2 * kHbfRound && G::WT == 256, "half-band front: the 4096-point decimating geometry");
+	const int TP = XM.hb_np;
+	const long long base = k * (long long) L.blk_stride + L.blk_offset;
+	const long long n_r = base - (G::N - L.in_len) + (long long) r * kHbfRound; // the round's first output
+	const long long lo = 2 * n_r - (2 * TP - 1);
+	const int len = 2 * kHbfRound - 1 + 2 * (2 * TP - 1);
+	const int npair = (len + 1) / 2; // (tap, centre) pairs; the last one is a tap alone
+	constexpr int NP = (kHbfRound + 2 * kHbfTapsMax + 255) / 256;
+	if (L.src.cur_fmt == kPcmF64 && lo >= L.src.cur_base && lo >= 0 && lo + 2 * (long long) npair <= XM.hb_end)
+	{
+		const double* const pa = L.src.cur + ((long long) chA * L.src.cur_stride + (lo - L.src.cur_base));
+		const double* const pb = L.src.cur + ((long long) chB * L.src.cur_stride + (lo - L.src.cur_base));
+		double ae[NP], ac[NP], be[NP], bc[NP];
+#pragma unroll
+		for (int u = 0; u < NP; u++)
+		{
+			const int j = tid + 256 * u;
+			const unsigned jj = (unsigned) (j < npair ? j : npair - 1) * 2u;
+			// (element alignment is enough for a 16-byte global load on this target)
+			R8B_IN_LOAD16U(pa + jj, ae[u], ac[u]);
+			R8B_IN_LOAD16U(pb + jj, be[u], bc[u]);
+		}
+#pragma unroll
+		for (int u = 0; u < NP; u++)
+		{
+			const int j = tid + 256 * u;
+			if (j < npair)
+			{
+				const int sl = hbf_pad(j);
+				xs[sl] = ae[u]; xs[kHbfRow + sl] = ac[u];
+				xs[2 * kHbfRow + sl] = be[u]; xs[3 * kHbfRow + sl] = bc[u];
+			}
+		}
+		return;
+	}
+	const int end = clamp_rel(XM.hb_end - lo);
+	const int lim = end < len ? end : len;
+	const SrcBlock sa = src_block(L.src, chA, lo), sb = src_block(L.src, chB, lo);
+	constexpr int NS = 2 * NP;
+	double va[NS], vb[NS];
+#pragma unroll
+	for (int u = 0; u < NS; u++)
+	{
+		const int i = tid + 256 * u;
+		const int ii = lim <= 0 ? 0 : (i < lim ? i : lim - 1);
+		va[u] = lim <= 0 ? 0.0 : src_block_load1(sa, ii);
+		vb[u] = lim <= 0 ? 0.0 : src_block_load1(sb, ii);
+	}
+#pragma unroll
+	for (int u = 0; u < NS; u++)
+	{
+		const int i = tid + 256 * u;
+		if (i < len)
+		{
+			const int sl = SlotHbf()(i);
+			xs[sl] = i < lim ? va[u] : 0.0;
+			xs[2 * kHbfRow + sl] = i < lim ? vb[u] : 0.0;
+		}
+	}
+}
+
+// the thread's eight outputs of round r, both channels: st.pr / st.pi [8 r + o] = window sample 2048 r + 8 t + o
+template<int TP, int RND, int LN, int UL>
+R8B_HD void cp_hbf_compute_t(const ConvLaunch& L, const ConvxLaunch& XM, const double* xs, ConvpState<LN, UL>& st, long long k,
+	int tid)
+{
+	constexpr int r = RND;
+	typedef ConvpGeom<LN, UL> G;
+	const long long base = k * (long long) L.blk_stride + L.blk_offset;
+	const long long n0 = base - (G::N - L.in_len) + (long long) r * kHbfRound + 8 * tid; // the thread's first output
+	double f[TP];
+#pragma unroll
+	for (int i = 0; i < TP; i++) f[i] = XM.hb_taps[i];
+#pragma unroll
+	for (int c = 0; c < 2; c++)
+	{
+		const LdsWin e = lds_win(xs + c * 2 * kHbfRow), ctr = lds_win(xs + c * 2 * kHbfRow + kHbfRow);
+		double ev[2 * TP + 7];
+#pragma unroll
+		for (int j = 0; j < 2 * TP + 7; j++) ev[j] = e[9 * tid + hbf_pad(j)]; // (hbf_pad(8 t + j) = 9 t + hbf_pad(j))
+		double cv[8];
+#pragma unroll
+		for (int o = 0; o < 8; o++)
+		{
+			// (centre of output 8 t + o: centre sample 8 t + o + TP - 1)
+			const int j = o + TP - 1;
+			cv[o] = ctr[9 * tid + hbf_pad(j)];
+		}
+#pragma unroll
+		for (int o = 0; o < 8; o++)
+		{
+			double s = cv[o];
+#pragma unroll
+			for (int kk = 0; kk < TP; kk++) s += f[kk] * (ev[o + TP + kk] + ev[o + TP - 1 - kk]);
+			// (convolver inputs in front of the stream's start are zeros, not decimator outputs)
+			s = n0 + o < 0 ? 0.0 : s;
+			if (c == 0) st.pr[8 * r + o] = s;
+			else st.pi[8 * r + o] = s;
+		}
+	}
+}
+
+// (RND, the round, at compile time: it indexes the state's register arrays)
+template<int RND, int LN, int UL>
+R8B_HD void cp_hbf_compute(const ConvLaunch& L, const ConvxLaunch& XM, const double* xs, ConvpState<LN, UL>& st, long long k,
+	int tid)
+{
+	if (XM.hb_np <= 4) cp_hbf_compute_t<4, RND>(L, XM, xs, st, k, tid);
+	else if (XM.hb_np <= 8) cp_hbf_compute_t<8, RND>(L, XM, xs, st, k, tid);
+	else cp_hbf_compute_t<kHbfTapsMax, RND>(L, XM, xs, st, k, tid);
+}
+
+// the thread's sixteen window samples into the array: element i holds window sample (i + wr) mod N (cp_load)
+template<int LN, int UL>
+R8B_HD void cp_hbf_scatter(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st, int tid)
+{
+	typedef ConvpGeom<LN, UL> G;
+	const int wr = (L.rot + G::N - L.in_len) & (G::N - 1);
+#pragma unroll
+	for (int r = 0; r < 2; r++)
+#pragma unroll
+		for (int o = 0; o < 8; o++)
+		{
+			const int w = r * kHbfRound + 8 * tid + o;
+			cd v;
+			v.re = st.pr[8 * r + o];
+			v.im = st.pi[8 * r + o];
+			buf[fslot<LN, UL>((w - wr) & (G::N - 1))] = v;
+		}
+}
+
+// ... and the first pass's sixteen back out of it (thread lt: elements lt + NT p)
+template<int LN, int UL>
+R8B_HD void cp_hbf_gather(const cd* buf, ConvpState<LN, UL>& st, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int R = G::E1, q = G::N / R;
+#pragma unroll
+	for (int p = 0; p < R; p++)
+	{
+		const cd v = buf[fslot<LN, UL>(lt + p * q)];
+		st.pr[p] = v.re;
+		st.pi[p] = v.im;
 	}
 }
 
@@ -2617,7 +2797,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 
 	constexpr int BM = MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 14 ? 0 :
 		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : (MODE == 16 ? 4 : (MODE == 17 ? 5 :
-		(MODE == 18 ? 1 : (MODE == 19 ? 0 : MODE)))));
+		(MODE == 18 ? 1 : (MODE == 19 || MODE == 20 ? 0 : MODE)))));
+	// mode 20: mode 0 of the decimating form behind a half-band decimator taken in the load (cp_hbf_*)
+	constexpr bool HBF = MODE == 20;
 	// mode 19: polyphase 3x form (cp_p3_*): a convolver-only mode with its own load, middle and store
 	constexpr bool P3 = convp_mode_p3(MODE);
 	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
@@ -2689,7 +2871,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			if (tid < TL::NE) twl_v = L.ptw[TL::src_index(tid)];
 		}
 		ex.stamp2();
-		if constexpr (P3) cp_p3_load<LN, UL>(L, st, k_of(tid), chA, chB, lt);
+		if constexpr (HBF) cp_hbf_gather<LN, UL>(buf_of(tid), st, lt);
+		else if constexpr (P3) cp_p3_load<LN, UL>(L, st, k_of(tid), chA, chB, lt);
 		else if constexpr (SOLO) cp_load_solo<LN, UL, BM>(L, st, k_of(tid), chA, lt);
 		else cp_load<LN, UL, BM, SP>(L, st, k_of(tid), chA, chB, lt);
 		}
@@ -2758,6 +2941,17 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		if constexpr (G::NPRE > 1) ConvpPre<LN, UL, 1>::prefetch(L, st, lt);
 		else hp_prefetch(st, lt);
 	};
+	if constexpr (HBF)
+	{
+		// (the decimator's outputs for the block's window: two rounds of staging + sliding-window sums, then through
+		// the array into the first pass's layout -- a barrier behind each step: they all work on the same LDS)
+		double* const xs = reinterpret_cast<double*>(buf);
+		ex.phase([&](int tid, St&) { cp_hbf_stage<LN, UL>(L, XM, xs, cur.k, 0, chA, chB, tid); });
+		ex.phase([&](int tid, St& st) { cp_hbf_compute<0, LN, UL>(L, XM, xs, st, cur.k, tid); });
+		ex.phase([&](int tid, St&) { cp_hbf_stage<LN, UL>(L, XM, xs, cur.k, 1, chA, chB, tid); });
+		ex.phase([&](int tid, St& st) { cp_hbf_compute<1, LN, UL>(L, XM, xs, st, cur.k, tid); });
+		ex.phase([&](int tid, St& st) { cp_hbf_scatter<LN, UL>(L, buf, st, tid); });
+	}
 	if constexpr (WALK)
 	{
 		// (a barrier between the two: the slowest wave of the PREVIOUS block still reads its run from the array the first

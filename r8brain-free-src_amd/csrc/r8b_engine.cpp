@@ -834,6 +834,13 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// eight elements per thread (r8b_convq.h): the 2048 -> 4096-point convolver-only block pair on 512 threads (four waves
 	// per SIMD instead of two); same blocks, same state, results differ from the 256-thread form by rounding
 	opt_["quad"] = 0;
+	// a half-band decimator in front of a 4096 -> 2048-point decimating convolver taken in the convolver's load (kernel mode
+	// 20: one launch, the decimator's stream never leaves LDS).  Off: measured on MI355X the fused launch takes 92.6 us
+	// + a 19 us history copy against 52.5 + 42.6 us for the two launches (176400 -> 44100, 1024 ch x 16384) -- a block
+	// cannot start before its 133 KB of raw samples have arrived and all workgroups ask at once: 38 000 of a block's
+	// 66 000 cycles are the two staging rounds at 4.2 TB/s (profiles/r06_experiments.txt item 10); the raw-domain
+	// history a call has to leave (avg 5 300 samples per channel) is 4x the convolver-domain one besides
+	opt_["fuse_hbconv"] = 0;
 	opt_["walk"] = 1;      // (0: a workgroup per block, as before round 5; 2: whatever the batch size -- tests)
 	opt_["walk_len"] = 0;  // blocks per workgroup of the walk form (0: the launch's whole run of blocks)
 	stat_["conv_blocks"] = 0;
@@ -850,7 +857,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 		{
 			const StagePlan& sp = plan_.stages[s];
 			StageDev& d = dev_[s];
-			const long long hist = stage_history(s);
+			// (a decimator that option fuse_hbconv may take into the convolver behind it: the larger history of the two forms)
+			const long long hist = std::max(stage_history(s), hbconv_possible(s) ? hbconv_history(s) : 0LL);
 			// (+ one block of the convolver in front of it: the block that holds a call's last output is written whole,
 			// ahead of what the call owes -- launch_stage, conv_once)
 			// (the same behind a fused convolver + whole-step interpolator: a block's interpolated outputs -- launch_fused)
@@ -1371,7 +1379,7 @@ bool Engine::set_option(const std::string& name, int value)
 	// Options that choose between fused and unfused kernels decide where a stage's history lives
 	// (unfused stages keep it in rings the fused kernels never write): once a stream has started they
 	// may only change after clear().
-	static const char* const structural[] = { "fuse", "fuse_hb", "fuse_hbd", "fold_tail", "fast_conv",
+	static const char* const structural[] = { "fuse", "fuse_hb", "fuse_hbd", "fuse_hbconv", "fold_tail", "fast_conv",
 		"pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park", "fuse_latency", "solo_fuse", "up3_poly" };
 	bool started = false;
 	for (const StagePlan& sp : plan_.stages) started = started || sp.m != 0;
@@ -1467,7 +1475,7 @@ bool Engine::stage_timing(size_t stage, double* ms_sum, int* launches, std::stri
 			break;
 		case kFrac: *kernel = sp.whole ? "k_whole" : "k_poly"; break;
 		case kHBUp: *kernel = group_len(stage) > 1 ? "k_hbcascade" : "k_hbup"; break;
-		case kHBDown: *kernel = group_len(stage) > 1 ? "k_hbdcascade" : "k_hbdown"; break;
+		case kHBDown: *kernel = fuse_hbconv(stage) ? "k_convp_hb" : (group_len(stage) > 1 ? "k_hbdcascade" : "k_hbdown"); break;
 		}
 	}
 	d.ms_sum = 0.0;
@@ -1717,6 +1725,19 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		ConvxLaunch X;
 		ConvLaunch& L = X.c;
 		fill_conv(s, L, src);
+		X.hb_n = X.hb_np = 0;
+		X.hb_end = 0;
+		for (double& v : X.hb_taps) v = 0.0;
+		if (hb_front_ >= 0)
+		{
+			// (launch_hbconv: `src` is the decimator's input stream)
+			const StagePlan& hp = plan_.stages[(size_t) hb_front_];
+			X.hb_n = hp.hb_n;
+			X.hb_np = hp.hb_n <= 4 ? 4 : (hp.hb_n <= 8 ? 8 : kHbfTapsMax);
+			X.hb_end = hp.m;
+			for (int i = 0; i < hp.hb_n; i++) X.hb_taps[i] = hp.hb_taps[i];
+			L.vec_ok = 0;
+		}
 		if (g.poly3)
 		{
 			// polyphase 3x form (ConvGeom::p3; r8b_convp.h mode 19): a block is a window of p3_n INPUT samples, its valid
@@ -1881,6 +1902,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 			if (path == kPathPairP3) launch_convp(X, 19, stream);
 			else if (path == kPathPair3) launch_convp(X, solo ? 11 + cxl : (sp ? 9 + cxl : (g.complex_h ? 7 : 3)), stream);
 			else if (path == kPathConvx3) launch_convx(X, 3, stream);
+			else if (path == kPathPair && hb_front_ >= 0) launch_convp(X, 20, stream);
 			else if (path == kPathPair) launch_convp(X, solo ? 10 + cxl : (sp ? 8 + cxl : (g.complex_h ? 6 : 0)), stream);
 			else launch_convx(X, 0, stream);
 			if (L.tail_ring != nullptr) tail_done_ = true;
@@ -1891,6 +1913,13 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 				if (once == 2 && pend > b) dd.park_cur ^= 1;
 				dd.park_base = b;
 				dd.park_end = pend;
+			}
+			if (hb_front_ >= 0)
+			{
+				// (the next call's first block: the one behind this call's last when every block is computed once, else the
+				// one that holds output b; its window starts n_in - in_len convolver inputs before the block)
+				const long long kn = once != 0 ? k1 + 1 : blk_of(b);
+				hb_next_raw_ = 2 * (kn * (long long) g.in_len - ((long long) g.n_in - g.in_len)) - 2 * kHbfTapsMax - 8;
 			}
 		}
 		else
@@ -2162,6 +2191,7 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 				dev_event_record(e0, stream);
 			}
 			if (r.fused && sp.desc.kind == kConv) launch_fused(s, r.wa, r.wb, src, dst, stream);
+			else if (r.fused && sp.desc.kind == kHBDown && fuse_hbconv(s)) launch_hbconv(s, r.wa, r.wb, src, dst, stream);
 			else if (r.fused && sp.desc.kind == kHBDown) launch_dcascade(s, r.glen, r.wa, r.wb, src, dst, stream);
 			else if (r.fused) launch_cascade(s, r.glen, r.wa, r.wb, src, dst, stream);
 			else launch_stage(s, r.m_prev, r.a, r.b, r.ps, src, dst, stream);
@@ -2242,6 +2272,47 @@ int Engine::process(const double* d_in, long long in_stride, int l, double* d_ou
 	return n;
 }
 
+// Half-band decimator s in front of convolver s + 1 as one launch (r8b_convp.h mode 20): linear-phase chains, the
+// 4096 -> 2048-point decimating geometry of the pair kernel (176400 -> 44100, 192000 -> 48000 ... at the 24-bit preset).
+bool Engine::fuse_hbconv(size_t s) const
+{
+	return opt_.at("fuse_hbconv") && opt_.at("fast_conv") && opt_.at("pair_conv") && hbconv_possible(s) &&
+		conv_path(plan_.stages[s + 1].cg) == kPathPair && use_pair(plan_.stages[s + 1].cg);
+}
+
+// ... whatever the options say (the rings are sized once, for either form)
+bool Engine::hbconv_possible(size_t s) const
+{
+	if (s + 1 >= plan_.stages.size()) return false;
+	const StagePlan& h = plan_.stages[s];
+	const StagePlan& c = plan_.stages[s + 1];
+	if (h.desc.kind != kHBDown || c.desc.kind != kConv || latency_chain()) return false;
+	if (h.out_skip != 0 || h.hb_n > kHbfTapsMax || h.hb_n < 1) return false;
+	const ConvGeom& g = c.cg;
+	if (g.poly3 || g.complex_h || !g.up_pow2 || g.up != 1 || !g.down_pow2 || g.down != 2) return false;
+	return g.n_in == 2 * kHbfRound && g.n_out == kHbfRound && (g.in_len & 1) == 0;
+}
+
+void Engine::launch_hbconv(size_t s, long long wa, long long wb, const SrcView& src, const DstView& dst, void* stream)
+{
+	struct Reset
+	{
+		long long& v;
+		~Reset() { v = -1; }
+	} reset{hb_front_};
+	hb_front_ = (long long) s;
+	hb_next_raw_ = LLONG_MIN;
+	launch_stage(s + 1, 0, wa, wb, PolyState(), src, dst, stream);
+	// History for the next call (stage 0: the caller's buffer is gone then): the raw stream from where the next call's
+	// first block starts reading -- not the whole stage_history() the pending copy was set up with
+	if (s == 0 && hb_next_raw_ != LLONG_MIN && (carry_ || !tail_done_))
+	{
+		long long p0 = std::max(carry_tail_.p0, hb_next_raw_);
+		p0 = std::min(p0, carry_tail_.p1);
+		carry_tail_.p0 = p0 < 0 ? 0 : p0;
+	}
+}
+
 int Engine::group_len(size_t s) const
 {
 	// (chains with a fractional latency: the convolver + interpolator pair -- fuse_latency_ok -- and the half-band runs,
@@ -2249,6 +2320,7 @@ int Engine::group_len(size_t s) const
 	const bool lat = latency_chain();
 	if (lat && !opt_.at("fuse_latency")) return 1;
 	if (fuse_with_next(s)) return 2;
+	if (fuse_hbconv(s)) return 2;
 	const StageKind kind = plan_.stages[s].desc.kind;
 	if (lat && kind != kHBUp && kind != kHBDown) return 1;
 	// Runs of decimators: one kernel saves two launches and the intermediate streams, but pays
@@ -2262,8 +2334,9 @@ int Engine::group_len(size_t s) const
 	if (opt_.at("fuse_hb") && (kind == kHBUp || (kind == kHBDown && down_ok)))
 	{
 		int n = 1;
+		// (a decimator that goes into the convolver behind it -- fuse_hbconv -- is not part of a run)
 		while (s + n < plan_.stages.size() && plan_.stages[s + n].desc.kind == kind &&
-			n < kMaxCascade) n++;
+			n < kMaxCascade && !fuse_hbconv(s + n)) n++;
 		return n;
 	}
 	return 1;
@@ -2271,10 +2344,18 @@ int Engine::group_len(size_t s) const
 
 // input samples a stage must keep from earlier calls.  A run of half-band decimators executed as
 // one kernel looks back over the accumulated filter spans of the whole run.
+long long Engine::hbconv_history(size_t s) const
+{
+	return 2LL * plan_.stages[s + 1].history() + 4 * kHbfTapsMax + 64;
+}
+
 long long Engine::stage_history(size_t s) const
 {
 	const StagePlan& sp = plan_.stages[s];
 	if (sp.desc.kind != kHBDown) return sp.history();
+	// (decimator + convolver as one launch: the convolver's history, in raw samples, + the decimator's own reach with its
+	// taps rounded up + the samples the decimator has taken without an output yet)
+	if (fuse_hbconv(s)) return hbconv_history(s);
 	long long span = 0;
 	int g = 0;
 	while (s + g < plan_.stages.size() && plan_.stages[s + g].desc.kind == kHBDown && g < kMaxCascade)
@@ -2472,6 +2553,7 @@ bool Engine::pcm_fused_in() const
 {
 	if (plan_.stages.empty()) return false;
 	const StagePlan& sp = plan_.stages[0];
+	if (fuse_hbconv(0)) return false; // (the first launch is a compile-time-sized convolver)
 	return !(sp.desc.kind == kConv && conv_path(eff_geom(0)) != kPathGeneric);
 }
 

@@ -128,6 +128,11 @@ private:
 	void ensure_ring(size_t s);
 	void ensure_work(size_t s, int slots, void* stream);
 	void take_carried_tail(TailLaunch& T, int* carry);
+	// half-band decimator s + convolver s + 1 as ONE launch (r8b_convp.h mode 20: the decimator taken in the block's load)
+	bool fuse_hbconv(size_t s) const;
+	bool hbconv_possible(size_t s) const;
+	long long hbconv_history(size_t s) const;
+	void launch_hbconv(size_t s, long long wa, long long wb, const SrcView& src, const DstView& dst, void* stream);
 	bool fuse_with_next(size_t s) const;
 	bool use_solo_fused(size_t s) const;
 	bool use_pair(const ConvGeom& g) const;
@@ -171,6 +176,10 @@ private:
 	bool tail_done_ = false; // stage-0 history already written by the convolver kernel
 	// the call's history copy while it waits for a launch to carry it (Engine::process, take_carried_tail)
 	TailLaunch carry_tail_{};
+	// launch_hbconv -> launch_stage: the half-band stage whose filter the convolver's launch takes in its load (-1: none),
+	// and back: where the next call's first block starts reading the RAW stream (the history the call has to leave)
+	long long hb_front_ = -1;
+	long long hb_next_raw_ = 0;
 	bool carry_ = false;
 };
 

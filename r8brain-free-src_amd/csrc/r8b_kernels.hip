@@ -115,6 +115,7 @@ typedef double r8b_d2_t __attribute__((ext_vector_type(2)));
 #ifndef R8B_NO_STORE16U
 struct __attribute__((aligned(8))) r8b_cd8_t { double re, im; };
 #define R8B_OUT_STORE16U(ptr, v) { r8b_cd8_t t_; t_.re = (v).re; t_.im = (v).im; *reinterpret_cast<r8b_cd8_t*>(ptr) = t_; }
+#define R8B_IN_LOAD16U(ptr, a, b) { const r8b_cd8_t t_ = *reinterpret_cast<const r8b_cd8_t*>(ptr); (a) = t_.re; (b) = t_.im; }
 #endif
 // nothing is scheduled across this point (no instruction is emitted)
 #ifndef R8B_NO_SCHED_FENCE
@@ -1107,6 +1108,8 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	convp_prepare<LN, UL>(X, MODE != 1 && MODE != 18, convp_mode_sp(MODE), convp_mode_solo(MODE), convp_mode_p3(MODE));
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
+	// (mode 20: the half-band front stages its raw samples over the array and what lies behind it)
+	if constexpr (MODE == 20) lds = lds > (size_t) kHbfLdsBytes ? lds : (size_t) kHbfLdsBytes;
 #ifdef R8B_DEV_ONLY_MODE
 	// (development builds: occupancy experiments with a truncated array -- timing only, results are wrong)
 	if (const char* e = getenv("R8B_FAKE_LDS")) lds = (size_t) atoi(e);
@@ -1153,6 +1156,14 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	static const std::string sym = symbol4("k_convp", LN, UL, MODE, FLENP);
 	launch_symbol_note(sym.c_str());
 	}
+}
+
+// (the half-band front, mode 20: the 4096 -> 2048-point decimating geometry)
+template<int LN, int DL>
+void launch_convp_hbf(const ConvxLaunch& X, hipStream_t stream)
+{
+	if constexpr (LN == 12 && DL == 1) launch_convp_t<LN, -DL, 20, 24>(X, stream);
+	else throw std::runtime_error("launch_convp: half-band front on a geometry it is not built for");
 }
 
 // (the polyphase 3x form: 1:1 geometries of 1024 ... 4096 points)
@@ -1408,6 +1419,11 @@ void R8B_LAUNCH(launch_convp)(const ConvxLaunch& X, int mode, void* stream)
 			(DL == 2 && (mode == 10 || mode == 11)))) \
 		{ \
 			launch_convp_solo_down<LN, DL>(X, mode, (hipStream_t) stream); \
+			R8B_PAIR_DONE; \
+		} \
+		if (ln == LN && X.c.down == (1 << DL) && mode == 20) \
+		{ \
+			launch_convp_hbf<LN, DL>(X, (hipStream_t) stream); \
 			R8B_PAIR_DONE; \
 		} \
 		if (ln == LN && X.c.down == (1 << DL) && mode < 8) \

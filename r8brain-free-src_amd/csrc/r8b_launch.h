@@ -245,12 +245,18 @@ struct SpanInfo
 };
 
 #ifndef R8B_CONVX_MAX_BLOCKS
-#define R8B_CONVX_MAX_BLOCKS 104
+#define R8B_CONVX_MAX_BLOCKS 99
 #endif
-// blocks per fused launch (longer calls are split).  104: the launch descriptor is a kernel argument, 672 + 32 x 104 =
-// 4000 of the 4096 bytes a launch can carry; 44100 -> 96000 at a 10 % transition band has 99 blocks per 16384-sample
-// call (0.253 -> 0.242 ms as one launch instead of two, profiles/r05_experiments.txt)
+// blocks per fused launch (longer calls are split).  99: the launch descriptor is a kernel argument, ~ 830 + 32 x 99 of
+// the 4096 bytes a launch can carry (104 until the half-band front's taps joined it in round 6); 44100 -> 96000 at a
+// 10 % transition band has 99 blocks per 16384-sample call (0.253 -> 0.242 ms as one launch instead of two,
+// profiles/r05_experiments.txt)
 static const int kConvxMaxBlocks = R8B_CONVX_MAX_BLOCKS;
+
+// pair form, mode 20 (r8b_convp.h cp_hbf_*): convolver inputs per staging round of the half-band front (two rounds per
+// 4096-point window), the longest half-band filter it takes
+static const int kHbfRound = 2048;
+static const int kHbfTapsMax = 14;
 
 struct ConvxLaunch
 {
@@ -298,6 +304,14 @@ struct ConvxLaunch
 	const double* park_src;
 	double* park_dst;
 	SpanInfo park_blk;
+	// pair form, mode 20 (r8b_convp.h cp_hbf_*): a half-band decimator in front of the convolver taken in the block's
+	// load -- c.src is the DECIMATOR's input stream (caller's buffer + history ring), the block's window of N convolver
+	// inputs is computed from 2 N + 4 hb_n raw samples in LDS (reference CDSPHBDownsampler.h:137-239 in front of
+	// CDSPBlockConvolver.h:283-350).  hb_n taps (0: no such front), rounded up to hb_np (4 / 8 / 14, the extra taps
+	// zero); raw positions >= hb_end have not arrived and read as zeros (only the zero taps ever reach them).
+	int hb_n = 0, hb_np = 0;
+	long long hb_end = 0;
+	double hb_taps[14];
 };
 static_assert(sizeof(ConvxLaunch) <= 4096, "ConvxLaunch is passed by value: 4096 bytes of kernel arguments");
 

@@ -395,7 +395,7 @@ void emul_convp_t(const ConvxLaunch& X0)
 	ConvxLaunch X = X0;
 	constexpr bool SOLO = convp_mode_solo(MODE);
 	convp_prepare<LN, UL>(X, MODE != 1 && MODE != 18, convp_mode_sp(MODE), SOLO, convp_mode_p3(MODE));
-	std::vector<double> lds((size_t) convp_lds_bytes<LN, UL>() / sizeof(double) + 2);
+	std::vector<double> lds((size_t) std::max(convp_lds_bytes<LN, UL>(), MODE == 20 ? kHbfLdsBytes : 0) / sizeof(double) + 2);
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;
@@ -451,6 +451,13 @@ void emul_convp_t(const ConvxLaunch& X0)
 			for (int j = 0; j < 16; j++) s.vr[j] = s.vi[j] = std::numeric_limits<double>::quiet_NaN();
 		convp_body<LN, UL, MODE, FLENP>(ex, X, reinterpret_cast<cd*>(base), convp_item<SUB>(X.c, i, SOLO));
 	}
+}
+
+template<int LN, int DL>
+void emul_convp_hbf(const ConvxLaunch& X)
+{
+	if constexpr (LN == 12 && DL == 1) emul_convp_t<LN, -DL, 20, 24>(X);
+	else throw std::runtime_error("emul launch_convp: half-band front on a geometry it is not built for");
 }
 
 template<int LN, int DL>
@@ -531,6 +538,11 @@ void launch_convp(const ConvxLaunch& X, int mode, void*)
 			(DL == 2 && (mode == 10 || mode == 11)))) \
 		{ \
 			emul_convp_solo_down<LN, DL>(X, mode); \
+			return; \
+		} \
+		if (ln == LN && X.c.down == (1 << DL) && mode == 20) \
+		{ \
+			emul_convp_hbf<LN, DL>(X); \
 			return; \
 		} \
 		if (ln == LN && X.c.down == (1 << DL) && mode < 8) \

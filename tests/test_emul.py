@@ -702,6 +702,49 @@ def run_history_three_ways(lib_kw, src, dst, maxin, tb):
     assert b.stat("tail_launches") == len(lens) and a.stat("tail_launches") < len(lens)
 
 
+HBCONV_TOPOLOGIES = [(176400.0, 44100.0, 7000), (352800.0, 44100.0, 8192)]
+
+
+def run_hbconv_fused(lib_kw, refwrap, src, dst, maxin, nch=3):
+    """a half-band decimator taken in the load of the decimating convolver behind it (kernel mode 20, option
+    fuse_hbconv): one launch instead of two, the SAME samples bit for bit (the decimator's sums in k_hbdown's order),
+    over ragged calls, a checkpoint into a fresh object, an odd channel count; and the reference's stream to the usual
+    tolerance"""
+    a = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=nch, **lib_kw)
+    b = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=nch, **lib_kw)
+    for o in (a, b):
+        o.set_option("fuse_hbd", 0)   # (the decimating cascade sums in another order than k_hbdown)
+        o.set_option("timing", 1)
+    a.set_option("fuse_hbconv", 1)    # (not the default: measured slower, profiles/r06_experiments.txt)
+    lens = [min(l, maxin) for l in (maxin, maxin, maxin // 3, 300, maxin, 17, 1, maxin - 5, 2500, maxin, 9, maxin)]
+    x = make_input(nch, sum(lens), 17)
+    ya, yb, counts, pos = [], [], [], 0
+    for i, l in enumerate(lens):
+        xi = x[:, pos:pos + l]
+        pos += l
+        u, v = a.process_host(xi), b.process_host(xi)
+        assert u.shape == v.shape and np.array_equal(u, v), (i, l)
+        ya.append(u)
+        counts.append(u.shape[1])
+        if i == 5:
+            blob = a.state_dict()
+            a = r8b.BatchResampler(src, dst, maxin, 2.0, 180.15, nch=nch, **lib_kw)
+            a.set_option("fuse_hbd", 0)
+            a.set_option("fuse_hbconv", 1)
+            a.set_option("timing", 1)
+            a.process_host(x[:, :200] * 0.5)
+            a.load_state_dict(blob)
+    na, nb = [t[0] for t in a.stage_timings()], [t[0] for t in b.stage_timings()]
+    assert "k_convp_hb" in na and "k_convp_hb" not in nb and len(na) == len(nb), (na, nb)
+    r, p = refwrap.batch_check(src, dst, maxin, lens, x, np.concatenate(ya, axis=1), counts, 2.0, 180.15)
+    assert r.max() <= RMS_TOL and p.max() <= PEAK_TOL, (r.max(), p.max())
+
+
+@pytest.mark.parametrize("src,dst,maxin", HBCONV_TOPOLOGIES)
+def test_emulated_half_band_front_of_the_convolver(emul, refwrap, src, dst, maxin):
+    run_hbconv_fused({"lib": emul}, refwrap, src, dst, maxin)
+
+
 HB_CARRY_TOPOLOGIES = [(176400.0, 44100.0, 16384, 2.0), (192000.0, 44100.0, 8192, 0.5), (44100.0, 2822400.0, 1024, 2.0),
                        (2822400.0, 176400.0, 8192, 2.0), (352800.0, 44100.0, 4096, 2.0)]
 

@@ -669,6 +669,18 @@ def test_hip_history_from_registers_equals_the_copy_kernel(torch, src, dst, maxi
         assert ya.shape == yb.shape and np.array_equal(ya, yb), (i, l)
 
 
+def _hbconv_topologies():
+    from test_emul import HBCONV_TOPOLOGIES
+    return HBCONV_TOPOLOGIES
+
+
+@pytest.mark.parametrize("src,dst,maxin", _hbconv_topologies())
+def test_hip_half_band_front_of_the_convolver(torch, refwrap, src, dst, maxin):
+    """kernel mode 20 (k_convp<12, -1, 20, 24>) == k_hbdown + k_convp bit for bit, and the reference's stream"""
+    from test_emul import run_hbconv_fused
+    run_hbconv_fused({"device": 0}, refwrap, src, dst, maxin, nch=5)
+
+
 def _hb_carry_topologies():
     from test_emul import HB_CARRY_TOPOLOGIES
     return HB_CARRY_TOPOLOGIES
