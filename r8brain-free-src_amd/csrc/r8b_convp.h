@@ -2841,6 +2841,32 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		if constexpr (G::SUB == 1) return true;
 		else return sub_of(tid) < cur.nvalid;
 	};
+	// The shared one-element copies (cp_park_slice_*, cp_tail_slice_*): requested at entry and stored in the last phase --
+	// or, on the 512-thread geometries (8192-point arrays: 255 registers and spills, blocks of 80 000+ cycles) and in the
+	// polyphase 3x form (three backward transforms per block, spills), requested AND stored in the last phase: twelve
+	// registers less held across the block for a load whose wait ends the workgroup (modes 8 / 9: 92 -> 0 bytes of scratch
+	// per lane, 12 / 13: 76 -> 32, 14 / 15: 28 -> 0)
+	constexpr bool LATE = G::WT > 256 || P3;
+	auto slices_out = [&](int tid, St& st)
+	{
+		if constexpr (LATE)
+		{
+			if constexpr (BM != 1)
+			{
+				st.tka = nullptr;
+				if ((L.tail_flags & 8) != 0) cp_tail_slice_load<G::WT>(L, st, (int) (cur.k - L.k0) / G::SUB, chA, chB, tid);
+			}
+			if constexpr (BM != 1 || SOLO)
+			{
+				st.pka = nullptr;
+				if (X.park_n > 0 && X.park_slices != 0)
+					cp_park_slice_load<G::WT>(XM, X.wdst, st, (int) (cur.k - L.k0) / G::SUB, chA, chB, tid);
+			}
+		}
+		(void) tid;
+		cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
+		cp_tail_slice_store(L, st, chA, chB, bvalid);
+	};
 	auto front = [&](int tid, St& st, cd& twl_v)
 	{
 		const int lt = lt_of(tid);
@@ -2892,7 +2918,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		if constexpr (BM != 1)
 		{
 			st.tka = nullptr;
-			if ((L.tail_flags & 8) != 0) cp_tail_slice_load<G::WT>(L, st, (int) (cur.k - L.k0) / G::SUB, chA, chB, tid);
+			if constexpr (!LATE)
+				if ((L.tail_flags & 8) != 0) cp_tail_slice_load<G::WT>(L, st, (int) (cur.k - L.k0) / G::SUB, chA, chB, tid);
 		}
 		if constexpr (BM != 1 || SOLO)
 		{
@@ -2905,7 +2932,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			if (X.park_n > 0)
 			{
 				if (X.park_slices != 0)
-					cp_park_slice_load<G::WT>(XM, X.wdst, st, (int) (cur.k - L.k0) / G::SUB, chA, chB, tid);
+				{
+					if constexpr (!LATE) cp_park_slice_load<G::WT>(XM, X.wdst, st, (int) (cur.k - L.k0) / G::SUB, chA, chB, tid);
+				}
 				else if (!WALK && cur.k == L.k0) cp_park_back<G::WT>(XM, X.wdst, chA, chB, bvalid, tid);
 			}
 		}
@@ -3222,8 +3251,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
-			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
-			cp_tail_slice_store(L, st, chA, chB, bvalid);
+			slices_out(tid, st);
 			cp_back2<LN, UL>(buf_of(tid), st, lt);
 			cp_scale_out<16>(st.vr, st.vi, level_shift(tid)); // (the first two components' outputs: where they were computed)
 			const unsigned nzb = ex.collect_bits();
@@ -3320,8 +3348,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
-			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
-			cp_tail_slice_store(L, st, chA, chB, bvalid);
+			slices_out(tid, st);
 			cp_split_last<LN, UL>(buf_of(tid), st.tw, st.vr + 8, st.vi + 8, lt);
 			cp_scale_out<16>(st.vr, st.vi, level_shift(tid));
 			cp_silence<LN, UL>(st, ex.collect_bits());
@@ -3341,8 +3368,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
-			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
-			cp_tail_slice_store(L, st, chA, chB, bvalid);
+			slices_out(tid, st);
 			ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
 			if constexpr (LEVELS)
 			{
@@ -3388,8 +3414,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.each([&](int tid, St& st)
 		{
 			const int lt = lt_of(tid);
-			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
-			cp_tail_slice_store(L, st, chA, chB, bvalid);
+			slices_out(tid, st);
 			cp_back2<LN, UL>(buf_of(tid), st, lt);
 			cp_scale_out<16>(st.vr, st.vi, level_shift(tid));
 			cp_silence<LN, UL>(st, ex.collect_bits());
@@ -3422,8 +3447,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		ex.each([&](int tid, St& st)
 		{
 			(void) tid;
-			cp_park_slice_store(X.wdst, st, chA, chB, bvalid);
-			cp_tail_slice_store(L, st, chA, chB, bvalid);
+			slices_out(tid, st);
 			if constexpr (WALK)
 			{
 				// (an interior block: whole output groups only -- convp_walk_range)
