@@ -87,17 +87,15 @@ typedef void* CR8BBatch;
  * keeps it to its own object).  "pair_conv" = 0 (r8b_batch_set_option, before the first sample) selects the one-channel
  * kernels (slower).
  *
- * STATED EXCEPTIONS to the tolerance -- all of them conversions whose REFERENCE block is 32768 points (a radix-3 ratio
- * with a transition band of 0.5 ... 0.6 %: 8 507 - 13 633 taps), which this library runs on 16384-point blocks of the
- * same filter.  Where such a convolver also DECIMATES BY 2 OR 4 IN THE SPECTRUM the reference's output contains the
- * residue of truncating the block's spectrum (-219 dB of the signal, CDSPBlockConvolver.h:329-344), and that residue
- * depends on the block length:
- *     ratio 3/2 (e.g. 32000 -> 48000) at tb 0.5 %:  RMS <= 1e-13 / peak <= 5e-12 against the reference
- *     ratio 3/4 (e.g. 64000 -> 48000) at tb 0.5 %:  RMS <= 1e-10 / peak <= 5e-10
- * The other re-blocked ratios (3/1, 1/3, 2/3) meet 1e-15.  Both are far inside the filters' own stop band (-180 dB);
- * per-call output counts, latency queries and chunk invariance are the reference's in every case (tests/cases.py
- * REBLOCK_CASES).  Minimum phase (r8b_batch_create_ex): see DESIGN.md section 6 -- the bound there is
- * the reference's own run-to-run noise of its cepstral designer, the kernels meet 1e-15 on the reference's taps.
+ * Block lengths.  Conversions whose REFERENCE block is 32768 points (a radix-3 ratio with a transition band of
+ * 0.5 ... 0.6 %: 8 507 - 13 633 taps) run on 16384-point blocks of the same filter where overlap-save does not depend
+ * on the block length (ratios 3/1, 1/3, 2/3), and on the REFERENCE'S OWN 32768-point block where the convolver also
+ * decimates by 2 or 4 in the spectrum (ratios 3/2, 3/4: the residue of truncating a block's spectrum, -219 dB of the
+ * signal, depends on the block length -- CDSPBlockConvolver.h:329-344); all of them meet the tolerance above (until
+ * round 6 the two decimating ratios ran on 16384-point blocks and met 1e-13 / 1e-10 only).  Per-call output counts,
+ * latency queries and chunk invariance are the reference's in every case (tests/cases.py REBLOCK_CASES, DESIGN.md
+ * section 6).  Minimum phase (r8b_batch_create_ex): see DESIGN.md section 6 -- the bound there is the reference's own
+ * run-to-run noise of its cepstral designer, the kernels meet 1e-15 on the reference's taps.
  * One sample the reference leaves undefined (a ONE-tap half-band up-sampler, >= 32x up-sampling below 55 dB: the
  * stream's first odd output reads an unwritten ring slot, CDSPHBUpsampler.h:606-693) is the filter's value here. */
 R8BSRC_DECL CR8BBatch r8b_batch_create(double SrcSampleRate, double DstSampleRate, int MaxInLen,
@@ -226,7 +224,9 @@ R8BSRC_DECL int r8b_batch_stage_count(CR8BBatch b);
  * CDSPBlockConvolver.h:283-350; so does this library where a call's last block parks what it holds of the next
  * call); "park_calls": calls that took outputs from the park buffer; "park_only_calls": calls served from it alone;
  * "pcm_staged_sides": planar PCM sides of r8b_batch_process_pcm calls that had to go through the staging rows (the
- * first / last stage's kernel is built for fp64 rows only). */
+ * first / last stage's kernel is built for fp64 rows only); "walk_blocks": blocks per channel that ran on the walk
+ * form of the fused pair kernel; "tail_launches": calls whose history copy (the input's tail for the next call,
+ * CDSPBlockConvolver.h:296-305) needed a launch of its own -- no convolver kept it and no half-band launch carried it. */
 R8BSRC_DECL long long r8b_batch_stat(CR8BBatch b, const char* name);
 R8BSRC_DECL int r8b_batch_stage_timing(CR8BBatch b, int stage, double* ms_sum, int* launches,
 	long long* in_samples, long long* out_samples, char* kernel, int cap);

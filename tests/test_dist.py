@@ -270,3 +270,35 @@ def test_fewer_channel_pairs_than_ranks_four_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == 1.0
+
+
+def test_native_channel_shards_equal_the_python_ones(tmp_path):
+    """include/r8b/ShardTransfer.h (the C++ / RCCL twin of sharding.scatter_channels / gather_channels): its shard
+    boundaries are sharding.channel_shard's for every (channels, world) of a sweep; the header and its GPU test compile
+    against the ROCm headers (the transfers themselves run in the GPU tier on a one-rank world)."""
+    import importlib
+    import os
+    import shutil
+    import subprocess
+    import pytest
+    if not os.path.exists("/opt/rocm/include/rccl/rccl.h") or shutil.which("g++") is None:
+        pytest.skip("ROCm headers / g++ not here")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sharding = importlib.import_module("r8brain-free-src_amd.sharding")
+    src = tmp_path / "shards.cpp"
+    src.write_text('#include <cstdio>\n#include "%s/include/r8b/ShardTransfer.h"\n'
+                   'int main() { for (int c = 1; c <= 40; c++) for (int w = 1; w <= 9; w++) for (int r = 0; r < w; r++) {'
+                   ' int lo, hi; r8b::channel_shard(c, r, w, &lo, &hi); std::printf("%%d %%d %%d %%d %%d\\n", c, w, r, lo, hi); }'
+                   ' int lo, hi; r8b::channel_shard(8192, 5, 8, &lo, &hi); std::printf("8192 8 5 %%d %%d\\n", lo, hi); return 0; }\n' % root)
+    exe = str(tmp_path / "shards")
+    subprocess.run(["g++", "-std=c++17", "-O0", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", str(src), "-o", exe], check=True)
+    out = subprocess.run([exe], stdout=subprocess.PIPE, text=True, check=True).stdout.split("\n")
+    n = 0
+    for line in out:
+        if line.strip():
+            c, w, r, lo, hi = (int(v) for v in line.split())
+            assert (lo, hi) == sharding.channel_shard(c, r, w), line
+            n += 1
+    assert n > 1000
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                    os.path.join(root, "tests", "cxx_rccl_world1.cpp")], check=True)
