@@ -15,8 +15,8 @@
 //                                                           links are busy together
 //
 // on the stream the caller passes (the root's own shard is a device-to-device copy on that stream).  Rows are fp64,
-// channel-major; a side whose row pitch equals the row length moves as ONE message per peer, other pitches as one
-// message per row inside the same group.  Nothing here touches the r8b_batch objects: keep data sharded at rest when the
+// channel-major; a shard travels as ONE dense message, pitched rows are packed / unpacked through a scratch buffer of
+// the caller (below).  Nothing here touches the r8b_batch objects: keep data sharded at rest when the
 // producer allows it (per call of BASELINE's 8192-channel configuration every link carries 128 MiB out and 279 MiB back
 // -- 0.9 + 1.9 ms at 153 GB/s against 0.19 ms of compute: link bound) and use these two only where the batch really
 // lives on one GPU.
@@ -44,30 +44,6 @@ inline void channel_shard(int channels, int rank, int world, int* lo, int* hi)
 
 namespace shard_detail {
 
-inline ncclResult_t send_rows(const double* p, long long stride, int rows, int n, int peer, ncclComm_t comm, hipStream_t s)
-{
-	if (rows <= 0 || n <= 0) return ncclSuccess;
-	if (stride == n) return ncclSend(p, (size_t) rows * (size_t) n, ncclDouble, peer, comm, s);
-	for (int r = 0; r < rows; r++)
-	{
-		const ncclResult_t e = ncclSend(p + (long long) r * stride, (size_t) n, ncclDouble, peer, comm, s);
-		if (e != ncclSuccess) return e;
-	}
-	return ncclSuccess;
-}
-
-inline ncclResult_t recv_rows(double* p, long long stride, int rows, int n, int peer, ncclComm_t comm, hipStream_t s)
-{
-	if (rows <= 0 || n <= 0) return ncclSuccess;
-	if (stride == n) return ncclRecv(p, (size_t) rows * (size_t) n, ncclDouble, peer, comm, s);
-	for (int r = 0; r < rows; r++)
-	{
-		const ncclResult_t e = ncclRecv(p + (long long) r * stride, (size_t) n, ncclDouble, peer, comm, s);
-		if (e != ncclSuccess) return e;
-	}
-	return ncclSuccess;
-}
-
 inline ncclResult_t copy_rows(double* dst, long long dst_stride, const double* src, long long src_stride, int rows, int n,
 	hipStream_t s)
 {
@@ -77,7 +53,20 @@ inline ncclResult_t copy_rows(double* dst, long long dst_stride, const double* s
 	return e == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
 }
 
+inline bool args_ok(int channels, int n, long long local_stride, long long root_stride, int root, int rank, int world)
+{
+	return channels >= 1 && n >= 0 && world >= 1 && rank >= 0 && rank < world && root >= 0 && root < world &&
+		local_stride >= n && (rank != root || root_stride >= n);
+}
+
 } // namespace shard_detail
+
+// The wire format is ONE message per shard: rows x n doubles, dense -- both ends of a transfer must agree on the message
+// sizes, whatever the pitch of their rows.  A side whose rows are pitched (stride != n: r8b_batch_process writes rows of
+// a fixed capacity, n varies from call to call) goes through `scratch`, a device buffer of the caller with room for that
+// side's share -- channels x n doubles on the root, (hi - lo) x n on the others --, packed / unpacked by one strided copy
+// on the same stream; dense sides need none (scratch may be null then; a pitched side without scratch is
+// ncclInvalidArgument).
 
 // Rows [channels][n] on rank `root` (root_rows, pitch root_stride doubles; ignored elsewhere) -> this rank's shard
 // (local_rows, pitch local_stride).  Every rank of the communicator calls it with the same channels / n / root.
@@ -85,64 +74,111 @@ inline ncclResult_t copy_rows(double* dst, long long dst_stride, const double* s
 // for tests on a one-GPU box (a world of one rank has no other transfer to exercise); never needed in production.
 inline ncclResult_t scatter_channels(const double* root_rows, long long root_stride, int channels, int n,
 	double* local_rows, long long local_stride, int root, int rank, int world, ncclComm_t comm, hipStream_t stream,
-	bool loopback = false)
+	double* scratch = nullptr, bool loopback = false)
 {
-	if (channels < 1 || n < 0 || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world ||
-		local_stride < n || (rank == root && root_stride < n)) return ncclInvalidArgument;
+	if (!shard_detail::args_ok(channels, n, local_stride, root_stride, root, rank, world)) return ncclInvalidArgument;
 	int lo, hi;
 	channel_shard(channels, rank, world, &lo, &hi);
 	if (n == 0) return ncclSuccess;
+	const bool is_root = rank == root, remote = world > 1 || loopback;
+	// root: a dense image of all rows to send from (its own shard never travels unless loopback);
+	// others (and the looped-back root): where the dense message lands
+	const double* send_base = root_rows;
+	double* recv_base = local_rows;
+	double* recv_scratch = nullptr;
+	if (is_root && remote && root_stride != n)
+	{
+		if (scratch == nullptr) return ncclInvalidArgument;
+		const ncclResult_t e = shard_detail::copy_rows(scratch, n, root_rows, root_stride, channels, n, stream);
+		if (e != ncclSuccess) return e;
+		send_base = scratch;
+	}
+	if ((!is_root || loopback) && local_stride != n)
+	{
+		// (a looped-back root with both sides pitched: its receive lands behind the send image)
+		if (scratch == nullptr) return ncclInvalidArgument;
+		recv_scratch = scratch + (is_root && root_stride != n ? (size_t) channels * (size_t) n : 0);
+		recv_base = recv_scratch;
+	}
+	const long long send_stride = send_base == root_rows ? root_stride : n;
 	ncclResult_t e = ncclGroupStart();
 	if (e != ncclSuccess) return e;
-	if (rank == root)
-	{
+	if (is_root)
 		for (int r = 0; r < world && e == ncclSuccess; r++)
 		{
 			int a, b;
 			channel_shard(channels, r, world, &a, &b);
-			if (r == root && !loopback) continue;
-			e = shard_detail::send_rows(root_rows + (long long) a * root_stride, root_stride, b - a, n, r, comm, stream);
+			if ((r == root && !loopback) || b <= a) continue;
+			e = ncclSend(send_base + (long long) a * send_stride, (size_t) (b - a) * (size_t) n, ncclDouble, r, comm, stream);
 		}
-		if (loopback && e == ncclSuccess) e = shard_detail::recv_rows(local_rows, local_stride, hi - lo, n, root, comm, stream);
-	}
-	else e = shard_detail::recv_rows(local_rows, local_stride, hi - lo, n, root, comm, stream);
+	if ((!is_root || loopback) && hi > lo && e == ncclSuccess)
+		e = ncclRecv(recv_base, (size_t) (hi - lo) * (size_t) n, ncclDouble, root, comm, stream);
 	const ncclResult_t g = ncclGroupEnd();
 	if (e != ncclSuccess) return e;
 	if (g != ncclSuccess) return g;
-	if (rank == root && !loopback)
+	if (recv_scratch != nullptr) return shard_detail::copy_rows(local_rows, local_stride, recv_scratch, n, hi - lo, n, stream);
+	if (is_root && !loopback)
 		return shard_detail::copy_rows(local_rows, local_stride, root_rows + (long long) lo * root_stride, root_stride, hi - lo, n, stream);
 	return ncclSuccess;
 }
 
 // The inverse: every rank's shard of n output samples per channel (the same n on every rank: all follow one schedule --
-// a rank without channels passes the n the others report, or 0 rows) -> rows [channels][n] on `root`.
+// a rank without channels passes the n the others report) -> rows [channels][n] on `root`.
 inline ncclResult_t gather_channels(const double* local_rows, long long local_stride, int channels, int n,
 	double* root_rows, long long root_stride, int root, int rank, int world, ncclComm_t comm, hipStream_t stream,
-	bool loopback = false)
+	double* scratch = nullptr, bool loopback = false)
 {
-	if (channels < 1 || n < 0 || world < 1 || rank < 0 || rank >= world || root < 0 || root >= world ||
-		local_stride < n || (rank == root && root_stride < n)) return ncclInvalidArgument;
+	if (!shard_detail::args_ok(channels, n, local_stride, root_stride, root, rank, world)) return ncclInvalidArgument;
 	int lo, hi;
 	channel_shard(channels, rank, world, &lo, &hi);
 	if (n == 0) return ncclSuccess;
+	const bool is_root = rank == root, remote = world > 1 || loopback;
+	const double* send_base = local_rows;
+	double* recv_base = root_rows;
+	double* recv_scratch = nullptr;
+	if ((!is_root || loopback) && local_stride != n && hi > lo)
+	{
+		if (scratch == nullptr) return ncclInvalidArgument;
+		const ncclResult_t e = shard_detail::copy_rows(scratch, n, local_rows, local_stride, hi - lo, n, stream);
+		if (e != ncclSuccess) return e;
+		send_base = scratch;
+	}
+	if (is_root && remote && root_stride != n)
+	{
+		if (scratch == nullptr) return ncclInvalidArgument;
+		recv_scratch = scratch + (send_base == scratch ? (size_t) (hi - lo) * (size_t) n : 0);
+		recv_base = recv_scratch;
+	}
+	const long long recv_stride = recv_base == root_rows ? root_stride : n;
 	ncclResult_t e = ncclGroupStart();
 	if (e != ncclSuccess) return e;
-	if (rank == root)
-	{
+	if (is_root)
 		for (int r = 0; r < world && e == ncclSuccess; r++)
 		{
 			int a, b;
 			channel_shard(channels, r, world, &a, &b);
-			if (r == root && !loopback) continue;
-			e = shard_detail::recv_rows(root_rows + (long long) a * root_stride, root_stride, b - a, n, r, comm, stream);
+			if ((r == root && !loopback) || b <= a) continue;
+			e = ncclRecv(recv_base + (long long) a * recv_stride, (size_t) (b - a) * (size_t) n, ncclDouble, r, comm, stream);
 		}
-		if (loopback && e == ncclSuccess) e = shard_detail::send_rows(local_rows, local_stride, hi - lo, n, root, comm, stream);
-	}
-	else e = shard_detail::send_rows(local_rows, local_stride, hi - lo, n, root, comm, stream);
+	if ((!is_root || loopback) && hi > lo && e == ncclSuccess)
+		e = ncclSend(send_base, (size_t) (hi - lo) * (size_t) n, ncclDouble, root, comm, stream);
 	const ncclResult_t g = ncclGroupEnd();
 	if (e != ncclSuccess) return e;
 	if (g != ncclSuccess) return g;
-	if (rank == root && !loopback)
+	if (recv_scratch != nullptr)
+	{
+		// (the peers' shards out of the dense image; the root's own -- not looped back -- straight from its rows, below)
+		for (int r = 0; r < world; r++)
+		{
+			int a, b;
+			channel_shard(channels, r, world, &a, &b);
+			if (r == root && !loopback) continue;
+			const ncclResult_t c = shard_detail::copy_rows(root_rows + (long long) a * root_stride, root_stride,
+				recv_scratch + (long long) a * n, n, b - a, n, stream);
+			if (c != ncclSuccess) return c;
+		}
+	}
+	if (is_root && !loopback)
 		return shard_detail::copy_rows(root_rows + (long long) lo * root_stride, root_stride, local_rows, local_stride, hi - lo, n, stream);
 	return ncclSuccess;
 }

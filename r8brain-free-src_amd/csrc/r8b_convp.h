@@ -791,14 +791,14 @@ R8B_HD void cp_hbf_stage(const ConvLaunch& L, const ConvxLaunch& XM, double* xs,
 {
 	typedef ConvpGeom<LN, UL> G;
 	static_assert(UL < 0 && G::SUB == 1 && G::N == 2 * kHbfRound && G::WT == 256, "half-band front: the 4096-point decimating geometry");
-	const int TP = XM.hb_np;
+	const int TP = XM.hbf.p.np;
 	const long long base = k * (long long) L.blk_stride + L.blk_offset;
 	const long long n_r = base - (G::N - L.in_len) + (long long) r * kHbfRound; // the round's first output
 	const long long lo = 2 * n_r - (2 * TP - 1);
 	const int len = 2 * kHbfRound - 1 + 2 * (2 * TP - 1);
 	const int npair = (len + 1) / 2; // (tap, centre) pairs; the last one is a tap alone
 	constexpr int NP = (kHbfRound + 2 * kHbfTapsMax + 255) / 256;
-	if (L.src.cur_fmt == kPcmF64 && lo >= L.src.cur_base && lo >= 0 && lo + 2 * (long long) npair <= XM.hb_end)
+	if (L.src.cur_fmt == kPcmF64 && lo >= L.src.cur_base && lo >= 0 && lo + 2 * (long long) npair <= XM.hbf.p.end)
 	{
 		const double* const pa = L.src.cur + ((long long) chA * L.src.cur_stride + (lo - L.src.cur_base));
 		const double* const pb = L.src.cur + ((long long) chB * L.src.cur_stride + (lo - L.src.cur_base));
@@ -825,7 +825,7 @@ R8B_HD void cp_hbf_stage(const ConvLaunch& L, const ConvxLaunch& XM, double* xs,
 		}
 		return;
 	}
-	const int end = clamp_rel(XM.hb_end - lo);
+	const int end = clamp_rel(XM.hbf.p.end - lo);
 	const int lim = end < len ? end : len;
 	const SrcBlock sa = src_block(L.src, chA, lo), sb = src_block(L.src, chB, lo);
 	constexpr int NS = 2 * NP;
@@ -862,7 +862,7 @@ R8B_HD void cp_hbf_compute_t(const ConvLaunch& L, const ConvxLaunch& XM, const d
 	const long long n0 = base - (G::N - L.in_len) + (long long) r * kHbfRound + 8 * tid; // the thread's first output
 	double f[TP];
 #pragma unroll
-	for (int i = 0; i < TP; i++) f[i] = XM.hb_taps[i];
+	for (int i = 0; i < TP; i++) f[i] = XM.hbf.p.taps[i];
 #pragma unroll
 	for (int c = 0; c < 2; c++)
 	{
@@ -897,8 +897,8 @@ template<int RND, int LN, int UL>
 R8B_HD void cp_hbf_compute(const ConvLaunch& L, const ConvxLaunch& XM, const double* xs, ConvpState<LN, UL>& st, long long k,
 	int tid)
 {
-	if (XM.hb_np <= 4) cp_hbf_compute_t<4, RND>(L, XM, xs, st, k, tid);
-	else if (XM.hb_np <= 8) cp_hbf_compute_t<8, RND>(L, XM, xs, st, k, tid);
+	if (XM.hbf.p.np <= 4) cp_hbf_compute_t<4, RND>(L, XM, xs, st, k, tid);
+	else if (XM.hbf.p.np <= 8) cp_hbf_compute_t<8, RND>(L, XM, xs, st, k, tid);
 	else cp_hbf_compute_t<kHbfTapsMax, RND>(L, XM, xs, st, k, tid);
 }
 

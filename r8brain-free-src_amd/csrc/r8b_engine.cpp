@@ -1725,17 +1725,16 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		ConvxLaunch X;
 		ConvLaunch& L = X.c;
 		fill_conv(s, L, src);
-		X.hb_n = X.hb_np = 0;
-		X.hb_end = 0;
-		for (double& v : X.hb_taps) v = 0.0;
 		if (hb_front_ >= 0)
 		{
-			// (launch_hbconv: `src` is the decimator's input stream)
+			// (launch_hbconv: `src` is the decimator's input stream; kernel mode 20 has no per-block spans, the front's
+			// parameters lie over the end of that array)
 			const StagePlan& hp = plan_.stages[(size_t) hb_front_];
-			X.hb_n = hp.hb_n;
-			X.hb_np = hp.hb_n <= 4 ? 4 : (hp.hb_n <= 8 ? 8 : kHbfTapsMax);
-			X.hb_end = hp.m;
-			for (int i = 0; i < hp.hb_n; i++) X.hb_taps[i] = hp.hb_taps[i];
+			HbFront& F = X.hbf.p;
+			F.n = hp.hb_n;
+			F.np = hp.hb_n <= 4 ? 4 : (hp.hb_n <= 8 ? 8 : kHbfTapsMax);
+			F.end = hp.m;
+			for (int i = 0; i < kHbfTapsMax; i++) F.taps[i] = i < hp.hb_n ? hp.hb_taps[i] : 0.0;
 			L.vec_ok = 0;
 		}
 		if (g.poly3)

@@ -330,17 +330,29 @@ R8B_HD int bitrev_n(int v, int bits) { return bits == 0 ? 0 : (int) (bitrev32((u
 // out, unnormalised.  No reordering pass exists anywhere: the spectral stage in between addresses
 // bins through bitrev().  `tw` holds exp(-2 pi i e / tw_len), e < tw_len.
 
-template<int R>
+// Where element i of a transform array sits: as it is, or with index bits 0-3 XOR bits 4-7 (SwXor, r8b_convp.h pswz: the
+// passes whose lanes are 8 or 16 elements apart -- sub-lengths 64 and below, up to 32 lanes on one bank group unswizzled
+// -- then spread over the banks).  The long-block kernel (k_conv_big) uses SwXor for both of its LDS arrays.
+struct SwNone
+{
+	static R8B_HD int at(int i) { return i; }
+};
+struct SwXor
+{
+	static R8B_HD int at(int i) { return i ^ ((i >> 4) & 15); }
+};
+
+template<int R, class SW = SwNone>
 R8B_HD void dif_pass_one(cd* buf, int n, int bidx, const cd* tw, int tw_len)
 {
 	const int q = n / R;
 	const int blk = bidx / q, j = bidx - blk * q;
-	cd* p0 = buf + (long) blk * n + j;
+	const int i0 = blk * n + j;
 	double vr[R], vi[R];
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
-		const cd v = p0[p * q];
+		const cd v = buf[SW::at(i0 + p * q)];
 		vr[p] = v.re;
 		vi[p] = v.im;
 	}
@@ -364,21 +376,21 @@ R8B_HD void dif_pass_one(cd* buf, int n, int bidx, const cd* tw, int tw_len)
 		cd v;
 		v.re = vr[p];
 		v.im = vi[p];
-		p0[p * q] = v;
+		buf[SW::at(i0 + p * q)] = v;
 	}
 }
 
-template<int R>
+template<int R, class SW = SwNone>
 R8B_HD void dit_pass_one(cd* buf, int n, int bidx, const cd* tw, int tw_len)
 {
 	const int q = n / R;
 	const int blk = bidx / q, j = bidx - blk * q;
-	cd* p0 = buf + (long) blk * n + j;
+	const int i0 = blk * n + j;
 	double vr[R], vi[R];
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
-		const cd v = p0[p * q];
+		const cd v = buf[SW::at(i0 + p * q)];
 		vr[p] = v.re;
 		vi[p] = v.im;
 	}
@@ -402,12 +414,13 @@ R8B_HD void dit_pass_one(cd* buf, int n, int bidx, const cd* tw, int tw_len)
 		cd v;
 		v.re = vr[p];
 		v.im = vi[p];
-		p0[p * q] = v;
+		buf[SW::at(i0 + p * q)] = v;
 	}
 }
 
 // one whole pass over a length-N complex buffer (all sub-blocks), strided over the threads
-R8B_HD void fft_pass(cd* buf, int N, int n, int radix, bool inverse, const cd* tw, int tw_len,
+template<class SW>
+R8B_HD void fft_pass_sw(cd* buf, int N, int n, int radix, bool inverse, const cd* tw, int tw_len,
 	int tid, int nthr)
 {
 	const int nb = N / radix;
@@ -415,19 +428,24 @@ R8B_HD void fft_pass(cd* buf, int N, int n, int radix, bool inverse, const cd* t
 	{
 		if (!inverse)
 		{
-			if (radix == 16) dif_pass_one<16>(buf, n, b, tw, tw_len);
-			else if (radix == 8) dif_pass_one<8>(buf, n, b, tw, tw_len);
-			else if (radix == 4) dif_pass_one<4>(buf, n, b, tw, tw_len);
-			else dif_pass_one<2>(buf, n, b, tw, tw_len);
+			if (radix == 16) dif_pass_one<16, SW>(buf, n, b, tw, tw_len);
+			else if (radix == 8) dif_pass_one<8, SW>(buf, n, b, tw, tw_len);
+			else if (radix == 4) dif_pass_one<4, SW>(buf, n, b, tw, tw_len);
+			else dif_pass_one<2, SW>(buf, n, b, tw, tw_len);
 		}
 		else
 		{
-			if (radix == 16) dit_pass_one<16>(buf, n, b, tw, tw_len);
-			else if (radix == 8) dit_pass_one<8>(buf, n, b, tw, tw_len);
-			else if (radix == 4) dit_pass_one<4>(buf, n, b, tw, tw_len);
-			else dit_pass_one<2>(buf, n, b, tw, tw_len);
+			if (radix == 16) dit_pass_one<16, SW>(buf, n, b, tw, tw_len);
+			else if (radix == 8) dit_pass_one<8, SW>(buf, n, b, tw, tw_len);
+			else if (radix == 4) dit_pass_one<4, SW>(buf, n, b, tw, tw_len);
+			else dit_pass_one<2, SW>(buf, n, b, tw, tw_len);
 		}
 	}
+}
+R8B_HD void fft_pass(cd* buf, int N, int n, int radix, bool inverse, const cd* tw, int tw_len,
+	int tid, int nthr)
+{
+	fft_pass_sw<SwNone>(buf, N, n, radix, inverse, tw, tw_len, tid, nthr);
 }
 
 // history copy (k_tail; carried by a half-band launch's second grid layer): workgroup w of nw of channel ch copies its
@@ -481,7 +499,7 @@ struct ZHalf
 {
 	const cd* zl;
 	int logN;
-	R8B_HD cd operator()(int k) const { return zl[bitrev_n(k >> 1, logN - 1)]; }
+	R8B_HD cd operator()(int k) const { return zl[SwXor::at(bitrev_n(k >> 1, logN - 1))]; }
 };
 
 // spectrum bin k (0 <= k <= N) of the 2N-point real sequence whose packed N-point complex DFT
@@ -661,7 +679,7 @@ R8B_HD void conv_load_r2(const ConvLaunch& L, cd* zl, long long k, int ch, int h
 			o.re = dr * w.re - di * w.im;
 			o.im = dr * w.im + di * w.re;
 		}
-		zl[j] = o;
+		zl[SwXor::at(j)] = o;
 	}
 }
 
@@ -676,7 +694,8 @@ R8B_HD void conv_spectral_half(const ConvLaunch& L, const cd* zl, cd* zb, int h,
 
 // K7: emit the valid part of block k that falls into the call's output range [L.a, L.b)
 // (reference CDSPBlockConvolver.h:512-593)
-R8B_HD void conv_store(const ConvLaunch& L, const double* y, long long k, int ch, int tid, int nthr)
+template<class SW>
+R8B_HD void conv_store_sw(const ConvLaunch& L, const double* y, long long k, int ch, int tid, int nthr)
 {
 	const long long t0 = k * (long long) L.in_len - L.fl2; // first time (virtual rate) of the block
 	const long long t1 = t0 + L.in_len;
@@ -690,8 +709,13 @@ R8B_HD void conv_store(const ConvLaunch& L, const double* y, long long k, int ch
 		long long c = q * L.down - kb;
 		if (c < 0) c += L.bl2;
 		const int idx = L.down_pow2 ? (int) (c / L.down) : (int) c;
-		dst_store(L.dst, ch, q, y[idx]);
+		// (real sample idx = part idx & 1 of complex element idx >> 1)
+		dst_store(L.dst, ch, q, y[2 * SW::at(idx >> 1) + (idx & 1)]);
 	}
+}
+R8B_HD void conv_store(const ConvLaunch& L, const double* y, long long k, int ch, int tid, int nthr)
+{
+	conv_store_sw<SwNone>(L, y, k, ch, tid, nthr);
 }
 
 // ------------------------------------------------------------------------------------ interpolators

@@ -226,23 +226,25 @@ __global__ __launch_bounds__(512) void k_conv_big(const ConvLaunch L)
 			int n = Nh;
 			for (int p = 1; p < L.n_fwd; p++)
 			{
-				fft_pass(zl, Nh, n, L.fwd_radix[p], false, L.tw, L.tw_len, tid, nthr);
+				fft_pass_sw<SwXor>(zl, Nh, n, L.fwd_radix[p], false, L.tw, L.tw_len, tid, nthr);
 				n /= L.fwd_radix[p];
 				__syncthreads();
 			}
 			conv_spectral_half(L, zl, zg, h, tid, nthr);
 			__syncthreads();
 		}
-		for (int i = tid; i < N2; i += nthr) zb[i] = zg[i];
+		// (both LDS arrays swizzled -- SwXor: the passes with short sub-lengths would otherwise put up to 32 lanes on
+		// one bank group)
+		for (int i = tid; i < N2; i += nthr) zb[SwXor::at(i)] = zg[i];
 		__syncthreads();
 		int n = 1;
 		for (int p = 0; p < L.n_inv; p++)
 		{
 			n *= L.inv_radix[p];
-			fft_pass(zb, N2, n, L.inv_radix[p], true, L.tw, L.tw_len, tid, nthr);
+			fft_pass_sw<SwXor>(zb, N2, n, L.inv_radix[p], true, L.tw, L.tw_len, tid, nthr);
 			__syncthreads();
 		}
-		conv_store(L, rb, k, ch, tid, nthr);
+		conv_store_sw<SwXor>(L, rb, k, ch, tid, nthr);
 		__syncthreads();
 	}
 }

@@ -245,18 +245,31 @@ struct SpanInfo
 };
 
 #ifndef R8B_CONVX_MAX_BLOCKS
-#define R8B_CONVX_MAX_BLOCKS 99
+#define R8B_CONVX_MAX_BLOCKS 104
 #endif
-// blocks per fused launch (longer calls are split).  99: the launch descriptor is a kernel argument, ~ 830 + 32 x 99 of
-// the 4096 bytes a launch can carry (104 until the half-band front's taps joined it in round 6); 44100 -> 96000 at a
-// 10 % transition band has 99 blocks per 16384-sample call (0.253 -> 0.242 ms as one launch instead of two,
-// profiles/r05_experiments.txt)
+// blocks per fused launch (longer calls are split).  104: the launch descriptor is a kernel argument, ~ 700 + 32 x 104
+// of the 4096 bytes a launch can carry; 44100 -> 96000 at a 10 % transition band has 99 - 104 blocks per 16384-sample
+// call (0.253 -> 0.242 ms as one launch instead of two, profiles/r05_experiments.txt; with 99 blocks per launch that
+// configuration fell back to two launches in round 6: 0.272)
 static const int kConvxMaxBlocks = R8B_CONVX_MAX_BLOCKS;
 
 // pair form, mode 20 (r8b_convp.h cp_hbf_*): convolver inputs per staging round of the half-band front (two rounds per
 // 4096-point window), the longest half-band filter it takes
 static const int kHbfRound = 2048;
 static const int kHbfTapsMax = 14;
+
+// pair form, mode 20 (r8b_convp.h cp_hbf_*): a half-band decimator in front of the convolver taken in the block's load --
+// c.src is the DECIMATOR's input stream (caller's buffer + history ring), the block's window of N convolver inputs is
+// computed from 2 N + 4 np raw samples in LDS (reference CDSPHBDownsampler.h:137-239 in front of
+// CDSPBlockConvolver.h:283-350).  n taps, rounded up to np (4 / 8 / 14, the extra taps zero); raw positions >= end have
+// not arrived and read as zeros (only the zero taps ever reach them).
+struct HbFront
+{
+	int n, np;
+	long long end;
+	double taps[kHbfTapsMax];
+};
+static_assert(sizeof(HbFront) <= 4 * sizeof(SpanInfo), "ConvxLaunch::hbf lies over the last four block entries");
 
 struct ConvxLaunch
 {
@@ -267,7 +280,17 @@ struct ConvxLaunch
 	const double* wtab;  // flen x out_step: wtab[i*out_step + t] = table[(t*in_step % out_step)*flen + i]
 	long long wa, wb;    // interpolator outputs to produce
 	DstView wdst;
-	SpanInfo blk[kConvxMaxBlocks]; // per block c.k0 + i (mode 1)
+	// per block c.k0 + i (mode 1) -- or, in the convolver-only mode 20 (which has no per-block spans), the half-band
+	// front's parameters in the array's last four entries (the descriptor has no room for both)
+	union
+	{
+		SpanInfo blk[kConvxMaxBlocks];
+		struct
+		{
+			SpanInfo unused_[kConvxMaxBlocks - 4];
+			HbFront p;
+		} hbf;
+	};
 	// pair form, mode 4 (two adjacent phases per thread, r8b_convp.h): the run of (A, B) pairs starts
 	// at LDS slot run_off; per block blk[].u_lo = run slot of the window of phase 0 of the block's first
 	// output group, .ph_lo = groups - 1, .pad = the phase the block's last group ends before (1 ..
@@ -304,14 +327,6 @@ struct ConvxLaunch
 	const double* park_src;
 	double* park_dst;
 	SpanInfo park_blk;
-	// pair form, mode 20 (r8b_convp.h cp_hbf_*): a half-band decimator in front of the convolver taken in the block's
-	// load -- c.src is the DECIMATOR's input stream (caller's buffer + history ring), the block's window of N convolver
-	// inputs is computed from 2 N + 4 hb_n raw samples in LDS (reference CDSPHBDownsampler.h:137-239 in front of
-	// CDSPBlockConvolver.h:283-350).  hb_n taps (0: no such front), rounded up to hb_np (4 / 8 / 14, the extra taps
-	// zero); raw positions >= hb_end have not arrived and read as zeros (only the zero taps ever reach them).
-	int hb_n = 0, hb_np = 0;
-	long long hb_end = 0;
-	double hb_taps[14];
 };
 static_assert(sizeof(ConvxLaunch) <= 4096, "ConvxLaunch is passed by value: 4096 bytes of kernel arguments");
 

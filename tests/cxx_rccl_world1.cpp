@@ -42,7 +42,8 @@ int main()
 	CR8BBatch looped = r8b_batch_create(44100.0, 96000.0, L, 2.0, 180.15, nch, 0);
 	if (!direct || !sharded || !looped) { std::printf("create: %s\n", r8b_last_error()); return 1; }
 	const int maxout = r8b_batch_max_out_len(direct), pitch_out = maxout + 8;
-	double *root_in, *local_in, *local_out, *root_out, *ref_out;
+	double *root_in, *local_in, *local_out, *root_out, *ref_out, *scratch;
+	CK(hipMalloc(&scratch, sizeof(double) * 2 * nch * (maxout > L ? maxout : L)));
 	CK(hipMalloc(&root_in, sizeof(double) * nch * pitch_in));
 	CK(hipMalloc(&local_in, sizeof(double) * nch * L));
 	CK(hipMalloc(&local_out, sizeof(double) * nch * maxout));
@@ -64,11 +65,11 @@ int main()
 		for (int pass = 0; pass < 2; pass++)
 		{
 			const bool loop = pass == 1;
-			NK(r8b::scatter_channels(root_in, pitch_in, nch, L, local_in, L, 0, 0, 1, comm, stream, loop));
+			NK(r8b::scatter_channels(root_in, pitch_in, nch, L, local_in, L, 0, 0, 1, comm, stream, scratch, loop));
 			const int n = r8b_batch_process(loop ? looped : sharded, local_in, L, L, local_out, maxout, stream);
 			if (n != nref) { std::printf("counts differ: %d vs %d (%s)\n", n, nref, r8b_last_error()); return 1; }
 			CK(hipMemsetAsync(root_out, 0xff, sizeof(double) * nch * pitch_out, stream));
-			NK(r8b::gather_channels(local_out, maxout, nch, n, root_out, pitch_out, 0, 0, 1, comm, stream, loop));
+			NK(r8b::gather_channels(local_out, maxout, nch, n, root_out, pitch_out, 0, 0, 1, comm, stream, scratch, loop));
 			CK(hipMemcpyAsync(a.data(), ref_out, sizeof(double) * a.size(), hipMemcpyDeviceToHost, stream));
 			CK(hipMemcpyAsync(b.data(), root_out, sizeof(double) * b.size(), hipMemcpyDeviceToHost, stream));
 			CK(hipStreamSynchronize(stream));
@@ -86,6 +87,8 @@ int main()
 	if (total <= 0) { std::printf("no output\n"); return 1; }
 	// argument errors come back as such
 	if (r8b::scatter_channels(root_in, L - 1, nch, L, local_in, L, 0, 0, 1, comm, stream) != ncclInvalidArgument) { std::printf("pitch check\n"); return 1; }
+	// ... and pitched rows that would have to travel without a scratch buffer
+	if (r8b::gather_channels(local_out, maxout, nch, 16, root_out, pitch_out, 0, 0, 1, comm, stream, nullptr, true) != ncclInvalidArgument) { std::printf("scratch check\n"); return 1; }
 	r8b_batch_delete(direct); r8b_batch_delete(sharded); r8b_batch_delete(looped);
 	NK(ncclCommDestroy(comm));
 	std::printf("%lld samples per channel through scatter / gather, both ways: OK\n", total);

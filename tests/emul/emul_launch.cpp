@@ -42,20 +42,20 @@ static void launch_conv_big(const ConvLaunch& L)
 				int n = Nh;
 				for (int p = 1; p < L.n_fwd; p++)
 				{
-					for (int t = 0; t < nthr; t++) fft_pass(zl.data(), Nh, n, L.fwd_radix[p], false, L.tw, L.tw_len, t, nthr);
+					for (int t = 0; t < nthr; t++) fft_pass_sw<SwXor>(zl.data(), Nh, n, L.fwd_radix[p], false, L.tw, L.tw_len, t, nthr);
 					n /= L.fwd_radix[p];
 				}
 				for (int t = 0; t < nthr; t++) conv_spectral_half(L, zl.data(), zg.data(), h, t, nthr);
 			}
-			for (int i = 0; i < N2; i++) zl[(size_t) i] = zg[(size_t) i];
+			for (int i = 0; i < N2; i++) zl[(size_t) SwXor::at(i)] = zg[(size_t) i];
 			int n = 1;
 			for (int p = 0; p < L.n_inv; p++)
 			{
 				n *= L.inv_radix[p];
-				for (int t = 0; t < nthr; t++) fft_pass(zl.data(), N2, n, L.inv_radix[p], true, L.tw, L.tw_len, t, nthr);
+				for (int t = 0; t < nthr; t++) fft_pass_sw<SwXor>(zl.data(), N2, n, L.inv_radix[p], true, L.tw, L.tw_len, t, nthr);
 			}
 			for (int t = 0; t < nthr; t++)
-				conv_store(L, reinterpret_cast<const double*>(zl.data()), k, ch, t, nthr);
+				conv_store_sw<SwXor>(L, reinterpret_cast<const double*>(zl.data()), k, ch, t, nthr);
 		}
 }
 
