@@ -35,11 +35,12 @@ for case in [c for c in T._cases(3 * n, seed) if c[2] >= 300][:n]:
     except pytest.skip.Exception:
         skipped += 1
     except AssertionError as e:
-        # (the two known differences, as in tools/wide_fuzz.py: a one-tap half-band up-sampler's first odd output, where
-        # the reference's own value is indeterminate; truncated 32768-point reference blocks within 1e-10)
+        # (the one known difference, as in tools/wide_fuzz.py: a one-tap half-band up-sampler's first odd output, where
+        # the reference's own value is indeterminate.  Until round 6 also: truncated 32768-point reference blocks within
+        # 1e-10 -- those chains now run the reference's own block and have to meet the bound)
         desc = T.r8b.BatchResampler(case[0], case[1], case[2], case[3], case[4], nch=1).describe()
         a = e.args[0] if e.args and isinstance(e.args[0], tuple) and len(e.args[0]) in (3, 4) else None
-        if "taps=1 " in desc or ("fft=32768/" in desc and a is not None and a[1] <= 1e-10 and a[2] <= 5e-10):
+        if "taps=1 " in desc:
             known += 1
         else:
             bad += 1; print("FAIL", case, str(e)[:300])
