@@ -218,11 +218,12 @@ template<int LN, int UL> R8B_HD int convp_lt(int tid)
 	else return tid & (ConvpGeom<LN, UL>::NT - 1);
 }
 
-template<int LN, int UL>
+// (HAF: the half-array form -- mode 21, cp_ha_* --: the forward transform alone in an array of N complex elements, identity map)
+template<int LN, int UL, bool HAF = false>
 R8B_HD int fslot(int p)
 {
 	typedef ConvpGeom<LN, UL> G;
-	if constexpr (UL <= 0 || G::NW == 1 || kSplit<LN, UL>) return pswz(p);
+	if constexpr (UL <= 0 || G::NW == 1 || kSplit<LN, UL> || HAF) return pswz(p);
 	else return pswz((p / G::FW) * G::BW + (p & (G::FW - 1)));
 }
 
@@ -241,11 +242,11 @@ R8B_HD int bslot(int p)
 // the LDS instruction's immediate offset -- instead of a full swizzle (4 ... 7 integer instructions) per access.
 R8B_HD constexpr int sw_xc(int m) { return (m ^ (m >> 4)) & 15; }
 R8B_HD constexpr int sw_hi(int m) { return m & ~15; }
-template<int LN, int UL>
+template<int LN, int UL, bool HAF = false>
 R8B_HD constexpr int fmap_c(int d)
 {
 	typedef ConvpGeom<LN, UL> G;
-	return (UL <= 0 || G::NW == 1 || kSplit<LN, UL>) ? d : (d / G::FW) * G::BW + (d & (G::FW - 1));
+	return (UL <= 0 || G::NW == 1 || kSplit<LN, UL> || HAF) ? d : (d / G::FW) * G::BW + (d & (G::FW - 1));
 }
 template<int LN, int UL>
 R8B_HD constexpr int bmap_c(int d)
@@ -616,18 +617,18 @@ R8B_HD void tw_expand(cd* twr)
 
 // ---- passes over the swizzled array ---------------------------------------------------------------
 
-template<int LN, int UL, int R, bool TW>
+template<int LN, int UL, int R, bool TW, bool HAF = false>
 R8B_HD void pdif(cd* buf, int n, int b, const cd* twr)
 {
 	const int q = n / R;
 	const int blk = b / q, j = b - blk * q;
 	const int e0 = blk * n + j;
-	const SwBase bb = sw_base(buf, fslot<LN, UL>(e0));
+	const SwBase bb = sw_base(buf, fslot<LN, UL, HAF>(e0));
 	double vr[R], vi[R];
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
-		const cd v = sw_ld(bb, fmap_c<LN, UL>(p * q));
+		const cd v = sw_ld(bb, fmap_c<LN, UL, HAF>(p * q));
 		vr[p] = v.re;
 		vi[p] = v.im;
 	}
@@ -650,8 +651,27 @@ R8B_HD void pdif(cd* buf, int n, int b, const cd* twr)
 		cd v;
 		v.re = vr[p];
 		v.im = vi[p];
-		sw_st(bb, fmap_c<LN, UL>(p * q), v);
+		sw_st(bb, fmap_c<LN, UL, HAF>(p * q), v);
 	}
+}
+
+// (the arithmetic of a backward pass on the R values a thread has loaded: twiddles, then the butterflies)
+template<int R, bool TW>
+R8B_HD void pdit_arith(const cd* twr, double* vr, double* vi)
+{
+	if constexpr (TW)
+	{
+#pragma unroll
+		for (int p = 1; p < R; p++)
+		{
+			const cd w = tw_get(twr, bitrev_c<R>(p));
+			const double tr = vr[p] * w.re + vi[p] * w.im;
+			const double ti = vi[p] * w.re - vr[p] * w.im;
+			vr[p] = tr;
+			vi[p] = ti;
+		}
+	}
+	dit_regs<R>(vr, vi);
 }
 
 template<int R, bool TW>
@@ -668,19 +688,7 @@ R8B_HD void pdit_regs(const cd* buf, int n, int b, const cd* twr, double* vr, do
 		vr[p] = v.re;
 		vi[p] = v.im;
 	}
-	if constexpr (TW)
-	{
-#pragma unroll
-		for (int p = 1; p < R; p++)
-		{
-			const cd w = tw_get(twr, bitrev_c<R>(p));
-			const double tr = vr[p] * w.re + vi[p] * w.im;
-			const double ti = vi[p] * w.re - vr[p] * w.im;
-			vr[p] = tr;
-			vi[p] = ti;
-		}
-	}
-	dit_regs<R>(vr, vi);
+	pdit_arith<R, TW>(twr, vr, vi);
 }
 
 // ---- phases -----------------------------------------------------------------------------------------
@@ -1191,7 +1199,7 @@ R8B_HD void cp_tail_slice_store(const ConvLaunch& L, const St& st, int chA, int 
 }
 
 // first forward pass, from the registers cp_load() filled
-template<int LN, int UL>
+template<int LN, int UL, bool HAF = false>
 R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
@@ -1219,14 +1227,14 @@ R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st,
 		vr[p] = tr;
 		vi[p] = ti;
 	}
-	const SwBase bb = sw_base(buf, fslot<LN, UL>(lt));
+	const SwBase bb = sw_base(buf, fslot<LN, UL, HAF>(lt));
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
 		cd v;
 		v.re = vr[p];
 		v.im = vi[p];
-		sw_st(bb, fmap_c<LN, UL>(p * q), v);
+		sw_st(bb, fmap_c<LN, UL, HAF>(p * q), v);
 	}
 }
 
@@ -1242,6 +1250,7 @@ struct ConvpPre
 			ptw_fetch<G::E1, G::NT, (n / G::E1 < G::NT ? n / G::E1 : G::NT)>(st.tw, L.ptw, I, lt);
 	}
 	// (ltw: the workgroup's twiddle table in LDS, ConvpTwLds)
+	template<bool HAF = false>
 	static R8B_HD void run(cd* buf, const ConvpState<LN, UL>& st, int lt, const cd* ltw)
 	{
 		typedef ConvpTwLds<LN, UL> TL;
@@ -1249,9 +1258,9 @@ struct ConvpPre
 		{
 			cd twr[TL::NBF];
 			twl_fetch<TL::NBF, (I == 1 ? TL::JM1 : TL::JM2)>(twr, ltw, I == 1 ? TL::O1 : TL::O2, lt);
-			pdif<LN, UL, G::E1, true>(buf, n, lt, twr);
+			pdif<LN, UL, G::E1, true, HAF>(buf, n, lt, twr);
 		}
-		else pdif<LN, UL, G::E1, true>(buf, n, lt, st.tw);
+		else pdif<LN, UL, G::E1, true, HAF>(buf, n, lt, st.tw);
 	}
 };
 
@@ -1274,16 +1283,16 @@ R8B_HD void cp_hp_prefetch(const ConvLaunch& L, ConvpState<LN, UL>& st, int lt)
 
 // middle pass, compute part: results (the backward array's positions 16 t + p after the first
 // backward pass) stay in st.vr / st.vi
-template<int LN, int UL, bool CX = false>
+template<int LN, int UL, bool CX = false, bool HAF = false>
 R8B_HD void cp_middle_compute(const cd* buf, ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
 	double zr[G::E1], zi[G::E1];
-	const SwBase bbf = sw_base(buf, fslot<LN, UL>(G::E1 * lt));
+	const SwBase bbf = sw_base(buf, fslot<LN, UL, HAF>(G::E1 * lt));
 #pragma unroll
 	for (int c = 0; c < G::E1; c++)
 	{
-		const cd v = sw_ld(bbf, fmap_c<LN, UL>(c));
+		const cd v = sw_ld(bbf, fmap_c<LN, UL, HAF>(c));
 		zr[c] = v.re;
 		zi[c] = v.im;
 	}
@@ -1447,6 +1456,101 @@ R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 			}
 		}
 	}
+}
+
+// ---- half-array form (round 6; MODE 21 = mode 0 of the 2048 -> 4096-point 2x up-sampling geometry; engine option "half") ----
+// Why.  The convolver-only kernel k_convp<11, 1, 0, 24> needs 115 registers -- four waves per SIMD -- but its 64 KB array
+// lets only two workgroups share a CU; with the array truncated so that four fit (wrong results, same instruction stream)
+// it measured 20 % faster (profiles/r06_experiments.txt item 2), and the eight-elements-per-thread form that gets the four
+// waves pays for them with three more passes through LDS (item 3).  This form gets them WITHOUT another pass: the
+// array is N2 DOUBLES (32 KB), not N2 complex values.
+//   * The forward transform has N = N2 / 2 complex points: it fits as it is (identity slot map, fslot<.., HAF>).
+//   * The two exchanges of the backward side -- middle pass -> radix-16 pass of sub-length 256 (inside 16 lanes of a
+//     wave), that pass -> last pass (across the workgroup) -- move the REAL parts of the 4096 elements through the
+//     array, then the IMAGINARY parts: the same bytes through LDS in twice as many 8-byte accesses (the LDS serves
+//     ds_read_b64 / ds_write_b64 at the rate of the 16-byte forms), the butterflies between them unchanged.
+// The exchange inside a wave costs nothing but program order (LDS serves a wave's accesses in issue order); the one
+// across the workgroup takes three barriers instead of one (real parts written | read | imaginary parts written | read).
+// Arithmetic, constants and their order are those of mode 0: results are BITWISE those of k_convp<11, 1, 0, 24>.
+// Slots: element e of the array of doubles at 8-byte slot dswz(e) = e ^ (bits 4-7 into bits 0-3) ^ (bit 8 into bit 4) --
+// every access pattern below meets 16 different slots mod 16 in each 16 consecutive lanes (ds_write_b64) and 32
+// different slots mod 32 in each 32 (ds_read_b64); linear over XOR like pswz(): one address per thread and pass, XOR
+// constants in address bits 3-7 plus the instruction's immediate offset.
+constexpr bool convp_mode_ha(int m) { return m == 21; }
+template<int LN, int UL> constexpr bool convp_ha_ok()
+{
+	typedef ConvpGeom<LN, UL> G;
+	return UL == 1 && G::SUB == 1 && !G::POST && G::B1 && G::R2 == 16 && G::NPRE == 3 && ConvpTwLds<LN, UL>::ON;
+}
+template<int LN, int UL> constexpr int convp_ha_array_bytes() { return ConvpGeom<LN, UL>::N2 * 8; }
+template<int LN, int UL> constexpr int convp_ha_lds_bytes()
+{
+	return convp_ha_array_bytes<LN, UL>() + kConvpFlagBytes + ConvpTwLds<LN, UL>::NE * 16;
+}
+R8B_HD constexpr int dswz(int e) { return e ^ ((e >> 4) & 15) ^ (((e >> 8) & 1) << 4); }
+R8B_HD constexpr int dsw_xc(int m) { return dswz(m) & 31; }
+R8B_HD constexpr int dsw_hi(int m) { return m & ~31; }
+#if defined(R8B_LDS_ABS) && defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) double lds_d_t;
+R8B_HD SwBase dw_base(const cd* buf, int slot0)
+{
+	SwBase b;
+	b.a = (unsigned) (size_t) (const lds_cd_t*) buf + ((unsigned) slot0 << 3);
+	return b;
+}
+R8B_HD double dw_ld(SwBase b, int m)
+{
+	return *(const lds_d_t*) (size_t) ((b.a ^ (unsigned) (dsw_xc(m) << 3)) + (unsigned) (dsw_hi(m) << 3));
+}
+R8B_HD void dw_st(SwBase b, int m, double v)
+{
+	*(lds_d_t*) (size_t) ((b.a ^ (unsigned) (dsw_xc(m) << 3)) + (unsigned) (dsw_hi(m) << 3)) = v;
+}
+#else
+R8B_HD SwBase dw_base(const cd* buf, int slot0)
+{
+	SwBase b;
+	b.p = reinterpret_cast<char*>(const_cast<cd*>(buf));
+	b.bb = slot0 << 3;
+	return b;
+}
+R8B_HD double dw_ld(SwBase b, int m)
+{
+	return *reinterpret_cast<const double*>(b.p + ((b.bb ^ (dsw_xc(m) << 3)) + (dsw_hi(m) << 3)));
+}
+R8B_HD void dw_st(SwBase b, int m, double v)
+{
+	*reinterpret_cast<double*>(b.p + ((b.bb ^ (dsw_xc(m) << 3)) + (dsw_hi(m) << 3))) = v;
+}
+#endif
+// one part (real or imaginary) of the middle pass's results: the thread's backward positions 16 lt + p
+R8B_HD void cp_ha_st_mid(cd* buf, const double* v, int lt)
+{
+	const SwBase bb = dw_base(buf, dswz(16 * lt));
+#pragma unroll
+	for (int p = 0; p < 16; p++) dw_st(bb, p, v[p]);
+}
+// ... of the radix-16 pass of sub-length 256: elements e0 + 16 p, e0 = (lt / 16) 256 + lt mod 16 (read, and written back)
+R8B_HD void cp_ha_ld_b1(const cd* buf, double* v, int lt)
+{
+	const SwBase bb = dw_base(buf, dswz((lt >> 4) * 256 + (lt & 15)));
+#pragma unroll
+	for (int p = 0; p < 16; p++) v[p] = dw_ld(bb, 16 * p);
+}
+R8B_HD void cp_ha_st_b1(cd* buf, const double* v, int lt)
+{
+	const SwBase bb = dw_base(buf, dswz((lt >> 4) * 256 + (lt & 15)));
+#pragma unroll
+	for (int p = 0; p < 16; p++) dw_st(bb, 16 * p, v[p]);
+}
+// ... of the last pass: elements lt + NT i
+template<int NT>
+R8B_HD void cp_ha_ld_b2(const cd* buf, double* v, int lt)
+{
+	static_assert(NT == 256, "half-array form: 4096-point backward transforms");
+	const SwBase bb = dw_base(buf, dswz(lt));
+#pragma unroll
+	for (int i = 0; i < 16; i++) v[i] = dw_ld(bb, NT * i);
 }
 
 // ---- split 2x up-sampling form (modes 8 / 9, 12 / 13 with a complex spectrum; geometry <13, 0>: 8192 -> 16384-point blocks)
@@ -2797,9 +2901,12 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 
 	constexpr int BM = MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 14 ? 0 :
 		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : (MODE == 16 ? 4 : (MODE == 17 ? 5 :
-		(MODE == 18 ? 1 : (MODE == 19 || MODE == 20 ? 0 : MODE)))));
+		(MODE == 18 ? 1 : (MODE == 19 || MODE == 20 || MODE == 21 ? 0 : MODE)))));
 	// mode 20: mode 0 of the decimating form behind a half-band decimator taken in the load (cp_hbf_*)
 	constexpr bool HBF = MODE == 20;
+	// mode 21: mode 0 in the half-array form (cp_ha_*: the backward side's exchanges by parts through an array of doubles)
+	constexpr bool HA = convp_mode_ha(MODE);
+	static_assert(!HA || convp_ha_ok<LN, UL>(), "half-array form: the 2048 -> 4096-point 2x up-sampling geometry");
 	// mode 19: polyphase 3x form (cp_p3_*): a convolver-only mode with its own load, middle and store
 	constexpr bool P3 = convp_mode_p3(MODE);
 	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
@@ -2826,7 +2933,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	auto buf_of = [&](int tid) { return buf + sub_of(tid) * G::NA; };
 	// (the workgroup's twiddle table in LDS, behind the array and the flag words: ConvpTwLds)
 	typedef ConvpTwLds<LN, UL> TL;
-	cd* const ltw = reinterpret_cast<cd*>(reinterpret_cast<unsigned char*>(buf) + convp_array_bytes<LN, UL>() + kConvpFlagBytes);
+	constexpr int ABYTES = HA ? convp_ha_array_bytes<LN, UL>() : convp_array_bytes<LN, UL>();
+	cd* const ltw = reinterpret_cast<cd*>(reinterpret_cast<unsigned char*>(buf) + ABYTES + kConvpFlagBytes);
 	auto k_of = [&](int tid)
 	{
 		if constexpr (G::SUB == 1) return cur.k;
@@ -2846,7 +2954,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	// polyphase 3x form (three backward transforms per block, spills), requested AND stored in the last phase: twelve
 	// registers less held across the block for a load whose wait ends the workgroup (modes 8 / 9: 92 -> 0 bytes of scratch
 	// per lane, 12 / 13: 76 -> 32, 14 / 15: 28 -> 0)
-	constexpr bool LATE = G::WT > 256 || P3;
+	// (... and in the half-array form, whose budget is 128 registers)
+	constexpr bool LATE = G::WT > 256 || P3 || HA;
 	auto slices_out = [&](int tid, St& st)
 	{
 		if constexpr (LATE)
@@ -2959,7 +3068,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			ex.post_shift(tid, sub_of(tid), lt, lsh);
 			cp_scale_in<LN, UL>(st, lsh);
 		}
-		cp_first<LN, UL>(L, buf_of(tid), st, lt);
+		cp_first<LN, UL, HA>(L, buf_of(tid), st, lt);
 		if constexpr (TL::ON && !WALK)
 		{
 			if (tid < TL::NE) twl_st(ltw, tid, twl_v);
@@ -3015,14 +3124,14 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	auto s_pre1 = [&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
-		ConvpPre<LN, UL, 1>::run(buf_of(tid), st, lt, ltw);
+		ConvpPre<LN, UL, 1>::template run<HA>(buf_of(tid), st, lt, ltw);
 		if constexpr (G::NPRE > 2) ConvpPre<LN, UL, 2>::prefetch(L, st, lt);
 		else hp_prefetch(st, lt);
 	};
 	auto s_pre2 = [&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
-		ConvpPre<LN, UL, 2>::run(buf_of(tid), st, lt, ltw);
+		ConvpPre<LN, UL, 2>::template run<HA>(buf_of(tid), st, lt, ltw);
 		hp_prefetch(st, lt);
 	};
 	// (two steps: every lane has read its forward data before any lane's backward data overwrites it --
@@ -3135,7 +3244,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	auto s_midc = [&](int tid, St& st)
 	{
 		const int lt = lt_of(tid);
-		cp_middle_compute<LN, UL, CX>(buf_of(tid), st, lt);
+		cp_middle_compute<LN, UL, CX, HA>(buf_of(tid), st, lt);
 		if constexpr (G::B1 && TL::ON) {} // (the pass fetches its twiddles from LDS itself)
 		else if constexpr (G::B1) ptw_fetch<16, G::NT, (16 < G::NT ? 16 : G::NT)>(st.tw, L.ptw, 3, lt);
 		else cp_back2_prefetch<LN, UL>(L, st, lt);
@@ -3277,6 +3386,30 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		});
 	}
 	else
+	if constexpr (HA)
+	{
+		// half-array form: the two exchanges of the backward side by parts -- real parts, then imaginary parts -- through
+		// the array of doubles.  The first stays inside sixteen lanes of a wave: program order (and the steps' ordering
+		// points) is all it needs; the second crosses the workgroup: written | barrier | read | barrier | written |
+		// barrier | read (the last read opens the body's last phase, below).
+		auto h_a1 = [&](int tid, St& st) { cp_ha_st_mid(buf_of(tid), st.vr, lt_of(tid)); };
+		auto h_a2 = [&](int tid, St& st) { cp_ha_ld_b1(buf_of(tid), st.er, lt_of(tid)); };
+		auto h_a3 = [&](int tid, St& st) { cp_ha_st_mid(buf_of(tid), st.vi, lt_of(tid)); };
+		auto h_a4 = [&](int tid, St& st)
+		{
+			const int lt = lt_of(tid);
+			cd twl[6];
+			twl_fetch<6, TL::JM3>(twl, ltw, TL::O3, lt);
+			cp_ha_ld_b1(buf_of(tid), st.vi, lt);
+			pdit_arith<16, true>(twl, st.er, st.vi);
+			cp_ha_st_b1(buf_of(tid), st.er, lt);
+			cp_back2_prefetch<LN, UL>(L, st, lt);
+		};
+		ex.wave_steps(s_pre1, s_pre2, s_midc, h_a1, h_a2, h_a3, h_a4);
+		ex.phase([&](int tid, St& st) { cp_ha_ld_b2<G::NT>(buf_of(tid), st.vr, lt_of(tid)); });
+		ex.phase([&](int tid, St& st) { cp_ha_st_b1(buf_of(tid), st.vi, lt_of(tid)); });
+	}
+	else
 	if constexpr (G::NPRE == 3) ex.wave_steps(s_pre1, s_pre2, s_midc, s_midw, s_b1);
 	else if constexpr (G::NPRE == 2 && G::B1) ex.wave_steps(s_pre1, s_midc, s_midw, s_b1);
 	else if constexpr (G::NPRE == 2) ex.wave_steps(s_pre1, s_midc, s_midw);
@@ -3415,6 +3548,14 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		{
 			const int lt = lt_of(tid);
 			slices_out(tid, st);
+			if constexpr (HA)
+			{
+				// (the imaginary parts of the last pass's elements; the real parts wait in st.vr)
+				cp_ha_ld_b2<G::NT>(buf_of(tid), st.vi, lt);
+				tw_expand<16>(st.tw);
+				pdit_arith<16, true>(st.tw, st.vr, st.vi);
+			}
+			else
 			cp_back2<LN, UL>(buf_of(tid), st, lt);
 			cp_scale_out<16>(st.vr, st.vi, level_shift(tid));
 			cp_silence<LN, UL>(st, ex.collect_bits());

@@ -834,6 +834,15 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// eight elements per thread (r8b_convq.h): the 2048 -> 4096-point convolver-only block pair on 512 threads (four waves
 	// per SIMD instead of two); same blocks, same state, results differ from the 256-thread form by rounding
 	opt_["quad"] = 0;
+	// half-array form of that block pair (r8b_convp.h cp_ha_*, kernel mode 21): the backward side's two exchanges move the
+	// real parts, then the imaginary parts through an array of DOUBLES -- 32 KB, four workgroups per CU, no pass added.
+	// Measured on MI355X (profiles/r06_experiments.txt item 12): 44100 -> 88200 at 1024 channels 0.1429 -> 0.1277 ms per
+	// call (kernel 0.138 -> 0.118), at 256 channels -9 %, at 4096 -13 %; launches that do not fill the chip twice gain
+	// nothing (64 channels: +0.5 %).  1: objects of at least 128 channels (decided per OBJECT, never per call: the two
+	// forms do the same arithmetic on the same values -- bitwise equal under host emulation -- but the device compiler
+	// contracts multiply-adds differently in the two kernels, so on the GPU they agree to rounding, 4e-17 RMS, and an
+	// object must stay with one of them to remain bitwise chunk invariant); 2: every object; 0: the 64 KB form
+	opt_["half"] = 1;
 	// a half-band decimator in front of a 4096 -> 2048-point decimating convolver taken in the convolver's load (kernel mode
 	// 20: one launch, the decimator's stream never leaves LDS).  Off: measured on MI355X the fused launch takes 92.6 us
 	// + a 19 us history copy against 52.5 + 42.6 us for the two launches (176400 -> 44100, 1024 ch x 16384) -- a block
@@ -1773,6 +1782,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
 		X.walk = 0;
 		X.quad = opt_.at("quad") != 0 ? 1 : 0;
+		X.half = opt_.at("half") == 2 || (opt_.at("half") == 1 && nch_ >= 128) ? 1 : 0;
 		X.park_src = nullptr; X.park_dst = nullptr;
 		X.park_blk = SpanInfo();
 		long long ca = a; // the first output this call has to compute

@@ -658,8 +658,9 @@ struct GpuExecP
 	int tid_ = (int) threadIdx.x;
 	unsigned* flags_; // one word per wave behind the array (r8b_convp.h kConvpFlagBytes)
 	unsigned* lv_;    // ... and the blocks' level words behind them (kConvpLevelWords)
-	__device__ __forceinline__ explicit GpuExecP(unsigned char* smem)
-		: flags_(reinterpret_cast<unsigned*>(smem + convp_array_bytes<LN, UL>())), lv_(flags_ + 16) {}
+	// (abytes: the array's size -- the half-array form's is another, r8b_convp.h convp_ha_array_bytes)
+	__device__ __forceinline__ explicit GpuExecP(unsigned char* smem, int abytes = convp_array_bytes<LN, UL>())
+		: flags_(reinterpret_cast<unsigned*>(smem + abytes)), lv_(flags_ + 16) {}
 	// workgroup-wide OR of a small bit set: every thread posts before a barrier, anybody collects after it
 	__device__ __forceinline__ void post_bits(int, unsigned v)
 	{
@@ -837,11 +838,14 @@ __device__ __forceinline__ void convp_pin(ConvxLaunch& H, const ConvxLaunch& X)
 }
 
 // 64 KB of LDS per workgroup: two workgroups per CU, i.e. two waves per SIMD and 256 registers each
+#ifndef R8B_DEV_MINBLK
+#define R8B_DEV_MINBLK 2 // (development builds: the register budget of the 256-thread kernels cut for more workgroups per CU)
+#endif
 #ifndef R8B_SPLIT_MINBLOCKS
 #define R8B_SPLIT_MINBLOCKS 3 // (R8B_SPLIT_UP2 development builds: workgroups per CU the register budget is cut for)
 #endif
 template<int LN, int UL, int MODE, int FLENP>
-__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLIT_MINBLOCKS : (ConvpGeom<LN, UL>::WT) > 256 ? 1 : 2)) void k_convp(const ConvxLaunch X)
+__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (convp_mode_ha(MODE) ? 4 : kSplit<LN, UL> ? R8B_SPLIT_MINBLOCKS : (ConvpGeom<LN, UL>::WT) > 256 ? 1 : R8B_DEV_MINBLK)) void k_convp(const ConvxLaunch X)
 {
 	extern __shared__ __align__(256) unsigned char smem_[];
 	// (development builds, the control of the occupancy experiment with a truncated array -- R8B_FAKE_LDS --: the array
@@ -883,7 +887,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (kSplit<LN, UL> ? R8B_SPLI
 		bg = (unsigned) __builtin_amdgcn_readfirstlane((int) bg);
 		pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
 	};
-	GpuExecP<LN, UL> ex(smem);
+	GpuExecP<LN, UL> ex(smem, convp_mode_ha(MODE) ? convp_ha_array_bytes<LN, UL>() : convp_array_bytes<LN, UL>());
 	// Kernel arguments live in memory: left to itself the compiler fetches each one where it is first needed --
 	// chains of dependent scalar loads at the start of the workgroup (measured: 3 300 cycles before the first sample
 	// load is issued) and one more load in front of most phases, whose wait is a wait on the LDS counter too, i.e. a
@@ -1110,6 +1114,8 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	convp_prepare<LN, UL>(X, MODE != 1 && MODE != 18, convp_mode_sp(MODE), convp_mode_solo(MODE), convp_mode_p3(MODE));
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
+	// (mode 21: the half-array form -- four workgroups per CU)
+	if constexpr (convp_mode_ha(MODE)) lds = (size_t) convp_ha_lds_bytes<LN, UL>();
 	// (mode 20: the half-band front stages its raw samples over the array and what lies behind it)
 	if constexpr (MODE == 20) lds = lds > (size_t) kHbfLdsBytes ? lds : (size_t) kHbfLdsBytes;
 #ifdef R8B_DEV_ONLY_MODE
@@ -1138,6 +1144,15 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 			static const std::string wsym = symbol4("k_convp_walk", LN, UL, MODE, FLENP);
 			launch_symbol_note(wsym.c_str());
 			launch_walk_blocks_add((long long) nwi);
+			return;
+		}
+	}
+	if constexpr (LN == 11 && UL == 1 && MODE == 0)
+	{
+		// half-array form (r8b_convp.h cp_ha_*, kernel mode 21): the same block pair in 32 KB of LDS, four workgroups per CU
+		if (X.half != 0 && X.quad == 0)
+		{
+			launch_convp_t<LN, UL, 21, FLENP>(X0, stream);
 			return;
 		}
 	}

@@ -323,6 +323,9 @@ struct ConvxLaunch
 	// eight elements per thread (r8b_convq.h: the 2048 -> 4096-point block pair on 512 threads, four waves per SIMD);
 	// the engine sets it where that form exists (option "quad") and the launcher takes it
 	int quad = 0;
+	// half-array form of the same block pair (r8b_convp.h cp_ha_*, kernel mode 21: the backward side's exchanges by parts
+	// through 32 KB of LDS, four workgroups per CU); engine option "half", taken by the launcher where the form exists
+	int half = 0;
 	long long park_j0, park_stride;
 	const double* park_src;
 	double* park_dst;

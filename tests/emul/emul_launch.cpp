@@ -391,11 +391,26 @@ void emul_convp_t(const ConvxLaunch& X0)
 			emul_convq(X0);
 			return;
 		}
+		// half-array form (r8b_convp.h cp_ha_*, kernel mode 21)
+		if (X0.half != 0)
+		{
+			emul_convp_t<LN, UL, 21, FLENP>(X0);
+			return;
+		}
+	}
+	{
+		// (the kernel instance a GPU launch would have started, as rocprofv3 names it: Engine::stage symbol)
+		static const std::string sym = "k_convp<" + std::to_string(LN) + ", " + std::to_string(UL) + ", " + std::to_string(MODE) +
+			", " + std::to_string(FLENP) + ">";
+		launch_symbol_note(sym.c_str());
 	}
 	ConvxLaunch X = X0;
 	constexpr bool SOLO = convp_mode_solo(MODE);
 	convp_prepare<LN, UL>(X, MODE != 1 && MODE != 18, convp_mode_sp(MODE), SOLO, convp_mode_p3(MODE));
-	std::vector<double> lds((size_t) std::max(convp_lds_bytes<LN, UL>(), MODE == 20 ? kHbfLdsBytes : 0) / sizeof(double) + 2);
+	// (the half-array form gets ITS allocation: an access beyond it is an error the poisoned vector does not hide)
+	int lds_bytes = std::max(convp_lds_bytes<LN, UL>(), MODE == 20 ? kHbfLdsBytes : 0);
+	if constexpr (convp_mode_ha(MODE)) lds_bytes = convp_ha_lds_bytes<LN, UL>();
+	std::vector<double> lds((size_t) lds_bytes / sizeof(double) + 2);
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;
 	constexpr int SUB = ConvpGeom<LN, UL>::SUB;

@@ -1246,6 +1246,84 @@ def run_quad_case(lib_kw, case, nch=5):
     assert np.sqrt((do * do).mean()) <= RMS_TOL and np.abs(do).max() <= PEAK_TOL
 
 
+# ---- half-array form (r8b_convp.h cp_ha_*, kernel mode 21, engine option "half"; round 6) ----------------------------------
+def _dswz(e):
+    return e ^ ((e >> 4) & 15) ^ (((e >> 8) & 1) << 4)
+
+
+def test_half_array_swizzle_is_conflict_free():
+    """r8b_convp.h dswz(): every access pattern of the half-array form's two exchanges (8-byte accesses to an array of 4096
+    doubles) meets 16 different slots mod 16 in each 16 consecutive lanes (ds_write_b64: 4 x 16 lanes, 32 banks of 4 bytes)
+    and 32 different slots mod 32 in each 32 (ds_read_b64: 2 x 32 lanes, 64 banks); the map is a permutation"""
+    def check(name, elems_of_lane, group):
+        for g0 in range(0, 256, group):
+            per_access = list(zip(*[elems_of_lane(b) for b in range(g0, g0 + group)]))
+            for acc in per_access:
+                assert len({_dswz(e) & (group - 1) for e in acc}) == group, (name, g0, acc)
+
+    mid = lambda lt: [16 * lt + p for p in range(16)]
+    b1 = lambda lt: [(lt >> 4) * 256 + (lt & 15) + 16 * p for p in range(16)]
+    b2 = lambda lt: [lt + 256 * i for i in range(16)]
+    check("middle write", mid, 16)
+    check("sub-length 256 read", b1, 32)
+    check("sub-length 256 write", b1, 16)
+    check("last pass read", b2, 32)
+    assert sorted(_dswz(e) for e in range(4096)) == list(range(4096))
+    # linear over XOR: slot(e0 | d) = (slot(e0) ^ (dswz(d) & 31)) + (d & ~31) for offsets d that share no bit with e0
+    for e0, ds in ((16 * 37, range(16)), ((5 << 8) + 9, [16 * p for p in range(16)]), (201, [256 * i for i in range(16)])):
+        for d in ds:
+            assert e0 & d == 0 and _dswz(e0 | d) == (_dswz(e0) ^ (_dswz(d) & 31)) + (d & ~31)
+
+
+def run_half_case(lib_kw, case, nch=5, bitwise=True):
+    """the half-array form of the 2048 -> 4096-point convolver-only block pair against the 64 KB form: the same arithmetic
+    on the same values -- BITWISE equal under host emulation (no contraction), to rounding on the GPU (the device
+    compiler contracts multiply-adds differently in the two kernels) -- over ragged calls, odd channel counts, history
+    tail and parked outputs; option values 0 / 2 = never / always (1 = objects of 128 channels and more)"""
+    src, dst, maxin, tb, att, opts = case
+    x = make_input(nch, 5 * maxin, 43)
+    lens = [maxin, maxin, maxin // 5, 17, 1, maxin - 1, maxin // 2]
+    outs = []
+    for h in (0, 1):
+        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, **lib_kw)
+        for k, v in opts.items():
+            b.set_option(k, v)
+        b.set_option("half", 2 * h)
+        ys, pos = [], 0
+        for l in lens:
+            ys.append(b.process_host(x[:, pos:pos + l]))
+            pos += l
+        outs.append(ys)
+    assert [y.shape for y in outs[0]] == [y.shape for y in outs[1]]
+    y0, y1 = np.concatenate(outs[0], axis=1), np.concatenate(outs[1], axis=1)
+    assert y1.shape[1] > 1000 and np.isfinite(y1).all()
+    if bitwise:
+        assert np.array_equal(y0, y1)
+    else:
+        d = y0 - y1
+        assert np.sqrt((d * d).mean()) <= 2e-16 and np.abs(d).max() <= 4e-15
+    # (the form really ran: the stage's last launch by its device symbol)
+    b.set_option("timing", 1)
+    b.process_host(x[:, :maxin])
+    assert "k_convp<11, 1, 21, 24>" in b.stage_symbols(), b.stage_symbols()
+    return y1
+
+
+@pytest.mark.parametrize("case", QUAD_CASES)
+def test_emulated_half_array_form_is_bitwise_the_full_one(emul, case):
+    run_half_case({"lib": emul}, case)
+
+
+def test_emulated_half_array_levels_and_silence(emul):
+    """... with partners of very different level and silent channels (cases.check_pair_scales)"""
+    case = PAIR_SCALE_CASES[2]   # 44100 -> 88200, convolver alone
+    src, dst, maxin, chunk, n, tb, att = case
+    b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=9, lib=emul)
+    b.set_option("half", 2)
+    rel_rms, rel_pk = check_pair_scales(b, case)
+    assert rel_rms <= RMS_TOL and rel_pk <= PEAK_TOL
+
+
 @pytest.mark.parametrize("case", QUAD_CASES)
 def test_emulated_eight_elements_per_thread_form(emul, case):
     run_quad_case({"lib": emul}, case)

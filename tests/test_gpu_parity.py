@@ -491,6 +491,40 @@ def test_hip_eight_elements_per_thread_form(torch, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", [0, 1, 2, 3, 4])
+def test_hip_half_array_form_against_the_full_one(torch, case):
+    """r8b_convp.h cp_ha_* (kernel mode 21, engine option "half": the 2048 -> 4096-point convolver-only block pair with the
+    backward side's exchanges by parts through 32 KB of LDS, four workgroups per CU) against the 64 KB form: the same
+    arithmetic, equal to rounding on the device (bit for bit under emulation: tests/test_emul.py), ragged calls"""
+    from test_emul import QUAD_CASES, run_half_case
+    y = run_half_case({"device": 0}, QUAD_CASES[case], nch=37, bitwise=False)
+    assert y.shape[0] == 37
+
+
+@pytest.mark.gpu
+def test_hip_half_array_form_is_chunk_invariant_and_the_default_of_large_objects(torch):
+    """an object of 128 channels and more runs the half-array form by default (option half = 1), and stays bitwise
+    independent of how the stream is cut into calls"""
+    nch, n = 130, 16000
+    x = make_input(nch, n, 5)
+    outs = []
+    for lens in ([n], [7000, 1, 4000, 99, 4900]):
+        b = r8b.BatchResampler(44100.0, 88200.0, 16384, 2.0, 180.15, nch=nch, device=0)
+        b.set_option("timing", 1)
+        ys, pos = [], 0
+        for l in lens:
+            ys.append(b.process_host(x[:, pos:pos + l]))
+            pos += l
+        assert b.stage_symbols() == ["k_convp<11, 1, 21, 24>"], b.stage_symbols()
+        outs.append(np.concatenate(ys, axis=1))
+    assert np.array_equal(outs[0], outs[1])
+    s = r8b.BatchResampler(44100.0, 88200.0, 16384, 2.0, 180.15, nch=8, device=0)
+    s.set_option("timing", 1)
+    s.process_host(x[:8, :16384])
+    assert s.stage_symbols() == ["k_convp<11, 1, 0, 24>"], s.stage_symbols()
+
+
+@pytest.mark.gpu
 def test_bench_contract(tmp_path):
     """bench.py prints ONE JSON line carrying the driver's contract fields plus `roofline` (live
     HIP-event timing of the dominant kernel) -- a short run of the real script."""
