@@ -53,6 +53,15 @@
 #ifndef R8B_OPAQUE2
 #define R8B_OPAQUE2(a, b)
 #endif
+// R8B_MEM_FENCE: no memory access moves across this point (device: an empty asm statement with a memory clobber -- the
+// scheduling fence alone does not keep the LDS reads of a window's later chunks from being hoisted to the loop's top)
+#ifndef R8B_MEM_FENCE
+#if defined(__HIP_DEVICE_COMPILE__)
+#define R8B_MEM_FENCE() asm volatile("" ::: "memory")
+#else
+#define R8B_MEM_FENCE()
+#endif
+#endif
 #ifndef R8B_OUT_STORE16
 #define R8B_OUT_STORE16(ptr, v) { *reinterpret_cast<cd*>(ptr) = (v); }
 #endif
@@ -1476,16 +1485,40 @@ R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 // every access pattern below meets 16 different slots mod 16 in each 16 consecutive lanes (ds_write_b64) and 32
 // different slots mod 32 in each 32 (ds_read_b64); linear over XOR like pswz(): one address per thread and pass, XOR
 // constants in address bits 3-7 plus the instruction's immediate offset.
-constexpr bool convp_mode_ha(int m) { return m == 21; }
+// (MODE 23 = mode 4 -- the whole-step interpolator fused in, two phases per thread -- in this form: the array is what
+// the interpolator's run of (A, B) pairs needs, kHaFusedElems complex values instead of 4096 -- three workgroups per
+// CU --, its first 32 KB carry the transforms as in mode 21; launch bound 256 x 3 = 168 registers: the rows of the
+// thread's phase pair are fetched when the last pass's results have gone to the run, not beside its butterflies)
+// (MODE 25: mode 5 -- adjacent windows up to three samples apart, In > Out -- likewise)
+constexpr bool convp_mode_ha(int m) { return m == 21 || m == 23 || m == 25; }
+constexpr bool convp_mode_ha_fused(int m) { return m == 23 || m == 25; }
+// (what leaves the workgroup at 52 KB with the flag words and the twiddle table: three of 53.1 KB -- 163 008 of a CU's
+// 163 840 bytes -- were NOT resident together on MI355X, the allocation is rounded up; BASELINE's cfg2 needs 3051)
+static const int kHaFusedElems = 3052;
+constexpr int convp_ha_minblocks(int m) { return convp_mode_ha_fused(m) ? 3 : 4; }
 template<int LN, int UL> constexpr bool convp_ha_ok()
 {
 	typedef ConvpGeom<LN, UL> G;
 	return UL == 1 && G::SUB == 1 && !G::POST && G::B1 && G::R2 == 16 && G::NPRE == 3 && ConvpTwLds<LN, UL>::ON;
 }
-template<int LN, int UL> constexpr int convp_ha_array_bytes() { return ConvpGeom<LN, UL>::N2 * 8; }
-template<int LN, int UL> constexpr int convp_ha_lds_bytes()
+template<int LN, int UL, int MODE = 21> constexpr int convp_ha_array_bytes()
 {
-	return convp_ha_array_bytes<LN, UL>() + kConvpFlagBytes + ConvpTwLds<LN, UL>::NE * 16;
+	return convp_mode_ha_fused(MODE) ? kHaFusedElems * 16 : ConvpGeom<LN, UL>::N2 * 8;
+}
+template<int LN, int UL, int MODE = 21> constexpr int convp_ha_lds_bytes()
+{
+	return convp_ha_array_bytes<LN, UL, MODE>() + kConvpFlagBytes + ConvpTwLds<LN, UL>::NE * 16;
+}
+// the array of kernel mode MODE (what lies behind it -- flag words, twiddle table -- starts there)
+template<int LN, int UL, int MODE> constexpr int convp_mode_array_bytes()
+{
+	return convp_mode_ha(MODE) ? convp_ha_array_bytes<LN, UL, MODE>() : convp_array_bytes<LN, UL>();
+}
+// does the interpolator's run of a fused launch fit the half-array form's array?  (host: the launcher's choice)
+// (the windows of a block's last, partly masked output group reach in_step + 48 slots past the run: Engine::use_pair_two)
+inline bool convp_ha_fused_fits(int run_off, int in_len, int in_step)
+{
+	return run_off + in_len + in_step + 32 + 16 <= kHaFusedElems;
 }
 R8B_HD constexpr int dswz(int e) { return e ^ ((e >> 4) & 15) ^ (((e >> 8) & 1) << 4); }
 R8B_HD constexpr int dsw_xc(int m) { return dswz(m) & 31; }
@@ -1498,9 +1531,11 @@ R8B_HD SwBase dw_base(const cd* buf, int slot0)
 	b.a = (unsigned) (size_t) (const lds_cd_t*) buf + ((unsigned) slot0 << 3);
 	return b;
 }
+// (volatile: every read ONE ds_read_b64 -- 256 B per clock and CU; left alone the compiler pairs the reads of a pass into
+// ds_read2_b64 / ds_read2st64_b64, which move half as many bytes per LDS cycle: MI355X_MICROARCH.md, LDS table)
 R8B_HD double dw_ld(SwBase b, int m)
 {
-	return *(const lds_d_t*) (size_t) ((b.a ^ (unsigned) (dsw_xc(m) << 3)) + (unsigned) (dsw_hi(m) << 3));
+	return *(const volatile lds_d_t*) (size_t) ((b.a ^ (unsigned) (dsw_xc(m) << 3)) + (unsigned) (dsw_hi(m) << 3));
 }
 R8B_HD void dw_st(SwBase b, int m, double v)
 {
@@ -2134,7 +2169,8 @@ R8B_HD void cp_solo_store_down(const ConvLaunch& L, const ConvpState<LN, UL>& st
 }
 
 // MODE 1: the block's valid outputs as one linear run of (A, B) pairs, y[u] = outputs at time t0 + u
-template<int LN, int UL>
+// (HAF: the half-array form -- the array ends behind the run's zero extension, nothing is stored past in_len)
+template<int LN, int UL, bool HAF = false>
 R8B_HD void cp_final_store(const ConvLaunch& L, cd* ybase, cd* y, const ConvpState<LN, UL>& st, long long k, int lt)
 {
 	// (ybase: the pair's array; y: the run inside it, ybase + run_off)
@@ -2157,7 +2193,7 @@ R8B_HD void cp_final_store(const ConvLaunch& L, cd* ybase, cd* y, const ConvpSta
 			ybase[i] = z;
 		}
 	}
-	if (nzero == 0 && L.fl2r + (int) (y - ybase) <= G::NT)
+	if (!HAF && nzero == 0 && L.fl2r + (int) (y - ybase) <= G::NT)
 	{
 		// (every block but the first ones of a stream, in the rotated layout of convp_prepare: fl2r = 0 or 1)
 		// The thread's element p is y[lt + fl2r + NT p]: one address register, no index arithmetic, and nothing
@@ -2518,7 +2554,9 @@ R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int pt)
 
 // (wd: where the outputs go -- the launch's X.wdst, or the park buffer for the part of the call's last block that
 // belongs to the next call, ConvxLaunch::park_dst)
-template<int T2, bool ALIGNED_ONLY = false>
+// (NBUF: chunks of the window in flight -- 2: a chunk's reads issued one chunk ahead of its multiply-adds; 1: the
+// half-array form, whose register budget is 168: a chunk's reads, then its multiply-adds, the CU's other workgroups in between)
+template<int T2, bool ALIGNED_ONLY = false, int NBUF = 2, int NBUFG = NBUF>
 R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const SpanInfo& Bm, const cd* y, const double* rows,
 	int pt, int chA, int chB, bool bvalid)
 {
@@ -2557,14 +2595,14 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 		{
 			const cd* w = y + (u_lo + in_step * gl + rq);
 			double a0[2] = { 0.0, 0.0 }, b0[2] = { 0.0, 0.0 }, a1[2] = { 0.0, 0.0 }, b1[2] = { 0.0, 0.0 };
-			cd v[2][CH];
+			cd v[NBUF][CH];
 #pragma unroll
 			for (int i = 0; i < CH; i++) v[0][i] = w[i];
 #pragma unroll
 			for (int c = 0; c < NCH; c++)
 			{
 				R8B_SCHED_FENCE();
-				if (c + 1 < NCH)
+				if (NBUF == 2 && c + 1 < NCH)
 				{
 #pragma unroll
 					for (int i = 0; i < CH; i++) v[(c + 1) & 1][i] = w[CH * (c + 1) + i];
@@ -2575,10 +2613,17 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 				for (int i = CH - 1; i >= 0; i--)
 				{
 					const int t = CH * c + i;
-					a0[t & 1] += rows[t] * v[c & 1][i].re;
-					b0[t & 1] += rows[t] * v[c & 1][i].im;
-					a1[t & 1] += rows[T2 + t] * v[c & 1][i].re;
-					b1[t & 1] += rows[T2 + t] * v[c & 1][i].im;
+					a0[t & 1] += rows[t] * v[c & (NBUF - 1)][i].re;
+					b0[t & 1] += rows[t] * v[c & (NBUF - 1)][i].im;
+					a1[t & 1] += rows[T2 + t] * v[c & (NBUF - 1)][i].re;
+					b1[t & 1] += rows[T2 + t] * v[c & (NBUF - 1)][i].im;
+				}
+				if (NBUF == 1 && c + 1 < NCH)
+				{
+					R8B_SCHED_FENCE();
+					R8B_MEM_FENCE();
+#pragma unroll
+					for (int i = 0; i < CH; i++) v[0][i] = w[CH * (c + 1) + i];
 				}
 			}
 			// (channel B's sums are only stored under a uniform condition: without this the compiler moves their
@@ -2623,14 +2668,14 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 		// the window in chunks of five taps, each chunk's reads issued one chunk ahead of its
 		// multiply-adds (two chunks of 16-byte values are live: the scheduler, left alone, reads all 25
 		// first -- 100 registers the prefetched samples of the next block then have to leave for)
-		cd v[2][CH];
+		cd v[NBUFG][CH];
 #pragma unroll
 		for (int i = 0; i < CH; i++) v[0][i] = w[i];
 #pragma unroll
 		for (int c = 0; c < NCH; c++)
 		{
 			R8B_SCHED_FENCE();
-			if (c + 1 < NCH)
+			if (NBUFG == 2 && c + 1 < NCH)
 			{
 #pragma unroll
 				for (int i = 0; i < CH; i++) v[(c + 1) & 1][i] = w[CH * (c + 1) + i];
@@ -2640,10 +2685,21 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 			for (int i = CH - 1; i >= 0; i--)
 			{
 				const int t = CH * c + i;
-				a0[t & 1] += rows[t] * v[c & 1][i].re;
-				b0[t & 1] += rows[t] * v[c & 1][i].im;
-				a1[t & 1] += rows[T2 + t] * v[c & 1][i].re;
-				b1[t & 1] += rows[T2 + t] * v[c & 1][i].im;
+				a0[t & 1] += rows[t] * v[c & (NBUFG - 1)][i].re;
+				b0[t & 1] += rows[t] * v[c & (NBUFG - 1)][i].im;
+				a1[t & 1] += rows[T2 + t] * v[c & (NBUFG - 1)][i].re;
+				b1[t & 1] += rows[T2 + t] * v[c & (NBUFG - 1)][i].im;
+			}
+			if (NBUFG == 1 && c + 1 < NCH)
+			{
+				// (the sums are only stored under conditions: left alone the compiler moves their multiply-adds behind
+				// those, away from the reads, and keeps the whole window live -- 100 registers)
+				R8B_FORCE4(a0[0], a0[1], a1[0], a1[1]);
+				R8B_FORCE4(b0[0], b0[1], b1[0], b1[1]);
+				R8B_SCHED_FENCE();
+				R8B_MEM_FENCE();
+#pragma unroll
+				for (int i = 0; i < CH; i++) v[0][i] = w[CH * (c + 1) + i];
 			}
 		}
 		const bool v0 = (gl > 0 || f0) && (gl < gmax || l0);
@@ -2901,7 +2957,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 
 	constexpr int BM = MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 14 ? 0 :
 		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : (MODE == 16 ? 4 : (MODE == 17 ? 5 :
-		(MODE == 18 ? 1 : (MODE == 19 || MODE == 20 || MODE == 21 ? 0 : MODE)))));
+		(MODE == 18 ? 1 : (MODE == 19 || MODE == 20 || MODE == 21 ? 0 : (MODE == 23 ? 4 : (MODE == 25 ? 5 : MODE)))))));
 	// mode 20: mode 0 of the decimating form behind a half-band decimator taken in the load (cp_hbf_*)
 	constexpr bool HBF = MODE == 20;
 	// mode 21: mode 0 in the half-array form (cp_ha_*: the backward side's exchanges by parts through an array of doubles)
@@ -2933,7 +2989,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	auto buf_of = [&](int tid) { return buf + sub_of(tid) * G::NA; };
 	// (the workgroup's twiddle table in LDS, behind the array and the flag words: ConvpTwLds)
 	typedef ConvpTwLds<LN, UL> TL;
-	constexpr int ABYTES = HA ? convp_ha_array_bytes<LN, UL>() : convp_array_bytes<LN, UL>();
+	constexpr int ABYTES = convp_mode_array_bytes<LN, UL, MODE>();
 	cd* const ltw = reinterpret_cast<cd*>(reinterpret_cast<unsigned char*>(buf) + ABYTES + kConvpFlagBytes);
 	auto k_of = [&](int tid)
 	{
@@ -3574,15 +3630,25 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		static_assert(UL >= 0, "the decimating form has no fused interpolator");
 		ex.phase([&](int tid, St& st)
 		{
+			if constexpr (HA)
+			{
+				// (the imaginary parts of the last pass's elements; the real parts wait in st.vr)
+				cp_ha_ld_b2<G::NT>(buf_of(tid), st.vi, lt_of(tid));
+				tw_expand<16>(st.tw);
+				pdit_arith<16, true>(st.tw, st.vr, st.vi);
+			}
+			else
 			if constexpr (G::POST) ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt_of(tid));
 			else cp_back2<LN, UL>(buf_of(tid), st, lt_of(tid));
-			if constexpr (!WALK) cp_rows2_fetch<T2>(X, st.rows2, st.pt);
+			if constexpr (!WALK && !HA) cp_rows2_fetch<T2>(X, st.rows2, st.pt);
 		});
 		ex.phase([&](int tid, St& st)
 		{
 			cp_scale_out<16>(st.vr, st.vi, level_shift(tid));
 			cp_silence<LN, UL>(st, ex.collect_bits());
-			cp_final_store<LN, UL>(L, buf_of(tid), buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
+			cp_final_store<LN, UL, HA>(L, buf_of(tid), buf_of(tid) + X.run_off, st, k_of(tid), lt_of(tid));
+			// (half-array form: the rows behind the results, whose registers they take)
+			if constexpr (HA) cp_rows2_fetch<T2>(X, st.rows2, st.pt);
 		});
 		// the interpolator: all 256 threads over the run of one block pair after the other
 		ex.each([&](int tid, St& st)
@@ -3596,8 +3662,12 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				return;
 			}
 			const int nv = G::SUB == 1 ? 1 : cur.nvalid;
+#ifndef R8B_HA_NBUF
+#define R8B_HA_NBUF 1
+#endif
+			constexpr int NBUF = HA ? R8B_HA_NBUF : 2;
 			for (int sb = 0; sb < nv; sb++)
-				cp_whole2_compute<T2>(X, X.wdst, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
+				cp_whole2_compute<T2, false, NBUF, (HA ? 1 : 2)>(X, X.wdst, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
 			if (ex.uniform(st.pf) != 0)
 			{
 				// (the call's last block: its outputs behind the call's range belong to the next call -- parked, not
@@ -3608,7 +3678,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				pd.mask = -1;
 				pd.off = -XM.wb;
 				pd.fmt = kPcmF64;
-				cp_whole2_compute<T2>(X, pd, XM.park_blk, buf + (nv - 1) * G::NA, st.rows2, st.pt, chA, chB, bvalid);
+				cp_whole2_compute<T2, false, NBUF, (HA ? 1 : 2)>(X, pd, XM.park_blk, buf + (nv - 1) * G::NA, st.rows2, st.pt, chA, chB, bvalid);
 			}
 		});
 	}

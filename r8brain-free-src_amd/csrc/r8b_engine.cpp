@@ -843,6 +843,10 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// contracts multiply-adds differently in the two kernels, so on the GPU they agree to rounding, 4e-17 RMS, and an
 	// object must stay with one of them to remain bitwise chunk invariant); 2: every object; 0: the 64 KB form
 	opt_["half"] = 1;
+	// ... and of the fused two-phase block pair 2048 -> 4096 points + whole-step interpolator (kernel mode 23: the array
+	// is the interpolator's run, 49 KB, three workgroups per CU; taken in place of mode 4 and its walk form).  Values as
+	// for "half"
+	opt_["half_fused"] = 0;
 	// a half-band decimator in front of a 4096 -> 2048-point decimating convolver taken in the convolver's load (kernel mode
 	// 20: one launch, the decimator's stream never leaves LDS).  Off: measured on MI355X the fused launch takes 92.6 us
 	// + a 19 us history copy against 52.5 + 42.6 us for the two launches (176400 -> 44100, 1024 ch x 16384) -- a block
@@ -1783,6 +1787,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		X.walk = 0;
 		X.quad = opt_.at("quad") != 0 ? 1 : 0;
 		X.half = opt_.at("half") == 2 || (opt_.at("half") == 1 && nch_ >= 128) ? 1 : 0;
+		X.half_fused = 0;
 		X.park_src = nullptr; X.park_dst = nullptr;
 		X.park_blk = SpanInfo();
 		long long ca = a; // the first output this call has to compute
@@ -2801,6 +2806,8 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	auto block_jhi = [&](long long k) { return ceil_div_nonneg((k * S + off - fl2c + in_len - w.fl2 - D) * Out, In); };
 	X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
 	X.walk = 0;
+	X.quad = 0; X.half = 0;
+	X.half_fused = opt_.at("half_fused") == 2 || (opt_.at("half_fused") == 1 && nch_ >= 128) ? 1 : 0;
 	X.park_src = nullptr; X.park_dst = nullptr;
 	X.park_blk = SpanInfo();
 	// Parked outputs (ConvxLaunch::park_*): the block that holds the call's last output is computed ONCE -- what it

@@ -821,7 +821,7 @@ __device__ __forceinline__ void convp_pin(ConvxLaunch& H, const ConvxLaunch& X)
 		"+s"(H.c.up_pow2), "+s"(H.c.src.cur_stride), "+s"(H.c.src.cur_base), "+s"(H.c.src.cur_fmt), "+s"(H.c.rot),
 		"+s"(H.c.fl2r), "+s"(H.c.tail_flags), "+s"(H.c.tail_bf)
 		: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
-	if constexpr (MODE == 4 || MODE == 5 || MODE == 16 || MODE == 17)
+	if constexpr (MODE == 4 || MODE == 5 || MODE == 16 || MODE == 17 || MODE == 23 || MODE == 25)
 		asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),
 			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt), "+s"(H.park_n), "+s"(H.park_out), "+s"(H.park_slices),
 			"+s"(H.c.t_zero)
@@ -845,7 +845,7 @@ __device__ __forceinline__ void convp_pin(ConvxLaunch& H, const ConvxLaunch& X)
 #define R8B_SPLIT_MINBLOCKS 3 // (R8B_SPLIT_UP2 development builds: workgroups per CU the register budget is cut for)
 #endif
 template<int LN, int UL, int MODE, int FLENP>
-__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (convp_mode_ha(MODE) ? 4 : kSplit<LN, UL> ? R8B_SPLIT_MINBLOCKS : (ConvpGeom<LN, UL>::WT) > 256 ? 1 : R8B_DEV_MINBLK)) void k_convp(const ConvxLaunch X)
+__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (convp_mode_ha(MODE) ? convp_ha_minblocks(MODE) : kSplit<LN, UL> ? R8B_SPLIT_MINBLOCKS : (ConvpGeom<LN, UL>::WT) > 256 ? 1 : R8B_DEV_MINBLK)) void k_convp(const ConvxLaunch X)
 {
 	extern __shared__ __align__(256) unsigned char smem_[];
 	// (development builds, the control of the occupancy experiment with a truncated array -- R8B_FAKE_LDS --: the array
@@ -887,7 +887,7 @@ __global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (convp_mode_ha(MODE) ? 4 :
 		bg = (unsigned) __builtin_amdgcn_readfirstlane((int) bg);
 		pr = (unsigned) __builtin_amdgcn_readfirstlane((int) pr);
 	};
-	GpuExecP<LN, UL> ex(smem, convp_mode_ha(MODE) ? convp_ha_array_bytes<LN, UL>() : convp_array_bytes<LN, UL>());
+	GpuExecP<LN, UL> ex(smem, convp_mode_array_bytes<LN, UL, MODE>());
 	// Kernel arguments live in memory: left to itself the compiler fetches each one where it is first needed --
 	// chains of dependent scalar loads at the start of the workgroup (measured: 3 300 cycles before the first sample
 	// load is issued) and one more load in front of most phases, whose wait is a wait on the LDS counter too, i.e. a
@@ -1115,7 +1115,7 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	auto kern = k_convp<LN, UL, MODE, FLENP>;
 	size_t lds = (size_t) convp_lds_bytes<LN, UL>();
 	// (mode 21: the half-array form -- four workgroups per CU)
-	if constexpr (convp_mode_ha(MODE)) lds = (size_t) convp_ha_lds_bytes<LN, UL>();
+	if constexpr (convp_mode_ha(MODE)) lds = (size_t) convp_ha_lds_bytes<LN, UL, MODE>();
 	// (mode 20: the half-band front stages its raw samples over the array and what lies behind it)
 	if constexpr (MODE == 20) lds = lds > (size_t) kHbfLdsBytes ? lds : (size_t) kHbfLdsBytes;
 #ifdef R8B_DEV_ONLY_MODE
@@ -1125,6 +1125,16 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
 	const unsigned npair = convp_mode_solo(MODE) ? (unsigned) X.c.nch : ((unsigned) X.c.nch + 1u) >> 1;
 	unsigned grid = nbg * npair;
+	if constexpr (LN == 11 && UL == 1 && (MODE == 4 || MODE == 5))
+	{
+		// half-array form with the whole-step interpolator fused in (kernel modes 23 / 25): 49 KB, three workgroups per CU;
+		// in place of mode 4 / 5 and of the walk form
+		if (X.half_fused != 0 && convp_ha_fused_fits(X.run_off, X.c.in_len, X.in_step))
+		{
+			launch_convp_t<LN, UL, MODE == 4 ? 23 : 25, FLENP>(X0, stream);
+			return;
+		}
+	}
 	if constexpr (convp_walk_ok<LN, UL, MODE>())
 	{
 		// (X.walk: the engine allows the walk form, at most that many blocks per workgroup; the launch's interior blocks

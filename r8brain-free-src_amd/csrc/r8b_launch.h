@@ -326,6 +326,9 @@ struct ConvxLaunch
 	// half-array form of the same block pair (r8b_convp.h cp_ha_*, kernel mode 21: the backward side's exchanges by parts
 	// through 32 KB of LDS, four workgroups per CU); engine option "half", taken by the launcher where the form exists
 	int half = 0;
+	// ... and of the fused two-phase block pair (kernel mode 23: the interpolator's run in 49 KB, three workgroups per CU;
+	// taken in place of mode 4 and its walk form); engine option "half_fused"
+	int half_fused = 0;
 	long long park_j0, park_stride;
 	const double* park_src;
 	double* park_dst;

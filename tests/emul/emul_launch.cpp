@@ -384,6 +384,15 @@ void emul_convq(const ConvxLaunch& X0)
 template<int LN, int UL, int MODE, int FLENP>
 void emul_convp_t(const ConvxLaunch& X0)
 {
+	if constexpr (LN == 11 && UL == 1 && (MODE == 4 || MODE == 5))
+	{
+		// half-array form with the interpolator fused in (kernel modes 23 / 25)
+		if (X0.half_fused != 0 && convp_ha_fused_fits(X0.run_off, X0.c.in_len, X0.in_step))
+		{
+			emul_convp_t<LN, UL, MODE == 4 ? 23 : 25, FLENP>(X0);
+			return;
+		}
+	}
 	if constexpr (LN == 11 && UL == 1 && MODE == 0)
 	{
 		if (X0.quad != 0)
@@ -409,7 +418,7 @@ void emul_convp_t(const ConvxLaunch& X0)
 	convp_prepare<LN, UL>(X, MODE != 1 && MODE != 18, convp_mode_sp(MODE), SOLO, convp_mode_p3(MODE));
 	// (the half-array form gets ITS allocation: an access beyond it is an error the poisoned vector does not hide)
 	int lds_bytes = std::max(convp_lds_bytes<LN, UL>(), MODE == 20 ? kHbfLdsBytes : 0);
-	if constexpr (convp_mode_ha(MODE)) lds_bytes = convp_ha_lds_bytes<LN, UL>();
+	if constexpr (convp_mode_ha(MODE)) lds_bytes = convp_ha_lds_bytes<LN, UL, MODE>();
 	std::vector<double> lds((size_t) lds_bytes / sizeof(double) + 2);
 	double* base = lds.data();
 	if (((size_t) base & 15) != 0) base++;

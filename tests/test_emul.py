@@ -1324,6 +1324,55 @@ def test_emulated_half_array_levels_and_silence(emul):
     assert rel_rms <= RMS_TOL and rel_pk <= PEAK_TOL
 
 
+# (the fused two-phase block pair in the half-array form: kernel mode 23, engine option "half_fused")
+HALF_FUSED_CASES = [(44100.0, 96000.0, 16384, 2.0, 180.15, {}), (44100.0, 96000.0, 6000, 2.0, 180.15, {"park": 0}),
+                    (22050.0, 48000.0, 16384, 2.0, 180.15, {}), (44100.0, 96000.0, 5000, 2.0, 180.15, {"fold_tail": 0}),
+                    (44100.0, 96000.0, 16384, 3.0, 150.0, {}),       # another filter: 1024 -> 2048-point blocks, stays on mode 4
+                    (44100.0, 48000.0, 16384, 2.0, 180.15, {})]      # 147 / 160 ... / 80 phases
+
+
+def run_half_fused_case(lib_kw, case, nch=5, bitwise=True, must_run=None):
+    """kernel mode 23 (the 2048 -> 4096-point block pair + whole-step interpolator with the transforms' backward exchanges
+    by parts and the interpolator's run in a 49 KB array) against a workgroup per block of mode 4: the same arithmetic on
+    the same values -- bit for bit under emulation, to rounding on the device --, ragged calls, odd channel counts"""
+    src, dst, maxin, tb, att, opts = case
+
+    def mk(h):
+        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, **lib_kw)
+        for k, v in opts.items():
+            b.set_option(k, v)
+        b.set_option("walk", 0)
+        b.set_option("half_fused", 2 * h)
+        b.set_option("timing", 1)
+        return b
+
+    a, b = mk(0), mk(1)
+    x = make_input(nch, 6 * maxin, 39)
+    lens = [maxin, maxin, maxin // 3, 300, maxin, 17, 1, maxin - 5, 2500, maxin]
+    pos = 0
+    ran = False
+    for l in lens:
+        if pos + l > x.shape[1]:
+            break
+        ya, yb = a.process_host(x[:, pos:pos + l]), b.process_host(x[:, pos:pos + l])
+        pos += l
+        assert ya.shape == yb.shape and np.isfinite(yb).all()
+        if bitwise:
+            assert np.array_equal(ya, yb), (case, pos)
+        else:
+            d = ya - yb
+            assert np.sqrt((d * d).mean()) <= 2e-16 and np.abs(d).max() <= 4e-15, (case, pos)
+        ran = ran or any(s in ("k_convp<11, 1, 23, 24>", "k_convp<11, 1, 25, 24>") for s in b.stage_symbols())
+    if must_run is not None:
+        assert ran == must_run, b.stage_symbols()
+    return ran
+
+
+@pytest.mark.parametrize("case", range(len(HALF_FUSED_CASES)))
+def test_emulated_half_array_fused_form_is_bitwise_mode_4(emul, case):
+    run_half_fused_case({"lib": emul}, HALF_FUSED_CASES[case], must_run=case not in (4,))
+
+
 @pytest.mark.parametrize("case", QUAD_CASES)
 def test_emulated_eight_elements_per_thread_form(emul, case):
     run_quad_case({"lib": emul}, case)

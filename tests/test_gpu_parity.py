@@ -502,6 +502,15 @@ def test_hip_half_array_form_against_the_full_one(torch, case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", range(len(test_emul.HALF_FUSED_CASES)))
+def test_hip_half_array_fused_form_against_mode_4(torch, case):
+    """kernel modes 23 / 25 (the fused two-phase block pair in the half-array form, option half_fused) against a workgroup
+    per block of modes 4 / 5: equal to rounding on the device (bit for bit under emulation), ragged calls"""
+    test_emul.run_half_fused_case({"device": 0}, test_emul.HALF_FUSED_CASES[case], nch=37, bitwise=False,
+                                  must_run=case not in (4,))
+
+
+@pytest.mark.gpu
 def test_hip_half_array_form_is_chunk_invariant_and_the_default_of_large_objects(torch):
     """an object of 128 channels and more runs the half-array form by default (option half = 1), and stays bitwise
     independent of how the stream is cut into calls"""
