@@ -1490,16 +1490,21 @@ R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 // CU --, its first 32 KB carry the transforms as in mode 21; launch bound 256 x 3 = 168 registers: the rows of the
 // thread's phase pair are fetched when the last pass's results have gone to the run, not beside its butterflies)
 // (MODE 25: mode 5 -- adjacent windows up to three samples apart, In > Out -- likewise)
-constexpr bool convp_mode_ha(int m) { return m == 21 || m == 23 || m == 25; }
+// (MODE 22: mode 3 -- the 3x strided store behind the block -- in this form)
+constexpr bool convp_mode_ha(int m) { return m == 21 || m == 22 || m == 23 || m == 25; }
 constexpr bool convp_mode_ha_fused(int m) { return m == 23 || m == 25; }
 // (what leaves the workgroup at 52 KB with the flag words and the twiddle table: three of 53.1 KB -- 163 008 of a CU's
 // 163 840 bytes -- were NOT resident together on MI355X, the allocation is rounded up; BASELINE's cfg2 needs 3051)
 static const int kHaFusedElems = 3052;
-constexpr int convp_ha_minblocks(int m) { return convp_mode_ha_fused(m) ? 3 : 4; }
+// (the launch bound's second number is WAVES PER SIMD: four for two workgroups of 512 threads as for four of 256)
+constexpr int convp_ha_minblocks(int m, int wt) { return wt > 256 ? 4 : (convp_mode_ha_fused(m) ? 3 : 4); }
+// (the 2048 -> 4096-point geometry; and, convolver-only modes, the 4096 -> 8192-point one: 512 threads, a middle pass that
+// is the folded radix-2 stage alone and three radix-16 passes behind it -- 64 KB instead of 128, TWO workgroups per CU)
 template<int LN, int UL> constexpr bool convp_ha_ok()
 {
 	typedef ConvpGeom<LN, UL> G;
-	return UL == 1 && G::SUB == 1 && !G::POST && G::B1 && G::R2 == 16 && G::NPRE == 3 && ConvpTwLds<LN, UL>::ON;
+	return UL == 1 && G::SUB == 1 && G::NPRE == 3 &&
+		((!G::POST && G::B1 && G::R2 == 16 && ConvpTwLds<LN, UL>::ON) || (G::POST && G::NPOST == 3 && G::RMB == 2 && G::E2 == 16));
 }
 template<int LN, int UL, int MODE = 21> constexpr int convp_ha_array_bytes()
 {
@@ -1507,7 +1512,7 @@ template<int LN, int UL, int MODE = 21> constexpr int convp_ha_array_bytes()
 }
 template<int LN, int UL, int MODE = 21> constexpr int convp_ha_lds_bytes()
 {
-	return convp_ha_array_bytes<LN, UL, MODE>() + kConvpFlagBytes + ConvpTwLds<LN, UL>::NE * 16;
+	return convp_ha_array_bytes<LN, UL, MODE>() + kConvpFlagBytes + (ConvpTwLds<LN, UL>::ON ? ConvpTwLds<LN, UL>::NE * 16 : 0);
 }
 // the array of kernel mode MODE (what lies behind it -- flag words, twiddle table -- starts there)
 template<int LN, int UL, int MODE> constexpr int convp_mode_array_bytes()
@@ -1577,6 +1582,24 @@ R8B_HD void cp_ha_st_b1(cd* buf, const double* v, int lt)
 	const SwBase bb = dw_base(buf, dswz((lt >> 4) * 256 + (lt & 15)));
 #pragma unroll
 	for (int p = 0; p < 16; p++) dw_st(bb, 16 * p, v[p]);
+}
+// the general pattern -- a radix-16 pass of sub-length NSUB: butterfly lt works on elements e0 + (NSUB / 16) p,
+// e0 = (lt / q) NSUB + lt mod q, q = NSUB / 16 (NSUB = 16: the thread's sixteen consecutive positions)
+template<int NSUB>
+R8B_HD void cp_ha_ld(const cd* buf, double* v, int lt)
+{
+	constexpr int q = NSUB / 16;
+	const SwBase bb = dw_base(buf, dswz((lt / q) * NSUB + (lt & (q - 1))));
+#pragma unroll
+	for (int p = 0; p < 16; p++) v[p] = dw_ld(bb, q * p);
+}
+template<int NSUB>
+R8B_HD void cp_ha_st(cd* buf, const double* v, int lt)
+{
+	constexpr int q = NSUB / 16;
+	const SwBase bb = dw_base(buf, dswz((lt / q) * NSUB + (lt & (q - 1))));
+#pragma unroll
+	for (int p = 0; p < 16; p++) dw_st(bb, q * p, v[p]);
 }
 // ... of the last pass: elements lt + NT i
 template<int NT>
@@ -2957,12 +2980,13 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 
 	constexpr int BM = MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 14 ? 0 :
 		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : (MODE == 16 ? 4 : (MODE == 17 ? 5 :
-		(MODE == 18 ? 1 : (MODE == 19 || MODE == 20 || MODE == 21 ? 0 : (MODE == 23 ? 4 : (MODE == 25 ? 5 : MODE)))))));
+		(MODE == 18 ? 1 : (MODE == 19 || MODE == 20 || MODE == 21 ? 0 : (MODE == 22 ? 3 : (MODE == 23 ? 4 : (MODE == 25 ? 5 : MODE))))))));
 	// mode 20: mode 0 of the decimating form behind a half-band decimator taken in the load (cp_hbf_*)
 	constexpr bool HBF = MODE == 20;
 	// mode 21: mode 0 in the half-array form (cp_ha_*: the backward side's exchanges by parts through an array of doubles)
 	constexpr bool HA = convp_mode_ha(MODE);
-	static_assert(!HA || convp_ha_ok<LN, UL>(), "half-array form: the 2048 -> 4096-point 2x up-sampling geometry");
+	static_assert(!HA || convp_ha_ok<LN, UL>(), "half-array form: the 2048 -> 4096-point and 4096 -> 8192-point 2x up-sampling geometries");
+	static_assert(!HA || !ConvpGeom<LN, UL>::POST || BM == 0 || BM == 3, "half-array form on 8192 points: convolver-only modes");
 	// mode 19: polyphase 3x form (cp_p3_*): a convolver-only mode with its own load, middle and store
 	constexpr bool P3 = convp_mode_p3(MODE);
 	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
@@ -3208,7 +3232,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			const int lt = lt_of(tid);
 			if constexpr (SP) cp_sp_middle<LN, UL, CXL>(L, buf_of(tid), st, lt);
 			else if constexpr (UL < 0) cp_middle_compute_down<LN, UL, CX>(buf_of(tid), st, lt);
-			else cp_middle_compute<LN, UL, CX>(buf_of(tid), st, lt);
+			else cp_middle_compute<LN, UL, CX, HA>(buf_of(tid), st, lt);
 			ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
 		};
 		auto d_midw = [&](int tid, St& st)
@@ -3276,6 +3300,43 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
 			});
 			ex.wave_steps(d_midw, d_post1, d_post2, d_post3);
+		}
+		else if constexpr (HA)
+		{
+			// half-array form on 8192 points: the three exchanges of the backward side by parts through an array of doubles.
+			// Middle -> sub-length 32 -> sub-length 512 inside a wave (program order); sub-length 512 -> 8192 across the
+			// workgroup: written | barrier | read | barrier | written | barrier | read (the body's last phase).
+			constexpr int N1 = ConvpPost<LN, UL, 1>::n, N2P = ConvpPost<LN, UL, 2>::n;
+			static_assert(N1 == 32 && N2P == 512 && ConvpPost<LN, UL, 3>::n == G::N2, "half-array form: pass plan 2 x 16 x 16 x 16");
+			auto g1 = [&](int tid, St& st) { cp_ha_st<16>(buf_of(tid), st.vr, lt_of(tid)); };
+			auto g2 = [&](int tid, St& st) { cp_ha_ld<N1>(buf_of(tid), st.er, lt_of(tid)); };
+			auto g3 = [&](int tid, St& st) { cp_ha_st<16>(buf_of(tid), st.vi, lt_of(tid)); };
+			auto g4 = [&](int tid, St& st)
+			{
+				const int lt = lt_of(tid);
+				cp_ha_ld<N1>(buf_of(tid), st.vi, lt);
+				pdit_arith<16, true>(st.tw, st.er, st.vi);
+				cp_ha_st<N1>(buf_of(tid), st.er, lt);
+				ConvpPost<LN, UL, 2>::prefetch(L, st, lt);
+			};
+			auto g5 = [&](int tid, St& st) { cp_ha_ld<N2P>(buf_of(tid), st.vr, lt_of(tid)); };
+			auto g6 = [&](int tid, St& st) { cp_ha_st<N1>(buf_of(tid), st.vi, lt_of(tid)); };
+			auto g7 = [&](int tid, St& st)
+			{
+				const int lt = lt_of(tid);
+				cp_ha_ld<N2P>(buf_of(tid), st.vi, lt);
+				pdit_arith<16, true>(st.tw, st.vr, st.vi);
+				cp_ha_st<N2P>(buf_of(tid), st.vr, lt);
+			};
+			ex.wave_steps(d_pre1, d_pre2, d_midc, g1, g2, g3, g4, g5, g6, g7);
+			ex.phase([&](int tid, St& st) { cp_ha_ld<G::N2>(buf_of(tid), st.vr, lt_of(tid)); });
+			// (the last pass's twiddles requested here, behind the imaginary parts whose registers they take: held from the
+			// wave-local steps on, across three barriers, they were spilled -- the budget is 128 registers)
+			ex.phase([&](int tid, St& st)
+			{
+				cp_ha_st<N2P>(buf_of(tid), st.vi, lt_of(tid));
+				ConvpPost<LN, UL, 3>::prefetch(L, st, lt_of(tid));
+			});
 		}
 		else
 		ex.wave_steps(d_pre1, d_pre2, d_midc, d_midw, d_post1, d_post2, d_post3);
@@ -3558,6 +3619,13 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		{
 			const int lt = lt_of(tid);
 			slices_out(tid, st);
+			if constexpr (HA)
+			{
+				// (the imaginary parts of the last pass's elements; the real parts wait in st.vr)
+				cp_ha_ld<G::N2>(buf_of(tid), st.vi, lt);
+				pdit_arith<16, true>(st.tw, st.vr, st.vi);
+			}
+			else
 			ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
 			if constexpr (LEVELS)
 			{

@@ -845,7 +845,7 @@ __device__ __forceinline__ void convp_pin(ConvxLaunch& H, const ConvxLaunch& X)
 #define R8B_SPLIT_MINBLOCKS 3 // (R8B_SPLIT_UP2 development builds: workgroups per CU the register budget is cut for)
 #endif
 template<int LN, int UL, int MODE, int FLENP>
-__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (convp_mode_ha(MODE) ? convp_ha_minblocks(MODE) : kSplit<LN, UL> ? R8B_SPLIT_MINBLOCKS : (ConvpGeom<LN, UL>::WT) > 256 ? 1 : R8B_DEV_MINBLK)) void k_convp(const ConvxLaunch X)
+__global__ __launch_bounds__((ConvpGeom<LN, UL>::WT), (convp_mode_ha(MODE) ? convp_ha_minblocks(MODE, (ConvpGeom<LN, UL>::WT)) : kSplit<LN, UL> ? R8B_SPLIT_MINBLOCKS : (ConvpGeom<LN, UL>::WT) > 256 ? 1 : R8B_DEV_MINBLK)) void k_convp(const ConvxLaunch X)
 {
 	extern __shared__ __align__(256) unsigned char smem_[];
 	// (development builds, the control of the occupancy experiment with a truncated array -- R8B_FAKE_LDS --: the array
@@ -1157,12 +1157,13 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 			return;
 		}
 	}
-	if constexpr (LN == 11 && UL == 1 && MODE == 0)
+	if constexpr ((LN == 11 || LN == 12) && UL == 1 && (MODE == 0 || MODE == 3))
 	{
-		// half-array form (r8b_convp.h cp_ha_*, kernel mode 21): the same block pair in 32 KB of LDS, four workgroups per CU
+		// half-array form (r8b_convp.h cp_ha_*, kernel modes 21 / 22): the same block pair in 32 KB of LDS, four workgroups
+		// per CU (4096 -> 8192 points: 64 KB, two workgroups of 512 threads)
 		if (X.half != 0 && X.quad == 0)
 		{
-			launch_convp_t<LN, UL, 21, FLENP>(X0, stream);
+			launch_convp_t<LN, UL, MODE == 0 ? 21 : 22, FLENP>(X0, stream);
 			return;
 		}
 	}

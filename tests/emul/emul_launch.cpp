@@ -400,10 +400,13 @@ void emul_convp_t(const ConvxLaunch& X0)
 			emul_convq(X0);
 			return;
 		}
-		// half-array form (r8b_convp.h cp_ha_*, kernel mode 21)
-		if (X0.half != 0)
+	}
+	if constexpr ((LN == 11 || LN == 12) && UL == 1 && (MODE == 0 || MODE == 3))
+	{
+		// half-array form (r8b_convp.h cp_ha_*, kernel modes 21 / 22)
+		if (X0.half != 0 && X0.quad == 0)
 		{
-			emul_convp_t<LN, UL, 21, FLENP>(X0);
+			emul_convp_t<LN, UL, MODE == 0 ? 21 : 22, FLENP>(X0);
 			return;
 		}
 	}

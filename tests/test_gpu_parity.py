@@ -491,13 +491,13 @@ def test_hip_eight_elements_per_thread_form(torch, case):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("case", range(len(test_emul.HALF_CASES)))
 def test_hip_half_array_form_against_the_full_one(torch, case):
     """r8b_convp.h cp_ha_* (kernel mode 21, engine option "half": the 2048 -> 4096-point convolver-only block pair with the
     backward side's exchanges by parts through 32 KB of LDS, four workgroups per CU) against the 64 KB form: the same
     arithmetic, equal to rounding on the device (bit for bit under emulation: tests/test_emul.py), ragged calls"""
-    from test_emul import QUAD_CASES, run_half_case
-    y = run_half_case({"device": 0}, QUAD_CASES[case], nch=37, bitwise=False)
+    from test_emul import HALF_CASES, run_half_case
+    y = run_half_case({"device": 0}, HALF_CASES[case], nch=37, bitwise=False)
     assert y.shape[0] == 37
 
 
