@@ -843,10 +843,12 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// contracts multiply-adds differently in the two kernels, so on the GPU they agree to rounding, 4e-17 RMS, and an
 	// object must stay with one of them to remain bitwise chunk invariant); 2: every object; 0: the 64 KB form
 	opt_["half"] = 1;
-	// ... and of the fused two-phase block pair 2048 -> 4096 points + whole-step interpolator (kernel mode 23: the array
-	// is the interpolator's run, 49 KB, three workgroups per CU; taken in place of mode 4 and its walk form).  Values as
-	// for "half"
-	opt_["half_fused"] = 0;
+	// ... and of the fused two-phase block pair 2048 -> 4096 points + whole-step interpolator (kernel modes 23 / 25: the
+	// array is the interpolator's run, 52 KB with flag words and twiddle table, three workgroups per CU; taken in place of
+	// modes 4 / 5 and of the walk form).  Measured on cfg2 (profiles/r06_experiments.txt item 13): -1.3 ... -2.1 % per call
+	// against the walk form, -4.2 % against a workgroup per block; kernel events level with the walk form.  Values as for
+	// "half"
+	opt_["half_fused"] = 1;
 	// a half-band decimator in front of a 4096 -> 2048-point decimating convolver taken in the convolver's load (kernel mode
 	// 20: one launch, the decimator's stream never leaves LDS).  Off: measured on MI355X the fused launch takes 92.6 us
 	// + a 19 us history copy against 52.5 + 42.6 us for the two launches (176400 -> 44100, 1024 ch x 16384) -- a block

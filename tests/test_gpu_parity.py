@@ -516,17 +516,18 @@ def test_hip_half_array_form_is_chunk_invariant_and_the_default_of_large_objects
     independent of how the stream is cut into calls"""
     nch, n = 130, 16000
     x = make_input(nch, n, 5)
-    outs = []
-    for lens in ([n], [7000, 1, 4000, 99, 4900]):
-        b = r8b.BatchResampler(44100.0, 88200.0, 16384, 2.0, 180.15, nch=nch, device=0)
-        b.set_option("timing", 1)
-        ys, pos = [], 0
-        for l in lens:
-            ys.append(b.process_host(x[:, pos:pos + l]))
-            pos += l
-        assert b.stage_symbols() == ["k_convp<11, 1, 21, 24>"], b.stage_symbols()
-        outs.append(np.concatenate(ys, axis=1))
-    assert np.array_equal(outs[0], outs[1])
+    for dst, sym in ((88200.0, "k_convp<11, 1, 21, 24>"), (96000.0, "k_convp<11, 1, 23, 24>"), (48000.0, "k_convp<11, 1, 25, 24>")):
+        outs = []
+        for lens in ([n], [7000, 1, 4000, 99, 4900]):
+            b = r8b.BatchResampler(44100.0, dst, 16384, 2.0, 180.15, nch=nch, device=0)
+            b.set_option("timing", 1)
+            ys, pos = [], 0
+            for l in lens:
+                ys.append(b.process_host(x[:, pos:pos + l]))
+                pos += l
+            assert b.stage_symbols()[0] == sym, b.stage_symbols()
+            outs.append(np.concatenate(ys, axis=1))
+        assert np.array_equal(outs[0], outs[1]), dst
     s = r8b.BatchResampler(44100.0, 88200.0, 16384, 2.0, 180.15, nch=8, device=0)
     s.set_option("timing", 1)
     s.process_host(x[:8, :16384])
@@ -564,7 +565,8 @@ def test_bench_contract(tmp_path):
     assert d["other_placement"]["placement"] == "stream-aligned"
     # `kernel` is the device symbol rocprofv3 prints for the dominant stage (profiles/*_kernel_stats.csv are keyed by it),
     # `label` the engine's name for the stage's form; `path_frac` is the whole call in the value window
-    assert r["label"] == "k_convp_whole" and r["kernel"] in ("k_convp_walk<11, 1, 4, 24>", "k_convp<11, 1, 4, 24>"), r
+    assert r["label"] == "k_convp_whole" and r["kernel"] in ("k_convp_walk<11, 1, 4, 24>", "k_convp<11, 1, 4, 24>",
+                                                            "k_convp<11, 1, 23, 24>"), r
     assert r["kernel"] in r["kernel_symbols"] and "frac_value_window" not in r
     path_bytes = 8.0 * 1024 * (16384 + d["config"]["out_msamples_per_s"] / d["value"] * 16384)
     assert abs(r["path_frac"] - path_bytes / (d["ms_per_step"] * 1e-3) / 1e9 / 8000.0) < 2e-3
@@ -664,6 +666,9 @@ def test_hip_walk_form_full_batch(torch):
     b = r8b.BatchResampler(44100.0, 96000.0, 16384, 2.0, 180.15, nch=1024, device=0)
     a.set_option("walk", 0)
     b.set_option("walk", 1)
+    # (objects of this size run the half-array form by default: the walk form is what this test is about)
+    a.set_option("half_fused", 0)
+    b.set_option("half_fused", 0)
     w0 = b.stat("walk_blocks")
     g = torch.Generator(device="cuda")
     g.manual_seed(5)
