@@ -236,11 +236,11 @@ R8B_HD int fslot(int p)
 	else return pswz((p / G::FW) * G::BW + (p & (G::FW - 1)));
 }
 
-template<int LN, int UL>
+template<int LN, int UL, bool HAF = false>
 R8B_HD int bslot(int p)
 {
 	typedef ConvpGeom<LN, UL> G;
-	if constexpr (UL >= 0 || G::NW == 1) return pswz(p);
+	if constexpr (UL >= 0 || G::NW == 1 || HAF) return pswz(p);
 	else return pswz((p / G::BW) * G::FW + (p & (G::BW - 1)));
 }
 
@@ -257,11 +257,11 @@ R8B_HD constexpr int fmap_c(int d)
 	typedef ConvpGeom<LN, UL> G;
 	return (UL <= 0 || G::NW == 1 || kSplit<LN, UL> || HAF) ? d : (d / G::FW) * G::BW + (d & (G::FW - 1));
 }
-template<int LN, int UL>
+template<int LN, int UL, bool HAF = false>
 R8B_HD constexpr int bmap_c(int d)
 {
 	typedef ConvpGeom<LN, UL> G;
-	return (UL >= 0 || G::NW == 1) ? d : (d / G::BW) * G::FW + (d & (G::BW - 1));
+	return (UL >= 0 || G::NW == 1 || HAF) ? d : (d / G::BW) * G::FW + (d & (G::BW - 1));
 }
 // SwBase: the per-pass address register.  On the GPU it is the ABSOLUTE LDS byte address of slot(e0): the XOR
 // constants live in address bits 4-7 and every block pair's array starts on a multiple of 256 bytes (the dynamic LDS
@@ -626,6 +626,25 @@ R8B_HD void tw_expand(cd* twr)
 
 // ---- passes over the swizzled array ---------------------------------------------------------------
 
+// (the arithmetic of a forward pass on the R values a thread has loaded: the butterflies, then the twiddles)
+template<int R, bool TW>
+R8B_HD void pdif_arith(const cd* twr, double* vr, double* vi)
+{
+	dif_regs<R>(vr, vi);
+	if constexpr (TW)
+	{
+#pragma unroll
+		for (int p = 1; p < R; p++)
+		{
+			const cd w = tw_get(twr, bitrev_c<R>(p));
+			const double tr = vr[p] * w.re - vi[p] * w.im;
+			const double ti = vr[p] * w.im + vi[p] * w.re;
+			vr[p] = tr;
+			vi[p] = ti;
+		}
+	}
+}
+
 template<int LN, int UL, int R, bool TW, bool HAF = false>
 R8B_HD void pdif(cd* buf, int n, int b, const cd* twr)
 {
@@ -641,19 +660,7 @@ R8B_HD void pdif(cd* buf, int n, int b, const cd* twr)
 		vr[p] = v.re;
 		vi[p] = v.im;
 	}
-	dif_regs<R>(vr, vi);
-	if constexpr (TW)
-	{
-#pragma unroll
-		for (int p = 1; p < R; p++)
-		{
-			const cd w = tw_get(twr, bitrev_c<R>(p));
-			const double tr = vr[p] * w.re - vi[p] * w.im;
-			const double ti = vr[p] * w.im + vi[p] * w.re;
-			vr[p] = tr;
-			vi[p] = ti;
-		}
-	}
+	pdif_arith<R, TW>(twr, vr, vi);
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
@@ -1207,19 +1214,11 @@ R8B_HD void cp_tail_slice_store(const ConvLaunch& L, const St& st, int chA, int 
 	}
 }
 
-// first forward pass, from the registers cp_load() filled
-template<int LN, int UL, bool HAF = false>
-R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st, int lt)
+// (the first pass's arithmetic: the butterfly over the thread's samples, then the twiddles -- loc: the expanded base set)
+template<int LN, int UL>
+R8B_HD void cp_first_arith(const ConvpState<LN, UL>& st, const cd* loc, double* vr, double* vi)
 {
-	typedef ConvpGeom<LN, UL> G;
-	constexpr int R = G::E1, q = G::N / R;
-	// (fetched by the caller ahead of the samples -- ptw_fetch_lean --, completed here)
-	constexpr int NBW = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
-	cd loc[NBW];
-#pragma unroll
-	for (int c = 0; c < NBW; c++) loc[c] = st.tw[c];
-	tw_expand<R>(loc);
-	double vr[R], vi[R];
+	constexpr int R = ConvpGeom<LN, UL>::E1;
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
@@ -1236,6 +1235,22 @@ R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st,
 		vr[p] = tr;
 		vi[p] = ti;
 	}
+}
+
+// first forward pass, from the registers cp_load() filled
+template<int LN, int UL, bool HAF = false>
+R8B_HD void cp_first(const ConvLaunch& L, cd* buf, const ConvpState<LN, UL>& st, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int R = G::E1, q = G::N / R;
+	// (fetched by the caller ahead of the samples -- ptw_fetch_lean --, completed here)
+	constexpr int NBW = R >= 16 ? 6 : (R >= 8 ? 4 : (R >= 4 ? 3 : 1));
+	cd loc[NBW];
+#pragma unroll
+	for (int c = 0; c < NBW; c++) loc[c] = st.tw[c];
+	tw_expand<R>(loc);
+	double vr[R], vi[R];
+	cp_first_arith<LN, UL>(st, loc, vr, vi);
 	const SwBase bb = sw_base(buf, fslot<LN, UL, HAF>(lt));
 #pragma unroll
 	for (int p = 0; p < R; p++)
@@ -1491,24 +1506,36 @@ R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 // thread's phase pair are fetched when the last pass's results have gone to the run, not beside its butterflies)
 // (MODE 25: mode 5 -- adjacent windows up to three samples apart, In > Out -- likewise)
 // (MODE 22: mode 3 -- the 3x strided store behind the block -- in this form)
-constexpr bool convp_mode_ha(int m) { return m == 21 || m == 22 || m == 23 || m == 25; }
+// (MODES 27 / 28: modes 0 / 3 of the 4096 -> 2048-point DECIMATING geometry -- there it is the FORWARD transform that has
+// the 4096 points: its two exchanges go by parts through 4096 doubles, the backward side's 2048 complex values fit as
+// they are; three workgroups per CU)
+constexpr bool convp_mode_ha(int m) { return m == 21 || m == 22 || m == 23 || m == 25 || m == 27 || m == 28; }
+constexpr bool convp_mode_ha_down(int m) { return m == 27 || m == 28; }
 constexpr bool convp_mode_ha_fused(int m) { return m == 23 || m == 25; }
 // (what leaves the workgroup at 52 KB with the flag words and the twiddle table: three of 53.1 KB -- 163 008 of a CU's
 // 163 840 bytes -- were NOT resident together on MI355X, the allocation is rounded up; BASELINE's cfg2 needs 3051)
 static const int kHaFusedElems = 3052;
 // (the launch bound's second number is WAVES PER SIMD: four for two workgroups of 512 threads as for four of 256)
-constexpr int convp_ha_minblocks(int m, int wt) { return wt > 256 ? 4 : (convp_mode_ha_fused(m) ? 3 : 4); }
+#ifndef R8B_HA_DOWN_WAVES
+#define R8B_HA_DOWN_WAVES 3 // (development builds: the decimating half-array form's register budget, 3 -> 168, 4 -> 128)
+#endif
+constexpr int convp_ha_minblocks(int m, int wt)
+{
+	return wt > 256 ? 4 : (convp_mode_ha_fused(m) ? 3 : (convp_mode_ha_down(m) ? R8B_HA_DOWN_WAVES : 4));
+}
 // (the 2048 -> 4096-point geometry; and, convolver-only modes, the 4096 -> 8192-point one: 512 threads, a middle pass that
 // is the folded radix-2 stage alone and three radix-16 passes behind it -- 64 KB instead of 128, TWO workgroups per CU)
 template<int LN, int UL> constexpr bool convp_ha_ok()
 {
 	typedef ConvpGeom<LN, UL> G;
-	return UL == 1 && G::SUB == 1 && G::NPRE == 3 &&
-		((!G::POST && G::B1 && G::R2 == 16 && ConvpTwLds<LN, UL>::ON) || (G::POST && G::NPOST == 3 && G::RMB == 2 && G::E2 == 16));
+	return (UL == 1 && G::SUB == 1 && G::NPRE == 3 &&
+		((!G::POST && G::B1 && G::R2 == 16 && ConvpTwLds<LN, UL>::ON) || (G::POST && G::NPOST == 3 && G::RMB == 2 && G::E2 == 16))) ||
+		(UL == -1 && LN == 12 && G::SUB == 1 && G::E1 == 16 && G::NPRE == 2 && G::NBF == 1 && G::NT == 256 && G::NPOST == 3 &&
+		!ConvpTwLds<LN, UL>::ON);
 }
 template<int LN, int UL, int MODE = 21> constexpr int convp_ha_array_bytes()
 {
-	return convp_mode_ha_fused(MODE) ? kHaFusedElems * 16 : ConvpGeom<LN, UL>::N2 * 8;
+	return convp_mode_ha_fused(MODE) ? kHaFusedElems * 16 : (UL < 0 ? ConvpGeom<LN, UL>::N * 8 : ConvpGeom<LN, UL>::N2 * 8);
 }
 template<int LN, int UL, int MODE = 21> constexpr int convp_ha_lds_bytes()
 {
@@ -1940,10 +1967,11 @@ R8B_HD void cp_solo_mid_b_down(const ConvLaunch& L, const cd* buf, ConvpState<LN
 // X = that channel's spectrum, from the forward bins m and N - m (positions D and 2D - 1).
 // hp[c * NT + t] = H of the thread's kept positions 2c, 2c + 1.
 template<int LN, int UL, bool CX = false>
+R8B_HD void cp_middle_down_arith(ConvpState<LN, UL>& st, double* zr, double* zi, int lt);
+
+template<int LN, int UL, bool CX = false>
 R8B_HD void cp_middle_compute_down(const cd* buf, ConvpState<LN, UL>& st, int lt)
 {
-	typedef ConvpGeom<LN, UL> G;
-	constexpr int D = 1 << G::DL;
 	double zr[16], zi[16];
 	const SwBase bbf = sw_base(buf, pswz(16 * lt));
 #pragma unroll
@@ -1953,6 +1981,16 @@ R8B_HD void cp_middle_compute_down(const cd* buf, ConvpState<LN, UL>& st, int lt
 		zr[c] = v.re;
 		zi[c] = v.im;
 	}
+	cp_middle_down_arith<LN, UL, CX>(st, zr, zi, lt);
+}
+
+// (the decimating middle pass on the thread's sixteen consecutive forward values: the last forward butterflies, the kept
+// bins times the kernel, the new Nyquist bin's fix-up, the first backward butterflies)
+template<int LN, int UL, bool CX>
+R8B_HD void cp_middle_down_arith(ConvpState<LN, UL>& st, double* zr, double* zi, int lt)
+{
+	typedef ConvpGeom<LN, UL> G;
+	constexpr int D = 1 << G::DL;
 #pragma unroll
 	for (int f = 0; f < G::NBF; f++) dif_regs<G::RM>(zr + G::RM * f, zi + G::RM * f);
 	if constexpr (CX)
@@ -2001,18 +2039,18 @@ R8B_HD void cp_middle_compute_down(const cd* buf, ConvpState<LN, UL>& st, int lt
 	for (int f = 0; f < G::NBB; f++) dit_regs<G::RMB>(st.vr + G::RMB * f, st.vi + G::RMB * f);
 }
 
-template<int LN, int UL>
+template<int LN, int UL, bool HAF = false>
 R8B_HD void cp_middle_write_down(cd* buf, const ConvpState<LN, UL>& st, int lt)
 {
 	typedef ConvpGeom<LN, UL> G;
-	const SwBase bb = sw_base(buf, bslot<LN, UL>(G::E2 * lt));
+	const SwBase bb = sw_base(buf, bslot<LN, UL, HAF>(G::E2 * lt));
 #pragma unroll
 	for (int p = 0; p < G::E2; p++)
 	{
 		cd v;
 		v.re = st.vr[p];
 		v.im = st.vi[p];
-		sw_st(bb, bmap_c<LN, UL>(p), v);
+		sw_st(bb, bmap_c<LN, UL, HAF>(p), v);
 	}
 }
 
@@ -2028,17 +2066,18 @@ struct ConvpPost
 	{
 		ptw_fetch<G::E2, G::NT, (n / G::E2 < G::NT ? n / G::E2 : G::NT)>(st.tw, L.ptw, 2 + I, lt);
 	}
+	template<bool HAF = false>
 	static R8B_HD void run(cd* buf, ConvpState<LN, UL>& st, int lt)
 	{
 		constexpr int R = G::E2, q = n / R;
 		const int blk = lt / q, j = lt - blk * q;
 		const int e0 = blk * n + j;
-		const SwBase bb = sw_base(buf, bslot<LN, UL>(e0));
+		const SwBase bb = sw_base(buf, bslot<LN, UL, HAF>(e0));
 		double vr[R], vi[R];
 #pragma unroll
 		for (int p = 0; p < R; p++)
 		{
-			const cd v = sw_ld(bb, bmap_c<LN, UL>(p * q));
+			const cd v = sw_ld(bb, bmap_c<LN, UL, HAF>(p * q));
 			vr[p] = v.re;
 			vi[p] = v.im;
 		}
@@ -2065,7 +2104,7 @@ struct ConvpPost
 				cd v;
 				v.re = vr[p];
 				v.im = vi[p];
-				sw_st(bb, bmap_c<LN, UL>(p * q), v);
+				sw_st(bb, bmap_c<LN, UL, HAF>(p * q), v);
 			}
 		}
 	}
@@ -2980,7 +3019,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 
 	constexpr int BM = MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 14 ? 0 :
 		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : (MODE == 16 ? 4 : (MODE == 17 ? 5 :
-		(MODE == 18 ? 1 : (MODE == 19 || MODE == 20 || MODE == 21 ? 0 : (MODE == 22 ? 3 : (MODE == 23 ? 4 : (MODE == 25 ? 5 : MODE))))))));
+		(MODE == 18 ? 1 : (MODE == 19 || MODE == 20 || MODE == 21 || MODE == 27 ? 0 : (MODE == 22 || MODE == 28 ? 3 : (MODE == 23 ? 4 : (MODE == 25 ? 5 : MODE))))))));
 	// mode 20: mode 0 of the decimating form behind a half-band decimator taken in the load (cp_hbf_*)
 	constexpr bool HBF = MODE == 20;
 	// mode 21: mode 0 in the half-array form (cp_ha_*: the backward side's exchanges by parts through an array of doubles)
@@ -3148,6 +3187,18 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			ex.post_shift(tid, sub_of(tid), lt, lsh);
 			cp_scale_in<LN, UL>(st, lsh);
 		}
+		if constexpr (HA && UL < 0)
+		{
+			// (decimating half-array form: the first pass's results stay in registers; their real parts go to the array)
+			constexpr int NBW = 6;
+			cd loc[NBW];
+#pragma unroll
+			for (int c = 0; c < NBW; c++) loc[c] = st.tw[c];
+			tw_expand<G::E1>(loc);
+			cp_first_arith<LN, UL>(st, loc, st.vr, st.vi);
+			cp_ha_st<G::N>(buf_of(tid), st.vr, lt);
+		}
+		else
 		cp_first<LN, UL, HA>(L, buf_of(tid), st, lt);
 		if constexpr (TL::ON && !WALK)
 		{
@@ -3199,6 +3250,13 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		front(tid, st, twl_v);
 		first_pass(tid, st, twl_v);
 	});
+	if constexpr (HA && UL < 0)
+	{
+		// (decimating half-array form, the exchange behind the first pass -- across the workgroup: real parts written |
+		// read | imaginary parts written | read, the last in the wave-local steps' first one)
+		ex.phase([&](int tid, St& st) { cp_ha_ld<256>(buf_of(tid), st.er, lt_of(tid)); });
+		ex.phase([&](int tid, St& st) { cp_ha_st<G::N>(buf_of(tid), st.vi, lt_of(tid)); });
+	}
 	// forward passes 1 .., the middle pass and the first backward pass stay inside each wave's own range
 	// of the array (ConvpGeom): wave-level ordering points instead of workgroup barriers between them
 	auto s_pre1 = [&](int tid, St& st)
@@ -3237,7 +3295,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		};
 		auto d_midw = [&](int tid, St& st)
 		{
-			if constexpr (UL < 0) cp_middle_write_down<LN, UL>(buf_of(tid), st, lt_of(tid));
+			if constexpr (UL < 0) cp_middle_write_down<LN, UL, HA>(buf_of(tid), st, lt_of(tid));
 			else cp_middle_write<LN, UL>(buf_of(tid), st, lt_of(tid));
 		};
 		auto d_post1 = [&](int tid, St& st)
@@ -3245,7 +3303,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			if constexpr (G::NPOST > 1)
 			{
 				const int lt = lt_of(tid);
-				ConvpPost<LN, UL, 1>::run(buf_of(tid), st, lt);
+				ConvpPost<LN, UL, 1>::template run<HA>(buf_of(tid), st, lt);
 				ConvpPost<LN, UL, 2>::prefetch(L, st, lt);
 			}
 		};
@@ -3254,7 +3312,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			if constexpr (G::NPOST > 2)
 			{
 				const int lt = lt_of(tid);
-				ConvpPost<LN, UL, 2>::run(buf_of(tid), st, lt);
+				ConvpPost<LN, UL, 2>::template run<HA>(buf_of(tid), st, lt);
 				ConvpPost<LN, UL, 3>::prefetch(L, st, lt);
 			}
 		};
@@ -3300,6 +3358,32 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
 			});
 			ex.wave_steps(d_midw, d_post1, d_post2, d_post3);
+		}
+		else if constexpr (HA && UL < 0)
+		{
+			// decimating half-array form: the forward side's second exchange (sub-length 256 -> the thread's sixteen
+			// consecutive positions) by parts inside the wave, then the backward side as it is -- its 2048 complex values
+			// in the wave's own part of the same 32 KB (identity slot maps)
+			static_assert(G::NPRE == 2 && G::NPOST == 3, "decimating half-array form: pass plan 16 x 16 x 16 | 4 x 8 x 8 x 8");
+			auto f1 = [&](int tid, St& st)
+			{
+				const int lt = lt_of(tid);
+				cp_ha_ld<256>(buf_of(tid), st.vi, lt);
+				pdif_arith<16, true>(st.tw, st.er, st.vi);
+				cp_ha_st<256>(buf_of(tid), st.er, lt);
+				hp_prefetch(st, lt);
+			};
+			auto f2 = [&](int tid, St& st) { cp_ha_ld<16>(buf_of(tid), st.er, lt_of(tid)); };
+			auto f3 = [&](int tid, St& st) { cp_ha_st<256>(buf_of(tid), st.vi, lt_of(tid)); };
+			auto f4 = [&](int tid, St& st)
+			{
+				const int lt = lt_of(tid);
+				double zi[16];
+				cp_ha_ld<16>(buf_of(tid), zi, lt);
+				cp_middle_down_arith<LN, UL, CX>(st, st.er, zi, lt);
+				ConvpPost<LN, UL, 1>::prefetch(L, st, lt);
+			};
+			ex.wave_steps(f1, f2, f3, f4, d_midw, d_post1, d_post2);
 		}
 		else if constexpr (HA)
 		{
@@ -3619,14 +3703,14 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		{
 			const int lt = lt_of(tid);
 			slices_out(tid, st);
-			if constexpr (HA)
+			if constexpr (HA && UL > 0)
 			{
 				// (the imaginary parts of the last pass's elements; the real parts wait in st.vr)
 				cp_ha_ld<G::N2>(buf_of(tid), st.vi, lt);
 				pdit_arith<16, true>(st.tw, st.vr, st.vi);
 			}
 			else
-			ConvpPost<LN, UL, G::NPOST>::run(buf_of(tid), st, lt);
+			ConvpPost<LN, UL, G::NPOST>::template run<HA>(buf_of(tid), st, lt);
 			if constexpr (LEVELS)
 			{
 				const int lsh = level_shift(tid);

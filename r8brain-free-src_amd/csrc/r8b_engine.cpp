@@ -1395,7 +1395,9 @@ bool Engine::set_option(const std::string& name, int value)
 	// (unfused stages keep it in rings the fused kernels never write): once a stream has started they
 	// may only change after clear().
 	static const char* const structural[] = { "fuse", "fuse_hb", "fuse_hbd", "fuse_hbconv", "fold_tail", "fast_conv",
-		"pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park", "fuse_latency", "solo_fuse", "up3_poly" };
+		"pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park", "fuse_latency", "solo_fuse", "up3_poly",
+		// (the half-array forms keep the state where it is, but round differently on the device: a stream stays with one)
+		"half", "half_fused", "quad" };
 	bool started = false;
 	for (const StagePlan& sp : plan_.stages) started = started || sp.m != 0;
 	for (const char* n : structural)

@@ -1157,6 +1157,15 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 			return;
 		}
 	}
+	if constexpr (LN == 12 && UL == -1 && (MODE == 0 || MODE == 3))
+	{
+		// ... of the 4096 -> 2048-point decimating geometry (kernel modes 27 / 28: the FORWARD transform's exchanges by parts)
+		if (X.half != 0)
+		{
+			launch_convp_t<LN, UL, MODE == 0 ? 27 : 28, FLENP>(X0, stream);
+			return;
+		}
+	}
 	if constexpr ((LN == 11 || LN == 12) && UL == 1 && (MODE == 0 || MODE == 3))
 	{
 		// half-array form (r8b_convp.h cp_ha_*, kernel modes 21 / 22): the same block pair in 32 KB of LDS, four workgroups

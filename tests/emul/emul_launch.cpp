@@ -401,6 +401,15 @@ void emul_convp_t(const ConvxLaunch& X0)
 			return;
 		}
 	}
+	if constexpr (LN == 12 && UL == -1 && (MODE == 0 || MODE == 3))
+	{
+		// ... of the decimating geometry (kernel modes 27 / 28)
+		if (X0.half != 0)
+		{
+			emul_convp_t<LN, UL, MODE == 0 ? 27 : 28, FLENP>(X0);
+			return;
+		}
+	}
 	if constexpr ((LN == 11 || LN == 12) && UL == 1 && (MODE == 0 || MODE == 3))
 	{
 		// half-array form (r8b_convp.h cp_ha_*, kernel modes 21 / 22)

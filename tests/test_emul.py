@@ -1306,7 +1306,8 @@ def run_half_case(lib_kw, case, nch=5, bitwise=True):
     b.set_option("timing", 1)
     b.process_host(x[:, :maxin])
     assert any(sym in b.stage_symbols() for sym in ("k_convp<11, 1, 21, 24>", "k_convp<11, 1, 22, 24>", "k_convp<12, 1, 21, 24>",
-                                                    "k_convp<12, 1, 22, 24>")), b.stage_symbols()
+                                                    "k_convp<12, 1, 22, 24>", "k_convp<12, -1, 27, 24>",
+                                                    "k_convp<12, -1, 28, 24>")), b.stage_symbols()
     return y1
 
 
@@ -1314,7 +1315,12 @@ def run_half_case(lib_kw, case, nch=5, bitwise=True):
 # geometry -- 512 threads, 64 KB instead of 128 -- alone and in front of the strided store)
 HALF_CASES = QUAD_CASES + [(48000.0, 32000.0, 6000, 3.0, 150.0, {}),
                            (44100.0, 88200.0, 12000, 1.0, 180.15, {}), (44100.0, 88200.0, 7000, 1.0, 180.15, {"park": 0}),
-                           (48000.0, 32000.0, 13000, 2.0, 180.15, {}), (96000.0, 64000.0, 5000, 2.0, 180.15, {"fold_tail": 0})]
+                           (48000.0, 32000.0, 13000, 2.0, 180.15, {}), (96000.0, 64000.0, 5000, 2.0, 180.15, {"fold_tail": 0}),
+                           # the decimating 4096 -> 2048-point geometry (kernel modes 27 / 28): alone, behind a half-band
+                           # decimator, in front of the strided store
+                           (88200.0, 44100.0, 16384, 2.0, 180.15, {}), (88200.0, 44100.0, 5000, 2.0, 180.15, {"park": 0}),
+                           (176400.0, 44100.0, 12000, 2.0, 180.15, {}), (88200.0, 44100.0, 3000, 2.0, 180.15, {"fold_tail": 0}),
+                           (32000.0, 48000.0, 6000, 3.0, 180.15, {}), (64000.0, 96000.0, 9000, 3.0, 180.15, {"park": 0})]
 
 
 @pytest.mark.parametrize("case", range(len(HALF_CASES)))
