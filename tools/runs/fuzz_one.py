@@ -6,9 +6,9 @@ import test_fuzz as T
 import refwrap as R
 O = T.O
 r8b = T.r8b
-case = (67337.82745715551, 46197.03787634388, 2823, 0.88, 60.88, 242469838)
+case = tuple(float(v) if i < 2 or i in (3, 4) else int(v) for i, v in enumerate(sys.argv[1:7])) if len(sys.argv) > 6 else (67337.82745715551, 46197.03787634388, 2823, 0.88, 60.88, 242469838)
 src, dst, maxin, tb, att, seed = case
-for opts in ({"half": 0, "half_fused": 0}, {"half": 2, "half_fused": 2}):
+for opts in ({"half": 0, "half_fused": 0}, {"half": 2, "half_fused": 2}, {"half": 0, "half_fused": 0, "pair_conv": 0}):
     b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=3)
     for k, v in opts.items():
         b.set_option(k, v)
