@@ -660,7 +660,21 @@ R8B_HD void pdif(cd* buf, int n, int b, const cd* twr)
 		vr[p] = v.re;
 		vi[p] = v.im;
 	}
-	pdif_arith<R, TW>(twr, vr, vi);
+	// (written out, not pdif_arith(): through the helper the split 2x up-sampling form -- modes 8 / 9, 256 registers -- came
+	// out with 84 bytes per lane of scratch)
+	dif_regs<R>(vr, vi);
+	if constexpr (TW)
+	{
+#pragma unroll
+		for (int p = 1; p < R; p++)
+		{
+			const cd w = tw_get(twr, bitrev_c<R>(p));
+			const double tr = vr[p] * w.re - vi[p] * w.im;
+			const double ti = vr[p] * w.im + vi[p] * w.re;
+			vr[p] = tr;
+			vi[p] = ti;
+		}
+	}
 #pragma unroll
 	for (int p = 0; p < R; p++)
 	{
