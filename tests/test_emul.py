@@ -532,6 +532,27 @@ def test_emulated_checkpoint_resume(emul, src, dst):
                          src, dst)
 
 
+@pytest.mark.parametrize("src,dst", [(44100.0, 96000.0), (44100.0, 88200.0), (88200.0, 44100.0), (48000.0, 32000.0)])
+def test_emulated_checkpoint_resume_on_the_half_array_forms(emul, src, dst):
+    """... on kernel modes 23 / 21 / 27 / 22 (options half = 2, half_fused = 2: forced on the small batch); the forms keep
+    the state where the full-array kernels keep it, a blob is bound to the options all the same (they round differently on
+    the device), and the options are refused once the stream has started"""
+    def make(h=2):
+        b = r8b.BatchResampler(src, dst, 700, 2.0, 180.15, nch=3, lib=emul)
+        b.set_option("half", h)
+        b.set_option("half_fused", h)
+        return b
+    blob = checkpoint_roundtrip(make, src, dst)
+    with pytest.raises(RuntimeError, match="differently configured"):
+        make(0).load_state_dict(blob)
+    b = make()
+    b.process_host(make_input(3, 700))
+    with pytest.raises((KeyError, RuntimeError)):
+        b.set_option("half", 0)
+    b.clear()
+    b.set_option("half", 0)
+
+
 def test_emulated_checkpoint_rejects_other_configuration(emul):
     a = r8b.BatchResampler(44100.0, 96000.0, 700, 2.0, 136.45, nch=3, lib=emul)
     a.process_host(make_input(3, 700))
