@@ -3829,7 +3829,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			}
 			const int nv = G::SUB == 1 ? 1 : cur.nvalid;
 #ifndef R8B_HA_NBUF
-#define R8B_HA_NBUF 1
+#define R8B_HA_NBUF 2 // (two chunks of the window in flight in the whole-group loop: -0.9 % on cfg2, 167 registers; 1: 152)
 #endif
 			constexpr int NBUF = HA ? R8B_HA_NBUF : 2;
 			for (int sb = 0; sb < nv; sb++)
