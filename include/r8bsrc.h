@@ -208,8 +208,8 @@ R8BSRC_DECL int r8b_batch_describe(CR8BBatch b, char* buf, int cap);
  * ("fuse", "conv_threads", ...).  Returns 0 if the knob exists.  Knobs that change where a stream's state lives
  * ("fuse", "fuse_hb", "fuse_hbd", "fold_tail", "fast_conv", "pair_conv", "pair_two", "pair_split", "pair_solo", "align_groups", "park", "fuse_latency")
  * or how a stream is rounded ("solo_fuse", "up3_poly", "half", "half_fused", "quad") are
- * refused (-1) once samples have been processed, until r8b_batch_clear().  "half" / "half_fused" (default 1: objects of
- * 128 channels and more; 2: every object; 0: never): the half-array forms of the 2x up-sampling, 2x decimating and fused
+ * refused (-1) once samples have been processed, until r8b_batch_clear().  "half" / "half_fused" (default 1: objects whose
+ * largest call holds at least 512 workgroups of the stage -- channel pairs x overlap-save blocks --; 2: every object; 0: never): the half-array forms of the 2x up-sampling, 2x decimating and fused
  * 2048 -> 4096-point pair kernels -- the full-array kernels' arithmetic with three or four workgroups
  * per CU instead of two; results agree with theirs to rounding (RMS 4e-17), the choice is a constant of the object.  "park" (default 1): every overlap-save
  * block is computed once -- the block that holds a call's last output keeps what it holds of the next call in a

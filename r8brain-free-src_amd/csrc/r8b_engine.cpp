@@ -838,7 +838,8 @@ Engine::Engine(const std::vector<StageDesc>& descs, int maxin, int nch, int devi
 	// real parts, then the imaginary parts through an array of DOUBLES -- 32 KB, four workgroups per CU, no pass added.
 	// Measured on MI355X (profiles/r06_experiments.txt item 12): 44100 -> 88200 at 1024 channels 0.1429 -> 0.1277 ms per
 	// call (kernel 0.138 -> 0.118), at 256 channels -9 %, at 4096 -13 %; launches that do not fill the chip twice gain
-	// nothing (64 channels: +0.5 %).  1: objects of at least 128 channels (decided per OBJECT, never per call: the two
+	// nothing (64 channels: +0.5 %).  1: objects whose largest call holds at least 512 workgroups of the stage -- channel
+	// pairs x blocks, Engine::half_worth -- (decided per OBJECT, never per call: the two
 	// forms do the same arithmetic on the same values -- bitwise equal under host emulation -- but the device compiler
 	// contracts multiply-adds differently in the two kernels, so on the GPU they agree to rounding, 4e-17 RMS, and an
 	// object must stay with one of them to remain bitwise chunk invariant); 2: every object; 0: the 64 KB form
@@ -1228,6 +1229,20 @@ void Engine::prepare_two_phase(size_t s)
 	dev_upload(d.ctab, ct.data(), ct.size() * sizeof(double));
 	d.nsets = nsets;
 	d.taps2 = T2;
+}
+
+// Is a half-array form (r8b_convp.h cp_ha_*) worth taking for convolver stage s?  The forms pay where a launch holds more
+// workgroups than the chip has slots for the full-array kernel -- two per CU, 512 --: channel pairs x blocks of the object's
+// LARGEST call.  A constant of the object (its channel count, its MaxInLen, the stage's block), never of a call: on the
+// device the two forms of a kernel agree to rounding only, and a stream stays with one.  Measured (r06_experiments.txt
+// item 12): 1024 ch x 16384 -10.6 %, 256 ch -8.9 %, 64 ch x 16384 (384 workgroups) +0.6 %, 64 ch x 1024 (32) +0.5 %.
+bool Engine::half_worth(size_t s) const
+{
+	const ConvGeom& g = plan_.stages[s].cg;
+	const long long pairs = ((long long) nch_ + 1) / 2;
+	const long long per_block = std::max(1, g.in_len / std::max(1, g.up)); // stage input samples one block brings
+	const long long blocks = ((long long) plan_.stage_max_in[s] + per_block - 1) / per_block;
+	return pairs * blocks >= 512;
 }
 
 bool Engine::use_pair_two(size_t s, int* run_off) const
@@ -1790,7 +1805,7 @@ void Engine::launch_stage(size_t s, long long m_prev, long long a, long long b,
 		X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
 		X.walk = 0;
 		X.quad = opt_.at("quad") != 0 ? 1 : 0;
-		X.half = opt_.at("half") == 2 || (opt_.at("half") == 1 && nch_ >= 128) ? 1 : 0;
+		X.half = opt_.at("half") == 2 || (opt_.at("half") == 1 && half_worth(s)) ? 1 : 0;
 		X.half_fused = 0;
 		X.park_src = nullptr; X.park_dst = nullptr;
 		X.park_blk = SpanInfo();
@@ -2811,7 +2826,7 @@ void Engine::launch_fused(size_t s, long long wa, long long wb, const SrcView& s
 	X.park_n = 0; X.park_out = 0; X.park_slices = 0; X.park_j0 = 0; X.park_stride = 0;
 	X.walk = 0;
 	X.quad = 0; X.half = 0;
-	X.half_fused = opt_.at("half_fused") == 2 || (opt_.at("half_fused") == 1 && nch_ >= 128) ? 1 : 0;
+	X.half_fused = opt_.at("half_fused") == 2 || (opt_.at("half_fused") == 1 && half_worth(s)) ? 1 : 0;
 	X.park_src = nullptr; X.park_dst = nullptr;
 	X.park_blk = SpanInfo();
 	// Parked outputs (ConvxLaunch::park_*): the block that holds the call's last output is computed ONCE -- what it

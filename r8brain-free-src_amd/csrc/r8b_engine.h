@@ -144,6 +144,7 @@ private:
 	int conv_path(const ConvGeom& g) const;
 	bool latency_chain() const; // some stage carries fractional-latency state (minimum phase): no fusing
 	bool use_pair_two(size_t s, int* run_off) const;
+	bool half_worth(size_t s) const;
 	void fused_blocking(size_t s, long long* S, long long* off) const;
 	bool stage_parks(size_t s) const;
 	int conv_once(size_t s, const DstView& dst) const;

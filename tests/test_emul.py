@@ -1300,7 +1300,7 @@ def run_half_case(lib_kw, case, nch=5, bitwise=True):
     """the half-array form of the 2048 -> 4096-point convolver-only block pair against the 64 KB form: the same arithmetic
     on the same values -- BITWISE equal under host emulation (no contraction), to rounding on the GPU (the device
     compiler contracts multiply-adds differently in the two kernels) -- over ragged calls, odd channel counts, history
-    tail and parked outputs; option values 0 / 2 = never / always (1 = objects of 128 channels and more)"""
+    tail and parked outputs; option values 0 / 2 = never / always (1 = objects whose largest call holds 512 workgroups and more: Engine::half_worth)"""
     src, dst, maxin, tb, att, opts = case
     x = make_input(nch, 5 * maxin, 43)
     lens = [maxin, maxin, maxin // 5, 17, 1, maxin - 1, maxin // 2]
@@ -1347,6 +1347,21 @@ HALF_CASES = QUAD_CASES + [(48000.0, 32000.0, 6000, 3.0, 150.0, {}),
 @pytest.mark.parametrize("case", range(len(HALF_CASES)))
 def test_emulated_half_array_form_is_bitwise_the_full_one(emul, case):
     run_half_case({"lib": emul}, HALF_CASES[case])
+
+
+def test_emulated_half_array_forms_are_chosen_by_the_objects_size(emul):
+    """option half = 1 (the default): channel pairs x blocks of the object's LARGEST call >= 512 (Engine::half_worth) -- a
+    constant of the object, whatever the calls it then gets"""
+    x = make_input(2, 3000, 7)
+    for maxin, sym in ((16384, "k_convp<11, 1, 0, 24>"), (700000, "k_convp<11, 1, 21, 24>")):
+        b = r8b.BatchResampler(44100.0, 88200.0, maxin, 2.0, 180.15, nch=2, lib=emul)
+        b.set_option("timing", 1)
+        b.process_host(x)
+        assert b.stage_symbols() == [sym], (maxin, b.stage_symbols())
+    b = r8b.BatchResampler(44100.0, 96000.0, 700000, 2.0, 180.15, nch=2, lib=emul)
+    b.set_option("timing", 1)
+    b.process_host(x)
+    assert b.stage_symbols()[0] == "k_convp<11, 1, 23, 24>", b.stage_symbols()
 
 
 def test_emulated_half_array_levels_and_silence(emul):

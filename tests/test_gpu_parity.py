@@ -512,7 +512,8 @@ def test_hip_half_array_fused_form_against_mode_4(torch, case):
 
 @pytest.mark.gpu
 def test_hip_half_array_form_is_chunk_invariant_and_the_default_of_large_objects(torch):
-    """an object of 128 channels and more runs the half-array form by default (option half = 1), and stays bitwise
+    """an object whose largest call holds 512 workgroups and more (channel pairs x blocks: here 65 x 13) runs the half-array
+    forms by default (options half = 1, half_fused = 1), a small one (4 x 13) the full-array kernels; each stays bitwise
     independent of how the stream is cut into calls"""
     nch, n = 130, 16000
     x = make_input(nch, n, 5)
