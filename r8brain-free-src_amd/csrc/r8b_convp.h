@@ -1523,9 +1523,10 @@ R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 // (MODES 27 / 28: modes 0 / 3 of the 4096 -> 2048-point DECIMATING geometry -- there it is the FORWARD transform that has
 // the 4096 points: its two exchanges go by parts through 4096 doubles, the backward side's 2048 complex values fit as
 // they are; three workgroups per CU)
-constexpr bool convp_mode_ha(int m) { return m == 21 || m == 22 || m == 23 || m == 25 || m == 27 || m == 28; }
+// (MODES 29 / 30 = 23 / 25, 31 / 32 = 21 / 22 with a COMPLEX kernel spectrum -- minimum-phase chains: modes 16 / 17 / 6 / 7)
+constexpr bool convp_mode_ha(int m) { return m == 21 || m == 22 || m == 23 || m == 25 || m == 27 || m == 28 || (m >= 29 && m <= 32); }
 constexpr bool convp_mode_ha_down(int m) { return m == 27 || m == 28; }
-constexpr bool convp_mode_ha_fused(int m) { return m == 23 || m == 25; }
+constexpr bool convp_mode_ha_fused(int m) { return m == 23 || m == 25 || m == 29 || m == 30; }
 // (what leaves the workgroup at 52 KB with the flag words and the twiddle table: three of 53.1 KB -- 163 008 of a CU's
 // 163 840 bytes -- were NOT resident together on MI355X, the allocation is rounded up; BASELINE's cfg2 needs 3051)
 static const int kHaFusedElems = 3052;
@@ -3022,7 +3023,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	(void) walk;
 	// modes 6 / 7: modes 0 / 3 with a complex kernel spectrum
 	// modes 16 / 17: modes 4 / 5 (fused interpolator, two phases per thread) with a complex kernel spectrum
-	constexpr bool CX = MODE == 6 || MODE == 7 || MODE == 16 || MODE == 17;
+	constexpr bool CX = MODE == 6 || MODE == 7 || MODE == 16 || MODE == 17 || (MODE >= 29 && MODE <= 32);
 	// modes 8 / 9: modes 0 / 3 of the split 2x up-sampling form (cp_sp_*: geometry <13, 0> only); 12 / 13: the same with a
 	// complex kernel spectrum
 	constexpr bool SP = convp_mode_sp(MODE);
@@ -3033,7 +3034,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 
 	constexpr int BM = MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 14 ? 0 :
 		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : (MODE == 16 ? 4 : (MODE == 17 ? 5 :
-		(MODE == 18 ? 1 : (MODE == 19 || MODE == 20 || MODE == 21 || MODE == 27 ? 0 : (MODE == 22 || MODE == 28 ? 3 : (MODE == 23 ? 4 : (MODE == 25 ? 5 : MODE))))))));
+		(MODE == 18 ? 1 : (MODE == 19 || MODE == 20 || MODE == 21 || MODE == 27 || MODE == 31 ? 0 : (MODE == 22 || MODE == 28 || MODE == 32 ? 3 :
+		(MODE == 23 || MODE == 29 ? 4 : (MODE == 25 || MODE == 30 ? 5 : MODE))))))));
 	// mode 20: mode 0 of the decimating form behind a half-band decimator taken in the load (cp_hbf_*)
 	constexpr bool HBF = MODE == 20;
 	// mode 21: mode 0 in the half-array form (cp_ha_*: the backward side's exchanges by parts through an array of doubles)

@@ -384,6 +384,22 @@ void emul_convq(const ConvxLaunch& X0)
 template<int LN, int UL, int MODE, int FLENP>
 void emul_convp_t(const ConvxLaunch& X0)
 {
+	if constexpr (LN == 11 && UL == 1 && (MODE == 16 || MODE == 17))
+	{
+		if (X0.half_fused != 0 && convp_ha_fused_fits(X0.run_off, X0.c.in_len, X0.in_step))
+		{
+			emul_convp_t<LN, UL, MODE == 16 ? 29 : 30, FLENP>(X0);
+			return;
+		}
+	}
+	if constexpr ((LN == 11 || LN == 12) && UL == 1 && (MODE == 6 || MODE == 7))
+	{
+		if (X0.half != 0)
+		{
+			emul_convp_t<LN, UL, MODE == 6 ? 31 : 32, FLENP>(X0);
+			return;
+		}
+	}
 	if constexpr (LN == 11 && UL == 1 && (MODE == 4 || MODE == 5))
 	{
 		// half-array form with the interpolator fused in (kernel modes 23 / 25)

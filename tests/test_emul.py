@@ -1305,8 +1305,10 @@ def run_half_case(lib_kw, case, nch=5, bitwise=True):
     x = make_input(nch, 5 * maxin, 43)
     lens = [maxin, maxin, maxin // 5, 17, 1, maxin - 1, maxin // 2]
     outs = []
+    opts = dict(opts)
+    phase = opts.pop("_phase", 0)   # (1: minimum-phase filters -- complex kernel spectra, kernel modes 31 / 32)
     for h in (0, 1):
-        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, **lib_kw)
+        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, phase=phase, **lib_kw)
         for k, v in opts.items():
             b.set_option(k, v)
         b.set_option("half", 2 * h)
@@ -1328,7 +1330,8 @@ def run_half_case(lib_kw, case, nch=5, bitwise=True):
     b.process_host(x[:, :maxin])
     assert any(sym in b.stage_symbols() for sym in ("k_convp<11, 1, 21, 24>", "k_convp<11, 1, 22, 24>", "k_convp<12, 1, 21, 24>",
                                                     "k_convp<12, 1, 22, 24>", "k_convp<12, -1, 27, 24>",
-                                                    "k_convp<12, -1, 28, 24>")), b.stage_symbols()
+                                                    "k_convp<12, -1, 28, 24>", "k_convp<11, 1, 31, 24>", "k_convp<11, 1, 32, 24>",
+                                                    "k_convp<12, 1, 31, 24>", "k_convp<12, 1, 32, 24>")), b.stage_symbols()
     return y1
 
 
@@ -1341,7 +1344,10 @@ HALF_CASES = QUAD_CASES + [(48000.0, 32000.0, 6000, 3.0, 150.0, {}),
                            # decimator, in front of the strided store
                            (88200.0, 44100.0, 16384, 2.0, 180.15, {}), (88200.0, 44100.0, 5000, 2.0, 180.15, {"park": 0}),
                            (176400.0, 44100.0, 12000, 2.0, 180.15, {}), (88200.0, 44100.0, 3000, 2.0, 180.15, {"fold_tail": 0}),
-                           (32000.0, 48000.0, 6000, 3.0, 180.15, {}), (64000.0, 96000.0, 9000, 3.0, 180.15, {"park": 0})]
+                           (32000.0, 48000.0, 6000, 3.0, 180.15, {}), (64000.0, 96000.0, 9000, 3.0, 180.15, {"park": 0}),
+                           # minimum phase (complex kernel spectra: kernel modes 31 / 32)
+                           (44100.0, 88200.0, 6000, 2.0, 180.15, {"_phase": 1}), (48000.0, 32000.0, 6000, 3.0, 150.0, {"_phase": 1}),
+                           (44100.0, 88200.0, 9000, 1.0, 180.15, {"_phase": 1}), (48000.0, 32000.0, 9000, 2.0, 180.15, {"_phase": 1})]
 
 
 @pytest.mark.parametrize("case", range(len(HALF_CASES)))
@@ -1378,7 +1384,8 @@ def test_emulated_half_array_levels_and_silence(emul):
 HALF_FUSED_CASES = [(44100.0, 96000.0, 16384, 2.0, 180.15, {}), (44100.0, 96000.0, 6000, 2.0, 180.15, {"park": 0}),
                     (22050.0, 48000.0, 16384, 2.0, 180.15, {}), (44100.0, 96000.0, 5000, 2.0, 180.15, {"fold_tail": 0}),
                     (44100.0, 96000.0, 16384, 3.0, 150.0, {}),       # another filter: 1024 -> 2048-point blocks, stays on mode 4
-                    (44100.0, 48000.0, 16384, 2.0, 180.15, {})]      # 147 / 160 ... / 80 phases
+                    (44100.0, 48000.0, 16384, 2.0, 180.15, {}),      # 147 / 160 ... / 80 phases
+                    (44100.0, 96000.0, 16384, 2.0, 180.15, {"_phase": 1}), (44100.0, 48000.0, 6000, 2.0, 180.15, {"_phase": 1})]
 
 
 def run_half_fused_case(lib_kw, case, nch=5, bitwise=True, must_run=None):
@@ -1387,8 +1394,11 @@ def run_half_fused_case(lib_kw, case, nch=5, bitwise=True, must_run=None):
     the same values -- bit for bit under emulation, to rounding on the device --, ragged calls, odd channel counts"""
     src, dst, maxin, tb, att, opts = case
 
+    opts = dict(opts)
+    phase = opts.pop("_phase", 0)   # (1: minimum-phase filters -- kernel modes 29 / 30 against 16 / 17)
+
     def mk(h):
-        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, **lib_kw)
+        b = r8b.BatchResampler(src, dst, maxin, tb, att, nch=nch, phase=phase, **lib_kw)
         for k, v in opts.items():
             b.set_option(k, v)
         b.set_option("walk", 0)
@@ -1412,7 +1422,8 @@ def run_half_fused_case(lib_kw, case, nch=5, bitwise=True, must_run=None):
         else:
             d = ya - yb
             assert np.sqrt((d * d).mean()) <= 2e-16 and np.abs(d).max() <= 4e-15, (case, pos)
-        ran = ran or any(s in ("k_convp<11, 1, 23, 24>", "k_convp<11, 1, 25, 24>") for s in b.stage_symbols())
+        ran = ran or any(s in ("k_convp<11, 1, 23, 24>", "k_convp<11, 1, 25, 24>", "k_convp<11, 1, 29, 24>", "k_convp<11, 1, 30, 24>")
+                         for s in b.stage_symbols())
     if must_run is not None:
         assert ran == must_run, b.stage_symbols()
     return ran
