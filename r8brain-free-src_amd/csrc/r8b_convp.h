@@ -1509,7 +1509,9 @@ R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 //     ds_read_b64 / ds_write_b64 at the rate of the 16-byte forms), the butterflies between them unchanged.
 // The exchange inside a wave costs nothing but program order (LDS serves a wave's accesses in issue order); the one
 // across the workgroup takes three barriers instead of one (real parts written | read | imaginary parts written | read).
-// Arithmetic, constants and their order are those of mode 0: results are BITWISE those of k_convp<11, 1, 0, 24>.
+// Arithmetic, constants and their order are those of mode 0: results are BITWISE those of k_convp<11, 1, 0, 24> under host
+// emulation (tests); on the device the compiler contracts multiply-adds differently in the two kernels -- they agree to
+// rounding, RMS 4e-17 --, so an object stays with one form (Engine::half_worth decides per object, never per call).
 // Slots: element e of the array of doubles at 8-byte slot dswz(e) = e ^ (bits 4-7 into bits 0-3) ^ (bit 8 into bit 4) --
 // every access pattern below meets 16 different slots mod 16 in each 16 consecutive lanes (ds_write_b64) and 32
 // different slots mod 32 in each 32 (ds_read_b64); linear over XOR like pswz(): one address per thread and pass, XOR
