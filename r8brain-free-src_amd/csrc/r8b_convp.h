@@ -1564,10 +1564,13 @@ template<int LN, int UL, int MODE> constexpr int convp_mode_array_bytes()
 	return convp_mode_ha(MODE) ? convp_ha_array_bytes<LN, UL, MODE>() : convp_array_bytes<LN, UL>();
 }
 // does the interpolator's run of a fused launch fit the half-array form's array?  (host: the launcher's choice)
-// (the windows of a block's last, partly masked output group reach in_step + 48 slots past the run: Engine::use_pair_two)
+// (the full-array kernels allow in_step + 48 slots past the run for the windows of a block's last, partly masked output
+// group -- Engine::use_pair_two; here a lane whose outputs are both masked reads nothing -- cp_whole2_compute SKIPM --, and
+// a stored output's window ends inside the run's zero extension: 32 + 16 slots)
 inline bool convp_ha_fused_fits(int run_off, int in_len, int in_step)
 {
-	return run_off + in_len + in_step + 32 + 16 <= kHaFusedElems;
+	(void) in_step;
+	return run_off + in_len + 32 + 16 <= kHaFusedElems;
 }
 R8B_HD constexpr int dswz(int e) { return e ^ ((e >> 4) & 15) ^ (((e >> 8) & 1) << 4); }
 R8B_HD constexpr int dsw_xc(int m) { return dswz(m) & 31; }
@@ -2635,7 +2638,9 @@ R8B_HD void cp_rows2_fetch(const ConvxLaunch& X, double* rows, int pt)
 // belongs to the next call, ConvxLaunch::park_dst)
 // (NBUF: chunks of the window in flight -- 2: a chunk's reads issued one chunk ahead of its multiply-adds; 1: the
 // half-array form, whose register budget is 168: a chunk's reads, then its multiply-adds, the CU's other workgroups in between)
-template<int T2, bool ALIGNED_ONLY = false, int NBUF = 2, int NBUFG = NBUF>
+// (SKIPM: lanes none of whose two outputs is stored in this round read nothing -- the half-array form, whose array ends
+// a few slots behind the run: the window of a MASKED output of a block's last group may begin up to in_step slots further)
+template<int T2, bool ALIGNED_ONLY = false, int NBUF = 2, int NBUFG = NBUF, bool SKIPM = false>
 R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const SpanInfo& Bm, const cd* y, const double* rows,
 	int pt, int chA, int chB, bool bvalid)
 {
@@ -2742,6 +2747,10 @@ R8B_HD void cp_whole2_compute(const ConvxLaunch& X, const DstView& wd, const Spa
 	if constexpr (!ALIGNED_ONLY)
 	for (int gl = set; gl <= gmax; gl += nsets)
 	{
+		if constexpr (SKIPM)
+		{
+			if (!((gl > 0 || f0) && (gl < gmax || l0)) && !((gl > 0 ? 2 * q + 1 < out_step : f1) && (gl < gmax || l1))) continue;
+		}
 		const cd* w = y + (u_lo + in_step * gl + rq);
 		double a0[2] = { 0.0, 0.0 }, b0[2] = { 0.0, 0.0 }, a1[2] = { 0.0, 0.0 }, b1[2] = { 0.0, 0.0 };
 		// the window in chunks of five taps, each chunk's reads issued one chunk ahead of its
@@ -3837,7 +3846,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 #endif
 			constexpr int NBUF = HA ? R8B_HA_NBUF : 2;
 			for (int sb = 0; sb < nv; sb++)
-				cp_whole2_compute<T2, false, NBUF, (HA ? 1 : 2)>(X, X.wdst, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
+				cp_whole2_compute<T2, false, NBUF, (HA ? 1 : 2), HA>(X, X.wdst, XM.blk[cur.k + sb - L.k0], buf + sb * G::NA, st.rows2, st.pt, chA, chB, bvalid);
 			if (ex.uniform(st.pf) != 0)
 			{
 				// (the call's last block: its outputs behind the call's range belong to the next call -- parked, not
@@ -3848,7 +3857,7 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 				pd.mask = -1;
 				pd.off = -XM.wb;
 				pd.fmt = kPcmF64;
-				cp_whole2_compute<T2, false, NBUF, (HA ? 1 : 2)>(X, pd, XM.park_blk, buf + (nv - 1) * G::NA, st.rows2, st.pt, chA, chB, bvalid);
+				cp_whole2_compute<T2, false, NBUF, (HA ? 1 : 2), HA>(X, pd, XM.park_blk, buf + (nv - 1) * G::NA, st.rows2, st.pt, chA, chB, bvalid);
 			}
 		});
 	}

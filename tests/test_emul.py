@@ -1385,7 +1385,10 @@ HALF_FUSED_CASES = [(44100.0, 96000.0, 16384, 2.0, 180.15, {}), (44100.0, 96000.
                     (22050.0, 48000.0, 16384, 2.0, 180.15, {}), (44100.0, 96000.0, 5000, 2.0, 180.15, {"fold_tail": 0}),
                     (44100.0, 96000.0, 16384, 3.0, 150.0, {}),       # another filter: 1024 -> 2048-point blocks, stays on mode 4
                     (44100.0, 48000.0, 16384, 2.0, 180.15, {}),      # 147 / 160 ... / 80 phases
-                    (44100.0, 96000.0, 16384, 2.0, 180.15, {"_phase": 1}), (44100.0, 48000.0, 6000, 2.0, 180.15, {"_phase": 1})]
+                    (44100.0, 96000.0, 16384, 2.0, 180.15, {"_phase": 1}), (44100.0, 48000.0, 6000, 2.0, 180.15, {"_phase": 1}),
+                    # In > Out with a long input step (320 / 147): the run ends 48 slots short of the array, masked lanes read nothing
+                    (48000.0, 44100.0, 16384, 2.0, 180.15, {}), (96000.0, 88200.0, 7000, 2.0, 180.15, {"park": 0}),
+                    (48000.0, 44100.0, 5000, 2.0, 180.15, {"_phase": 1})]
 
 
 def run_half_fused_case(lib_kw, case, nch=5, bitwise=True, must_run=None):
@@ -1419,7 +1422,7 @@ def run_half_fused_case(lib_kw, case, nch=5, bitwise=True, must_run=None):
         assert ya.shape == yb.shape and np.isfinite(yb).all()
         if bitwise:
             assert np.array_equal(ya, yb), (case, pos)
-        else:
+        elif ya.size:   # (a one-sample call of a decimating chain may owe no output)
             d = ya - yb
             assert np.sqrt((d * d).mean()) <= 2e-16 and np.abs(d).max() <= 4e-15, (case, pos)
         ran = ran or any(s in ("k_convp<11, 1, 23, 24>", "k_convp<11, 1, 25, 24>", "k_convp<11, 1, 29, 24>", "k_convp<11, 1, 30, 24>")

@@ -70,4 +70,5 @@ prof minphase --src 44100 --dst 96000 --phase 1
 prof solo192 --src 192000 --dst 44100 --tb 0.5
 prof up3 --src 16000 --dst 48000
 prof exact32 --src 32000 --dst 48000 --tb 0.5
+prof r4844 --src 48000 --dst 44100
 ls $out/*
