@@ -1526,9 +1526,11 @@ R8B_HD void cp_back2(const cd* buf, ConvpState<LN, UL>& st, int lt)
 // the 4096 points: its two exchanges go by parts through 4096 doubles, the backward side's 2048 complex values fit as
 // they are; three workgroups per CU)
 // (MODES 29 / 30 = 23 / 25, 31 / 32 = 21 / 22 with a COMPLEX kernel spectrum -- minimum-phase chains: modes 16 / 17 / 6 / 7)
-constexpr bool convp_mode_ha(int m) { return m == 21 || m == 22 || m == 23 || m == 25 || m == 27 || m == 28 || (m >= 29 && m <= 32); }
+// (MODE 33 = mode 5 of the 4096 -> 4096-point 1:1 geometry -- BASELINE's cfg3 --: BOTH transforms have the 4096 points there,
+// all four exchanges go by parts -- two of them across the workgroup --; the array is the interpolator's run as in mode 25)
+constexpr bool convp_mode_ha(int m) { return m == 21 || m == 22 || m == 23 || m == 25 || m == 27 || m == 28 || (m >= 29 && m <= 33); }
 constexpr bool convp_mode_ha_down(int m) { return m == 27 || m == 28; }
-constexpr bool convp_mode_ha_fused(int m) { return m == 23 || m == 25 || m == 29 || m == 30; }
+constexpr bool convp_mode_ha_fused(int m) { return m == 23 || m == 25 || m == 29 || m == 30 || m == 33; }
 // (what leaves the workgroup at 52 KB with the flag words and the twiddle table: three of 53.1 KB -- 163 008 of a CU's
 // 163 840 bytes -- were NOT resident together on MI355X, the allocation is rounded up; BASELINE's cfg2 needs 3051)
 static const int kHaFusedElems = 3052;
@@ -1548,7 +1550,9 @@ template<int LN, int UL> constexpr bool convp_ha_ok()
 	return (UL == 1 && G::SUB == 1 && G::NPRE == 3 &&
 		((!G::POST && G::B1 && G::R2 == 16 && ConvpTwLds<LN, UL>::ON) || (G::POST && G::NPOST == 3 && G::RMB == 2 && G::E2 == 16))) ||
 		(UL == -1 && LN == 12 && G::SUB == 1 && G::E1 == 16 && G::NPRE == 2 && G::NBF == 1 && G::NT == 256 && G::NPOST == 3 &&
-		!ConvpTwLds<LN, UL>::ON);
+		!ConvpTwLds<LN, UL>::ON) ||
+		(UL == 0 && LN == 12 && G::SUB == 1 && G::E1 == 16 && G::NPRE == 2 && G::NBF == 1 && G::NT == 256 && !G::POST && G::B1 &&
+		G::R2 == 16 && ConvpTwLds<LN, UL>::ON);
 }
 template<int LN, int UL, int MODE = 21> constexpr int convp_ha_array_bytes()
 {
@@ -3046,13 +3050,15 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	constexpr int BM = MODE == 6 || MODE == 8 || MODE == 10 || MODE == 12 || MODE == 14 ? 0 :
 		(MODE == 7 || MODE == 9 || MODE == 11 || MODE == 13 || MODE == 15 ? 3 : (MODE == 16 ? 4 : (MODE == 17 ? 5 :
 		(MODE == 18 ? 1 : (MODE == 19 || MODE == 20 || MODE == 21 || MODE == 27 || MODE == 31 ? 0 : (MODE == 22 || MODE == 28 || MODE == 32 ? 3 :
-		(MODE == 23 || MODE == 29 ? 4 : (MODE == 25 || MODE == 30 ? 5 : MODE))))))));
+		(MODE == 23 || MODE == 29 ? 4 : (MODE == 25 || MODE == 30 || MODE == 33 ? 5 : MODE))))))));
 	// mode 20: mode 0 of the decimating form behind a half-band decimator taken in the load (cp_hbf_*)
 	constexpr bool HBF = MODE == 20;
 	// mode 21: mode 0 in the half-array form (cp_ha_*: the backward side's exchanges by parts through an array of doubles)
 	constexpr bool HA = convp_mode_ha(MODE);
 	static_assert(!HA || convp_ha_ok<LN, UL>(), "half-array form: the 2048 -> 4096-point and 4096 -> 8192-point 2x up-sampling geometries");
 	static_assert(!HA || !ConvpGeom<LN, UL>::POST || BM == 0 || BM == 3, "half-array form on 8192 points: convolver-only modes");
+	// (the forward transform's exchanges by parts too: the decimating form, and the 1:1 form where both sides go that way)
+	constexpr bool HAF = HA && UL <= 0;
 	// mode 19: polyphase 3x form (cp_p3_*): a convolver-only mode with its own load, middle and store
 	constexpr bool P3 = convp_mode_p3(MODE);
 	// (development builds, R8B_SPLIT_UP2: the other modes of the geometry are compiled as before and must not be launched)
@@ -3214,9 +3220,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			ex.post_shift(tid, sub_of(tid), lt, lsh);
 			cp_scale_in<LN, UL>(st, lsh);
 		}
-		if constexpr (HA && UL < 0)
+		if constexpr (HAF)
 		{
-			// (decimating half-array form: the first pass's results stay in registers; their real parts go to the array)
+			// (half-array form of the forward side: the first pass's results stay in registers; their real parts go to the array)
 			constexpr int NBW = 6;
 			cd loc[NBW];
 #pragma unroll
@@ -3277,9 +3283,9 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 		front(tid, st, twl_v);
 		first_pass(tid, st, twl_v);
 	});
-	if constexpr (HA && UL < 0)
+	if constexpr (HAF)
 	{
-		// (decimating half-array form, the exchange behind the first pass -- across the workgroup: real parts written |
+		// (half-array form of the forward side, the exchange behind the first pass -- across the workgroup: real parts written |
 		// read | imaginary parts written | read, the last in the wave-local steps' first one)
 		ex.phase([&](int tid, St& st) { cp_ha_ld<256>(buf_of(tid), st.er, lt_of(tid)); });
 		ex.phase([&](int tid, St& st) { cp_ha_st<G::N>(buf_of(tid), st.vi, lt_of(tid)); });
@@ -3616,6 +3622,42 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 	else
 	if constexpr (HA)
 	{
+		// (1:1 geometry: the forward side's second exchange by parts in front of them -- sub-length 256 -> the thread's sixteen
+		// consecutive positions, inside the wave --, then the middle pass's arithmetic on the values in registers)
+		auto f1 = [&](int tid, St& st)
+		{
+			if constexpr (HAF)
+			{
+				const int lt = lt_of(tid);
+				cd twr[TL::NBF];
+				twl_fetch<TL::NBF, TL::JM1>(twr, ltw, TL::O1, lt);
+				cp_ha_ld<256>(buf_of(tid), st.vi, lt);
+				pdif_arith<16, true>(twr, st.er, st.vi);
+				cp_ha_st<256>(buf_of(tid), st.er, lt);
+				hp_prefetch(st, lt);
+			}
+		};
+		auto f2 = [&](int tid, St& st) { if constexpr (HAF) cp_ha_ld<16>(buf_of(tid), st.er, lt_of(tid)); };
+		auto f3 = [&](int tid, St& st) { if constexpr (HAF) cp_ha_st<256>(buf_of(tid), st.vi, lt_of(tid)); };
+		auto f4 = [&](int tid, St& st)
+		{
+			if constexpr (HAF)
+			{
+				static_assert(!HAF || (UL == 0 && !CX && G::RM == 16), "1:1 half-array form: a real kernel spectrum, radix 16 in the middle");
+				double zi[16];
+				cp_ha_ld<16>(buf_of(tid), zi, lt_of(tid));
+				dif_regs<16>(st.er, zi);
+#pragma unroll
+				for (int c = 0; c < 8; c++)
+				{
+					st.vr[2 * c] = st.er[2 * c] * st.hp[c].re;
+					st.vi[2 * c] = zi[2 * c] * st.hp[c].re;
+					st.vr[2 * c + 1] = st.er[2 * c + 1] * st.hp[c].im;
+					st.vi[2 * c + 1] = zi[2 * c + 1] * st.hp[c].im;
+				}
+				dit_regs<16>(st.vr, st.vi);
+			}
+		};
 		// half-array form: the two exchanges of the backward side by parts -- real parts, then imaginary parts -- through
 		// the array of doubles.  The first stays inside sixteen lanes of a wave: program order (and the steps' ordering
 		// points) is all it needs; the second crosses the workgroup: written | barrier | read | barrier | written |
@@ -3633,6 +3675,8 @@ R8B_HD void convp_body(Exec& ex, const ConvxLaunch& X, const ConvxLaunch& XM, cd
 			cp_ha_st_b1(buf_of(tid), st.er, lt);
 			cp_back2_prefetch<LN, UL>(L, st, lt);
 		};
+		if constexpr (HAF) ex.wave_steps(f1, f2, f3, f4, h_a1, h_a2, h_a3, h_a4);
+		else
 		ex.wave_steps(s_pre1, s_pre2, s_midc, h_a1, h_a2, h_a3, h_a4);
 		ex.phase([&](int tid, St& st) { cp_ha_ld_b2<G::NT>(buf_of(tid), st.vr, lt_of(tid)); });
 		ex.phase([&](int tid, St& st) { cp_ha_st_b1(buf_of(tid), st.vi, lt_of(tid)); });

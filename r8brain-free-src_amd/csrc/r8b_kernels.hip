@@ -821,7 +821,8 @@ __device__ __forceinline__ void convp_pin(ConvxLaunch& H, const ConvxLaunch& X)
 		"+s"(H.c.up_pow2), "+s"(H.c.src.cur_stride), "+s"(H.c.src.cur_base), "+s"(H.c.src.cur_fmt), "+s"(H.c.rot),
 		"+s"(H.c.fl2r), "+s"(H.c.tail_flags), "+s"(H.c.tail_bf)
 		: "s"(H.c.src.cur), "s"(H.c.hp), "s"(H.c.ptw));
-	if constexpr (MODE == 4 || MODE == 5 || MODE == 16 || MODE == 17 || MODE == 23 || MODE == 25 || MODE == 29 || MODE == 30)
+	if constexpr (MODE == 4 || MODE == 5 || MODE == 16 || MODE == 17 || MODE == 23 || MODE == 25 || MODE == 29 || MODE == 30 ||
+		MODE == 33)
 		asm volatile("" : "+s"(H.run_off), "+s"(H.in_step), "+s"(H.out_step), "+s"(H.nsets), "+s"(H.wdst.stride),
 			"+s"(H.wdst.mask), "+s"(H.wdst.off), "+s"(H.wdst.fmt), "+s"(H.park_n), "+s"(H.park_out), "+s"(H.park_slices),
 			"+s"(H.c.t_zero)
@@ -1125,6 +1126,15 @@ void launch_convp_t(const ConvxLaunch& X0, hipStream_t stream)
 	lds_opt_in(reinterpret_cast<const void*>(kern), "hipFuncSetAttribute(k_convp)");
 	const unsigned npair = convp_mode_solo(MODE) ? (unsigned) X.c.nch : ((unsigned) X.c.nch + 1u) >> 1;
 	unsigned grid = nbg * npair;
+	if constexpr (LN == 12 && UL == 0 && MODE == 5)
+	{
+		// ... of the 4096 -> 4096-point 1:1 geometry (kernel mode 33: both transforms' exchanges by parts; BASELINE's cfg3)
+		if (X.half_fused != 0 && convp_ha_fused_fits(X.run_off, X.c.in_len, X.in_step))
+		{
+			launch_convp_t<LN, UL, 33, FLENP>(X0, stream);
+			return;
+		}
+	}
 	if constexpr (LN == 11 && UL == 1 && (MODE == 16 || MODE == 17))
 	{
 		// ... with a complex kernel spectrum (kernel modes 29 / 30: minimum-phase chains)

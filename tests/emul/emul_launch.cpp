@@ -384,6 +384,15 @@ void emul_convq(const ConvxLaunch& X0)
 template<int LN, int UL, int MODE, int FLENP>
 void emul_convp_t(const ConvxLaunch& X0)
 {
+	if constexpr (LN == 12 && UL == 0 && MODE == 5)
+	{
+		// (kernel mode 33: the 1:1 geometry, both transforms by parts)
+		if (X0.half_fused != 0 && convp_ha_fused_fits(X0.run_off, X0.c.in_len, X0.in_step))
+		{
+			emul_convp_t<LN, UL, 33, FLENP>(X0);
+			return;
+		}
+	}
 	if constexpr (LN == 11 && UL == 1 && (MODE == 16 || MODE == 17))
 	{
 		if (X0.half_fused != 0 && convp_ha_fused_fits(X0.run_off, X0.c.in_len, X0.in_step))

@@ -1388,7 +1388,10 @@ HALF_FUSED_CASES = [(44100.0, 96000.0, 16384, 2.0, 180.15, {}), (44100.0, 96000.
                     (44100.0, 96000.0, 16384, 2.0, 180.15, {"_phase": 1}), (44100.0, 48000.0, 6000, 2.0, 180.15, {"_phase": 1}),
                     # In > Out with a long input step (320 / 147): the run ends 48 slots short of the array, masked lanes read nothing
                     (48000.0, 44100.0, 16384, 2.0, 180.15, {}), (96000.0, 88200.0, 7000, 2.0, 180.15, {"park": 0}),
-                    (48000.0, 44100.0, 5000, 2.0, 180.15, {"_phase": 1})]
+                    (48000.0, 44100.0, 5000, 2.0, 180.15, {"_phase": 1}),
+                    # the 1:1 geometry (kernel mode 33: both transforms' exchanges by parts; BASELINE's cfg3)
+                    (96000.0, 44100.0, 16384, 2.0, 180.15, {}), (96000.0, 44100.0, 5000, 2.0, 180.15, {"park": 0}),
+                    (44100.0, 16000.0, 9000, 2.0, 180.15, {"fold_tail": 0})]
 
 
 def run_half_fused_case(lib_kw, case, nch=5, bitwise=True, must_run=None):
@@ -1425,8 +1428,8 @@ def run_half_fused_case(lib_kw, case, nch=5, bitwise=True, must_run=None):
         elif ya.size:   # (a one-sample call of a decimating chain may owe no output)
             d = ya - yb
             assert np.sqrt((d * d).mean()) <= 2e-16 and np.abs(d).max() <= 4e-15, (case, pos)
-        ran = ran or any(s in ("k_convp<11, 1, 23, 24>", "k_convp<11, 1, 25, 24>", "k_convp<11, 1, 29, 24>", "k_convp<11, 1, 30, 24>")
-                         for s in b.stage_symbols())
+        ran = ran or any(s in ("k_convp<11, 1, 23, 24>", "k_convp<11, 1, 25, 24>", "k_convp<11, 1, 29, 24>", "k_convp<11, 1, 30, 24>",
+                               "k_convp<12, 0, 33, 24>") for s in b.stage_symbols())
     if must_run is not None:
         assert ran == must_run, b.stage_symbols()
     return ran
