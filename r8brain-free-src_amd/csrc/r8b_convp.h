@@ -1570,11 +1570,12 @@ template<int LN, int UL, int MODE> constexpr int convp_mode_array_bytes()
 // does the interpolator's run of a fused launch fit the half-array form's array?  (host: the launcher's choice)
 // (the full-array kernels allow in_step + 48 slots past the run for the windows of a block's last, partly masked output
 // group -- Engine::use_pair_two; here a lane whose outputs are both masked reads nothing -- cp_whole2_compute SKIPM --, and
-// a stored output's window ends inside the run's zero extension: 32 + 16 slots)
+// a stored output's window -- 24 taps inside the run, one or three padded ones behind it -- ends inside the run's zero
+// extension, kConvxRunPad slots, which cp_final_store writes: that is all the array has to hold)
 inline bool convp_ha_fused_fits(int run_off, int in_len, int in_step)
 {
 	(void) in_step;
-	return run_off + in_len + 32 + 16 <= kHaFusedElems;
+	return run_off + in_len + kConvxRunPad <= kHaFusedElems;
 }
 R8B_HD constexpr int dswz(int e) { return e ^ ((e >> 4) & 15) ^ (((e >> 8) & 1) << 4); }
 R8B_HD constexpr int dsw_xc(int m) { return dswz(m) & 31; }

@@ -1391,7 +1391,9 @@ HALF_FUSED_CASES = [(44100.0, 96000.0, 16384, 2.0, 180.15, {}), (44100.0, 96000.
                     (48000.0, 44100.0, 5000, 2.0, 180.15, {"_phase": 1}),
                     # the 1:1 geometry (kernel mode 33: both transforms' exchanges by parts; BASELINE's cfg3)
                     (96000.0, 44100.0, 16384, 2.0, 180.15, {}), (96000.0, 44100.0, 5000, 2.0, 180.15, {"park": 0}),
-                    (44100.0, 16000.0, 9000, 2.0, 180.15, {"fold_tail": 0})]
+                    (44100.0, 16000.0, 9000, 2.0, 180.15, {"fold_tail": 0}),
+                    # a run that ends 4 slots short of the array (input step 320, run offset 336, in_len 2680)
+                    (16000.0, 44100.0, 16384, 2.0, 180.15, {}), (32000.0, 88200.0, 6000, 2.0, 180.15, {"park": 0})]
 
 
 def run_half_fused_case(lib_kw, case, nch=5, bitwise=True, must_run=None):
